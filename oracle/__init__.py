@@ -1,0 +1,5 @@
+"""CPU oracle package (TEST INFRASTRUCTURE ONLY -- see oracle/fm_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package.  The product package (fm_index_amd) never does.
+"""

@@ -1,0 +1,625 @@
+/*
+ * fm_oracle.c -- CPU ORACLE (test infrastructure, see fm_oracle.h).
+ *
+ * Restates, in plain C, the algorithm of the reference's count/locate path.
+ * Citations are file:line under /root/reference.  The bit-vector / wavelet
+ * matrix layer restates the *behaviour* of vers-vecs ^1.10.1 (Cargo.toml:16),
+ * whose source is not on this machine: per-level bit planes (MSB first, zeros
+ * stably before ones), 512-bit blocks + 8192-bit superblocks, rank clamped at
+ * len, select1 returning len when out of range.
+ */
+#define _GNU_SOURCE
+#include "fm_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+const char *orc_error_message(int code) {
+  switch (code) {
+    case ORC_OK: return "ok";
+    case ORC_ERR_START_ZERO: /* sais.rs:129-131 */
+      return "the given text must not start with zero character";
+    case ORC_ERR_END_ZERO: /* sais.rs:135-137 */
+      return "the given text must end with exactly one zero character";
+    case ORC_ERR_SYMBOL_RANGE: return "symbol exceeds max_character";
+    default: return "invalid argument";
+  }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* util.rs:1-3 */
+uint32_t orc_log2(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+/* text.rs:61-63 */
+uint32_t orc_max_bits(uint64_t max_character) { return orc_log2(max_character) + 1; }
+
+/* sais.rs:115-139 */
+int orc_validate_text(const uint8_t *text, uint64_t n) {
+  if (n == 0 || n == 1) return ORC_OK; /* sais.rs:121-126 */
+  if (text[0] == 0) return ORC_ERR_START_ZERO;
+  /* rposition of the last non-zero must be n-2 (sais.rs:133-134) */
+  int64_t last = -1;
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--)
+    if (text[i] != 0) { last = i; break; }
+  if (last != (int64_t)n - 2) return ORC_ERR_END_ZERO;
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* suffix array                                                        */
+/* ------------------------------------------------------------------ */
+typedef struct { const uint8_t *t; uint64_t n; } naive_ctx;
+static int naive_cmp(const void *a, const void *b, void *c) {
+  const naive_ctx *x = (const naive_ctx *)c;
+  uint64_t i = *(const uint32_t *)a, j = *(const uint32_t *)b;
+  uint64_t li = x->n - i, lj = x->n - j, l = li < lj ? li : lj;
+  int r = memcmp(x->t + i, x->t + j, l); /* slice comparison: sais.rs:553 */
+  if (r) return r;
+  return li < lj ? -1 : (li > lj ? 1 : 0);
+}
+void orc_suffix_array_naive(const uint8_t *text, uint64_t n, uint32_t *sa) {
+  for (uint64_t i = 0; i < n; i++) sa[i] = (uint32_t)i;
+  naive_ctx c = {text, n};
+  qsort_r(sa, n, sizeof(uint32_t), naive_cmp, &c);
+}
+
+typedef struct { const uint32_t *rank; uint64_t h, n; } dbl_ctx;
+static int dbl_cmp(const void *a, const void *b, void *c) {
+  const dbl_ctx *x = (const dbl_ctx *)c;
+  uint64_t i = *(const uint32_t *)a + x->h, j = *(const uint32_t *)b + x->h;
+  /* a suffix that ends first is the smaller one (slice order) */
+  int64_t ri = i < x->n ? (int64_t)x->rank[i] : -1;
+  int64_t rj = j < x->n ? (int64_t)x->rank[j] : -1;
+  return ri < rj ? -1 : (ri > rj ? 1 : 0);
+}
+void orc_suffix_array(const uint8_t *text, uint64_t n, uint32_t *sa) {
+  if (n == 0) return;
+  uint32_t *rank = (uint32_t *)malloc(n * sizeof(uint32_t));
+  uint32_t *nrank = (uint32_t *)malloc(n * sizeof(uint32_t));
+  uint64_t cnt[257];
+  memset(cnt, 0, sizeof cnt);
+  for (uint64_t i = 0; i < n; i++) cnt[text[i] + 1]++;
+  for (int c = 0; c < 256; c++) cnt[c + 1] += cnt[c];
+  for (uint64_t i = 0; i < n; i++) rank[i] = (uint32_t)cnt[text[i]];
+  {
+    uint64_t pos[256];
+    for (int c = 0; c < 256; c++) pos[c] = cnt[c];
+    for (uint64_t i = 0; i < n; i++) sa[pos[text[i]]++] = (uint32_t)i;
+  }
+  for (uint64_t h = 1;; h *= 2) {
+    dbl_ctx ctx = {rank, h, n};
+    int any = 0;
+    uint64_t g0 = 0;
+    while (g0 < n) {
+      uint64_t g1 = g0 + 1;
+      uint32_t r = rank[sa[g0]];
+      while (g1 < n && rank[sa[g1]] == r) g1++;
+      if (g1 - g0 > 1) {
+        any = 1;
+        qsort_r(sa + g0, g1 - g0, sizeof(uint32_t), dbl_cmp, &ctx);
+        /* new ranks: sub-group head index */
+        uint64_t head = g0;
+        for (uint64_t p = g0; p < g1; p++) {
+          if (p > g0 && dbl_cmp(&sa[p - 1], &sa[p], &ctx) != 0) head = p;
+          nrank[sa[p]] = (uint32_t)head;
+        }
+      } else {
+        nrank[sa[g0]] = (uint32_t)g0;
+      }
+      g0 = g1;
+    }
+    memcpy(rank, nrank, n * sizeof(uint32_t));
+    if (!any) break;
+  }
+  free(rank);
+  free(nrank);
+}
+
+/* sais.rs:9-32 (count_chars + get_bucket_start_pos) */
+void orc_bucket_start(const uint8_t *text, uint64_t n, uint64_t max_character,
+                      uint64_t *cs) {
+  uint64_t m = max_character + 1;
+  uint64_t *occ = (uint64_t *)calloc(m, sizeof(uint64_t));
+  for (uint64_t i = 0; i < n; i++) occ[text[i]]++;
+  uint64_t sum = 0;
+  for (uint64_t c = 0; c < m; c++) { cs[c] = sum; sum += occ[c]; }
+  free(occ);
+}
+
+/* fm_index.rs:44-58 */
+void orc_bwt(const uint8_t *text, uint64_t n, const uint32_t *sa, uint8_t *bwt) {
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t k = sa[i];
+    bwt[i] = k > 0 ? text[k - 1] : 0;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* RsVec                                                               */
+/* ------------------------------------------------------------------ */
+#define BLK_WORDS 8u     /* 512 bits  */
+#define SUP_BLKS 16u     /* 8192 bits */
+void orc_rsvec_build(orc_rsvec *v, uint64_t *words, uint64_t len) {
+  v->len = len;
+  v->nwords = (len + 63) / 64;
+  v->words = words;
+  uint64_t nblk = v->nwords / BLK_WORDS + 1, nsup = nblk / SUP_BLKS + 1;
+  v->blk = (uint16_t *)malloc(nblk * sizeof(uint16_t));
+  v->sup = (uint64_t *)malloc(nsup * sizeof(uint64_t));
+  uint64_t total = 0, insup = 0;
+  for (uint64_t b = 0; b < nblk; b++) {
+    if (b % SUP_BLKS == 0) { v->sup[b / SUP_BLKS] = total; insup = 0; }
+    v->blk[b] = (uint16_t)insup;
+    uint64_t w0 = b * BLK_WORDS, w1 = w0 + BLK_WORDS;
+    if (w1 > v->nwords) w1 = v->nwords;
+    uint64_t c = 0;
+    for (uint64_t w = w0; w < w1; w++) c += (uint64_t)__builtin_popcountll(words[w]);
+    total += c;
+    insup += c;
+  }
+  v->ones = total;
+}
+void orc_rsvec_free(orc_rsvec *v) {
+  free(v->words); free(v->blk); free(v->sup);
+  memset(v, 0, sizeof *v);
+}
+uint64_t orc_rsvec_rank1(const orc_rsvec *v, uint64_t i) {
+  if (i >= v->len) return v->ones; /* clamp */
+  uint64_t w = i >> 6, b = w / BLK_WORDS;
+  uint64_t r = v->sup[b / SUP_BLKS] + v->blk[b];
+  for (uint64_t k = b * BLK_WORDS; k < w; k++) r += (uint64_t)__builtin_popcountll(v->words[k]);
+  uint64_t m = (i & 63) ? (v->words[w] & ((1ull << (i & 63)) - 1)) : 0;
+  return r + (uint64_t)__builtin_popcountll(m);
+}
+uint64_t orc_rsvec_rank0(const orc_rsvec *v, uint64_t i) {
+  uint64_t ii = i > v->len ? v->len : i;
+  return ii - orc_rsvec_rank1(v, i);
+}
+int orc_rsvec_get(const orc_rsvec *v, uint64_t i) { return (int)((v->words[i >> 6] >> (i & 63)) & 1); }
+uint64_t orc_rsvec_select1(const orc_rsvec *v, uint64_t k) {
+  if (k >= v->ones) return v->len;
+  uint64_t nblk = v->nwords / BLK_WORDS + 1, nsup = nblk / SUP_BLKS + 1;
+  uint64_t lo = 0, hi = nsup; /* last superblock with sup <= k */
+  while (hi - lo > 1) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (v->sup[mid] <= k) lo = mid; else hi = mid;
+  }
+  uint64_t rem = k - v->sup[lo];
+  uint64_t b = lo * SUP_BLKS, bend = b + SUP_BLKS;
+  if (bend > nblk) bend = nblk;
+  while (b + 1 < bend && v->blk[b + 1] <= rem) b++;
+  rem -= v->blk[b];
+  uint64_t w = b * BLK_WORDS;
+  for (;; w++) {
+    uint64_t c = (uint64_t)__builtin_popcountll(v->words[w]);
+    if (rem < c) break;
+    rem -= c;
+  }
+  uint64_t x = v->words[w];
+  for (uint64_t j = 0; j < rem; j++) x &= x - 1;
+  return w * 64 + (uint64_t)__builtin_ctzll(x);
+}
+
+/* ------------------------------------------------------------------ */
+/* WaveletMatrix                                                       */
+/* ------------------------------------------------------------------ */
+void orc_wm_build(orc_wm *w, const uint8_t *vals, uint64_t n, uint32_t bits) {
+  w->bits = bits;
+  w->len = n;
+  w->lv = (orc_rsvec *)calloc(bits, sizeof(orc_rsvec));
+  w->zeros = (uint64_t *)calloc(bits, sizeof(uint64_t));
+  uint8_t *cur = (uint8_t *)malloc(n ? n : 1), *nxt = (uint8_t *)malloc(n ? n : 1);
+  memcpy(cur, vals, n);
+  uint64_t nwords = (n + 63) / 64;
+  int nt = orc_max_threads();
+  uint64_t *zc = (uint64_t *)calloc((size_t)nt + 1, sizeof(uint64_t));
+  for (uint32_t l = 0; l < bits; l++) {
+    uint32_t sh = bits - 1 - l;
+    uint64_t *words = (uint64_t *)calloc(nwords + BLK_WORDS, sizeof(uint64_t));
+    /* chunk boundaries are multiples of 64 so word writes never race */
+    uint64_t chunk = ((n / (uint64_t)nt) / 64 + 1) * 64;
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; t++) {
+      uint64_t a = (uint64_t)t * chunk, b = a + chunk;
+      if (a > n) a = n;
+      if (b > n) b = n;
+      uint64_t z = 0;
+      for (uint64_t i = a; i < b; i++) {
+        uint64_t bit = (cur[i] >> sh) & 1u;
+        words[i >> 6] |= bit << (i & 63);
+        z += bit ^ 1u;
+      }
+      zc[t + 1] = z;
+    }
+    for (int t = 0; t < nt; t++) zc[t + 1] += zc[t];
+    uint64_t zeros = zc[nt];
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; t++) {
+      uint64_t a = (uint64_t)t * chunk, b = a + chunk;
+      if (a > n) a = n;
+      if (b > n) b = n;
+      uint64_t pz = zc[t], po = zeros + (a - zc[t]);
+      for (uint64_t i = a; i < b; i++) {
+        if ((cur[i] >> sh) & 1u) nxt[po++] = cur[i]; else nxt[pz++] = cur[i];
+      }
+    }
+    zc[0] = 0;
+    w->zeros[l] = zeros;
+    orc_rsvec_build(&w->lv[l], words, n);
+    uint8_t *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  free(zc);
+  free(cur);
+  free(nxt);
+}
+void orc_wm_free(orc_wm *w) {
+  for (uint32_t l = 0; l < w->bits; l++) orc_rsvec_free(&w->lv[l]);
+  free(w->lv); free(w->zeros);
+  memset(w, 0, sizeof *w);
+}
+uint64_t orc_wm_get(const orc_wm *w, uint64_t i) {
+  uint64_t v = 0;
+  for (uint32_t l = 0; l < w->bits; l++) {
+    const orc_rsvec *b = &w->lv[l];
+    uint64_t bit = (uint64_t)orc_rsvec_get(b, i);
+    v = (v << 1) | bit;
+    i = bit ? w->zeros[l] + orc_rsvec_rank1(b, i) : orc_rsvec_rank0(b, i);
+  }
+  return v;
+}
+/* rank_u64_unchecked(i, c) = rank_range(0..i, c): both range ends are mapped
+ * through every level */
+uint64_t orc_wm_rank(const orc_wm *w, uint64_t i, uint64_t c) {
+  uint64_t s = 0, e = i;
+  for (uint32_t l = 0; l < w->bits; l++) {
+    const orc_rsvec *b = &w->lv[l];
+    if ((c >> (w->bits - 1 - l)) & 1u) {
+      s = w->zeros[l] + orc_rsvec_rank1(b, s);
+      e = w->zeros[l] + orc_rsvec_rank1(b, e);
+    } else {
+      s = orc_rsvec_rank0(b, s);
+      e = orc_rsvec_rank0(b, e);
+    }
+  }
+  return e - s;
+}
+
+/* ------------------------------------------------------------------ */
+/* SOSampledSuffixArray                                                */
+/* ------------------------------------------------------------------ */
+static void bv_append_bits(uint64_t *w, uint64_t *pos, uint64_t v, uint64_t nb) {
+  uint64_t p = *pos, o = p & 63;
+  w[p >> 6] |= v << o;
+  if (o + nb > 64) w[(p >> 6) + 1] |= v >> (64 - o);
+  *pos = p + nb;
+}
+static uint64_t bv_get_bits(const uint64_t *w, uint64_t p, uint64_t nb) {
+  uint64_t o = p & 63, v = w[p >> 6] >> o;
+  if (o + nb > 64) v |= w[(p >> 6) + 1] << (64 - o);
+  return nb == 64 ? v : (v & ((1ull << nb) - 1));
+}
+static void ssa_init(orc_ssa *s, uint64_t n, uint64_t level) {
+  memset(s, 0, sizeof *s);
+  if (n == 0) return; /* sample.rs:22-24 (Default) */
+  s->word_size = orc_log2(n) + 1;    /* sample.rs:27 */
+  if (n <= (1ull << level)) level = 0; /* sample.rs:28-31 */
+  s->level = level;
+  s->len = n;
+  s->nsamples = ((n - 1) >> level) + 1; /* sample.rs:33 */
+  s->bits = (uint64_t *)calloc((s->nsamples * s->word_size + 63) / 64 + 1, sizeof(uint64_t));
+}
+void orc_ssa_sample(orc_ssa *s, const uint32_t *sa, uint64_t n, uint64_t level) {
+  ssa_init(s, n, level);
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < s->nsamples; i++) /* sample.rs:35-37 */
+    bv_append_bits(s->bits, &pos, sa[i << s->level], s->word_size);
+}
+void orc_ssa_from_samples(orc_ssa *s, const uint32_t *samples, uint64_t n, uint64_t level) {
+  ssa_init(s, n, level);
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < s->nsamples; i++)
+    bv_append_bits(s->bits, &pos, samples[i], s->word_size);
+}
+void orc_ssa_free(orc_ssa *s) { free(s->bits); memset(s, 0, sizeof *s); }
+int orc_ssa_get(const orc_ssa *s, uint64_t i, uint64_t *out) { /* sample.rs:46-60 */
+  if (i >= s->len) return 0;
+  if ((i & ((1ull << s->level) - 1)) == 0) {
+    *out = bv_get_bits(s->bits, (i >> s->level) * s->word_size, s->word_size);
+    return 1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* FMIndexBackend                                                      */
+/* ------------------------------------------------------------------ */
+static uint64_t fm_len(const void *p) { return ((const orc_fm *)p)->bw.len; } /* fm_index.rs:78-80 */
+static uint64_t fm_get_l(const void *p, uint64_t i) {                           /* fm_index.rs:82-84 */
+  return orc_wm_get(&((const orc_fm *)p)->bw, i);
+}
+static uint64_t fm_lf_map2(const void *p, uint64_t c, uint64_t i) {             /* fm_index.rs:93-95 */
+  const orc_fm *f = (const orc_fm *)p;
+  return f->cs[c] + orc_wm_rank(&f->bw, i, c);
+}
+static uint64_t fm_lf_map(const void *p, uint64_t i) {                          /* fm_index.rs:86-91 */
+  const orc_fm *f = (const orc_fm *)p;
+  uint64_t c = fm_get_l(p, i);
+  return f->cs[c] + orc_wm_rank(&f->bw, i, c);
+}
+static uint64_t fm_get_sa(const void *p, uint64_t i) {                          /* fm_index.rs:127-140 */
+  const orc_fm *f = (const orc_fm *)p;
+  uint64_t steps = 0, sa;
+  for (;;) {
+    if (orc_ssa_get(&f->ssa, i, &sa)) return (sa + steps) % f->bw.len;
+    i = fm_lf_map(p, i);
+    steps++;
+  }
+}
+orc_backend orc_fm_backend(orc_fm *f) {
+  orc_backend b = {f, fm_get_l, fm_lf_map, fm_lf_map2, fm_len,
+                   f->has_locate ? fm_get_sa : NULL, f->max_character};
+  return b;
+}
+static int check_symbols(const uint8_t *text, uint64_t n, uint64_t max_character) {
+  if (max_character >= 255) return ORC_OK;
+  for (uint64_t i = 0; i < n; i++)
+    if (text[i] > max_character) return ORC_ERR_SYMBOL_RANGE; /* count_chars would panic, sais.rs:18 */
+  return ORC_OK;
+}
+int orc_fm_new(orc_fm **out, const uint8_t *text, uint64_t n, uint64_t max_character,
+               int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  int rc = check_symbols(text, n, max_character);
+  if (rc) return rc;
+  rc = orc_validate_text(text, n);
+  if (rc) return rc;
+  orc_fm *f = (orc_fm *)calloc(1, sizeof(orc_fm));
+  f->max_character = max_character;
+  f->cs = (uint64_t *)calloc(max_character + 1, sizeof(uint64_t));
+  orc_bucket_start(text, n, max_character, f->cs);          /* fm_index.rs:32 */
+  uint32_t *sa = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_suffix_array(text, n, sa);                             /* fm_index.rs:33 */
+  uint8_t *bwt = (uint8_t *)malloc(n ? n : 1);
+  orc_bwt(text, n, sa, bwt);                                 /* fm_index.rs:34 */
+  orc_wm_build(&f->bw, bwt, n, orc_max_bits(max_character));
+  if (level >= 0) {
+    orc_ssa_sample(&f->ssa, sa, n, (uint64_t)level);         /* frontend.rs:213-221 */
+    f->has_locate = 1;
+  }
+  free(bwt);
+  free(sa);
+  *out = f;
+  return ORC_OK;
+}
+int orc_fm_from_bwt(orc_fm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                    const uint64_t *cs, const uint32_t *samples, int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  orc_fm *f = (orc_fm *)calloc(1, sizeof(orc_fm));
+  f->max_character = max_character;
+  f->cs = (uint64_t *)calloc(max_character + 1, sizeof(uint64_t));
+  memcpy(f->cs, cs, (max_character + 1) * sizeof(uint64_t));
+  orc_wm_build(&f->bw, bwt, n, orc_max_bits(max_character));
+  if (level >= 0 && samples) {
+    orc_ssa_from_samples(&f->ssa, samples, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  *out = f;
+  return ORC_OK;
+}
+void orc_fm_free(orc_fm *f) {
+  if (!f) return;
+  orc_wm_free(&f->bw);
+  orc_ssa_free(&f->ssa);
+  free(f->cs);
+  free(f);
+}
+uint64_t orc_fm_heap_bytes(const orc_fm *f) {
+  uint64_t t = (f->max_character + 1) * 8;
+  for (uint32_t l = 0; l < f->bw.bits; l++) {
+    const orc_rsvec *v = &f->bw.lv[l];
+    uint64_t nblk = v->nwords / BLK_WORDS + 1;
+    t += v->nwords * 8 + nblk * 2 + (nblk / SUP_BLKS + 1) * 8;
+  }
+  t += (f->ssa.nsamples * f->ssa.word_size + 7) / 8;
+  return t;
+}
+
+/* ------------------------------------------------------------------ */
+/* RLFMIndexBackend                                                    */
+/* ------------------------------------------------------------------ */
+static uint64_t rl_len(const void *p) { return ((const orc_rlfm *)p)->len; } /* rlfmi.rs:118-120 */
+static uint64_t rl_get_l(const void *p, uint64_t i) {                        /* rlfmi.rs:122-125 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  return orc_wm_get(&f->s, orc_rsvec_rank1(&f->b, i + 1) - 1);
+}
+static uint64_t rl_lf_map(const void *p, uint64_t i) {                       /* rlfmi.rs:127-133 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  uint64_t c = rl_get_l(p, i);
+  uint64_t j = orc_rsvec_rank1(&f->b, i);
+  uint64_t nr = orc_wm_rank(&f->s, j, c);
+  return orc_rsvec_select1(&f->bp, f->cs[c] + nr) + i - orc_rsvec_select1(&f->b, j);
+}
+static uint64_t rl_lf_map2(const void *p, uint64_t c, uint64_t i) {          /* rlfmi.rs:135-143 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  uint64_t j = orc_rsvec_rank1(&f->b, i);
+  uint64_t nr = orc_wm_rank(&f->s, j, c);
+  if (rl_get_l(p, i) != c) return orc_rsvec_select1(&f->bp, f->cs[c] + nr);
+  return orc_rsvec_select1(&f->bp, f->cs[c] + nr) + i - orc_rsvec_select1(&f->b, j);
+}
+static uint64_t rl_get_sa(const void *p, uint64_t i) {                       /* rlfmi.rs:176-189 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  uint64_t steps = 0, sa;
+  for (;;) {
+    if (orc_ssa_get(&f->ssa, i, &sa)) return (sa + steps) % f->len;
+    i = rl_lf_map(p, i);
+    steps++;
+  }
+}
+orc_backend orc_rlfm_backend(orc_rlfm *f) {
+  orc_backend b = {f, rl_get_l, rl_lf_map, rl_lf_map2, rl_len,
+                   f->has_locate ? rl_get_sa : NULL, f->max_character};
+  return b;
+}
+static void bits_set(uint64_t *w, uint64_t i) { w[i >> 6] |= 1ull << (i & 63); }
+int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_character,
+                 int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  int rc = check_symbols(text, n, max_character);
+  if (rc) return rc;
+  rc = orc_validate_text(text, n);
+  if (rc) return rc;
+  orc_rlfm *f = (orc_rlfm *)calloc(1, sizeof(orc_rlfm));
+  uint64_t m = max_character + 1;                               /* rlfmi.rs:38 */
+  f->len = n;
+  f->max_character = max_character;
+  uint32_t *sa = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_suffix_array(text, n, sa);                                /* rlfmi.rs:39 */
+  uint64_t nw = (n + 63) / 64 + BLK_WORDS;
+  uint64_t *bw = (uint64_t *)calloc(nw, 8), *bpw = (uint64_t *)calloc(nw, 8);
+  uint8_t *heads = (uint8_t *)malloc(n ? n : 1);
+  uint64_t r = 0;
+  /* run lengths grouped per symbol, in row order (runs_by_char, rlfmi.rs:47) */
+  uint64_t *run_len = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+  uint64_t *runs_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t c0 = 0;                                              /* rlfmi.rs:41 */
+  for (uint64_t i = 0; i < n; i++) {                            /* rlfmi.rs:48-68 */
+    uint32_t k = sa[i];
+    uint64_t c = k > 0 ? text[k - 1] : text[n - 1];
+    if (c0 != c) {
+      heads[r] = (uint8_t)c;
+      run_len[r] = 1;
+      r++;
+      bits_set(bw, i);
+      runs_of[c]++;
+    } else {
+      run_len[r - 1]++;
+    }
+    c0 = c;
+  }
+  f->runs = r;
+  orc_wm_build(&f->s, heads, r, orc_max_bits(max_character));  /* rlfmi.rs:69-70 */
+  f->cs = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t acc = 0;
+  for (uint64_t c = 0; c < m; c++) { f->cs[c] = acc; acc += runs_of[c]; } /* rlfmi.rs:72-76 */
+  /* B': for c ascending, for each run of c in row order: 1 0^{len-1} (rlfmi.rs:71-83) */
+  uint64_t *start_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  {
+    uint64_t *chars_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+    for (uint64_t k = 0; k < r; k++) chars_of[heads[k]] += run_len[k];
+    uint64_t a = 0;
+    for (uint64_t c = 0; c < m; c++) { start_of[c] = a; a += chars_of[c]; }
+    free(chars_of);
+  }
+  for (uint64_t k = 0; k < r; k++) {
+    uint64_t c = heads[k];
+    bits_set(bpw, start_of[c]);
+    start_of[c] += run_len[k];
+  }
+  orc_rsvec_build(&f->b, bw, n);                                /* rlfmi.rs:85 */
+  orc_rsvec_build(&f->bp, bpw, n);                              /* rlfmi.rs:86 */
+  if (level >= 0) {
+    orc_ssa_sample(&f->ssa, sa, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  free(start_of); free(runs_of); free(run_len); free(heads); free(sa);
+  *out = f;
+  return ORC_OK;
+}
+void orc_rlfm_free(orc_rlfm *f) {
+  if (!f) return;
+  orc_wm_free(&f->s);
+  orc_rsvec_free(&f->b);
+  orc_rsvec_free(&f->bp);
+  orc_ssa_free(&f->ssa);
+  free(f->cs);
+  free(f);
+}
+
+/* ------------------------------------------------------------------ */
+/* driver (wrapper.rs)                                                 */
+/* ------------------------------------------------------------------ */
+int orc_search(const orc_backend *b, const uint8_t *pat, uint64_t m, uint64_t *ps,
+               uint64_t *pe, uint64_t *steps) {
+  uint64_t s = *ps, e = *pe, k = 0;        /* wrapper.rs:105-106 */
+  for (uint64_t j = m; j-- > 0;) {         /* wrapper.rs:108: pattern.iter().rev() */
+    uint64_t c = pat[j];
+    if (c > b->max_character) return ORC_ERR_SYMBOL_RANGE;
+    s = b->lf_map2(b->self, c, s);         /* wrapper.rs:109 */
+    e = b->lf_map2(b->self, c, e);         /* wrapper.rs:110 */
+    k++;
+    if (s == e) break;                     /* wrapper.rs:111-113 */
+  }
+  *ps = s; *pe = e;
+  if (steps) *steps = k;
+  return ORC_OK;
+}
+void orc_locate_range(const orc_backend *b, uint64_t s, uint64_t e, uint64_t *out) {
+  /* wrapper.rs:203-217 (match_prefix_only == false) + wrapper.rs:238-242 */
+  for (uint64_t i = s; i < e; i++) out[i - s] = b->get_sa(b->self, i);
+}
+
+int orc_count_batch(const orc_backend *b, const uint8_t *pat, const uint64_t *off,
+                    uint64_t npat, const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e,
+                    uint64_t *out_steps, int nthreads) {
+  int err = 0;
+  uint64_t n = b->len(b->self);
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (int64_t k = 0; k < (int64_t)npat; k++) {
+    uint64_t s = s0e0 ? s0e0[2 * k] : 0, e = s0e0 ? s0e0[2 * k + 1] : n, st = 0; /* wrapper.rs:41 */
+    int rc = orc_search(b, pat + off[k], off[k + 1] - off[k], &s, &e, &st);
+    if (rc) {
+#pragma omp atomic write
+      err = rc;
+    }
+    out_s[k] = s; out_e[k] = e;
+    if (out_steps) out_steps[k] = st;
+  }
+  return err;
+}
+void orc_locate_batch(const orc_backend *b, const uint64_t *s, const uint64_t *e,
+                      uint64_t npat, const uint64_t *out_off, uint64_t *out_pos,
+                      int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+  for (int64_t k = 0; k < (int64_t)npat; k++)
+    if (e[k] > s[k]) orc_locate_range(b, s[k], e[k], out_pos + out_off[k]);
+}
+void orc_lf_map2_batch(const orc_backend *b, const uint64_t *c, const uint64_t *i,
+                       uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->lf_map2(b->self, c[j], i[j]);
+}
+void orc_lf_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->lf_map(b->self, i[j]);
+}
+void orc_get_l_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->get_l(b->self, i[j]);
+}
+void orc_get_sa_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->get_sa(b->self, i[j]);
+}
+
+/* tests/testutil/mod.rs:62-86 with match_prefix_only = match_suffix_only = false */
+uint64_t orc_naive_search(const uint8_t *text, uint64_t n, const uint8_t *pat, uint64_t m,
+                          uint64_t *out, uint64_t cap) {
+  uint64_t cnt = 0;
+  if (m > n) return 0;
+  for (uint64_t i = 0; i + m <= n; i++) {
+    if (memcmp(text + i, pat, m) == 0) {
+      if (cnt < cap) out[cnt] = i;
+      cnt++;
+    }
+  }
+  return cnt;
+}

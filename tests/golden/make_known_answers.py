@@ -1,0 +1,83 @@
+"""Writes tests/golden/reference_known_answers.json.
+
+These are the known answers the reference's OWN tests hold for the count/locate
+path, harvested by hand (inputs and expected outputs only -- data, no code).
+Each entry cites the reference file:line (relative to the reference repo root).
+Run once in the build container; the JSON is committed.
+"""
+import json
+import os
+
+Z = "\x00"  # the terminator character
+
+LOREM = (
+    "Lorem ipsum dolor sit amet, consectetur adipiscing elit, sed do eiusmod tempor incididunt ut labore et dolore magna aliqua."
+    "Ut enim ad minim veniam, quis nostrud exercitation ullamco laboris nisi ut aliquip ex ea commodo consequat."
+    "Duis aute irure dolor in reprehenderit in voluptate velit esse cillum dolore eu fugiat nulla pariatur."
+    "Excepteur sint occaecat cupidatat non proident, sunt in culpa qui officia deserunt mollit anim id est laborum."
+)
+
+G = {
+    "_comment": "Known answers harvested from the reference's own tests (inputs + expected outputs).",
+    "mississippi": {
+        "text": "mississippi" + Z,
+        "lf_chain_from_0": {"expected": [1, 6, 7, 2, 8, 10, 3, 9, 11, 4, 5, 0],
+                            "source": "src/fm_index.rs:149-160, src/rlfmi.rs:271-282"},
+        "lf_map2_ranges": {"expected": {Z: [0, 1], "i": [1, 5], "m": [5, 6], "p": [6, 8], "s": [8, 12]},
+                           "source": "src/rlfmi.rs:285-309"},
+        "search_ranges": {"expected": {"iss": [3, 5], "ppi": [7, 8], "si": [8, 10], "ssi": [10, 12]},
+                          "source": "src/rlfmi.rs:312-328"},
+        "bwt": {"expected": "ipssm" + Z + "pissii", "source": "src/rlfmi.rs:259-268"},
+        "rlfm_S": {"expected": "ipsm" + Z + "pisi", "source": "src/rlfmi.rs:197-206"},
+        "rlfm_B": {"expected": [1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 0], "source": "src/rlfmi.rs:209-231"},
+        "rlfm_Bp": {"expected": [1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 0], "source": "src/rlfmi.rs:234-248"},
+        "rlfm_cs": {"expected": {Z: 0, "i": 1, "m": 4, "p": 5, "s": 7}, "source": "src/rlfmi.rs:251-256"},
+        "fl_map": {"expected": [5, 0, 7, 10, 11, 4, 1, 6, 2, 3, 8, 9],
+                   "source": "src/fm_index.rs:163-173, src/rlfmi.rs:340-350 (next tier)"},
+    },
+    "readme": {
+        "text": LOREM + Z, "level": 2, "pattern": "dolor", "count": 4,
+        "positions_in_order": [246, 12, 300, 103],
+        "backward_16_from_first_match": "Duis aute irure ",
+        "forward_20_from_match_3": "dolore magna aliqua.",
+        "source": "README.md:35-85 (doctest via src/lib.rs:148-150)",
+    },
+    "small": {"text": "a" + Z, "level": 2, "pattern": "a", "count": 1, "positions": [0],
+              "source": "tests/test_fmindex.rs:5-24, tests/test_rlfmindex.rs:5-24"},
+    "sampling_grid": {
+        "cases": [[1, 10], [1, 25], [2, 8], [2, 9], [2, 10], [2, 25], [3, 24], [3, 25]],
+        "rule": "for sa=[0..n): get(i)==Some(i) iff i mod 2^level == 0",
+        "not_sampled": {"level": 4, "n": 10, "rule": "all Some(i)"},
+        "empty": "get(0) == None",
+        "source": "src/suffix_array/sample.rs:96-136",
+    },
+    "invalid_texts": {
+        "cases": [
+            {"text": "nozero", "message": "the given text must end with exactly one zero character"},
+            {"text": "toomanyzeros" + Z + Z,
+             "message": "the given text must end with exactly one zero character"},
+            {"text": Z + "starting_with_zero" + Z,
+             "message": "the given text must not start with zero character"},
+        ],
+        "source": "src/suffix_array/sais.rs:128-139, 400-425",
+    },
+    "suffix_array_inputs": {
+        "cases_str": ["mmiissiissiippii" + Z, "mm" + Z + "ii" + Z + "s" + Z + "sii" + Z + "ssii" + Z + "ppii" + Z],
+        "cases_u8": [[3, 2, 1, 0], [3, 0], [0]],
+        "rule": "equals naive suffix sort (src/suffix_array/sais.rs:546-557)",
+        "source": "src/suffix_array/sais.rs:427-466",
+    },
+    "len": {"text": "text" + Z, "expected": 5, "source": "tests/test_api.rs:13-67"},
+    "log2": {"cases": [[2, 1], [3, 1], [4, 2], [5, 2], [6, 2], [7, 2], [8, 3]], "source": "src/util.rs:9-18"},
+}
+
+if __name__ == "__main__":
+    ref = "/root/reference/README.md"
+    if os.path.exists(ref):  # data check against the reference's README text
+        readme = open(ref).read()
+        for sentence in LOREM.split("."):
+            assert sentence[:24] in readme, sentence[:24]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json")
+    with open(out, "w") as f:
+        json.dump(G, f, indent=1)
+    print("wrote", out, "lorem n =", len(LOREM) + 1)

@@ -1,0 +1,306 @@
+"""fm_index_amd -- host-side mirror of the reference's Search / Match /
+MatchWithLocate surface (reference: src/frontend.rs:26-98, 110-243) over the
+C ABI of libfmx.so (include/fmx.h).  Same names, argument meaning and error
+behaviour as the Rust crate for the count / locate path:
+
+    text  = Text(b"mississippi\\0")            # Text::new            (text.rs:28-33)
+    index = FMIndexWithLocate(text, 2)         # FMIndexWithLocate::new (frontend.rs:213-221)
+    s = index.search(b"ssi")                   # SearchIndex::search  (frontend.rs:30-34)
+    s.count()                                  # Search::count        (frontend.rs:80)
+    [m.locate() for m in s.iter_matches()]     # MatchWithLocate::locate (frontend.rs:96-98)
+    index.search(b"i").search(b"ss")           # refinement prepends  (wrapper.rs:99-124)
+
+plus the batched forms the GPU exists for (`search_many`, `locate_many`).
+Every query runs in HIP kernels; importing works without a GPU, calling does not.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+__all__ = ["Text", "Error", "FMIndex", "FMIndexWithLocate", "RLFMIndex", "RLFMIndexWithLocate",
+           "Search", "Match", "SearchBatch", "pack_patterns"]
+
+
+class Error(Exception):
+    """Error::InvalidText(msg) (src/error.rs:3-15); other ABI failures carry their code."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def _check(rc):
+    if rc != L.OK:
+        raise Error(rc, L.lib().fmx_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(x):
+    if isinstance(x, str):
+        x = x.encode("latin-1")
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def pack_patterns(patterns):
+    """list of byte strings -> (flat u8, offsets u64[npat+1])."""
+    pats = [_u8(p) for p in patterns]
+    off = np.zeros(len(pats) + 1, dtype=np.uint64)
+    if pats:
+        off[1:] = np.cumsum([len(p) for p in pats], dtype=np.uint64)
+    flat = np.concatenate(pats) if pats and int(off[-1]) else np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(flat, dtype=np.uint8), off
+
+
+class Text:
+    """Text (text.rs:11-64): the symbols INCLUDING the trailing 0, plus max_character."""
+
+    def __init__(self, text, max_character=255):  # Text::new: max_value of u8
+        self._t = _u8(text)
+        self._max = int(max_character)
+
+    @classmethod
+    def with_max_character(cls, text, max_character):  # text.rs:44-49
+        return cls(text, max_character)
+
+    def text(self):
+        return self._t
+
+    def max_character(self):
+        return self._max
+
+
+class _Index:
+    _kind = L.KIND_FM
+
+    def __init__(self, text, level=None, device=0, keep_sa=False):
+        if not isinstance(text, Text):
+            text = Text(text)
+        self._lib = L.lib()
+        self._h = C.c_void_p()
+        t = text.text()
+        lvl = L.NO_LOCATE if level is None else int(level)
+        rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), 1, text.max_character(),
+                                 self._kind, lvl, L.FLAG_KEEP_SA if keep_sa else 0, device,
+                                 C.byref(self._h))
+        _check(rc)
+
+    @classmethod
+    def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False):
+        """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
+        self = cls.__new__(cls)
+        self._lib = L.lib()
+        self._h = C.c_void_p()
+        lvl = L.NO_LOCATE if level is None else int(level)
+        _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, 1, max_character, cls._kind, lvl,
+                                       L.FLAG_KEEP_SA if keep_sa else 0, device,
+                                       C.byref(self._h)))
+        return self
+
+    # -- SearchIndex (frontend.rs:26-44) --
+    def search(self, pattern):
+        return Search(self, None, None).search(pattern)
+
+    def len(self):
+        return int(self._lib.fmx_len(self._h))
+
+    __len__ = len
+
+    def heap_size(self):
+        return int(self._lib.fmx_index_bytes(self._h))
+
+    # -- batched --
+    def search_many(self, patterns=None, flat=None, off=None, s0e0=None):
+        """count for a batch: returns SearchBatch (s, e, counts as numpy u64)."""
+        if flat is None:
+            flat, off = pack_patterns(patterns)
+        flat = _u8(flat)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        npat = len(off) - 1
+        s = np.zeros(max(npat, 1), dtype=np.uint64)
+        e = np.zeros(max(npat, 1), dtype=np.uint64)
+        c = np.zeros(max(npat, 1), dtype=np.uint64)
+        se = None if s0e0 is None else np.ascontiguousarray(s0e0, dtype=np.uint64)
+        _check(self._lib.fmx_count_batch(self._h, _p(flat), _p(off), npat, _p(se), _p(s), _p(e),
+                                         _p(c)))
+        return SearchBatch(self, s[:npat], e[:npat], c[:npat])
+
+    def locate_many(self, s, e):
+        """(offsets u64[npat+1], positions u64[total]) in the reference's iteration order."""
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        e = np.ascontiguousarray(e, dtype=np.uint64)
+        off = np.zeros(len(s) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(e - s, dtype=np.uint64)
+        pos = np.zeros(max(int(off[-1]), 1), dtype=np.uint64)
+        _check(self._lib.fmx_locate_batch(self._h, _p(s), _p(e), len(s), _p(off), _p(pos)))
+        return off, pos[:int(off[-1])]
+
+    # -- the backend trait, batched (backend.rs:9-15, 29-31) --
+    def _scalar(self, fn, *arrs):
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in arrs]
+        k = len(arrs[-1])
+        out = np.zeros(max(k, 1), dtype=np.uint64)
+        _check(fn(self._h, *[_p(a) for a in arrs], k, _p(out)))
+        return out[:k]
+
+    def get_l(self, i):
+        return self._scalar(self._lib.fmx_get_l_batch, i)
+
+    def lf_map(self, i):
+        return self._scalar(self._lib.fmx_lf_map_batch, i)
+
+    def lf_map2(self, c, i):
+        return self._scalar(self._lib.fmx_lf_map2_batch, c, i)
+
+    def get_sa(self, i):
+        return self._scalar(self._lib.fmx_get_sa_batch, i)
+
+    # -- export / checks --
+    def export_bwt(self):
+        out = np.zeros(max(self.len(), 1), dtype=np.uint8)
+        _check(self._lib.fmx_export_bwt(self._h, _p(out)))
+        return out[:self.len()]
+
+    def export_cs(self):
+        out = np.zeros(int(self._lib.fmx_max_character(self._h)) + 1, dtype=np.uint64)
+        _check(self._lib.fmx_export_cs(self._h, _p(out)))
+        return out
+
+    def export_sa_samples(self):
+        out = np.zeros(max(int(self._lib.fmx_num_samples(self._h)), 1), dtype=np.uint32)
+        _check(self._lib.fmx_export_sa_samples(self._h, _p(out)))
+        return out[:int(self._lib.fmx_num_samples(self._h))]
+
+    def export_sa(self):
+        out = np.zeros(max(self.len(), 1), dtype=np.uint32)
+        _check(self._lib.fmx_export_sa(self._h, _p(out)))
+        return out[:self.len()]
+
+    def verify_sa(self):
+        v = C.c_uint64(0)
+        _check(self._lib.fmx_verify_sa(self._h, C.byref(v)))
+        return int(v.value)
+
+    def level(self):
+        lv = int(self._lib.fmx_level(self._h))
+        return None if lv == L.NO_LOCATE else lv
+
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fmx_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FMIndex(_Index):
+    """FMIndex::new(&text) (frontend.rs:195-203) -- count only."""
+    _kind = L.KIND_FM
+
+    def __init__(self, text, device=0, keep_sa=False):
+        super().__init__(text, None, device, keep_sa)
+
+
+class FMIndexWithLocate(_Index):
+    """FMIndexWithLocate::new(&text, level) (frontend.rs:205-221)."""
+    _kind = L.KIND_FM
+
+    def __init__(self, text, level, device=0, keep_sa=False):
+        super().__init__(text, level, device, keep_sa)
+
+
+class RLFMIndex(_Index):
+    """RLFMIndex::new(&text) (frontend.rs:223-231)."""
+    _kind = L.KIND_RLFM
+
+    def __init__(self, text, device=0, keep_sa=False):
+        super().__init__(text, None, device, keep_sa)
+
+
+class RLFMIndexWithLocate(_Index):
+    """RLFMIndexWithLocate::new(&text, level) (frontend.rs:233-243)."""
+    _kind = L.KIND_RLFM
+
+    def __init__(self, text, level, device=0, keep_sa=False):
+        super().__init__(text, level, device, keep_sa)
+
+
+class Search:
+    """Search (frontend.rs:70-84): an SA interval [s, e) that can be refined."""
+
+    def __init__(self, index, s, e):
+        self._ix = index
+        self._s = s
+        self._e = e
+
+    def search(self, pattern):  # wrapper.rs:103-124: prepends `pattern`
+        flat, off = pack_patterns([pattern])
+        se = None if self._s is None else np.array([self._s, self._e], dtype=np.uint64)
+        b = self._ix.search_many(flat=flat, off=off, s0e0=se)
+        return Search(self._ix, int(b.s[0]), int(b.e[0]))
+
+    def count(self):  # wrapper.rs:132-134
+        return self._e - self._s
+
+    def get_range(self):  # wrapper.rs:126-129 (test-only in the reference)
+        return (self._s, self._e)
+
+    def iter_matches(self):  # wrapper.rs:137-139, 203-217: rows s..e-1 ascending
+        for i in range(self._s, self._e):
+            yield Match(self._ix, i)
+
+    def locate_all(self):
+        """iter_matches().map(|m| m.locate()).collect() in one kernel launch."""
+        _, pos = self._ix.locate_many([self._s], [self._e])
+        return [int(x) for x in pos]
+
+
+class Match:
+    """Match / MatchWithLocate (frontend.rs:86-98)."""
+
+    def __init__(self, index, i):
+        self._ix = index
+        self._i = i
+
+    def locate(self):  # wrapper.rs:238-242 -> get_sa
+        lib = self._ix._lib
+        v = int(lib.fmx_get_sa(self._ix._h, self._i))
+        if v == 0xFFFFFFFFFFFFFFFF:
+            raise Error(L.ERR_NO_LOCATE, lib.fmx_last_error().decode())
+        return v
+
+    def iter_chars_backward(self):  # wrapper.rs:154-161: get_l then lf_map
+        i = self._i
+        lib = self._ix._lib
+        while True:
+            yield int(lib.fmx_get_l(self._ix._h, i))
+            i = int(lib.fmx_lf_map(self._ix._h, i))
+
+
+class SearchBatch:
+    """Result of search_many: per-pattern (s, e, count) arrays (numpy u64)."""
+
+    def __init__(self, index, s, e, counts):
+        self._ix = index
+        self.s = s
+        self.e = e
+        self.counts = counts
+
+    def count(self):
+        return self.counts
+
+    def locate(self):
+        return self._ix.locate_many(self.s, self.e)

@@ -1,0 +1,372 @@
+// fmx_api.hip -- the C ABI declared in include/fmx.h: handle lifetime, error
+// reporting, host-pointer marshalling.  All compute is in fmx_build.hip /
+// fmx_query.hip; nothing here has a CPU fallback.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "fmx_internal.h"
+
+// ---------------------------------------------------------------------------
+// errors (error.rs:3-15: one variant, InvalidText(msg), Display "invalid text: {msg}")
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+const char *fmx_error_message(int code) {
+  switch (code) {
+    case FMX_OK: return "ok";
+    case FMX_ERR_TEXT_START_ZERO:  // sais.rs:129-131
+      return "invalid text: the given text must not start with zero character";
+    case FMX_ERR_TEXT_END_ZERO:    // sais.rs:135-137
+      return "invalid text: the given text must end with exactly one zero character";
+    case FMX_ERR_SYMBOL_RANGE: return "symbol exceeds max_character";
+    case FMX_ERR_ARG: return "invalid argument";
+    case FMX_ERR_UNSUPPORTED: return "unsupported";
+    case FMX_ERR_HIP: return "HIP error";
+    case FMX_ERR_NO_LOCATE: return "index was built without a sampled suffix array";
+    default: return "unknown error";
+  }
+}
+void fmx_set_error(int code, const char *detail) {
+  g_last_error = fmx_error_message(code);
+  if (detail) {
+    g_last_error += ": ";
+    g_last_error += detail;
+  }
+}
+int fmx_hip_fail(hipError_t e, const char *what, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s at line %d: %s", what, line, hipGetErrorString(e));
+  fmx_set_error(FMX_ERR_HIP, buf);
+  return FMX_ERR_HIP;
+}
+const char *fmx_last_error(void) { return g_last_error.c_str(); }
+
+static int fail(int code, const char *detail = nullptr) {
+  fmx_set_error(code, detail);
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------
+static int select_device(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(FMX_ERR_HIP, "no HIP device available (libfmx has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(FMX_ERR_ARG, "device ordinal out of range");
+  FMX_HIP(hipSetDevice(device));
+  return FMX_OK;
+}
+
+void fmx_free(fmx_index *idx) {
+  if (!idx) return;
+  (void)hipSetDevice(idx->device);
+  for (int i = 0; i < idx->nalloc; i++) (void)hipFree(idx->d_alloc[i]);
+  if (idx->dev.status) (void)hipFree(idx->dev.status);
+  if (idx->d_steps) (void)hipFree(idx->d_steps);
+  if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+  if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+  free(idx->h_cs);
+  free(idx);
+}
+
+static int build_common(const void *text, int text_on_device, uint64_t n, uint32_t sym_bytes,
+                        uint64_t max_character, uint32_t kind, uint32_t level, uint32_t flags,
+                        int device, fmx_index **out) {
+  if (!out) return fail(FMX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (sym_bytes != 1) return fail(FMX_ERR_UNSUPPORTED, "only sym_bytes == 1 (u8 text) is implemented");
+  if (max_character == 0 || max_character > 255) return fail(FMX_ERR_ARG, "max_character must be in 1..=255 for u8 text");
+  if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM) return fail(FMX_ERR_ARG, "unknown kind");
+  if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
+  if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
+  if (int rc = select_device(device)) return rc;
+
+  fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
+  idx->device = device;
+  idx->n = n;
+  idx->sym_bytes = sym_bytes;
+  idx->max_character = max_character;
+  idx->kind = kind;
+  idx->level_requested = level;
+  idx->flags = flags;
+
+  int rc = FMX_OK;
+  uint8_t *d_text = nullptr;
+  bool own_text = false;
+  do {
+    hipError_t e;
+    if ((e = hipMalloc((void **)&idx->dev.status, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&idx->d_steps, sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMemset(idx->dev.status, 0, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(idx->d_steps, 0, sizeof(uint64_t))) != hipSuccess ||
+        (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess) {
+      rc = fmx_hip_fail(e, "handle resources", __LINE__);
+      break;
+    }
+
+    if (text_on_device) {
+      d_text = (uint8_t *)text;
+    } else {
+      if ((e = hipMalloc((void **)&d_text, n ? n : 1)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      own_text = true;
+      if (n && (e = hipMemcpy(d_text, text, n, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
+    }
+    rc = fmx_build_impl(idx, d_text);
+  } while (0);
+  if (own_text && d_text) (void)hipFree(d_text);
+  if (rc != FMX_OK) {
+    fmx_free(idx);
+    return rc;
+  }
+  *out = idx;
+  return FMX_OK;
+}
+
+int fmx_build(const void *text, uint64_t n, uint32_t sym_bytes, uint64_t max_character,
+              uint32_t kind, uint32_t level, uint32_t flags, int device, fmx_index **out) {
+  return build_common(text, 0, n, sym_bytes, max_character, kind, level, flags, device, out);
+}
+int fmx_build_dev(const void *d_text, uint64_t n, uint32_t sym_bytes, uint64_t max_character,
+                  uint32_t kind, uint32_t level, uint32_t flags, int device, fmx_index **out) {
+  return build_common(d_text, 1, n, sym_bytes, max_character, kind, level, flags, device, out);
+}
+
+// ---------------------------------------------------------------------------
+// accessors
+// ---------------------------------------------------------------------------
+uint64_t fmx_len(const fmx_index *idx) { return idx ? idx->n : 0; }
+uint64_t fmx_index_bytes(const fmx_index *idx) { return idx ? idx->bytes : 0; }
+uint64_t fmx_max_character(const fmx_index *idx) { return idx ? idx->max_character : 0; }
+uint32_t fmx_kind(const fmx_index *idx) { return idx ? idx->kind : 0; }
+uint32_t fmx_level(const fmx_index *idx) { return idx ? idx->dev.sa_level : FMX_NO_LOCATE; }
+int fmx_device(const fmx_index *idx) { return idx ? idx->device : -1; }
+uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0; }
+uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
+double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
+
+void fmx_set_timing(fmx_index *idx, int enabled) {
+  if (idx) { idx->timing = enabled; idx->ev_valid = 0; }
+}
+double fmx_last_kernel_ms(const fmx_index *idx) {
+  if (!idx || !idx->ev_valid) return -1.0;
+  float ms = 0;
+  if (hipEventSynchronize(idx->ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, idx->ev0, idx->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+uint64_t fmx_last_steps(const fmx_index *idx) {
+  if (!idx || !idx->ev_valid) return 0;
+  (void)hipEventSynchronize(idx->ev1);
+  uint64_t v = 0;
+  if (hipMemcpy(&v, idx->d_steps, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return v;
+}
+
+static int status_to_code(uint32_t bits) {
+  if (bits & (1u << FMX_ERR_SYMBOL_RANGE)) return FMX_ERR_SYMBOL_RANGE;
+  if (bits & (1u << FMX_ERR_ARG)) return FMX_ERR_ARG;
+  return bits ? FMX_ERR_ARG : FMX_OK;
+}
+int fmx_stream_status(const fmx_index *idx) {
+  if (!idx) return FMX_ERR_ARG;
+  uint32_t bits = 0;
+  FMX_HIP(hipSetDevice(idx->device));
+  FMX_HIP(hipMemcpy(&bits, idx->dev.status, sizeof bits, hipMemcpyDeviceToHost));
+  if (bits) FMX_HIP(hipMemset(idx->dev.status, 0, sizeof bits));
+  int code = status_to_code(bits);
+  if (code) fmx_set_error(code, code == FMX_ERR_SYMBOL_RANGE ? "pattern symbol exceeds max_character" : "row index out of range");
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------
+#define CHECK_IDX(idx)                                   \
+  if (!(idx)) return fail(FMX_ERR_ARG, "index is NULL"); \
+  FMX_HIP(hipSetDevice((idx)->device))
+
+int fmx_count_batch_dev(const fmx_index *idx, const void *d_pat, const uint64_t *d_pat_off,
+                        uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_out_s,
+                        uint64_t *d_out_e, uint64_t *d_out_count, void *stream) {
+  CHECK_IDX(idx);
+  if (npat && (!d_pat_off)) return fail(FMX_ERR_ARG, "pat_off is NULL");
+  return fmx_launch_count(idx, (const uint8_t *)d_pat, d_pat_off, npat, d_s0e0, d_out_s, d_out_e,
+                          d_out_count, (hipStream_t)stream);
+}
+int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                    uint64_t *d_out_off, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_offsets(d_s, d_e, npat, d_out_off, (hipStream_t)stream);
+}
+int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                         uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,
+                         uint64_t *d_out_pos, void *stream) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  return fmx_launch_locate(idx, d_s, d_e, npat, d_out_off, total_hits, d_out_pos, (hipStream_t)stream);
+}
+int fmx_get_l_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_scalar(idx, 0, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
+int fmx_lf_map_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_scalar(idx, 1, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
+int fmx_lf_map2_batch_dev(const fmx_index *idx, const uint64_t *d_c, const uint64_t *d_i, uint64_t k,
+                          uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_scalar(idx, 2, d_c, d_i, k, d_out, (hipStream_t)stream);
+}
+int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  return fmx_launch_scalar(idx, 3, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points (copy in, same kernels, copy out, synchronise)
+// ---------------------------------------------------------------------------
+namespace {
+struct Scratch {  // device buffers freed on scope exit
+  void *p[12];
+  int n = 0;
+  ~Scratch() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
+  hipError_t get(void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e == hipSuccess) p[n++] = *out;
+    return e;
+  }
+};
+}  // namespace
+
+int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_off, uint64_t npat,
+                    const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count) {
+  CHECK_IDX(idx);
+  if (npat == 0) return FMX_OK;
+  if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
+  uint64_t total = pat_off[npat];
+  Scratch sc;
+  void *d_pat, *d_off, *d_se = nullptr, *d_s, *d_e, *d_c;
+  FMX_HIP(sc.get(&d_pat, total));
+  FMX_HIP(sc.get(&d_off, (npat + 1) * 8));
+  FMX_HIP(sc.get(&d_s, npat * 8));
+  FMX_HIP(sc.get(&d_e, npat * 8));
+  FMX_HIP(sc.get(&d_c, npat * 8));
+  if (total) FMX_HIP(hipMemcpy(d_pat, pat, total, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_off, pat_off, (npat + 1) * 8, hipMemcpyHostToDevice));
+  if (s0e0) {
+    FMX_HIP(sc.get(&d_se, npat * 16));
+    FMX_HIP(hipMemcpy(d_se, s0e0, npat * 16, hipMemcpyHostToDevice));
+  }
+  if (int rc = fmx_launch_count(idx, (const uint8_t *)d_pat, (const uint64_t *)d_off, npat,
+                                (const uint64_t *)d_se, (uint64_t *)d_s, (uint64_t *)d_e,
+                                (uint64_t *)d_c, 0))
+    return rc;
+  FMX_HIP(hipDeviceSynchronize());
+  if (out_s) FMX_HIP(hipMemcpy(out_s, d_s, npat * 8, hipMemcpyDeviceToHost));
+  if (out_e) FMX_HIP(hipMemcpy(out_e, d_e, npat * 8, hipMemcpyDeviceToHost));
+  if (out_count) FMX_HIP(hipMemcpy(out_count, d_c, npat * 8, hipMemcpyDeviceToHost));
+  return fmx_stream_status(idx);
+}
+
+int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                     const uint64_t *out_off, uint64_t *out_pos) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  if (npat == 0) return FMX_OK;
+  if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
+  uint64_t total = out_off[npat];
+  if (total == 0) return FMX_OK;
+  Scratch sc;
+  void *d_s, *d_e, *d_off, *d_pos;
+  FMX_HIP(sc.get(&d_s, npat * 8));
+  FMX_HIP(sc.get(&d_e, npat * 8));
+  FMX_HIP(sc.get(&d_off, (npat + 1) * 8));
+  FMX_HIP(sc.get(&d_pos, total * 8));
+  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_off, out_off, (npat + 1) * 8, hipMemcpyHostToDevice));
+  if (int rc = fmx_launch_locate(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat,
+                                 (const uint64_t *)d_off, total, (uint64_t *)d_pos, 0))
+    return rc;
+  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipMemcpy(out_pos, d_pos, total * 8, hipMemcpyDeviceToHost));
+  return fmx_stream_status(idx);
+}
+
+static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const uint64_t *i,
+                       uint64_t k, uint64_t *out) {
+  CHECK_IDX(idx);
+  if (op == 3 && idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  if (k == 0) return FMX_OK;
+  Scratch sc;
+  void *d_c = nullptr, *d_i, *d_o;
+  FMX_HIP(sc.get(&d_i, k * 8));
+  FMX_HIP(sc.get(&d_o, k * 8));
+  FMX_HIP(hipMemcpy(d_i, i, k * 8, hipMemcpyHostToDevice));
+  if (c) {
+    FMX_HIP(sc.get(&d_c, k * 8));
+    FMX_HIP(hipMemcpy(d_c, c, k * 8, hipMemcpyHostToDevice));
+  }
+  if (int rc = fmx_launch_scalar(idx, op, (const uint64_t *)d_c, (const uint64_t *)d_i, k,
+                                 (uint64_t *)d_o, 0))
+    return rc;
+  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipMemcpy(out, d_o, k * 8, hipMemcpyDeviceToHost));
+  return fmx_stream_status(idx);
+}
+int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 0, nullptr, i, k, out); }
+int fmx_lf_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 1, nullptr, i, k, out); }
+int fmx_lf_map2_batch(const fmx_index *idx, const uint64_t *c, const uint64_t *i, uint64_t k, uint64_t *out) {
+  if (!c) return fail(FMX_ERR_ARG, "c is NULL");
+  return scalar_host(idx, 2, c, i, k, out);
+}
+int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 3, nullptr, i, k, out); }
+
+// one trait method per call
+uint64_t fmx_get_l(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_l_batch(idx, &i, 1, &o) ? ~0ull : o; }
+uint64_t fmx_lf_map(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_lf_map_batch(idx, &i, 1, &o) ? ~0ull : o; }
+uint64_t fmx_lf_map2(const fmx_index *idx, uint64_t c, uint64_t i) { uint64_t o = ~0ull; return fmx_lf_map2_batch(idx, &c, &i, 1, &o) ? ~0ull : o; }
+uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_sa_batch(idx, &i, 1, &o) ? ~0ull : o; }
+
+// ---------------------------------------------------------------------------
+// export / verification
+// ---------------------------------------------------------------------------
+int fmx_export_bwt(const fmx_index *idx, void *host_out) {
+  CHECK_IDX(idx);
+  if (idx->kind != FMX_KIND_FM) return fail(FMX_ERR_UNSUPPORTED, "export_bwt: FM index only");
+  if (idx->n == 0) return FMX_OK;
+  Scratch sc;
+  void *d;
+  FMX_HIP(sc.get(&d, idx->n));
+  if (int rc = fmx_launch_export_l(idx, (uint8_t *)d, 0)) return rc;
+  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipMemcpy(host_out, d, idx->n, hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {
+  if (!idx || !idx->h_cs) return fail(FMX_ERR_ARG);
+  memcpy(host_out, idx->h_cs, (idx->max_character + 1) * sizeof(uint64_t));
+  return FMX_OK;
+}
+int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  FMX_HIP(hipMemcpy(host_out, idx->dev.samples, idx->nsamples * 4, hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+int fmx_export_sa(const fmx_index *idx, uint32_t *host_out) {
+  CHECK_IDX(idx);
+  if (!idx->d_sa) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
+  if (idx->n) FMX_HIP(hipMemcpy(host_out, idx->d_sa, idx->n * 4, hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+int fmx_verify_sa(const fmx_index *idx, uint64_t *violations) {
+  CHECK_IDX(idx);
+  if (!idx->d_sa || !idx->d_text) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
+  return fmx_verify_sa_impl(idx, violations);
+}

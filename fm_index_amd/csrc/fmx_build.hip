@@ -1,0 +1,548 @@
+// fmx_build.hip -- index construction, entirely on the GPU.
+//
+// Replaces FMIndexBackend::new (fm_index.rs:25-58) / RLFMIndexBackend::new
+// (rlfmi.rs:30-96) for the query path's inputs:
+//   text validation        sais.rs:115-139
+//   C array                sais.rs:9-32  (count_chars + get_bucket_start_pos)
+//   suffix array           sais.rs:115-144 (the reference uses SA-IS on the CPU; the array
+//                          is uniquely defined -- sais.rs:546-557 -- so it is built here
+//                          by GPU prefix doubling over rocPRIM radix sorts instead)
+//   BWT                    fm_index.rs:44-58
+//   SA samples             suffix_array/sample.rs:21-44
+//   rank structure         vers-vecs WaveletMatrix::from_slice -> 128-B multi-ary
+//                          wavelet-matrix records (fmx_internal.h)
+#include <hipcub/hipcub.hpp>
+#include <vector>
+#include <chrono>
+#include "fmx_device.h"
+
+#define BLK 256
+
+namespace {
+
+struct DevPool {  // temporaries freed when the builder returns
+  std::vector<void *> v;
+  ~DevPool() {
+    for (void *p : v) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t get(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    if (e == hipSuccess) v.push_back(p);
+    *out = (T *)p;
+    return e;
+  }
+  void release(void *p) {
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == p) {
+        (void)hipFree(p);
+        v.erase(v.begin() + i);
+        return;
+      }
+  }
+};
+
+inline unsigned nblocks(uint64_t n, unsigned per = BLK) {
+  uint64_t b = (n + per - 1) / per;
+  return (unsigned)(b ? b : 1);
+}
+
+// ---- text statistics: histogram, last non-zero index, (validation inputs) ------
+struct TextStats {
+  unsigned long long hist[256];
+  unsigned long long last_nonzero_plus1;  // 0 when every symbol is zero
+  unsigned long long max_sym;
+};
+__global__ __launch_bounds__(BLK) void k_text_stats(const uint8_t *__restrict__ t, uint64_t n,
+                                                     TextStats *st) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long last = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * BLK;
+  for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    uint32_t c = t[i];
+    atomicAdd(&h[c], 1u);
+    if (c) last = i + 1;
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+  if (last) atomicMax(&st->last_nonzero_plus1, last);
+}
+
+// ---- suffix sorting by prefix doubling -----------------------------------------
+// initial key: the first `k` symbols, `bits` bits each, zero-padded past the end
+__global__ __launch_bounds__(BLK) void k_init_keys(const uint8_t *__restrict__ t, uint32_t n,
+                                                    uint32_t bits, uint32_t k,
+                                                    uint64_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ idx) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    uint64_t p = i + j;
+    uint64_t c = p < n ? t[p] : 0;
+    key = (key << bits) | c;
+  }
+  keys[i] = key;
+  idx[i] = (uint32_t)i;
+}
+// head[p] = p if sorted position p starts a new key group, else 0; counts groups
+__global__ __launch_bounds__(BLK) void k_flag_heads(const uint64_t *__restrict__ keys, uint32_t n,
+                                                     uint32_t *__restrict__ head,
+                                                     unsigned long long *ngroups) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  bool is_head = false;
+  if (p < n) {
+    is_head = (p == 0) || (keys[p] != keys[p - 1]);
+    head[p] = is_head ? (uint32_t)p : 0u;
+  }
+  unsigned long long b = __ballot(is_head);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(ngroups, (unsigned long long)__popcll(b));
+}
+struct MaxOp {
+  __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const {
+    return a > b ? a : b;
+  }
+};
+__global__ __launch_bounds__(BLK) void k_scatter_rank(const uint32_t *__restrict__ sa,
+                                                       const uint32_t *__restrict__ head,
+                                                       uint32_t n, uint32_t *__restrict__ rank) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p < n) rank[sa[p]] = head[p];
+}
+// doubling key: (rank[i], rank[i+h]+1 or 0 when the suffix ends first)
+__global__ __launch_bounds__(BLK) void k_double_keys(const uint32_t *__restrict__ sa,
+                                                      const uint32_t *__restrict__ rank,
+                                                      uint32_t n, uint64_t h,
+                                                      uint64_t *__restrict__ keys) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  uint64_t i = sa[p];
+  uint64_t hi = rank[i];
+  uint64_t j = i + h;
+  uint64_t lo = j < n ? (uint64_t)rank[j] + 1ull : 0ull;
+  keys[p] = (hi << 32) | lo;
+}
+
+// ---- BWT + samples -------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_bwt(const uint8_t *__restrict__ t,
+                                              const uint32_t *__restrict__ sa, uint32_t n,
+                                              uint8_t *__restrict__ bwt) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  uint32_t k = sa[p];
+  bwt[p] = k > 0 ? t[k - 1] : (uint8_t)0;  // fm_index.rs:50-55
+}
+// RLFM: c_i = T[SA[i]-1], or T[n-1] when SA[i] == 0  (rlfmi.rs:48-53)
+__global__ __launch_bounds__(BLK) void k_bwt_cyclic(const uint8_t *__restrict__ t,
+                                                     const uint32_t *__restrict__ sa, uint32_t n,
+                                                     uint8_t *__restrict__ bwt) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  uint32_t k = sa[p];
+  bwt[p] = k > 0 ? t[k - 1] : t[n - 1];
+}
+__global__ __launch_bounds__(BLK) void k_samples(const uint32_t *__restrict__ sa, uint64_t nsamp,
+                                                  uint32_t level, uint32_t *__restrict__ out) {
+  uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j < nsamp) out[j] = sa[j << level];  // sample.rs:35-37
+}
+
+// ---- multi-ary wavelet matrix levels --------------------------------------------
+// one thread per 16-B piece; planes written now, counters after the scan
+template <int FMT>
+__global__ __launch_bounds__(BLK) void k_mwm_pieces(const uint8_t *__restrict__ cur, uint32_t n,
+                                                     uint32_t shift, uint32_t mask, uint32_t nrec,
+                                                     uint4 *__restrict__ rec,
+                                                     uint32_t *__restrict__ hist) {
+  constexpr int PER = (FMT == 3) ? 32 : 16;
+  constexpr int NCODE = (FMT == 3) ? 8 : 16;
+  uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;  // piece index
+  if (t >= (uint64_t)nrec * 8) return;                    // whole groups drop out together
+  const uint32_t g = (uint32_t)(t & 7);
+  const uint32_t r = (uint32_t)(t >> 3);
+  const uint64_t base = t * PER;
+  uint32_t pl[4] = {0, 0, 0, 0};
+  uint32_t valid = 0;
+  alignas(16) uint8_t sy[PER];
+  if (base + PER <= n) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(cur + base);  // base % 16 == 0
+    for (int q = 0; q < PER / 16; q++) *reinterpret_cast<uint4 *>(&sy[q * 16]) = src[q];
+  } else {
+    for (int j = 0; j < PER; j++) sy[j] = (base + j < n) ? cur[base + j] : (uint8_t)0;
+  }
+  for (int j = 0; j < PER; j++) {
+    uint64_t p = base + j;
+    if (p < n) {
+      uint32_t code = ((uint32_t)sy[j] >> shift) & mask;
+      valid |= 1u << j;
+      pl[0] |= (code & 1u) << j;
+      pl[1] |= ((code >> 1) & 1u) << j;
+      pl[2] |= ((code >> 2) & 1u) << j;
+      if (FMT == 4) pl[3] |= ((code >> 3) & 1u) << j;
+    }
+  }
+  uint4 piece;
+  piece.x = 0;
+  if (FMT == 3) {
+    piece.y = pl[0]; piece.z = pl[1]; piece.w = pl[2];
+  } else {
+    piece.y = 0;
+    piece.z = pl[0] | (pl[1] << 16);
+    piece.w = pl[2] | (pl[3] << 16);
+  }
+  rec[t] = piece;
+  // per-record histogram: lane g keeps the totals of the codes whose counters it owns
+  uint32_t own0 = 0, own1 = 0;
+  for (uint32_t code = 0; code < (uint32_t)NCODE; code++) {
+    uint32_t m = fmx_piece_match<FMT>(piece, code) & valid;
+    uint32_t tot = fmx_group_sum(__popc(m));
+    if (FMT == 3) {
+      if (g == code) own0 = tot;
+    } else {
+      if (g == (code >> 1)) { if (code & 1u) own1 = tot; else own0 = tot; }
+    }
+  }
+  if (FMT == 3) {
+    hist[(size_t)g * nrec + r] = own0;
+  } else {
+    hist[(size_t)(2 * g) * nrec + r] = own0;
+    hist[(size_t)(2 * g + 1) * nrec + r] = own1;
+  }
+}
+// scan = exclusive sum over hist laid out [code][record]; counter = scan - scan[code][0]
+template <int FMT>
+__global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict__ scan,
+                                                       uint32_t nrec, uint4 *__restrict__ rec,
+                                                       uint32_t *__restrict__ C) {
+  constexpr int NCODE = (FMT == 3) ? 8 : 16;
+  uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t < 16) C[t] = t < NCODE ? scan[(size_t)t * nrec] : 0u;
+  if (t >= (uint64_t)nrec * 8) return;
+  const uint32_t g = (uint32_t)(t & 7);
+  const uint32_t r = (uint32_t)(t >> 3);
+  uint4 p = rec[t];
+  if (FMT == 3) {
+    p.x = scan[(size_t)g * nrec + r] - scan[(size_t)g * nrec];
+  } else {
+    p.x = scan[(size_t)(2 * g) * nrec + r] - scan[(size_t)(2 * g) * nrec];
+    p.y = scan[(size_t)(2 * g + 1) * nrec + r] - scan[(size_t)(2 * g + 1) * nrec];
+  }
+  rec[t] = p;
+}
+
+// ---- verification (FMX_FLAG_KEEP_SA) ---------------------------------------------
+__global__ __launch_bounds__(BLK) void k_verify_sa(const uint8_t *__restrict__ t,
+                                                    const uint32_t *__restrict__ sa, uint32_t n,
+                                                    uint32_t *__restrict__ mark,
+                                                    unsigned long long *bad) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  uint32_t b = sa[p];
+  if (b >= n) { atomicAdd(bad, 1ull); return; }
+  atomicAdd(&mark[b], 1u);
+  if (p == 0) return;
+  uint32_t a = sa[p - 1];
+  if (a >= n) return;
+  // suffix a must be < suffix b (slice order: a suffix that ends first is smaller)
+  for (uint64_t j = 0;; j++) {
+    uint64_t pa = a + j, pb = b + j;
+    if (pa >= n) return;                     // a ended first: ok
+    if (pb >= n) { atomicAdd(bad, 1ull); return; }
+    uint8_t ca = t[pa], cb = t[pb];
+    if (ca < cb) return;
+    if (ca > cb) { atomicAdd(bad, 1ull); return; }
+  }
+}
+__global__ __launch_bounds__(BLK) void k_count_not_one(const uint32_t *mark, uint32_t n,
+                                                        unsigned long long *bad) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p < n && mark[p] != 1u) atomicAdd(bad, 1ull);
+}
+
+// ---- helpers ---------------------------------------------------------------------
+int keep(fmx_index *idx, void *p, uint64_t bytes) {
+  if (idx->nalloc >= 64) return FMX_ERR_ARG;
+  idx->d_alloc[idx->nalloc++] = p;
+  idx->bytes += bytes;
+  return FMX_OK;
+}
+
+// level split: fewest levels (<= 4 bits each), widths as even as possible, wide ones first
+// L=3 -> [3]; 5 -> [3,2]; 7 -> [4,3]; 8 -> [4,4]; 9 -> [3,3,3]
+void split_levels(uint32_t L, uint32_t *nlv, uint32_t *bits) {
+  uint32_t k = (L + 3) / 4;
+  if (k == 0) k = 1;
+  uint32_t base = L / k, extra = L % k;
+  for (uint32_t l = 0; l < k; l++) bits[l] = base + (l < extra ? 1u : 0u);
+  *nlv = k;
+}
+
+// suffix array of d_text[0..n) into d_sa (u32) -- prefix doubling
+int suffix_sort(const uint8_t *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, DevPool &pool) {
+  uint64_t *keys_a, *keys_b;
+  uint32_t *vals_b, *rank, *head;
+  unsigned long long *d_ng;
+  FMX_HIP(pool.get(&keys_a, n));
+  FMX_HIP(pool.get(&keys_b, n));
+  FMX_HIP(pool.get(&vals_b, n));
+  FMX_HIP(pool.get(&rank, n));
+  FMX_HIP(pool.get(&head, n));
+  FMX_HIP(pool.get(&d_ng, 1));
+  uint32_t k = 64 / sym_bits;
+  if (k > 32) k = 32;
+  // temp storage: the larger of the sort and scan requirements
+  size_t tmp_sort = 0, tmp_scan = 0;
+  {
+    hipcub::DoubleBuffer<uint64_t> kb(keys_a, keys_b);
+    hipcub::DoubleBuffer<uint32_t> vb(d_sa, vals_b);
+    FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, kb, vb, (size_t)n, 0, 64,
+                                               (hipStream_t)0));
+    FMX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, head, head, MaxOp(), (size_t)n,
+                                              (hipStream_t)0));
+  }
+  size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tmp_bytes));
+
+  hipLaunchKernelGGL(k_init_keys, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
+                     d_sa);
+  uint64_t *keys_cur = keys_a, *keys_alt = keys_b;
+  uint32_t *sa_cur = d_sa, *sa_alt = vals_b;
+  int end_bit = (int)(k * sym_bits);
+  uint64_t h = k;
+  for (int round = 0;; round++) {
+    hipcub::DoubleBuffer<uint64_t> kb(keys_cur, keys_alt);
+    hipcub::DoubleBuffer<uint32_t> vb(sa_cur, sa_alt);
+    size_t tb = tmp_bytes;
+    FMX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, kb, vb, (size_t)n, 0, end_bit,
+                                               (hipStream_t)0));
+    keys_cur = kb.Current(); keys_alt = kb.Alternate();
+    sa_cur = vb.Current();   sa_alt = vb.Alternate();
+    FMX_HIP(hipMemsetAsync(d_ng, 0, sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(k_flag_heads, dim3(nblocks(n)), dim3(BLK), 0, 0, keys_cur, n, head, d_ng);
+    unsigned long long ng = 0;
+    FMX_HIP(hipMemcpy(&ng, d_ng, sizeof ng, hipMemcpyDeviceToHost));
+    if (ng == n) break;
+    if (h >= n) {  // cannot happen for distinct suffixes; guard against an endless loop
+      fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
+      return FMX_ERR_HIP;
+    }
+    tb = tmp_bytes;
+    FMX_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, head, MaxOp(), (size_t)n,
+                                              (hipStream_t)0));
+    hipLaunchKernelGGL(k_scatter_rank, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, head, n, rank);
+    hipLaunchKernelGGL(k_double_keys, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, rank, n, h,
+                       keys_cur);
+    end_bit = 64;
+    h *= 2;
+  }
+  if (sa_cur != d_sa)
+    FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, 0));
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(keys_a); pool.release(keys_b); pool.release(vals_b);
+  pool.release(rank); pool.release(head); pool.release(tmp); pool.release(d_ng);
+  return FMX_OK;
+}
+
+// builds the multi-ary wavelet matrix over d_seq[0..len) (u8 symbols of `L` bits).
+// d_seq is consumed (sorted in place between levels).
+int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t L, DevPool &pool) {
+  uint32_t nlv, bits[FMX_MAX_LEVELS];
+  split_levels(L, &nlv, bits);
+  memset(w, 0, sizeof *w);
+  w->nlevels = nlv;
+  w->bits = L;
+  w->len = len;
+  uint8_t *cur = d_seq, *alt = nullptr;
+  if (nlv > 1) FMX_HIP(pool.get(&alt, len));
+  uint32_t shift = L;
+  for (uint32_t l = 0; l < nlv; l++) {
+    shift -= bits[l];
+    FmxLevel &lv = w->lv[l];
+    lv.fmt = bits[l] == 4 ? 4 : 3;
+    lv.shift = shift;
+    lv.mask = (1u << bits[l]) - 1u;
+    uint32_t per_rec = lv.fmt == 3 ? 256u : 128u;
+    lv.nrec = len / per_rec + 1;  // +1: position `len` itself must be addressable
+    uint32_t ncode = lv.fmt == 3 ? 8u : 16u;
+    uint4 *rec;
+    uint32_t *C, *hist, *scan;
+    FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
+    if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
+    FMX_HIP(hipMalloc((void **)&C, 16 * sizeof(uint32_t)));
+    if (int rc = keep(idx, C, 64)) return rc;
+    size_t nh = (size_t)ncode * lv.nrec;
+    FMX_HIP(pool.get(&hist, nh));
+    FMX_HIP(pool.get(&scan, nh));
+    unsigned grid = nblocks((uint64_t)lv.nrec * 8);
+    if (lv.fmt == 3)
+      hipLaunchKernelGGL(k_mwm_pieces<3>, dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
+                         lv.nrec, rec, hist);
+    else
+      hipLaunchKernelGGL(k_mwm_pieces<4>, dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
+                         lv.nrec, rec, hist);
+    size_t tb = 0;
+    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, scan, nh, (hipStream_t)0));
+    uint8_t *tmp;
+    FMX_HIP(pool.get(&tmp, tb));
+    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, scan, nh, (hipStream_t)0));
+    if (lv.fmt == 3)
+      hipLaunchKernelGGL(k_mwm_counters<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C);
+    else
+      hipLaunchKernelGGL(k_mwm_counters<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C);
+    FMX_HIP(hipGetLastError());
+    lv.rec = rec;
+    lv.C = C;
+    if (l + 1 < nlv) {
+      // stable sort of the whole sequence by this level's code -> order of the next level
+      size_t sb = 0;
+      FMX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, sb, cur, alt, (size_t)len, (int)lv.shift,
+                                                (int)(lv.shift + bits[l]), (hipStream_t)0));
+      uint8_t *stmp;
+      FMX_HIP(pool.get(&stmp, sb));
+      FMX_HIP(hipcub::DeviceRadixSort::SortKeys(stmp, sb, cur, alt, (size_t)len, (int)lv.shift,
+                                                (int)(lv.shift + bits[l]), (hipStream_t)0));
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(stmp);
+      uint8_t *x = cur; cur = alt; alt = x;
+    }
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(hist); pool.release(scan); pool.release(tmp);
+  }
+  return FMX_OK;
+}
+
+}  // namespace
+
+int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
+  uint32_t n = (uint32_t)idx->n;
+  *violations = 0;
+  if (n == 0) return FMX_OK;
+  uint32_t *mark;
+  unsigned long long *bad;
+  FMX_HIP(hipMalloc((void **)&mark, (size_t)n * 4));
+  FMX_HIP(hipMalloc((void **)&bad, 8));
+  FMX_HIP(hipMemset(mark, 0, (size_t)n * 4));
+  FMX_HIP(hipMemset(bad, 0, 8));
+  hipLaunchKernelGGL(k_verify_sa, dim3(nblocks(n)), dim3(BLK), 0, 0, idx->d_text, idx->d_sa, n, mark,
+                     bad);
+  hipLaunchKernelGGL(k_count_not_one, dim3(nblocks(n)), dim3(BLK), 0, 0, mark, n, bad);
+  unsigned long long hb = 0;
+  FMX_HIP(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(mark);
+  (void)hipFree(bad);
+  *violations = hb;
+  return FMX_OK;
+}
+
+int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
+  auto t0 = std::chrono::steady_clock::now();
+  DevPool pool;
+  const uint32_t n = (uint32_t)idx->n;
+  const uint32_t maxc = (uint32_t)idx->max_character;
+  const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);  // text.rs:61-63
+
+  // -- statistics + validation (sais.rs:115-139) --
+  TextStats *d_st;
+  FMX_HIP(pool.get(&d_st, 1));
+  FMX_HIP(hipMemset(d_st, 0, sizeof(TextStats)));
+  if (n) {
+    unsigned grid = nblocks(n, BLK * 16);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_text_stats, dim3(grid), dim3(BLK), 0, 0, d_text, (uint64_t)n, d_st);
+  }
+  TextStats st;
+  FMX_HIP(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
+  for (uint32_t c = maxc + 1; c < 256; c++)
+    if (st.hist[c]) {  // count_chars would index out of bounds (sais.rs:18)
+      fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
+      return FMX_ERR_SYMBOL_RANGE;
+    }
+  if (n >= 2) {  // lengths 0 and 1 bypass validation (sais.rs:121-126)
+    uint8_t first = 0;
+    FMX_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
+    if (first == 0) {
+      fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
+      return FMX_ERR_TEXT_START_ZERO;
+    }
+    if (st.last_nonzero_plus1 != (unsigned long long)n - 1) {  // rposition == n-2
+      fmx_set_error(FMX_ERR_TEXT_END_ZERO, nullptr);
+      return FMX_ERR_TEXT_END_ZERO;
+    }
+  }
+  // -- C array (sais.rs:9-32) --
+  idx->h_cs = (uint64_t *)calloc(maxc + 1, sizeof(uint64_t));
+  {
+    uint64_t sum = 0;
+    for (uint32_t c = 0; c <= maxc; c++) { idx->h_cs[c] = sum; sum += st.hist[c]; }
+  }
+
+  // -- suffix array --
+  uint32_t *d_sa;
+  FMX_HIP(pool.get(&d_sa, n));
+  if (n) {
+    if (int rc = suffix_sort(d_text, n, L, d_sa, pool)) return rc;
+  }
+
+  // -- SA samples (sample.rs:21-44) --
+  FmxDev &dv = idx->dev;
+  dv.n = n;
+  dv.max_character = maxc;
+  dv.kind = idx->kind;
+  dv.sa_level = FMX_NO_LOCATE;
+  if (idx->level_requested != FMX_NO_LOCATE && n > 0) {
+    uint32_t level = idx->level_requested;
+    if (level >= 32 || (uint64_t)n <= (1ull << level)) level = 0;  // sample.rs:28-31
+    uint64_t nsamp = (((uint64_t)n - 1) >> level) + 1;             // sample.rs:33
+    uint32_t *d_samp;
+    FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint32_t)));
+    if (int rc = keep(idx, d_samp, nsamp * 4)) return rc;
+    hipLaunchKernelGGL(k_samples, dim3(nblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    dv.samples = d_samp;
+    dv.sa_level = level;
+    idx->nsamples = nsamp;
+  }
+
+  // -- BWT (fm_index.rs:44-58) --
+  uint8_t *d_bwt;
+  FMX_HIP(pool.get(&d_bwt, n));
+  if (n) hipLaunchKernelGGL(k_bwt, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+  FMX_HIP(hipGetLastError());
+
+  if (idx->kind == FMX_KIND_FM) {
+    FMX_HIP(hipDeviceSynchronize());
+    if (int rc = build_mwm(idx, &dv.bw, d_bwt, n, L, pool)) return rc;
+    // K[c] = cs[c] - S_c
+    uint64_t *d_cs;
+    uint32_t *d_K;
+    FMX_HIP(pool.get(&d_cs, maxc + 1));
+    FMX_HIP(hipMemcpy(d_cs, idx->h_cs, (maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMalloc((void **)&d_K, (maxc + 1) * sizeof(uint32_t)));
+    if (int rc = keep(idx, d_K, (maxc + 1) * 4)) return rc;
+    if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
+    dv.K = d_K;
+  } else {
+    fmx_set_error(FMX_ERR_UNSUPPORTED, "RLFM index is not implemented yet");
+    return FMX_ERR_UNSUPPORTED;
+  }
+
+  if (idx->flags & FMX_FLAG_KEEP_SA) {
+    uint8_t *kt;
+    FMX_HIP(hipMalloc((void **)&kt, n ? n : 1));
+    if (n) FMX_HIP(hipMemcpy(kt, d_text, n, hipMemcpyDeviceToDevice));
+    if (int rc = keep(idx, kt, n)) return rc;
+    idx->d_text = kt;
+    // hand the SA over to the index instead of freeing it
+    for (size_t i = 0; i < pool.v.size(); i++)
+      if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
+    if (int rc = keep(idx, d_sa, (uint64_t)n * 4)) return rc;
+    idx->d_sa = d_sa;
+  }
+  FMX_HIP(hipDeviceSynchronize());
+  idx->build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return FMX_OK;
+}

@@ -1,0 +1,163 @@
+// fmx_device.h -- gfx950 device functions: 8-lane-group cooperative rank / access
+// on the 128-byte records described in fmx_internal.h.
+//
+// Execution shape: a 64-lane wavefront is 8 groups of 8 lanes.  One group owns one
+// query endpoint; lane g of the group loads piece g (16 B) of the record, so one
+// global_load_dwordx4 wave-instruction fetches 8 whole, distinct 128-B lines.  The
+// per-piece popcounts are summed with three DPP adds inside the group (quad_perm,
+// quad_perm, row_half_mirror) -- no LDS traffic, no bpermute.
+#pragma once
+#include "fmx_internal.h"
+
+#define FMX_GROUP 8
+
+__device__ __forceinline__ uint32_t fmx_dpp_xor1(uint32_t v) {  // quad_perm [1,0,3,2]
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t fmx_dpp_xor2(uint32_t v) {  // quad_perm [2,3,0,1]
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t fmx_dpp_half_mirror(uint32_t v) {  // lane i <- 7-i (per 8)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+}
+// sum over the 8 lanes of a group; every lane receives the total
+__device__ __forceinline__ uint32_t fmx_group_sum(uint32_t v) {
+  v += fmx_dpp_xor1(v);
+  v += fmx_dpp_xor2(v);
+  v += fmx_dpp_half_mirror(v);
+  return v;
+}
+
+// ---- per-piece helpers -------------------------------------------------------
+// bitmask (over the piece's entries) of entries whose level code == code
+template <int FMT>
+__device__ __forceinline__ uint32_t fmx_piece_match(const uint4 &p, uint32_t code) {
+  if (FMT == 3) {
+    uint32_t a = p.y ^ ((code & 1u) - 1u);
+    uint32_t b = p.z ^ (((code >> 1) & 1u) - 1u);
+    uint32_t c = p.w ^ (((code >> 2) & 1u) - 1u);
+    return a & b & c;
+  } else {
+    uint32_t a = p.z ^ ((code & 1u) - 1u);
+    uint32_t b = (p.z ^ (((code >> 1) & 1u) - 1u)) >> 16;
+    uint32_t c = p.w ^ (((code >> 2) & 1u) - 1u);
+    uint32_t d = (p.w ^ (((code >> 3) & 1u) - 1u)) >> 16;
+    return a & b & c & d & 0xFFFFu;
+  }
+}
+// code stored at entry `bit` of this piece
+template <int FMT>
+__device__ __forceinline__ uint32_t fmx_piece_code(const uint4 &p, uint32_t bit) {
+  if (FMT == 3) {
+    return ((p.y >> bit) & 1u) | (((p.z >> bit) & 1u) << 1) | (((p.w >> bit) & 1u) << 2);
+  } else {
+    return ((p.z >> bit) & 1u) | (((p.z >> (16 + bit)) & 1u) << 1) | (((p.w >> bit) & 1u) << 2) |
+           (((p.w >> (16 + bit)) & 1u) << 3);
+  }
+}
+// this lane's contribution to rank_code(pos): masked popcount + the record counter
+template <int FMT>
+__device__ __forceinline__ uint32_t fmx_piece_rank(const uint4 &p, uint32_t off, uint32_t code,
+                                                   uint32_t g) {
+  constexpr int PER = (FMT == 3) ? 32 : 16;
+  int nb = (int)off - (int)(g * PER);
+  nb = nb < 0 ? 0 : (nb > PER ? PER : nb);
+  uint32_t mask = (uint32_t)((1ull << nb) - 1ull);
+  uint32_t v = __popc(fmx_piece_match<FMT>(p, code) & mask);
+  if (FMT == 3) {
+    v += (g == code) ? p.x : 0u;
+  } else {
+    v += (g == (code >> 1)) ? ((code & 1u) ? p.y : p.x) : 0u;
+  }
+  return v;
+}
+
+template <int FMT>
+__device__ __forceinline__ uint4 fmx_load_piece(const FmxLevel &L, uint32_t pos, uint32_t g) {
+  constexpr int SH = (FMT == 3) ? 8 : 7;
+  return L.rec[(size_t)(pos >> SH) * 8u + g];
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t fmx_off(uint32_t pos) {
+  return (FMT == 3) ? (pos & 255u) : (pos & 127u);
+}
+
+// rank of `code` among the first `pos` entries of level L  (all 8 lanes get it)
+__device__ __forceinline__ uint32_t fmx_level_rank(const FmxLevel &L, uint32_t pos, uint32_t code,
+                                                   uint32_t g) {
+  if (L.fmt == 3) {
+    uint4 p = fmx_load_piece<3>(L, pos, g);
+    return fmx_group_sum(fmx_piece_rank<3>(p, fmx_off<3>(pos), code, g));
+  } else {
+    uint4 p = fmx_load_piece<4>(L, pos, g);
+    return fmx_group_sum(fmx_piece_rank<4>(p, fmx_off<4>(pos), code, g));
+  }
+}
+
+// rank_c(i) over the whole multi-ary wavelet matrix, minus the symbol-only start
+// chain (folded into K[c]): the value r with lf_map2(c,i) = K[c] + r  (fm_index.rs:93-95)
+__device__ __forceinline__ uint32_t fmx_mwm_rank(const FmxMwm &w, uint32_t c, uint32_t pos,
+                                                 uint32_t g) {
+  uint32_t r = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    uint32_t code = (c >> L.shift) & L.mask;
+    r = fmx_level_rank(L, pos, code, g);
+    if (l + 1 < w.nlevels) pos = L.C[code] + r;
+  }
+  return r;
+}
+
+// both endpoints of one backward-search step, loads issued together
+__device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint32_t ps,
+                                              uint32_t pe, uint32_t g, uint32_t &rs,
+                                              uint32_t &re) {
+  rs = 0;
+  re = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    uint32_t code = (c >> L.shift) & L.mask;
+    if (L.fmt == 3) {
+      uint4 a = fmx_load_piece<3>(L, ps, g);
+      uint4 b = fmx_load_piece<3>(L, pe, g);
+      rs = fmx_group_sum(fmx_piece_rank<3>(a, fmx_off<3>(ps), code, g));
+      re = fmx_group_sum(fmx_piece_rank<3>(b, fmx_off<3>(pe), code, g));
+    } else {
+      uint4 a = fmx_load_piece<4>(L, ps, g);
+      uint4 b = fmx_load_piece<4>(L, pe, g);
+      rs = fmx_group_sum(fmx_piece_rank<4>(a, fmx_off<4>(ps), code, g));
+      re = fmx_group_sum(fmx_piece_rank<4>(b, fmx_off<4>(pe), code, g));
+    }
+    if (l + 1 < w.nlevels) {
+      uint32_t base = L.C[code];
+      ps = base + rs;
+      pe = base + re;
+    }
+  }
+}
+
+// access + rank along the same positions (fm_index.rs:82-91: get_l then rank of that
+// symbol): returns r with lf_map(i) = K[sym] + r and the symbol itself.
+__device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, uint32_t g,
+                                               uint32_t &sym) {
+  uint32_t r = 0;
+  sym = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    uint32_t code;
+    if (L.fmt == 3) {
+      uint4 p = fmx_load_piece<3>(L, pos, g);
+      uint32_t off = fmx_off<3>(pos);
+      code = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
+      r = fmx_group_sum(fmx_piece_rank<3>(p, off, code, g));
+    } else {
+      uint4 p = fmx_load_piece<4>(L, pos, g);
+      uint32_t off = fmx_off<4>(pos);
+      code = fmx_group_sum((g == (off >> 4)) ? fmx_piece_code<4>(p, off & 15u) : 0u);
+      r = fmx_group_sum(fmx_piece_rank<4>(p, off, code, g));
+    }
+    sym |= code << L.shift;
+    if (l + 1 < w.nlevels) pos = L.C[code] + r;
+  }
+  return r;
+}

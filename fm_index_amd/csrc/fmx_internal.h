@@ -1,0 +1,122 @@
+// fmx_internal.h -- structures shared by the builder, the query kernels and the C ABI.
+//
+// HBM layout (see DESIGN.md "Data layout"):
+//   The BWT (fm_index.rs:44-58) is stored as a *multi-ary wavelet matrix*: the
+//   L = max_bits symbol bits (text.rs:61-63) are split MSB-first into levels of 3 or
+//   4 bits.  Every level is an array of 128-byte records; one record holds the bit
+//   planes of 256 (3-bit level) or 128 (4-bit level) consecutive entries TOGETHER
+//   with the per-code rank counters for the record start -- "level-interleaved"
+//   planes + counters in one cache line, so one aligned 128-B load answers one rank.
+//   A record is 8 pieces of 16 B; an 8-lane group loads one record with a single
+//   dwordx4 per lane and every lane's piece is self-contained:
+//     fmt 3:  piece g = { cnt[g], plane0, plane1, plane2 }   of entries [32g, 32g+32)
+//     fmt 4:  piece g = { cnt[2g], cnt[2g+1], plane0|plane1<<16, plane2|plane3<<16 }
+//                                                           of entries [16g, 16g+16)
+//   Between levels the whole sequence is stably sorted by the level's code (the
+//   wavelet-matrix trick generalised to 8-/16-ary), so position p maps to
+//   C[code] + rank_code(p) on the next level.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "fmx.h"
+
+#define FMX_MAX_LEVELS 8
+
+struct FmxLevel {
+  const uint4 *rec;   // nrec records x 8 pieces
+  const uint32_t *C;  // 16 entries: #entries of this level with a smaller code
+  uint32_t fmt;       // 3 or 4
+  uint32_t shift;     // code = (sym >> shift) & mask
+  uint32_t mask;
+  uint32_t nrec;
+};
+
+struct FmxMwm {
+  FmxLevel lv[FMX_MAX_LEVELS];
+  uint32_t nlevels;
+  uint32_t bits;
+  uint32_t len;  // entries
+  uint32_t pad;
+};
+
+// bit vector with rank/select support in 128-B records (RLFM: B and B', rlfmi.rs:19-20):
+//   piece g = { ones before this PIECE (absolute), 96 payload bits }  -> 768 bits / record
+struct FmxBits {
+  const uint4 *rec;
+  const uint32_t *sel;  // select hints: record index holding the (k*FMX_SEL_STEP)-th one
+  uint32_t nrec;
+  uint32_t len;
+  uint32_t ones;
+  uint32_t nsel;
+};
+#define FMX_SEL_STEP 512u
+#define FMX_BITS_PER_REC 768u
+#define FMX_BITS_PER_PIECE 96u
+
+struct FmxDev {  // passed BY VALUE to every query kernel
+  FmxMwm bw;            // FM: BWT.  RLFM: run heads S (rlfmi.rs:17)
+  const uint32_t *K;    // K[c] = cs[c] - S_c (wrapping u32), c in 0..=max_character
+  const uint32_t *samples;  // SOSampledSuffixArray payload as plain u32 (sample.rs:21-44)
+  uint32_t *status;     // sticky device-side error bits
+  uint32_t n;           // len incl. terminator
+  uint32_t max_character;
+  uint32_t sa_level;    // effective level; FMX_NO_LOCATE when absent
+  uint32_t kind;
+  FmxBits b, bp;        // RLFM only
+  const uint32_t *cs;   // RLFM only: run-based C array (rlfmi.rs:72-76)
+};
+
+struct fmx_index {
+  FmxDev dev;
+  int device;
+  uint64_t n;
+  uint32_t sym_bytes;
+  uint64_t max_character;
+  uint32_t kind;
+  uint32_t level_requested;
+  uint32_t flags;
+  uint64_t bytes;        // HBM bytes held
+  uint64_t nsamples;
+  uint64_t runs;
+  double build_ms;
+  // owned device allocations
+  void *d_alloc[64];
+  int nalloc;
+  uint64_t *h_cs;        // character-based C array (sais.rs:9-32), host copy
+  uint8_t *d_text;       // FMX_FLAG_KEEP_SA
+  uint32_t *d_sa;        // FMX_FLAG_KEEP_SA
+  // instrumentation
+  int timing;
+  hipEvent_t ev0, ev1;
+  int ev_valid;
+  uint64_t *d_steps;     // device counter
+};
+
+// ---- internal entry points --------------------------------------------------
+void fmx_set_error(int code, const char *detail);
+int fmx_hip_fail(hipError_t e, const char *what, int line);
+#define FMX_HIP(x)                                        \
+  do {                                                    \
+    hipError_t _e = (x);                                  \
+    if (_e != hipSuccess) return fmx_hip_fail(_e, #x, __LINE__); \
+  } while (0)
+
+int fmx_build_impl(fmx_index *idx, const uint8_t *d_text);
+
+int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t *d_off,
+                     uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
+                     uint64_t *d_cnt, hipStream_t st);
+int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                      uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
+                      hipStream_t st);
+int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
+                       hipStream_t st);
+// op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa
+int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
+                      uint64_t k, uint64_t *d_out, hipStream_t st);
+// K[c] for every symbol, from the finished wavelet levels (used by the builder)
+int fmx_launch_export_l(const fmx_index *idx, uint8_t *d_out, hipStream_t st);
+int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations);
+int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,
+                         uint32_t max_character, hipStream_t st);

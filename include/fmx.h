@@ -1,0 +1,165 @@
+/*
+ * fmx.h -- C ABI of libfmx: MI355X-native batched FM-index backward search
+ * (count) and sampled-suffix-array locate.
+ *
+ * This is the drop-in boundary for ONE hot path of the Rust crate
+ * ajalab/fm-index v0.3.1: Search::search -> lf_map2 loop and the locate walk.
+ * The reference has no FFI of its own; the seam is the crate-private trait pair
+ * `SearchIndexBackend` + `HasPosition` (src/backend.rs:5-31) consumed by the
+ * generic driver in src/wrapper.rs.  Every entry point below names the
+ * reference item it replaces (paths relative to the reference repo root).
+ * INTEGRATION.md shows the Rust `extern "C"` block + `impl SearchIndexBackend`
+ * shim a maintainer would add.
+ *
+ * Conventions
+ *  - rows / positions / counts are uint64_t (= Rust usize); the engine keeps
+ *    uint32_t internally and rejects texts with n >= 2^32 (FMX_ERR_UNSUPPORTED).
+ *  - symbols are `sym_bytes` wide (only 1 = u8 is implemented this round).
+ *  - `*_dev` entry points take DEVICE pointers and are asynchronous on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).  The plain
+ *    variants take HOST pointers, copy, run the same kernels, and synchronise.
+ *  - A handle is immutable after build: any number of threads may issue queries
+ *    on it concurrently; build/free are exclusive.
+ *  - All compute runs in HIP kernels on the GPU.  There is no CPU fallback:
+ *    every call fails with FMX_ERR_HIP when no device is usable.
+ */
+#ifndef FMX_H
+#define FMX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fmx_index fmx_index;
+
+/* ---- status codes ------------------------------------------------------- */
+#define FMX_OK 0
+/* Error::InvalidText("the given text must not start with zero character")  (sais.rs:128-132) */
+#define FMX_ERR_TEXT_START_ZERO 1
+/* Error::InvalidText("the given text must end with exactly one zero character") (sais.rs:133-138) */
+#define FMX_ERR_TEXT_END_ZERO 2
+/* a text or pattern symbol exceeds max_character: the reference panics on cs[c]
+ * (fm_index.rs:94, rlfmi.rs:139, sais.rs:18); the ABI reports it instead */
+#define FMX_ERR_SYMBOL_RANGE 3
+#define FMX_ERR_ARG 4
+#define FMX_ERR_UNSUPPORTED 5
+#define FMX_ERR_HIP 6
+/* locate on an index built without a sampling level (FMIndex / RLFMIndex have no
+ * MatchWithLocate impl: frontend.rs:110-133) */
+#define FMX_ERR_NO_LOCATE 7
+
+/* ---- index kinds (frontend.rs:110-193) ---------------------------------- */
+#define FMX_KIND_FM 0   /* FMIndex / FMIndexWithLocate     (src/fm_index.rs) */
+#define FMX_KIND_RLFM 1 /* RLFMIndex / RLFMIndexWithLocate (src/rlfmi.rs)    */
+#define FMX_NO_LOCATE 0xFFFFFFFFu /* `level` value for the count-only types */
+
+/* build flags */
+#define FMX_FLAG_KEEP_SA 1u /* keep text + full suffix array in HBM (tests / export) */
+
+/* Message of the last failing call on this thread.  For the two InvalidText codes it
+ * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
+const char *fmx_last_error(void);
+const char *fmx_error_message(int code);
+
+/* ---- construction ------------------------------------------------------- */
+/* FMIndex::new / FMIndexWithLocate::new / RLFMIndex::new / RLFMIndexWithLocate::new
+ * (frontend.rs:195-267 -> fm_index.rs:25-42, rlfmi.rs:30-96).  `text` is a HOST
+ * buffer of n symbols INCLUDING the trailing 0 (Text::text, text.rs:52-54);
+ * `max_character` is Text::max_character (text.rs:28-49; 255 for Text::new on u8).
+ * Validation is sais.rs:115-139.  Suffix sorting, BWT, rank records and SA samples
+ * are all built on the GPU `device`. */
+int fmx_build(const void *text, uint64_t n, uint32_t sym_bytes, uint64_t max_character,
+              uint32_t kind, uint32_t level, uint32_t flags, int device, fmx_index **out);
+/* same, text already resident in HBM on `device` */
+int fmx_build_dev(const void *d_text, uint64_t n, uint32_t sym_bytes, uint64_t max_character,
+                  uint32_t kind, uint32_t level, uint32_t flags, int device, fmx_index **out);
+void fmx_free(fmx_index *idx); /* Drop */
+
+/* ---- SearchIndex (frontend.rs:26-44) ------------------------------------ */
+uint64_t fmx_len(const fmx_index *idx);         /* SearchIndexBackend::len, backend.rs:25 */
+uint64_t fmx_index_bytes(const fmx_index *idx); /* heap_size (frontend.rs:41-44): HBM bytes */
+uint64_t fmx_max_character(const fmx_index *idx);
+uint32_t fmx_kind(const fmx_index *idx);
+uint32_t fmx_level(const fmx_index *idx); /* effective level (sample.rs:28-31) or FMX_NO_LOCATE */
+int fmx_device(const fmx_index *idx);
+
+/* ---- SearchIndexBackend / HasPosition, one call = one trait method ------- */
+/* (backend.rs:9-15, 29-31).  Each runs the device kernel on a batch of one; on
+ * error they return UINT64_MAX and set fmx_last_error(). */
+uint64_t fmx_get_l(const fmx_index *idx, uint64_t i);              /* fm_index.rs:82-84  */
+uint64_t fmx_lf_map(const fmx_index *idx, uint64_t i);             /* fm_index.rs:86-91  */
+uint64_t fmx_lf_map2(const fmx_index *idx, uint64_t c, uint64_t i); /* fm_index.rs:93-95 */
+uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i);             /* fm_index.rs:127-140 */
+
+/* batched forms of the same four methods (device pointers, async) */
+int fmx_get_l_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                        void *stream);
+int fmx_lf_map_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                         void *stream);
+int fmx_lf_map2_batch_dev(const fmx_index *idx, const uint64_t *d_c, const uint64_t *d_i,
+                          uint64_t k, uint64_t *d_out, void *stream);
+int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                         void *stream);
+/* host-pointer forms */
+int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+int fmx_lf_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+int fmx_lf_map2_batch(const fmx_index *idx, const uint64_t *c, const uint64_t *i, uint64_t k,
+                      uint64_t *out);
+int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+
+/* ---- Search::search(..).count()  (wrapper.rs:37-42, 103-134) -------------- */
+/* For pattern k = pat[pat_off[k] .. pat_off[k+1]):
+ *     (s,e) = s0e0 ? (s0e0[2k], s0e0[2k+1]) : (0, len)          wrapper.rs:41 / 105-106
+ *     for c in pattern reversed { s=lf_map2(c,s); e=lf_map2(c,e); if s==e break }
+ *     out_s[k]=s; out_e[k]=e; out_count[k]=e-s                   wrapper.rs:132-134
+ * `s0e0` (nullable) is the refinement entry: Search::search on an existing Search
+ * prepends (wrapper.rs:99-124).  Any of out_s/out_e/out_count may be NULL.
+ * A pattern symbol > max_character makes the call report FMX_ERR_SYMBOL_RANGE
+ * (that pattern's outputs are 0).  The dev form reports it through
+ * fmx_stream_status() after the stream has been synchronised. */
+int fmx_count_batch_dev(const fmx_index *idx, const void *d_pat, const uint64_t *d_pat_off,
+                        uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_out_s,
+                        uint64_t *d_out_e, uint64_t *d_out_count, void *stream);
+int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_off, uint64_t npat,
+                    const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count);
+/* sticky device-side status of *_dev calls on this handle; reading clears it */
+int fmx_stream_status(const fmx_index *idx);
+
+/* ---- Search::iter_matches().map(MatchWithLocate::locate) ------------------ */
+/* (wrapper.rs:137-139, 203-217, 238-242 -> fm_index.rs:127-140, sample.rs:46-60)
+ *     out_pos[out_off[k] + j] = get_sa(s[k] + j),  j = 0 .. e[k]-s[k]-1
+ * i.e. suffix-array order, exactly the reference's iteration order.  `out_off` has
+ * npat+1 entries (exclusive scan of the counts; out_off[npat] = total hits). */
+int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                         uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,
+                         uint64_t *d_out_pos, void *stream);
+int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                     const uint64_t *out_off, uint64_t *out_pos);
+/* exclusive scan helper on the device: d_out_off[k] = sum_{j<k}(e[j]-s[j]), k = 0..npat */
+int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                    uint64_t *d_out_off, void *stream);
+
+/* ---- instrumentation / export (tests, bench, checkers) -------------------- */
+/* milliseconds the last *_dev query kernel of each type took, measured with HIP
+ * events on the launch stream when timing is enabled */
+void fmx_set_timing(fmx_index *idx, int enabled);
+double fmx_last_kernel_ms(const fmx_index *idx);
+/* LF steps executed by the last count / locate call when timing is enabled (else 0) */
+uint64_t fmx_last_steps(const fmx_index *idx);
+double fmx_build_ms(const fmx_index *idx);
+int fmx_export_bwt(const fmx_index *idx, void *host_out);            /* n symbols (fm_index.rs:50-55) */
+int fmx_export_cs(const fmx_index *idx, uint64_t *host_out);         /* max_character+1 (sais.rs:9-32) */
+int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out); /* ((n-1)>>level)+1 */
+uint64_t fmx_num_samples(const fmx_index *idx);
+int fmx_export_sa(const fmx_index *idx, uint32_t *host_out);         /* needs FMX_FLAG_KEEP_SA */
+/* needs FMX_FLAG_KEEP_SA: number of adjacent suffix pairs out of order + number of
+ * indices not hit exactly once (0 = the array IS the suffix array) */
+int fmx_verify_sa(const fmx_index *idx, uint64_t *violations);
+uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r (rlfmi.rs:43) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,57 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/fmx.h declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "fmx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    from fm_index_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_library()
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(so, n), "libfmx.so does not export " + n
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert set(names) == bound, (set(names) ^ bound)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import fm_index_amd as F
+    with pytest.raises(F.Error) as ei:
+        F.FMIndex(b"abc\x00")
+    assert ei.value.code == F._lib.ERR_HIP  # loud failure, not a silent CPU path
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under fm_index_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "fm_index_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "fm_oracle" not in txt and "import oracle" not in txt and \
+                    "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_error_messages_match_reference(golden):
+    from fm_index_amd import _lib
+    l = _lib.lib()
+    msgs = {c["message"] for c in golden["invalid_texts"]["cases"]}
+    got = {l.fmx_error_message(1).decode(), l.fmx_error_message(2).decode()}
+    assert got == {"invalid text: " + m for m in msgs}  # error.rs:11 Display format

@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: pattern-chars/s of batched backward search
+(count) on a 1 GB sigma=4 DNA text (config 2: FMIndex, 1 Mi length-32 patterns that are
+substrings of the text, so all 32 steps execute), plus locate hits/s (config 3) as an
+extra field.  One process per GPU; for N > 1 the patterns are sharded contiguously
+(N x 1 Mi patterns, weak scaling), the index is replicated, and the counts are gathered
+with one RCCL all-gather inside the timed region (config 5).
+
+A "step" = one pass of the count kernel over this rank's pattern batch, inputs and
+outputs resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes: one 512-bit block per level per endpoint
+BYTES_PER_CHAR_L3 = 2 * 3 * 64      # 384 B per executed backward-search step at L = 3
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=30, help="text length 2^k incl. terminator")
+    ap.add_argument("--npat", type=int, default=1 << 20, help="patterns per GPU")
+    ap.add_argument("--plen", type=int, default=32)
+    ap.add_argument("--level", type=int, default=2, help="SA sampling level for the locate leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-locate", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    import fm_index_amd as F
+    from fm_index_amd import workload as W
+    from fm_index_amd import _lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = L.lib()
+
+    n = 1 << args.log2n
+    npat, m = args.npat, args.plen
+    # ---- synthetic inputs: text seed 1, patterns seed 3 / 7 ----
+    t0 = time.time()
+    text = W.dna_text_torch(n, 1, dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    level = None if args.no_locate else args.level
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=level, device=local) \
+        if level is not None else F.FMIndex.from_device_text(text.data_ptr(), n, 4, device=local)
+    build_ms = lib.fmx_build_ms(index.handle())
+    # global pattern set = world * npat substrings; this rank owns a contiguous shard
+    seed = 3 if world == 1 else 7
+    total_pat = npat * world
+    z = W.splitmix64_torch(seed, rank * npat, npat, dev)
+    pos = W.umod_torch(z, n - 1 - m)
+    idx2d = pos[:, None] + torch.arange(m, dtype=torch.int64, device=dev)[None, :]
+    pat = text[idx2d].reshape(-1).contiguous()
+    off = (torch.arange(npat + 1, dtype=torch.int64, device=dev) * m).contiguous()
+    del idx2d
+    d_s = torch.empty(npat, dtype=torch.int64, device=dev)
+    d_e = torch.empty(npat, dtype=torch.int64, device=dev)
+    d_c = torch.empty(npat, dtype=torch.int64, device=dev)
+    gathered = torch.empty(total_pat, dtype=torch.int64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    h = index.handle()
+
+    def step():
+        rc = lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat,
+                                     None, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
+                                     C.c_void_p(d_c.data_ptr()), sp)
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_c)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # kernel-only time over the timed region: HIP events on the launch stream
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)] if world > 1 else None
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for k in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ev_ms = ev0.elapsed_time(ev1)
+    assert lib.fmx_stream_status(h) == 0
+
+    # ---- validation + step census (outside the timed region) ----
+    lib.fmx_set_timing(h, 1)
+    step()
+    torch.cuda.synchronize()
+    kernel_ms_single = lib.fmx_last_kernel_ms(h)
+    steps_exec = int(lib.fmx_last_steps(h))
+    lib.fmx_set_timing(h, 0)
+    assert steps_exec == npat * m, (steps_exec, npat * m)   # substrings: every step executes
+    assert bool((d_c >= 1).all()), "a substring of the text must occur at least once"
+    # every pattern's own source position must lie in its SA interval's located set (below)
+
+    chars_per_step_rank = npat * m
+    value = chars_per_step_rank * world * args.steps / dt
+    # dominant kernel: fmx_count_kernel; avg launch duration from the event bracket of the timed
+    # region at N=1 (launches are back to back on one stream); per-launch event at N>1
+    avg_kernel_s = (ev_ms / 1e3) / args.steps if world == 1 else kernel_ms_single / 1e3
+    achieved = chars_per_step_rank * BYTES_PER_CHAR_L3 / avg_kernel_s / 1e9
+    roofline = {"bound": "hbm", "kernel": "fmx_count_kernel", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_char": BYTES_PER_CHAR_L3,
+                "layout_bytes_per_char": 2 * 128,
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
+
+    out = {
+        "metric": "pattern-chars/sec backward search (count), 1 GB text",
+        "value": value, "unit": "pattern-chars/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d "
+                               "substring patterns per GPU" % (args.log2n, npat, m),
+                   "text_len": n, "patterns_per_gpu": npat, "pattern_len": m,
+                   "parallelism": "patterns sharded x%d, index replicated" % world,
+                   "index_bytes": index.heap_size(), "build_ms": round(build_ms, 1),
+                   "textgen_s": round(t_gen, 2)},
+        "roofline": roofline,
+    }
+
+    # ---- locate leg (config 3), rank 0 reports ----
+    if level is not None:
+        d_off = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+        lib.fmx_offsets_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                            C.c_void_p(d_off.data_ptr()), sp)
+        total_hits = int(d_off[-1].item())
+        d_pos = torch.empty(max(total_hits, 1), dtype=torch.int64, device=dev)
+
+        def locate_step():
+            rc = lib.fmx_locate_batch_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
+                                          npat, C.c_void_p(d_off.data_ptr()), total_hits,
+                                          C.c_void_p(d_pos.data_ptr()), sp)
+            if rc != 0:
+                raise RuntimeError(lib.fmx_last_error().decode())
+        locate_step()
+        torch.cuda.synchronize()
+        lsteps = max(3, args.steps // 2)
+        lib.fmx_set_timing(h, 1)
+        kms = []
+        t0 = time.perf_counter()
+        for _ in range(lsteps):
+            locate_step()
+            torch.cuda.synchronize()
+            kms.append(lib.fmx_last_kernel_ms(h))
+        ldt = time.perf_counter() - t0
+        lf_steps = int(lib.fmx_last_steps(h))
+        lib.fmx_set_timing(h, 0)
+        # property checks at full size: every located position really holds the pattern, and
+        # each pattern's source position is among its hits
+        hit_pat = torch.repeat_interleave(torch.arange(npat, device=dev), d_c)
+        chk = torch.ones(total_hits, dtype=torch.bool, device=dev)
+        for j in range(m):
+            chk &= text[d_pos[:total_hits] + j] == pat.view(npat, m)[hit_pat, j]
+        assert bool(chk.all()), "located position does not hold the pattern"
+        found_src = torch.zeros(npat, dtype=torch.bool, device=dev)
+        found_src[hit_pat[d_pos[:total_hits] == pos[hit_pat]]] = True
+        assert bool(found_src.all()), "source position missing from locate output"
+        kavg = sum(kms) / len(kms) / 1e3
+        lbytes = lf_steps * 3 * 64 + total_hits * 64   # steps*L*64 + 64 per hit
+        out["locate"] = {"hits_per_s": total_hits * lsteps / ldt, "hits": total_hits,
+                         "lf_steps": lf_steps, "level": args.level,
+                         "ms_per_batch": ldt / lsteps * 1e3,
+                         "roofline": {"bound": "hbm", "kernel": "fmx_locate_kernel",
+                                      "achieved": round(lbytes / kavg / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(lbytes / kavg / 1e9 / HBM_PEAK_GBS, 4),
+                                      "avg_kernel_ms": round(kavg * 1e3, 4), "traffic": None}}
+        del hit_pat, chk, found_src
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import fm_oracle as O
+        t0 = time.time()
+        bwt = index.export_bwt()
+        cs = index.export_cs()
+        oi = O.OracleIndex.from_bwt(bwt, cs, 4, native=True)
+        del bwt
+        t_ob = time.time() - t0
+        cores = os.cpu_count() or 1
+        pat_h = pat.cpu().numpy()
+        s_h = d_s.cpu().numpy().view(np.uint64)
+        e_h = d_e.cpu().numpy().view(np.uint64)
+
+        def cpu_run(k, threads):
+            offk = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
+            t = time.perf_counter()
+            so, eo = oi.count_batch(pat_h[:k * m], offk, nthreads=threads)
+            return time.perf_counter() - t, so, eo
+        k0 = 1 << 14
+        t_probe, so, eo = cpu_run(k0, cores)
+        k = int(min(npat, max(k0, k0 * args.cpu_seconds / max(t_probe, 1e-6))))
+        t_all, so, eo = cpu_run(k, cores)
+        assert (so == s_h[:k]).all() and (eo == e_h[:k]).all(), "GPU != oracle on the CPU sample"
+        k1 = max(1024, k // cores)
+        t_one, _, _ = cpu_run(k1, 1)
+        out["cpu_baseline"] = {"value": k * m / t_all, "unit": "pattern-chars/s", "cores": cores,
+                               "kind": "port",
+                               "sample": "first %d of the %d patterns (same text, same index), "
+                                         "%.1f s; GPU (s,e) bit-identical on the sample" % (k, npat, t_all),
+                               "single_thread_value": k1 * m / t_one,
+                               "oracle_build_s": round(t_ob, 1)}
+        oi.close()
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -338,7 +338,6 @@ uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; retu
 // ---------------------------------------------------------------------------
 int fmx_export_bwt(const fmx_index *idx, void *host_out) {
   CHECK_IDX(idx);
-  if (idx->kind != FMX_KIND_FM) return fail(FMX_ERR_UNSUPPORTED, "export_bwt: FM index only");
   if (idx->n == 0) return FMX_OK;
   Scratch sc;
   void *d;

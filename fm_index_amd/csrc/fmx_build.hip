@@ -232,6 +232,73 @@ __global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict
   rec[t] = p;
 }
 
+
+// ---- RLFM construction (rlfmi.rs:30-96) --------------------------------------------
+// run starts: c0 starts at 0, a run begins wherever c != c0  (rlfmi.rs:41, 56-59)
+__global__ __launch_bounds__(BLK) void k_run_flags(const uint8_t *__restrict__ L, uint32_t n,
+                                                    uint8_t *__restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  uint8_t prev = i ? L[i - 1] : (uint8_t)0;
+  flags[i] = L[i] != prev ? 1 : 0;
+}
+__global__ __launch_bounds__(BLK) void k_iota(uint32_t *out, uint32_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)i;
+}
+// run length of the q-th run in (head, row) order
+__global__ __launch_bounds__(BLK) void k_sorted_run_lens(const uint32_t *__restrict__ starts,
+                                                          const uint32_t *__restrict__ order,
+                                                          uint32_t r, uint32_t n,
+                                                          uint32_t *__restrict__ lens) {
+  uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (q >= r) return;
+  uint32_t k = order[q];
+  uint32_t end = k + 1 < r ? starts[k + 1] : n;
+  lens[q] = end - starts[k];
+}
+__global__ __launch_bounds__(BLK) void k_scatter_ones(const uint32_t *__restrict__ pos, uint32_t r,
+                                                       uint8_t *__restrict__ flags) {
+  uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (q < r) flags[pos[q]] = 1;
+}
+// bit-vector records: one thread per 96-bit piece
+__global__ __launch_bounds__(BLK) void k_bits_pieces(const uint8_t *__restrict__ flags, uint32_t n,
+                                                      uint32_t npieces, uint4 *__restrict__ rec,
+                                                      uint32_t *__restrict__ cnt) {
+  uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t >= npieces) return;
+  uint64_t base = t * FMX_BITS_PER_PIECE;
+  uint32_t w[3] = {0, 0, 0};
+  for (uint32_t j = 0; j < FMX_BITS_PER_PIECE; j++) {
+    uint64_t p = base + j;
+    if (p < n && flags[p]) w[j >> 5] |= 1u << (j & 31u);
+  }
+  uint4 pc;
+  pc.x = 0; pc.y = w[0]; pc.z = w[1]; pc.w = w[2];
+  rec[t] = pc;
+  cnt[t] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]);
+}
+__global__ __launch_bounds__(BLK) void k_bits_counters(const uint32_t *__restrict__ base,
+                                                        uint32_t npieces, uint4 *__restrict__ rec) {
+  uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t < npieces) rec[t].x = base[t];
+}
+__global__ __launch_bounds__(BLK) void k_fill_u32(uint32_t *out, uint32_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+// sel[m / STEP] = record holding the m-th one, for every multiple m of STEP
+__global__ __launch_bounds__(BLK) void k_select_hints(const uint4 *__restrict__ rec, uint32_t nrec,
+                                                       uint32_t ones, uint32_t *__restrict__ sel) {
+  uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (r >= nrec) return;
+  uint32_t b0 = rec[r * 8].x;
+  uint32_t b1 = r + 1 < nrec ? rec[(r + 1) * 8].x : ones;
+  uint32_t m = (b0 + FMX_SEL_STEP - 1) / FMX_SEL_STEP * FMX_SEL_STEP;
+  for (; m < b1; m += FMX_SEL_STEP) sel[m / FMX_SEL_STEP] = (uint32_t)r;
+}
+
 // ---- verification (FMX_FLAG_KEEP_SA) ---------------------------------------------
 __global__ __launch_bounds__(BLK) void k_verify_sa(const uint8_t *__restrict__ t,
                                                     const uint32_t *__restrict__ sa, uint32_t n,
@@ -414,6 +481,134 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
   return FMX_OK;
 }
 
+
+// FmxBits (rank/select records + select hints) from one flag byte per bit
+int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, DevPool &pool) {
+  memset(bv, 0, sizeof *bv);
+  bv->len = n;
+  bv->nrec = n / FMX_BITS_PER_REC + 1;  // position `len` itself must be addressable
+  uint32_t npieces = bv->nrec * 8;
+  uint4 *rec;
+  uint32_t *cnt, *base;
+  FMX_HIP(hipMalloc((void **)&rec, (size_t)bv->nrec * 128));
+  if (int rc = keep(idx, rec, (uint64_t)bv->nrec * 128)) return rc;
+  FMX_HIP(pool.get(&cnt, (size_t)npieces + 1));
+  FMX_HIP(pool.get(&base, (size_t)npieces + 1));
+  FMX_HIP(hipMemset(cnt, 0, ((size_t)npieces + 1) * 4));
+  hipLaunchKernelGGL(k_bits_pieces, dim3(nblocks(npieces)), dim3(BLK), 0, 0, d_flags, n, npieces, rec,
+                     cnt);
+  size_t tb = 0;
+  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, base, (size_t)npieces + 1,
+                                           (hipStream_t)0));
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tb));
+  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, base, (size_t)npieces + 1, (hipStream_t)0));
+  hipLaunchKernelGGL(k_bits_counters, dim3(nblocks(npieces)), dim3(BLK), 0, 0, base, npieces, rec);
+  uint32_t ones = 0;
+  FMX_HIP(hipMemcpy(&ones, base + npieces, 4, hipMemcpyDeviceToHost));
+  bv->ones = ones;
+  bv->nsel = ones / FMX_SEL_STEP + 2;
+  uint32_t *sel;
+  FMX_HIP(hipMalloc((void **)&sel, (size_t)bv->nsel * 4));
+  if (int rc = keep(idx, sel, (uint64_t)bv->nsel * 4)) return rc;
+  hipLaunchKernelGGL(k_fill_u32, dim3(nblocks(bv->nsel)), dim3(BLK), 0, 0, sel, bv->nsel, bv->nrec - 1);
+  hipLaunchKernelGGL(k_select_hints, dim3(nblocks(bv->nrec)), dim3(BLK), 0, 0, rec, bv->nrec, ones, sel);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  bv->rec = rec;
+  bv->sel = sel;
+  pool.release(cnt); pool.release(base); pool.release(tmp);
+  return FMX_OK;
+}
+
+// RLFMIndexBackend::new (rlfmi.rs:30-96) from the L column (d_L is consumed)
+int build_rlfm(fmx_index *idx, uint8_t *d_L, uint32_t n, uint32_t L, DevPool &pool) {
+  FmxDev &dv = idx->dev;
+  const uint32_t maxc = (uint32_t)idx->max_character;
+  uint8_t *flags, *heads;
+  uint32_t *starts, *d_num;
+  FMX_HIP(pool.get(&flags, n));
+  FMX_HIP(pool.get(&heads, n));
+  FMX_HIP(pool.get(&starts, n));
+  FMX_HIP(pool.get(&d_num, 1));
+  hipLaunchKernelGGL(k_run_flags, dim3(nblocks(n)), dim3(BLK), 0, 0, d_L, n, flags);
+  // S = run heads (rlfmi.rs:57), starts = first row of every run
+  size_t t1 = 0, t2 = 0;
+  hipcub::CountingInputIterator<uint32_t> rows(0);
+  FMX_HIP(hipcub::DeviceSelect::Flagged(nullptr, t1, d_L, flags, heads, d_num, (int)n, (hipStream_t)0));
+  FMX_HIP(hipcub::DeviceSelect::Flagged(nullptr, t2, rows, flags, starts, d_num, (int)n, (hipStream_t)0));
+  size_t tb = t1 > t2 ? t1 : t2;
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tb));
+  size_t tt = tb;
+  FMX_HIP(hipcub::DeviceSelect::Flagged(tmp, tt, d_L, flags, heads, d_num, (int)n, (hipStream_t)0));
+  tt = tb;
+  FMX_HIP(hipcub::DeviceSelect::Flagged(tmp, tt, rows, flags, starts, d_num, (int)n, (hipStream_t)0));
+  uint32_t r = 0;
+  FMX_HIP(hipMemcpy(&r, d_num, 4, hipMemcpyDeviceToHost));
+  idx->runs = r;
+  pool.release(tmp);
+  // B (rlfmi.rs:46, 58, 61, 85)
+  if (int rc = build_bits(idx, &dv.b, flags, n, pool)) return rc;
+  // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
+  TextStats *d_st;
+  FMX_HIP(pool.get(&d_st, 1));
+  FMX_HIP(hipMemset(d_st, 0, sizeof(TextStats)));
+  {
+    unsigned grid = nblocks(r, BLK * 16);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_text_stats, dim3(grid), dim3(BLK), 0, 0, heads, (uint64_t)r, d_st);
+  }
+  TextStats st;
+  FMX_HIP(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> rcs(maxc + 1);
+  {
+    uint64_t acc = 0;
+    for (uint32_t c = 0; c <= maxc; c++) { rcs[c] = acc; acc += st.hist[c]; }
+  }
+  // B' (rlfmi.rs:71-83): runs in (head, row) order, each 1 0^{len-1}
+  uint32_t *order, *order2, *lens, *fpos;
+  uint8_t *hk2;
+  FMX_HIP(pool.get(&order, r));
+  FMX_HIP(pool.get(&order2, r));
+  FMX_HIP(pool.get(&lens, r));
+  FMX_HIP(pool.get(&fpos, r));
+  FMX_HIP(pool.get(&hk2, r));
+  hipLaunchKernelGGL(k_iota, dim3(nblocks(r)), dim3(BLK), 0, 0, order, r);
+  size_t sb = 0;
+  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0, 8,
+                                             (hipStream_t)0));
+  uint8_t *stmp;
+  FMX_HIP(pool.get(&stmp, sb));
+  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0, 8,
+                                             (hipStream_t)0));
+  hipLaunchKernelGGL(k_sorted_run_lens, dim3(nblocks(r)), dim3(BLK), 0, 0, starts, order2, r, n, lens);
+  size_t eb = 0;
+  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, eb, lens, fpos, (size_t)r, (hipStream_t)0));
+  uint8_t *etmp;
+  FMX_HIP(pool.get(&etmp, eb));
+  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(etmp, eb, lens, fpos, (size_t)r, (hipStream_t)0));
+  FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
+  hipLaunchKernelGGL(k_scatter_ones, dim3(nblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
+  FMX_HIP(hipDeviceSynchronize());
+  if (int rc = build_bits(idx, &dv.bp, flags, n, pool)) return rc;
+  pool.release(order); pool.release(order2); pool.release(lens); pool.release(fpos);
+  pool.release(hk2); pool.release(stmp); pool.release(etmp); pool.release(flags);
+  pool.release(starts);
+  // S as a multi-ary wavelet matrix over the r run heads (rlfmi.rs:69-70)
+  if (int rc = build_mwm(idx, &dv.bw, heads, r, L, pool)) return rc;
+  uint64_t *d_cs;
+  uint32_t *d_K;
+  FMX_HIP(pool.get(&d_cs, maxc + 1));
+  FMX_HIP(hipMemcpy(d_cs, rcs.data(), (maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  FMX_HIP(hipMalloc((void **)&d_K, (maxc + 1) * sizeof(uint32_t)));
+  if (int rc = keep(idx, d_K, (maxc + 1) * 4)) return rc;
+  if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
+  dv.K = d_K;
+  (void)d_L;
+  return FMX_OK;
+}
+
 }  // namespace
 
 int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
@@ -524,8 +719,14 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
     if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
     dv.K = d_K;
   } else {
-    fmx_set_error(FMX_ERR_UNSUPPORTED, "RLFM index is not implemented yet");
-    return FMX_ERR_UNSUPPORTED;
+    if (n < 2) {  // the reference hits unreachable!() (rlfmi.rs:62-65) / has nothing to index
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "RLFM index needs a text of at least 2 symbols");
+      return FMX_ERR_UNSUPPORTED;
+    }
+    // c_i = T[SA[i]-1], or T[n-1] when SA[i] == 0 (rlfmi.rs:48-53)
+    hipLaunchKernelGGL(k_bwt_cyclic, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+    FMX_HIP(hipDeviceSynchronize());
+    if (int rc = build_rlfm(idx, d_bwt, n, L, pool)) return rc;
   }
 
   if (idx->flags & FMX_FLAG_KEEP_SA) {

@@ -161,3 +161,110 @@ __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, ui
   }
   return r;
 }
+
+// ===========================================================================
+// RLFM (rlfmi.rs): bit vectors B / B' with rank1 / select1, and the LF formulas
+// ===========================================================================
+// record = 8 pieces of { ones before this piece (absolute), 96 payload bits }
+__device__ __forceinline__ uint32_t fmx_lowmask(uint32_t k) {  // k in 0..32
+  return k >= 32u ? 0xFFFFFFFFu : ((1u << k) - 1u);
+}
+__device__ __forceinline__ uint32_t fmx_div3(uint32_t x) {
+  return (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33);
+}
+// rank1(i) (clamped like vers-vecs RsVec::rank1) and the bit B[i] (0 past the end)
+__device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i, uint32_t g,
+                                                  uint32_t &bit_i) {
+  if (i > bv.len) i = bv.len;
+  uint32_t rec = fmx_div3(i >> 8);            // i / 768
+  uint32_t within = i - rec * FMX_BITS_PER_REC;
+  uint32_t p = fmx_div3(within >> 5);         // within / 96
+  uint32_t bit = within - p * FMX_BITS_PER_PIECE;
+  uint4 pc = bv.rec[(size_t)rec * 8u + g];
+  uint32_t c = __popc(pc.y & fmx_lowmask(bit < 32u ? bit : 32u));
+  if (bit > 32u) c += __popc(pc.z & fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u));
+  if (bit > 64u) c += __popc(pc.w & fmx_lowmask(bit - 64u));
+  uint32_t word = bit < 32u ? pc.y : (bit < 64u ? pc.z : pc.w);
+  uint32_t mine = (g == p) ? 1u : 0u;
+  bit_i = fmx_group_sum(mine * ((word >> (bit & 31u)) & 1u));
+  return fmx_group_sum(mine * (pc.x + c));
+}
+// position of the r-th (0-based) set bit of w; r < popc(w)
+__device__ __forceinline__ uint32_t fmx_select32(uint32_t w, uint32_t r) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (int sh = 16; sh; sh >>= 1) {
+    uint32_t c = __popc((w >> pos) & ((1u << sh) - 1u));
+    if (r >= c) { r -= c; pos += sh; }
+  }
+  return pos;
+}
+// select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
+__device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
+  if (k >= bv.ones) return bv.len;
+  uint32_t h = k / FMX_SEL_STEP;
+  uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
+  while (lo < hi) {  // group-uniform binary search over record bases
+    uint32_t mid = (lo + hi + 1u) >> 1;
+    uint32_t x = bv.rec[(size_t)mid * 8u].x;
+    if (x <= k) lo = mid; else hi = mid - 1u;
+  }
+  uint4 pc = bv.rec[(size_t)lo * 8u + g];
+  uint32_t p = fmx_group_sum(pc.x <= k ? 1u : 0u) - 1u;  // last piece whose base <= k
+  uint32_t rem = k - pc.x;                                // meaningful on lane p only
+  uint32_t c0 = __popc(pc.y), c1 = __popc(pc.z);
+  uint32_t pos;
+  if (rem < c0) pos = fmx_select32(pc.y, rem);
+  else if (rem < c0 + c1) pos = 32u + fmx_select32(pc.z, rem - c0);
+  else pos = 64u + fmx_select32(pc.w, rem - c0 - c1);
+  pos = fmx_group_sum((g == p) ? pos : 0u);
+  return lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
+}
+
+// RLFMIndexBackend::lf_map2 (rlfmi.rs:135-143)
+__device__ __forceinline__ uint32_t fmx_rlfm_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i,
+                                                     uint32_t g) {
+  uint32_t bi;
+  uint32_t j = fmx_bits_rank(ix.b, i, g, bi);             // b.rank1(i)
+  uint32_t nr = ix.K[c] + fmx_mwm_rank(ix.bw, c, j, g);   // cs[c] + s.rank(j, c)
+  uint32_t l;                                             // get_l(i) = s[b.rank1(i+1) - 1]
+  (void)fmx_mwm_lf(ix.bw, j - 1u + bi, g, l);
+  uint32_t r = fmx_bits_select(ix.bp, nr, g);             // bp.select1(cs[c] + nr)
+  if (l == c) r = r + i - fmx_bits_select(ix.b, j, g);    // + i - b.select1(j)
+  return r;
+}
+// RLFMIndexBackend::get_l + lf_map (rlfmi.rs:122-133)
+__device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i, uint32_t g,
+                                                    uint32_t &sym) {
+  uint32_t bi;
+  uint32_t j = fmx_bits_rank(ix.b, i, g, bi);
+  (void)fmx_mwm_lf(ix.bw, j - 1u + bi, g, sym);
+  uint32_t nr = ix.K[sym] + fmx_mwm_rank(ix.bw, sym, j, g);
+  return fmx_bits_select(ix.bp, nr, g) + i - fmx_bits_select(ix.b, j, g);
+}
+
+// kind-dispatching forms used by the kernels
+template <int KIND>
+__device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
+                                                 uint32_t &e, uint32_t g) {
+  if (KIND == FMX_KIND_FM) {
+    uint32_t rs, re;
+    fmx_mwm_rank2(ix.bw, c, s, e, g, rs, re);
+    uint32_t kc = ix.K[c];
+    s = kc + rs;  // fm_index.rs:93-95
+    e = kc + re;
+  } else {
+    s = fmx_rlfm_lf_map2(ix, c, s, g);
+    e = fmx_rlfm_lf_map2(ix, c, e, g);
+  }
+}
+template <int KIND>
+__device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
+                                                   uint32_t &sym) {
+  if (KIND == FMX_KIND_FM) {
+    uint32_t r = fmx_mwm_lf(ix.bw, i, g, sym);
+    return ix.K[sym] + r;  // fm_index.rs:86-91
+  } else {
+    return fmx_rlfm_lf_map(ix, i, g, sym);
+  }
+}

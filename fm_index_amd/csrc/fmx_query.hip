@@ -26,6 +26,7 @@ static inline unsigned fmx_grid_for_groups(uint64_t units) {
 // ---------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------
+template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
     FmxDev ix, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
@@ -63,11 +64,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
         if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_SYMBOL_RANGE);
         s = 0; e = 0; done = true;
       } else {
-        uint32_t rs, re;
-        fmx_mwm_rank2(ix.bw, c, s, e, g, rs, re);
-        uint32_t kc = ix.K[c];
-        s = kc + rs;                                   // wrapper.rs:109
-        e = kc + re;                                   // wrapper.rs:110
+        fmx_lf_map2_pair<KIND>(ix, c, s, e, g);        // wrapper.rs:109-110
         nsteps++;
         if (s == e || j == 0) done = true;             // wrapper.rs:111-113
       }
@@ -108,6 +105,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
 }
 
 // in place: out_pos[h] holds SA row i on entry and get_sa(i) on exit.
+template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(FmxDev ix, uint64_t total,
                                                                 uint64_t *__restrict__ out_pos,
                                                                 uint64_t *__restrict__ steps_out) {
@@ -137,8 +135,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(FmxDev ix, uint64
     } else {
       // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
       uint32_t sym;
-      uint32_t r = fmx_mwm_lf(ix.bw, row, g, sym);
-      row = ix.K[sym] + r;
+      row = fmx_lf_map_any<KIND>(ix, row, g, sym);
       steps++;
       nsteps++;
     }
@@ -230,6 +227,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_tile_scan_kernel(const uint64_t
 // ---------------------------------------------------------------------------
 // the four trait methods, batched (backend.rs:9-15, 29-31)
 // ---------------------------------------------------------------------------
+template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op,
                                                                 const uint64_t *__restrict__ cc,
                                                                 const uint64_t *__restrict__ ii,
@@ -246,22 +244,22 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
       if (c > ix.max_character || i64 > ix.n) {
         if (g == 0) atomicOr(ix.status, 1u << (c > ix.max_character ? FMX_ERR_SYMBOL_RANGE : FMX_ERR_ARG));
       } else {
-        uint32_t r = fmx_mwm_rank(ix.bw, (uint32_t)c, (uint32_t)i64, g);
-        res = (uint32_t)(ix.K[c] + r);
+        uint32_t a = (uint32_t)i64, b2 = (uint32_t)i64;
+        fmx_lf_map2_pair<KIND>(ix, (uint32_t)c, a, b2, g);
+        res = a;
       }
     } else if (i64 >= ix.n) {
       if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
     } else if (op == 0 || op == 1) {  // get_l / lf_map
       uint32_t sym;
-      uint32_t r = fmx_mwm_lf(ix.bw, (uint32_t)i64, g, sym);
-      res = op == 0 ? (uint64_t)sym : (uint64_t)(uint32_t)(ix.K[sym] + r);
+      uint32_t r = fmx_lf_map_any<KIND>(ix, (uint32_t)i64, g, sym);
+      res = op == 0 ? (uint64_t)sym : (uint64_t)r;
     } else {  // get_sa (fm_index.rs:127-140)
       uint32_t row = (uint32_t)i64, steps = 0;
       const uint32_t lmask = (1u << ix.sa_level) - 1u;
       while ((row & lmask) != 0) {
         uint32_t sym;
-        uint32_t r = fmx_mwm_lf(ix.bw, row, g, sym);
-        row = ix.K[sym] + r;
+        row = fmx_lf_map_any<KIND>(ix, row, g, sym);
         steps++;
       }
       uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
@@ -273,20 +271,25 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
 }
 
 // export: L column of rows [0, n) as one byte per row (get_l, fm_index.rs:82-84)
+template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, uint8_t *__restrict__ out) {
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   for (uint64_t q = gid; q < ix.n; q += ngroups) {
     uint32_t sym;
-    (void)fmx_mwm_lf(ix.bw, (uint32_t)q, g, sym);
+    (void)fmx_lf_map_any<KIND>(ix, (uint32_t)q, g, sym);
     if (g == 0) out[q] = (uint8_t)sym;
   }
 }
 int fmx_launch_export_l(const fmx_index *idx, uint8_t *d_out, hipStream_t st) {
   if (idx->n == 0) return FMX_OK;
-  hipLaunchKernelGGL(fmx_export_l_kernel, dim3(fmx_grid_for_groups(idx->n)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, d_out);
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(idx->n)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
+  else
+    hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(idx->n)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -327,8 +330,13 @@ int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t 
   if (npat == 0) return FMX_OK;
   unsigned grid = fmx_grid_for_groups(npat);
   fmx_time_begin(idx, st);
-  hipLaunchKernelGGL(fmx_count_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, d_pat, d_off,
-                     npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr);
+  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
+  else
+    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_RLFM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -357,8 +365,13 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   hipLaunchKernelGGL(fmx_expand_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
                      d_s, d_e, d_off, npat, d_pos);
   fmx_time_begin(idx, st);
-  hipLaunchKernelGGL(fmx_locate_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, total, d_pos, idx->timing ? idx->d_steps : nullptr);
+  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(total)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
+  else
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(total)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -367,8 +380,12 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st) {
   if (k == 0) return FMX_OK;
-  hipLaunchKernelGGL(fmx_scalar_kernel, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, op, d_c, d_i, k, d_out);
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK),
+                       0, st, idx->dev, op, d_c, d_i, k, d_out);
+  else
+    hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(k)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -1,0 +1,135 @@
+"""GPU parity tests for RLFMIndex / RLFMIndexWithLocate (src/rlfmi.rs) through the C ABI."""
+import numpy as np
+import pytest
+
+import fm_index_amd as F
+from fm_index_amd import workload as W
+from oracle import fm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def b(s):
+    return s.encode("latin-1")
+
+
+def test_mississippi_known_answers_rlfm(golden):
+    g = golden["mississippi"]
+    idx = F.RLFMIndexWithLocate(F.Text(b(g["text"])), 2)
+    assert idx.len() == 12
+    i, chain = 0, []
+    for _ in range(12):
+        i = int(idx.lf_map([i])[0])
+        chain.append(i)
+    assert chain == g["lf_chain_from_0"]["expected"]                 # rlfmi.rs:271-282
+    for ch, (s, e) in g["lf_map2_ranges"]["expected"].items():       # rlfmi.rs:285-309
+        assert int(idx.lf_map2([ord(ch)], [0])[0]) == s
+        assert int(idx.lf_map2([ord(ch)], [12])[0]) == e
+    for pat, se in g["search_ranges"]["expected"].items():           # rlfmi.rs:312-328
+        assert idx.search(b(pat)).get_range() == tuple(se)
+    assert bytes(int(x) for x in idx.get_l(np.arange(12))) == b(g["bwt"]["expected"])  # :259-268
+    assert int(idx._lib.fmx_num_runs(idx.handle())) == len(g["rlfm_S"]["expected"])    # :197-206
+
+
+def test_readme_and_small_rlfm(golden):
+    g = golden["readme"]
+    index = F.RLFMIndexWithLocate(F.Text(b(g["text"])), g["level"])
+    search = index.search(b(g["pattern"]))
+    assert search.count() == g["count"]
+    assert [m.locate() for m in search.iter_matches()] == g["positions_in_order"]
+    assert search.locate_all() == g["positions_in_order"]
+    g = golden["small"]
+    idx = F.RLFMIndexWithLocate(F.Text(b(g["text"])), g["level"])
+    s = idx.search(b(g["pattern"]))
+    assert s.count() == g["count"] and s.locate_all() == g["positions"]
+
+
+def test_invalid_texts_rlfm(golden):
+    for case in golden["invalid_texts"]["cases"]:
+        with pytest.raises(F.Error) as ei:
+            F.RLFMIndex(F.Text(b(case["text"])))
+        assert str(ei.value) == "invalid text: " + case["message"]
+
+
+@pytest.mark.parametrize("maxc,alpha,n", [(4, 4, 777), (255, 3, 2000), (255, 255, 1555), (49, 2, 3000)])
+def test_rlfm_trait_methods_every_c_and_i(maxc, alpha, n):
+    t = (W.splitmix64_np(maxc * 7 + alpha, 0, n) % np.uint64(alpha)).astype(np.uint8) + \
+        (48 if maxc == 49 else 1)
+    t[-1] = 0
+    gi = F.RLFMIndexWithLocate(F.Text.with_max_character(t, maxc), 2)
+    oi = O.OracleIndex(t, maxc, level=2, kind="rlfm")
+    cc, ii = np.meshgrid(np.arange(maxc + 1), np.arange(n + 1))
+    assert (gi.lf_map2(cc.ravel(), ii.ravel()) == oi.lf_map2(cc.ravel(), ii.ravel())).all()
+    rows = np.arange(n)
+    assert (gi.get_l(rows) == oi.get_l(rows)).all()
+    assert (gi.lf_map(rows) == oi.lf_map(rows)).all()
+    assert (gi.get_sa(rows) == oi.get_sa(rows)).all()
+
+
+def test_rlfm_property_vs_bruteforce_and_oracle():
+    """tests/test_rlfmindex.rs:26-89 shape."""
+    for ti in range(20):
+        size = 2 + int(W.splitmix64_np(1500 + ti, 0, 1)[0] % np.uint64(1023))
+        text = (W.splitmix64_np(2500 + ti, 0, size) % np.uint64(8)).astype(np.uint8) + 1
+        text[-1] = 0
+        level = int(W.splitmix64_np(3500 + ti, 0, 1)[0] % np.uint64(4))
+        gi = F.RLFMIndexWithLocate(F.Text(text), level)
+        oi = O.OracleIndex(text, 255, level=level, kind="rlfm")
+        flat, off = W.ragged_patterns_np(100, min(9, size), 7, 4500 + ti)
+        gb = gi.search_many(flat=flat, off=off)
+        os_, oe = oi.count_batch(flat, off)
+        assert (gb.s == os_).all() and (gb.e == oe).all()
+        goff, gpos = gb.locate()
+        ooff, opos = oi.locate_batch(os_, oe)
+        assert (goff == ooff).all() and (gpos == opos).all()
+        for k in range(0, 100, 9):
+            p = flat[int(off[k]):int(off[k + 1])]
+            if len(p):
+                assert int(gb.counts[k]) == len(O.naive_search(text, p))
+
+
+def test_rlfm_repetitive_text_long_runs():
+    """the case RLFM exists for (lib.rs:45-47): few, long runs -> sparse B / B', select hints
+    and the binary search between hints are exercised."""
+    n = 200000
+    t = W.repetitive_text_np(n, 5, base_len=256, mut_per_1024=1)
+    gi = F.RLFMIndexWithLocate(F.Text(t), 3)
+    oi = O.OracleIndex(t, 255, level=3, kind="rlfm")
+    fm = F.FMIndex(F.Text(t))
+    runs = int(gi._lib.fmx_num_runs(gi.handle()))
+    assert runs < n // 4
+    flat, off, _ = W.substring_patterns_np(t, 4000, 12, 8)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off, nthreads=8)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    fb = fm.search_many(flat=flat, off=off)   # identical to FMIndex counts
+    assert (fb.s == gb.s).all() and (fb.e == gb.e).all()
+    rows = np.arange(0, n, 37)
+    assert (gi.lf_map(rows) == oi.lf_map(rows)).all()
+    sub = slice(0, 300)
+    goff, gpos = gi.locate_many(gb.s[sub], gb.e[sub])
+    ooff, opos = oi.locate_batch(os_[sub], oe[sub], nthreads=8)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    # all-equal text: a single long run per symbol
+    t2 = np.array([3] * 5000 + [0], dtype=np.uint8)
+    g2 = F.RLFMIndexWithLocate(F.Text(t2), 2)
+    o2 = O.OracleIndex(t2, 255, level=2, kind="rlfm")
+    cc, ii = np.meshgrid(np.array([0, 3, 4]), np.arange(5002))
+    assert (g2.lf_map2(cc.ravel(), ii.ravel()) == o2.lf_map2(cc.ravel(), ii.ravel())).all()
+    assert g2.search(bytes([3] * 10)).locate_all() == o2.locate(bytes([3] * 10))
+
+
+def test_config4_shape_byte_text_rlfm():
+    """BASELINE config 4 shape at a size the oracle handles: sigma=255 text, len-16 substrings."""
+    n = 1 << 19
+    t = W.byte_text_np(n, 4)
+    gi = F.RLFMIndex(F.Text(t))
+    oi = O.OracleIndex(t, 255, kind="rlfm")
+    flat, off, _ = W.substring_patterns_np(t, 20000, 16, 6)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off, nthreads=8)
+    assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts >= 1).all()
+    flat_r, off_r = W.random_patterns_np(5000, 16, 255, 9)
+    gb = gi.search_many(flat=flat_r, off=off_r)
+    os_, oe = oi.count_batch(flat_r, off_r, nthreads=8)
+    assert (gb.s == os_).all() and (gb.e == oe).all()

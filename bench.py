@@ -81,7 +81,7 @@ def main():
     d_s = torch.empty(npat, dtype=torch.int64, device=dev)
     d_e = torch.empty(npat, dtype=torch.int64, device=dev)
     d_c = torch.empty(npat, dtype=torch.int64, device=dev)
-    gathered = torch.empty(total_pat, dtype=torch.int64, device=dev) if world > 1 else None
+    from fm_index_amd import sharding
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     h = index.handle()
@@ -92,8 +92,9 @@ def main():
                                      C.c_void_p(d_c.data_ptr()), sp)
         if rc != 0:
             raise RuntimeError(lib.fmx_last_error().decode())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, d_c)
+        if world > 1:   # config 5: RCCL all-gather of the per-pattern counts over xGMI
+            return sharding.gather_counts(d_c, total_pat)
+        return d_c
 
     def barrier():
         if world > 1:
@@ -106,8 +107,6 @@ def main():
     # kernel-only time over the timed region: HIP events on the launch stream
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)] if world > 1 else None
     t0 = time.perf_counter()
     ev0.record(stream)
     for k in range(args.steps):

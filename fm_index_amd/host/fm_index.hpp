@@ -1,0 +1,148 @@
+// fm_index.hpp -- header-only C++ mirror of the reference's public surface for the
+// count / locate path, over the C ABI in include/fmx.h.
+//
+//   reference (Rust)                                   here (C++)
+//   Text::new / Text::with_max_character  text.rs:28-49      fmx::Text
+//   FMIndex::new(&text)                   frontend.rs:195    fmx::FMIndex(text)
+//   FMIndexWithLocate::new(&text, level)  frontend.rs:205    fmx::FMIndexWithLocate(text, level)
+//   RLFMIndex / RLFMIndexWithLocate       frontend.rs:223    fmx::RLFMIndex / fmx::RLFMIndexWithLocate
+//   SearchIndex::search / len / heap_size frontend.rs:26-44  .search(p) / .len() / .heap_size()
+//   Search::search / count / iter_matches frontend.rs:70-84  Search::search / count / iter_matches
+//   MatchWithLocate::locate               frontend.rs:96-98  Match::locate
+//   Error::InvalidText(msg)               error.rs:3-15      fmx::Error (what() == Display)
+//
+// Single queries go through the batched entry points with a batch of one; use
+// search_many / locate_many for throughput.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "fmx.h"
+
+namespace fmx {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != FMX_OK) throw Error(rc, fmx_last_error());
+}
+
+class Text {  // text.rs:11-64
+ public:
+  explicit Text(std::vector<uint8_t> t, uint64_t max_character = 255)
+      : t_(std::move(t)), max_(max_character) {}
+  static Text with_max_character(std::vector<uint8_t> t, uint64_t m) { return Text(std::move(t), m); }
+  const std::vector<uint8_t> &text() const { return t_; }
+  uint64_t max_character() const { return max_; }
+
+ private:
+  std::vector<uint8_t> t_;
+  uint64_t max_;
+};
+
+class Index;
+
+class Match {  // frontend.rs:86-98
+ public:
+  Match(const Index *ix, uint64_t i) : ix_(ix), i_(i) {}
+  uint64_t locate() const;  // wrapper.rs:238-242
+  uint64_t row() const { return i_; }
+
+ private:
+  const Index *ix_;
+  uint64_t i_;
+};
+
+class Search {  // frontend.rs:70-84
+ public:
+  Search(const Index *ix, uint64_t s, uint64_t e, bool fresh) : ix_(ix), s_(s), e_(e), fresh_(fresh) {}
+  Search search(const std::vector<uint8_t> &pattern) const;   // wrapper.rs:103-124 (prepends)
+  Search search(const std::string &p) const { return search(std::vector<uint8_t>(p.begin(), p.end())); }
+  uint64_t count() const { return e_ - s_; }                  // wrapper.rs:132-134
+  std::pair<uint64_t, uint64_t> get_range() const { return {s_, e_}; }
+  std::vector<Match> iter_matches() const {                   // wrapper.rs:203-217
+    std::vector<Match> m;
+    for (uint64_t i = s_; i < e_; i++) m.emplace_back(ix_, i);
+    return m;
+  }
+  std::vector<uint64_t> locate_all() const;                   // iter_matches().map(locate)
+
+ private:
+  const Index *ix_;
+  uint64_t s_, e_;
+  bool fresh_;
+};
+
+class Index {
+ public:
+  Index(const Text &text, uint32_t kind, uint32_t level, int device = 0) {
+    check(fmx_build(text.text().data(), text.text().size(), 1, text.max_character(), kind, level, 0,
+                    device, &h_));
+  }
+  Index(const Index &) = delete;
+  Index &operator=(const Index &) = delete;
+  ~Index() { fmx_free(h_); }
+  Search search(const std::vector<uint8_t> &p) const { return Search(this, 0, 0, true).search(p); }
+  Search search(const std::string &p) const { return search(std::vector<uint8_t>(p.begin(), p.end())); }
+  uint64_t len() const { return fmx_len(h_); }
+  uint64_t heap_size() const { return fmx_index_bytes(h_); }
+  const fmx_index *handle() const { return h_; }
+  // batched: patterns[k] -> (s, e)
+  void search_many(const std::vector<std::vector<uint8_t>> &patterns, std::vector<uint64_t> &s,
+                   std::vector<uint64_t> &e) const {
+    std::vector<uint8_t> flat;
+    std::vector<uint64_t> off(1, 0);
+    for (auto &p : patterns) {
+      flat.insert(flat.end(), p.begin(), p.end());
+      off.push_back(flat.size());
+    }
+    if (flat.empty()) flat.push_back(0);
+    s.assign(patterns.size(), 0);
+    e.assign(patterns.size(), 0);
+    check(fmx_count_batch(h_, flat.data(), off.data(), patterns.size(), nullptr, s.data(), e.data(),
+                          nullptr));
+  }
+
+ private:
+  fmx_index *h_ = nullptr;
+};
+
+struct FMIndex : Index {
+  explicit FMIndex(const Text &t, int device = 0) : Index(t, FMX_KIND_FM, FMX_NO_LOCATE, device) {}
+};
+struct FMIndexWithLocate : Index {
+  FMIndexWithLocate(const Text &t, uint32_t level, int device = 0) : Index(t, FMX_KIND_FM, level, device) {}
+};
+struct RLFMIndex : Index {
+  explicit RLFMIndex(const Text &t, int device = 0) : Index(t, FMX_KIND_RLFM, FMX_NO_LOCATE, device) {}
+};
+struct RLFMIndexWithLocate : Index {
+  RLFMIndexWithLocate(const Text &t, uint32_t level, int device = 0) : Index(t, FMX_KIND_RLFM, level, device) {}
+};
+
+inline Search Search::search(const std::vector<uint8_t> &pattern) const {
+  uint64_t off[2] = {0, pattern.size()};
+  uint64_t se[2] = {s_, e_};
+  uint64_t s = 0, e = 0;
+  uint8_t dummy = 0;
+  check(fmx_count_batch(ix_->handle(), pattern.empty() ? &dummy : pattern.data(), off, 1,
+                        fresh_ ? nullptr : se, &s, &e, nullptr));
+  return Search(ix_, s, e, false);
+}
+inline std::vector<uint64_t> Search::locate_all() const {
+  uint64_t off[2] = {0, e_ - s_};
+  std::vector<uint64_t> pos(e_ - s_);
+  check(fmx_locate_batch(ix_->handle(), &s_, &e_, 1, off, pos.data()));
+  return pos;
+}
+inline uint64_t Match::locate() const {
+  uint64_t v = fmx_get_sa(ix_->handle(), i_);
+  if (v == ~0ull) throw Error(FMX_ERR_NO_LOCATE, fmx_last_error());
+  return v;
+}
+
+}  // namespace fmx

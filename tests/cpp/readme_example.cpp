@@ -1,0 +1,33 @@
+// The reference's README example (README.md:35-64) written against the C++ host mirror.
+// Built by tests/test_abi_cpu.py (compile + link only on CPU) and run by the -m gpu tests.
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include "fm_index.hpp"
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  std::ifstream f(argv[1], std::ios::binary);  // the README text incl. trailing \0
+  std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  try {
+    fmx::Text text(bytes);
+    fmx::FMIndexWithLocate index(text, 2);
+    auto search = index.search(std::string("dolor"));
+    std::printf("count %llu\n", (unsigned long long)search.count());
+    std::printf("positions");
+    for (auto &m : search.iter_matches()) std::printf(" %llu", (unsigned long long)m.locate());
+    std::printf("\n");
+    auto refined = index.search(std::string("lor")).search(std::string("do"));
+    std::printf("refined %llu\n", (unsigned long long)refined.count());
+    try {
+      fmx::FMIndex bad(fmx::Text(std::vector<uint8_t>{'n', 'o'}));
+    } catch (const fmx::Error &e) {
+      std::printf("error %s\n", e.what());
+    }
+  } catch (const fmx::Error &e) {
+    std::printf("FAILED %d %s\n", e.code, e.what());
+    return 1;
+  }
+  return 0;
+}

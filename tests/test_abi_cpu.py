@@ -55,3 +55,22 @@ def test_error_messages_match_reference(golden):
     msgs = {c["message"] for c in golden["invalid_texts"]["cases"]}
     got = {l.fmx_error_message(1).decode(), l.fmx_error_message(2).decode()}
     assert got == {"invalid text: " + m for m in msgs}  # error.rs:11 Display format
+
+
+def build_readme_example(tmpdir):
+    """g++ build of the C++ host mirror's README example against libfmx.so (C ABI only)."""
+    import subprocess
+    from fm_index_amd import _lib
+    exe = os.path.join(str(tmpdir), "readme_example")
+    subprocess.check_call([
+        "g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+        "-I" + os.path.join(ROOT, "fm_index_amd", "host"),
+        os.path.join(ROOT, "tests", "cpp", "readme_example.cpp"), "-o", exe,
+        "-L" + os.path.dirname(_lib.LIB_PATH), "-lfmx",
+        "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    exe = build_readme_example(tmp_path)
+    assert os.path.exists(exe)

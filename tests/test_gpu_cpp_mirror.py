@@ -1,0 +1,21 @@
+"""Runs the reference's README example through the C++ host mirror (fm_index.hpp -> C ABI)."""
+import subprocess
+
+import pytest
+
+from test_abi_cpu import build_readme_example
+
+pytestmark = pytest.mark.gpu
+
+
+def test_readme_example_cpp(golden, tmp_path):
+    exe = build_readme_example(tmp_path)
+    txt = tmp_path / "lorem.bin"
+    txt.write_bytes(golden["readme"]["text"].encode("latin-1"))
+    out = subprocess.run([exe, str(txt)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "count 4"
+    assert lines[1] == "positions 246 12 300 103"          # README.md:64, in this order
+    assert lines[2] == "refined 4"
+    assert lines[3] == "error invalid text: the given text must end with exactly one zero character"

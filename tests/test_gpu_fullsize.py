@@ -1,0 +1,102 @@
+"""BASELINE.json full sizes (n = 2^30) through size-independent properties:
+suffix-array sortedness + permutation checked on the device, count >= 1 for substrings, every
+located position holds its pattern, the source position is among the hits, executed steps, and
+bit-identity with the CPU oracle (fed the exported BWT) on a pattern sample.  Config 4 (RLFM
+over a sigma=255 text) additionally asserts RLFM (s,e) == FM (s,e)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fm_index_amd as F
+from fm_index_amd import _lib as L
+from fm_index_amd import workload as W
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 30
+
+
+def _count_dev(index, pat, off, npat):
+    import torch
+    lib = L.lib()
+    dev = pat.device
+    s = torch.empty(npat, dtype=torch.int64, device=dev)
+    e = torch.empty(npat, dtype=torch.int64, device=dev)
+    c = torch.empty(npat, dtype=torch.int64, device=dev)
+    rc = lib.fmx_count_batch_dev(index.handle(), C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()),
+                                 npat, None, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()),
+                                 C.c_void_p(c.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert lib.fmx_stream_status(index.handle()) == 0
+    return s, e, c
+
+
+def test_config2_config3_dna_1gb():
+    import torch
+    from oracle import fm_oracle as O
+    dev = torch.device("cuda", 0)
+    lib = L.lib()
+    text = W.dna_text_torch(N, 1, dev)
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=2, keep_sa=True)
+    assert index.len() == N and index.level() == 2
+    assert index.verify_sa() == 0                      # the array IS the suffix array
+    npat, m = 1 << 20, 32
+    pat, off, pos = W.substring_patterns_torch(text, npat, m, 3)
+    s, e, c = _count_dev(index, pat, off, npat)
+    assert bool((c >= 1).all())
+    # config 2b: uniform random patterns -> early exit path, checked against the oracle below
+    rflat, roff = W.random_patterns_np(1 << 16, 32, 4, 5)
+    rb = index.search_many(flat=rflat, off=roff)
+    # locate (config 3): exact positions verified against the text itself
+    d_off = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+    assert lib.fmx_offsets_dev(index.handle(), C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                               C.c_void_p(d_off.data_ptr()), None) == 0
+    total = int(d_off[-1].item())
+    assert total == int(c.sum().item())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    assert lib.fmx_locate_batch_dev(index.handle(), C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()),
+                                    npat, C.c_void_p(d_off.data_ptr()), total,
+                                    C.c_void_p(d_pos.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    hit_pat = torch.repeat_interleave(torch.arange(npat, device=dev), c)
+    ok = torch.ones(total, dtype=torch.bool, device=dev)
+    for j in range(m):
+        ok &= text[d_pos + j] == pat.view(npat, m)[hit_pat, j]
+    assert bool(ok.all())
+    found = torch.zeros(npat, dtype=torch.bool, device=dev)
+    found[hit_pat[d_pos == pos[hit_pat]]] = True
+    assert bool(found.all())
+    # hits of one pattern are distinct
+    key = hit_pat * N + d_pos
+    assert int(torch.unique(key).numel()) == total
+    # oracle (independent rank structure + driver) on a sample, from the exported BWT
+    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4,
+                                samples=index.export_sa_samples(), level=2)
+    k = 1 << 15
+    so, eo = oi.count_batch(pat[:k * m].cpu().numpy(), np.arange(k + 1, dtype=np.uint64) * np.uint64(m),
+                            nthreads=16)
+    assert (so == s[:k].cpu().numpy().view(np.uint64)).all()
+    assert (eo == e[:k].cpu().numpy().view(np.uint64)).all()
+    ooff, opos = oi.locate_batch(so[:4096], eo[:4096], nthreads=16)
+    assert (opos == d_pos[:int(ooff[-1])].cpu().numpy().view(np.uint64)).all()
+    rs, re = oi.count_batch(rflat, roff, nthreads=16)
+    assert (rs == rb.s).all() and (re == rb.e).all()
+
+
+def test_config4_rlfm_byte_text_1gb():
+    import torch
+    dev = torch.device("cuda", 0)
+    text = W.byte_text_torch(N, 4, dev)
+    npat, m = 1 << 20, 16
+    pat, off, pos = W.substring_patterns_torch(text, npat, m, 6)
+    rl = F.RLFMIndex.from_device_text(text.data_ptr(), N, 255)
+    s, e, c = _count_dev(rl, pat, off, npat)
+    assert bool((c >= 1).all())
+    runs = int(L.lib().fmx_num_runs(rl.handle()))
+    assert 0.99 * N < runs <= N
+    rl.close()
+    fm = F.FMIndex.from_device_text(text.data_ptr(), N, 255)
+    s2, e2, c2 = _count_dev(fm, pat, off, npat)
+    assert bool((s == s2).all()) and bool((e == e2).all())

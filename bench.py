@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-locate", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the real path) | gloo (single-GPU rehearsal of the N>1 code "
+                         "path: all ranks share cuda:0 and gather through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -50,8 +53,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "gloo":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(local)
@@ -93,6 +101,8 @@ def main():
         if rc != 0:
             raise RuntimeError(lib.fmx_last_error().decode())
         if world > 1:   # config 5: RCCL all-gather of the per-pattern counts over xGMI
+            if args.dist_backend == "gloo":
+                return sharding.gather_counts(d_c.cpu(), total_pat)
             return sharding.gather_counts(d_c, total_pat)
         return d_c
 
@@ -115,7 +125,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64,
+                          device="cpu" if args.dist_backend == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ev_ms = ev0.elapsed_time(ev1)

@@ -211,11 +211,14 @@ __global__ __launch_bounds__(BLK) void k_mwm_pieces(const uint8_t *__restrict__ 
     hist[(size_t)(2 * g + 1) * nrec + r] = own1;
   }
 }
-// scan = exclusive sum over hist laid out [code][record]; counter = scan - scan[code][0]
+// scan = exclusive sum over hist laid out [code][record]; counter = scan - scan[code][0] + add,
+// add = C[code] on a non-last level (the counter then IS the next-level position base) or the
+// caller's table (cs[] when the matrix has a single level), else 0.
 template <int FMT>
 __global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict__ scan,
                                                        uint32_t nrec, uint4 *__restrict__ rec,
-                                                       uint32_t *__restrict__ C) {
+                                                       uint32_t *__restrict__ C, int fold_c,
+                                                       const uint32_t *__restrict__ addend) {
   constexpr int NCODE = (FMT == 3) ? 8 : 16;
   uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (t < 16) C[t] = t < NCODE ? scan[(size_t)t * nrec] : 0u;
@@ -224,14 +227,16 @@ __global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict
   const uint32_t r = (uint32_t)(t >> 3);
   uint4 p = rec[t];
   if (FMT == 3) {
-    p.x = scan[(size_t)g * nrec + r] - scan[(size_t)g * nrec];
+    uint32_t b = scan[(size_t)g * nrec];
+    p.x = scan[(size_t)g * nrec + r] - b + (fold_c ? b : 0u) + (addend ? addend[g] : 0u);
   } else {
-    p.x = scan[(size_t)(2 * g) * nrec + r] - scan[(size_t)(2 * g) * nrec];
-    p.y = scan[(size_t)(2 * g + 1) * nrec + r] - scan[(size_t)(2 * g + 1) * nrec];
+    uint32_t b0 = scan[(size_t)(2 * g) * nrec], b1 = scan[(size_t)(2 * g + 1) * nrec];
+    p.x = scan[(size_t)(2 * g) * nrec + r] - b0 + (fold_c ? b0 : 0u) + (addend ? addend[2 * g] : 0u);
+    p.y = scan[(size_t)(2 * g + 1) * nrec + r] - b1 + (fold_c ? b1 : 0u) +
+          (addend ? addend[2 * g + 1] : 0u);
   }
   rec[t] = p;
 }
-
 
 // ---- RLFM construction (rlfmi.rs:30-96) --------------------------------------------
 // run starts: c0 starts at 0, a run begins wherever c != c0  (rlfmi.rs:41, 56-59)
@@ -415,7 +420,8 @@ int suffix_sort(const uint8_t *d_text, uint32_t n, uint32_t sym_bits, uint32_t *
 
 // builds the multi-ary wavelet matrix over d_seq[0..len) (u8 symbols of `L` bits).
 // d_seq is consumed (sorted in place between levels).
-int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t L, DevPool &pool) {
+int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t L, DevPool &pool,
+              const uint64_t *single_level_add = nullptr, uint32_t nadd = 0) {
   uint32_t nlv, bits[FMX_MAX_LEVELS];
   split_levels(L, &nlv, bits);
   memset(w, 0, sizeof *w);
@@ -455,10 +461,20 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
     uint8_t *tmp;
     FMX_HIP(pool.get(&tmp, tb));
     FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, scan, nh, (hipStream_t)0));
+    int fold_c = (l + 1 < nlv) ? 1 : 0;
+    uint32_t *d_add = nullptr;
+    if (nlv == 1 && single_level_add) {  // cs[] folded into the only level's counters
+      uint32_t hadd[16] = {0};
+      for (uint32_t c = 0; c < 16 && c < nadd; c++) hadd[c] = (uint32_t)single_level_add[c];
+      FMX_HIP(pool.get(&d_add, 16));
+      FMX_HIP(hipMemcpy(d_add, hadd, sizeof hadd, hipMemcpyHostToDevice));
+    }
     if (lv.fmt == 3)
-      hipLaunchKernelGGL(k_mwm_counters<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C);
+      hipLaunchKernelGGL(k_mwm_counters<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C, fold_c,
+                         (const uint32_t *)d_add);
     else
-      hipLaunchKernelGGL(k_mwm_counters<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C);
+      hipLaunchKernelGGL(k_mwm_counters<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, rec, C, fold_c,
+                         (const uint32_t *)d_add);
     FMX_HIP(hipGetLastError());
     lv.rec = rec;
     lv.C = C;
@@ -596,7 +612,7 @@ int build_rlfm(fmx_index *idx, uint8_t *d_L, uint32_t n, uint32_t L, DevPool &po
   pool.release(hk2); pool.release(stmp); pool.release(etmp); pool.release(flags);
   pool.release(starts);
   // S as a multi-ary wavelet matrix over the r run heads (rlfmi.rs:69-70)
-  if (int rc = build_mwm(idx, &dv.bw, heads, r, L, pool)) return rc;
+  if (int rc = build_mwm(idx, &dv.bw, heads, r, L, pool, rcs.data(), maxc + 1)) return rc;
   uint64_t *d_cs;
   uint32_t *d_K;
   FMX_HIP(pool.get(&d_cs, maxc + 1));
@@ -692,7 +708,9 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
     if (level >= 32 || (uint64_t)n <= (1ull << level)) level = 0;  // sample.rs:28-31
     uint64_t nsamp = (((uint64_t)n - 1) >> level) + 1;             // sample.rs:33
     uint32_t *d_samp;
-    FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint32_t)));
+    // +4: the locate kernel reads the sample through an aligned 16-B chunk
+    FMX_HIP(hipMalloc((void **)&d_samp, (nsamp + 4) * sizeof(uint32_t)));
+    FMX_HIP(hipMemset(d_samp, 0, (nsamp + 4) * sizeof(uint32_t)));
     if (int rc = keep(idx, d_samp, nsamp * 4)) return rc;
     hipLaunchKernelGGL(k_samples, dim3(nblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
     dv.samples = d_samp;
@@ -708,8 +726,8 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
 
   if (idx->kind == FMX_KIND_FM) {
     FMX_HIP(hipDeviceSynchronize());
-    if (int rc = build_mwm(idx, &dv.bw, d_bwt, n, L, pool)) return rc;
-    // K[c] = cs[c] - S_c
+    if (int rc = build_mwm(idx, &dv.bw, d_bwt, n, L, pool, idx->h_cs, maxc + 1)) return rc;
+    // K[c] = cs[c] - S_c (all zero when cs[] was folded into a single level)
     uint64_t *d_cs;
     uint32_t *d_K;
     FMX_HIP(pool.get(&d_cs, maxc + 1));

@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t fmx_mwm_rank(const FmxMwm &w, uint32_t c, ui
     const FmxLevel &L = w.lv[l];
     uint32_t code = (c >> L.shift) & L.mask;
     r = fmx_level_rank(L, pos, code, g);
-    if (l + 1 < w.nlevels) pos = L.C[code] + r;
+    if (l + 1 < w.nlevels) pos = r;  // C_l[code] is folded into the counters
   }
   return r;
 }
@@ -128,10 +128,9 @@ __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint3
       rs = fmx_group_sum(fmx_piece_rank<4>(a, fmx_off<4>(ps), code, g));
       re = fmx_group_sum(fmx_piece_rank<4>(b, fmx_off<4>(pe), code, g));
     }
-    if (l + 1 < w.nlevels) {
-      uint32_t base = L.C[code];
-      ps = base + rs;
-      pe = base + re;
+    if (l + 1 < w.nlevels) {  // C_l[code] is folded into the counters
+      ps = rs;
+      pe = re;
     }
   }
 }
@@ -157,7 +156,7 @@ __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, ui
       r = fmx_group_sum(fmx_piece_rank<4>(p, off, code, g));
     }
     sym |= code << L.shift;
-    if (l + 1 < w.nlevels) pos = L.C[code] + r;
+    if (l + 1 < w.nlevels) pos = r;  // C_l[code] folded
   }
   return r;
 }

@@ -14,7 +14,10 @@
 //                                                           of entries [16g, 16g+16)
 //   Between levels the whole sequence is stably sorted by the level's code (the
 //   wavelet-matrix trick generalised to 8-/16-ary), so position p maps to
-//   C[code] + rank_code(p) on the next level.
+//   C[code] + rank_code(p) on the next level.  The counters are stored ABSOLUTE:
+//   a non-last level's cnt[code] already includes C[code] (so cnt + popcount IS the next
+//   position), and when there is a single level cnt[c] includes cs[c] (sais.rs:9-32), so
+//   cnt + popcount IS lf_map2(c, i) (fm_index.rs:93-95) and K[] is all zero.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

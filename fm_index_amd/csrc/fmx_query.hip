@@ -11,10 +11,17 @@
 // early (the `s == e` break of wrapper.rs:111-113, or a short locate walk) picks
 // up the next unit while its wave-mates keep stepping -- no lane idles on
 // divergence except in the tail.  Integer / popcount work only; HBM-bound.
+#include <cstdlib>
 #include "fmx_device.h"
 
 #define FMX_BLOCK 256
 #define FMX_MAX_BLOCKS 2048  // 256 CUs x 8 resident 256-thread blocks
+
+// kernel variant selector for experiments (FMX_VARIANT=0 forces the generic kernels)
+static inline int fmx_variant() {
+  const char *v = getenv("FMX_VARIANT");
+  return v ? atoi(v) : 1;
+}
 
 static inline unsigned fmx_grid_for_groups(uint64_t units) {
   uint64_t blocks = (units * FMX_GROUP + FMX_BLOCK - 1) / FMX_BLOCK;
@@ -87,20 +94,127 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// count, single 3-bit level (L <= 3: DNA, the BASELINE configs 1/2/3/5).
+// The record counters are absolute (cs[] folded in), so one 128-B line per endpoint IS
+// lf_map2(c, i); no level descriptors, no K[] lookup.  Per step: the two record loads and
+// the NEXT pattern byte are issued together, then one wait; the second record load is
+// skipped when both interval ends fall into the same record (e - s < 256 most of the time).
+// PPG = patterns a group advances concurrently (independent chains -> more loads in flight).
+// ---------------------------------------------------------------------------
+template <int PPG, bool SKIP>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
+    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
+    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+
+  uint64_t k[PPG], pbeg[PPG];
+  uint32_t j[PPG], s[PPG], e[PPG], c[PPG];
+  bool active[PPG], fresh[PPG];
+  uint32_t nsteps = 0;
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < PPG; q++) {
+    k[q] = gid + (uint64_t)q * ngroups;
+    active[q] = k[q] < npat;
+    fresh[q] = true;
+    any |= active[q];
+    pbeg[q] = 0; j[q] = 0; s[q] = 0; e[q] = 0; c[q] = 0;
+  }
+  while (any) {
+#pragma unroll
+    for (int q = 0; q < PPG; q++) {
+      if (active[q] && fresh[q]) {
+        pbeg[q] = off[k[q]];
+        j[q] = (uint32_t)(off[k[q] + 1] - pbeg[q]);
+        if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
+          s[q] = (uint32_t)s0e0[2 * k[q]];
+          e[q] = (uint32_t)s0e0[2 * k[q] + 1];
+        } else {               // (0, len)   wrapper.rs:41
+          s[q] = 0;
+          e[q] = n;
+        }
+        c[q] = j[q] ? pat[pbeg[q] + j[q] - 1] : 0u;   // last symbol: pattern.iter().rev()
+        fresh[q] = false;
+      }
+    }
+    // issue every load of this round first
+    uint4 a[PPG], b[PPG];
+    uint32_t cn[PPG];
+    bool stepping[PPG];
+#pragma unroll
+    for (int q = 0; q < PPG; q++) {
+      stepping[q] = active[q] && j[q] != 0 && c[q] <= max_character;
+      cn[q] = 0;
+      if (stepping[q]) {
+        uint32_t rs = s[q] >> 8, re = e[q] >> 8;
+        a[q] = rec[(size_t)rs * 8u + g];
+        if (SKIP) {
+          b[q] = make_uint4(0u, 0u, 0u, 0u);
+          if (re != rs) b[q] = rec[(size_t)re * 8u + g];
+        } else {
+          b[q] = rec[(size_t)re * 8u + g];
+        }
+        if (j[q] > 1) cn[q] = pat[pbeg[q] + j[q] - 2];
+      }
+    }
+    any = false;
+#pragma unroll
+    for (int q = 0; q < PPG; q++) {
+      if (!active[q]) continue;
+      bool done = (j[q] == 0);
+      if (!done) {
+        if (!stepping[q]) {                            // reference: panic on cs[c]
+          if (g == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
+          s[q] = 0; e[q] = 0; done = true;
+        } else {
+          uint4 be = b[q];
+          if (SKIP && (s[q] >> 8) == (e[q] >> 8)) be = a[q];
+          uint32_t ns = fmx_group_sum(fmx_piece_rank<3>(a[q], s[q] & 255u, c[q], g));  // wrapper.rs:109
+          uint32_t ne = fmx_group_sum(fmx_piece_rank<3>(be, e[q] & 255u, c[q], g));    // wrapper.rs:110
+          s[q] = ns; e[q] = ne;
+          c[q] = cn[q];
+          j[q]--;
+          nsteps++;
+          if (ns == ne || j[q] == 0) done = true;      // wrapper.rs:111-113
+        }
+      }
+      if (done) {
+        if (g == 0) {
+          if (out_s) out_s[k[q]] = s[q];
+          if (out_e) out_e[k[q]] = e[q];
+          if (out_cnt) out_cnt[k[q]] = (uint64_t)(e[q] - s[q]);   // wrapper.rs:132-134
+        }
+        k[q] += (uint64_t)PPG * ngroups;
+        active[q] = k[q] < npat;
+        fresh[q] = true;
+      }
+      any |= active[q];
+    }
+  }
+  if (steps_out && g == 0 && nsteps)
+    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---------------------------------------------------------------------------
 // locate
 // ---------------------------------------------------------------------------
 // exclusive offsets -> rows: out_pos[off[k] + j] = s[k] + j   (wrapper.rs:203-217: i = s..e-1
 // ascending).  One 8-lane group per pattern, lanes stride over its rows.
+template <typename T>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
-    const uint64_t *__restrict__ off, uint64_t npat, uint64_t *__restrict__ out_pos) {
+    const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos) {
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   for (uint64_t k = gid; k < npat; k += ngroups) {
     uint64_t a = s[k], b = e[k], o = off[k];
     uint64_t cnt = b > a ? b - a : 0;
-    for (uint64_t t = g; t < cnt; t += FMX_GROUP) out_pos[o + t] = a + t;
+    for (uint64_t t = g; t < cnt; t += FMX_GROUP) out_pos[o + t] = (T)(a + t);
   }
 }
 
@@ -138,6 +252,72 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(FmxDev ix, uint64
       row = fmx_lf_map_any<KIND>(ix, row, g, sym);
       steps++;
       nsteps++;
+    }
+  }
+  if (steps_out && g == 0 && nsteps)
+    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// locate walk, single 3-bit level (DNA).  Every iteration a group issues exactly ONE 16-B
+// load per lane whose address depends on its state -- a record piece while walking
+// (fm_index.rs:134-137) or the aligned chunk holding its SA sample once the row is sampled
+// (sample.rs:46-60) -- so walking and finishing groups of one wave overlap their latencies
+// instead of serialising two branches.  The next hit's row is prefetched a walk ahead.
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3_kernel(
+    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
+    uint32_t sa_level, uint64_t total, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  const uint32_t lmask = (1u << sa_level) - 1u;
+  const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
+
+  uint64_t h = gid;
+  bool active = h < total;
+  uint32_t row = active ? rows[h] : 0u;
+  uint64_t hn = h + ngroups;                       // next hit of this group
+  uint32_t steps = 0, nsteps = 0;
+  // a finished position is stored one iteration late, right BEHIND that iteration's loads: the
+  // single vmcnt(0) that waits for the loads then also covers the store (vmcnt is in order), so
+  // the store's completion is never waited for on its own
+  bool pending = false;
+  uint64_t pend_h = 0, pend_v = 0;
+  while (active || pending) {
+    const bool flush = pending;
+    const uint64_t fl_h = pend_h, fl_v = pend_v;
+    pending = false;
+    if (!active) {
+      if (flush && g == 0) out_pos[fl_h] = fl_v;
+    } else {
+      const bool sampled = (row & lmask) == 0;
+      const uint32_t si = row >> sa_level;
+      const uint4 *addr = sampled ? (samp4 + (si >> 2)) : (rec + ((size_t)(row >> 8) * 8u + g));
+      const uint4 p = *addr;
+      // the next hit's row rides along with every probe (an L1/L2 hit after its first touch), so
+      // starting the next walk never waits on a dependent load of its own
+      const uint32_t row_next = (hn < total) ? rows[hn] : 0u;
+      if (flush && g == 0) out_pos[fl_h] = fl_v;   // issued behind this iteration's loads
+      if (sampled) {
+        uint32_t w = si & 3u;
+        uint32_t sa = w == 0 ? p.x : (w == 1 ? p.y : (w == 2 ? p.z : p.w));
+        uint64_t v = (uint64_t)sa + steps;          // fm_index.rs:131-133: (sa + steps) % len
+        if (v >= n) v -= n;
+        pend_v = v;
+        pend_h = h;
+        pending = true;
+        h = hn;
+        active = h < total;
+        row = row_next;
+        steps = 0;
+        hn = h + ngroups;
+      } else {
+        const uint32_t off = row & 255u;
+        uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
+        row = fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));  // lf_map: counters are absolute
+        steps++;
+        nsteps++;
+      }
     }
   }
   if (steps_out && g == 0 && nsteps)
@@ -331,7 +511,21 @@ int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t 
   unsigned grid = fmx_grid_for_groups(npat);
   fmx_time_begin(idx, st);
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
-  if (idx->kind == FMX_KIND_FM)
+  const FmxMwm &w = idx->dev.bw;
+  int variant = fmx_variant();
+  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && variant != 0) {
+#define FMX_F3_LAUNCH(PPG, SKIP)                                                                   \
+  hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP>), dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), \
+                     dim3(FMX_BLOCK), 0, st, w.lv[0].rec, idx->dev.n, idx->dev.max_character,        \
+                     idx->dev.status, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+    switch (variant) {
+      case 2: FMX_F3_LAUNCH(2, false); break;
+      case 3: FMX_F3_LAUNCH(1, true); break;
+      case 4: FMX_F3_LAUNCH(2, true); break;
+      case 5: FMX_F3_LAUNCH(4, false); break;
+      default: FMX_F3_LAUNCH(1, false); break;
+    }
+  } else if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
                        d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
   else
@@ -362,10 +556,26 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
                       hipStream_t st) {
   if (npat == 0 || total == 0) return FMX_OK;
-  hipLaunchKernelGGL(fmx_expand_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
+  const FmxMwm &w = idx->dev.bw;
+  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
+  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && fmx_variant() != 0) {
+    // rows in their own read-only buffer: the walk's loads never alias its stores
+    uint32_t *rows = nullptr;
+    FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0,
+                       st, d_s, d_e, d_off, npat, rows);
+    fmx_time_begin(idx, st);
+    hipLaunchKernelGGL(fmx_locate_f3_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
+                       w.lv[0].rec, idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, rows, d_pos,
+                       steps);
+    fmx_time_end(idx, st);
+    FMX_HIP(hipGetLastError());
+    FMX_HIP(hipFreeAsync(rows, st));
+    return FMX_OK;
+  }
+  hipLaunchKernelGGL(fmx_expand_kernel<uint64_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
                      d_s, d_e, d_off, npat, d_pos);
   fmx_time_begin(idx, st);
-  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(total)),
                        dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);

@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-locate", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm"],
+                    help="dna = config 2/3 (headline); bytes-fm / bytes-rlfm = config 4 text "
+                         "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real path) | gloo (single-GPU rehearsal of the N>1 code "
                          "path: all ranks share cuda:0 and gather through host memory)")
@@ -68,17 +71,27 @@ def main():
 
     n = 1 << args.log2n
     npat, m = args.npat, args.plen
+    dna = args.workload == "dna"
+    if not dna and args.plen == 32:
+        m = 16                                   # config 4: length-16 patterns
+    maxc = 4 if dna else 255
+    Lbits = 3 if dna else 8
+    # 2 endpoints x L levels x 64 B (FM); 2 x (2L+4) probes x 64 B (RLFM)
+    bytes_per_char = 2 * (2 * Lbits + 4) * 64 if args.workload == "bytes-rlfm" else 2 * Lbits * 64
     # ---- synthetic inputs: text seed 1, patterns seed 3 / 7 ----
     t0 = time.time()
-    text = W.dna_text_torch(n, 1, dev)
+    text = W.dna_text_torch(n, 1, dev) if dna else W.byte_text_torch(n, 4, dev)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     level = None if args.no_locate else args.level
-    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=level, device=local) \
-        if level is not None else F.FMIndex.from_device_text(text.data_ptr(), n, 4, device=local)
+    if args.workload == "bytes-rlfm":
+        cls = F.RLFMIndexWithLocate if level is not None else F.RLFMIndex
+    else:
+        cls = F.FMIndexWithLocate if level is not None else F.FMIndex
+    index = cls.from_device_text(text.data_ptr(), n, maxc, level=level, device=local)
     build_ms = lib.fmx_build_ms(index.handle())
     # global pattern set = world * npat substrings; this rank owns a contiguous shard
-    seed = 3 if world == 1 else 7
+    seed = (3 if world == 1 else 7) if dna else 6
     total_pat = npat * world
     z = W.splitmix64_torch(seed, rank * npat, npat, dev)
     pos = W.umod_torch(z, n - 1 - m)
@@ -148,12 +161,11 @@ def main():
     # dominant kernel: fmx_count_kernel; avg launch duration from the event bracket of the timed
     # region at N=1 (launches are back to back on one stream); per-launch event at N>1
     avg_kernel_s = (ev_ms / 1e3) / args.steps if world == 1 else kernel_ms_single / 1e3
-    achieved = chars_per_step_rank * BYTES_PER_CHAR_L3 / avg_kernel_s / 1e9
+    achieved = chars_per_step_rank * bytes_per_char / avg_kernel_s / 1e9
     roofline = {"bound": "hbm", "kernel": "fmx_count_kernel", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "algorithmic_bytes_per_char": BYTES_PER_CHAR_L3,
-                "layout_bytes_per_char": 2 * 128,
+                "algorithmic_bytes_per_char": bytes_per_char,
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
 
     out = {
@@ -161,8 +173,10 @@ def main():
         "value": value, "unit": "pattern-chars/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d "
-                               "substring patterns per GPU" % (args.log2n, npat, m),
+        "config": {"workload": ("config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d "
+                                "substring patterns per GPU" % (args.log2n, npat, m)) if dna else
+                               ("config4 (%s): n=2^%d sigma=255 byte text (L=8), %d x len-%d substring "
+                                "patterns per GPU" % (args.workload, args.log2n, npat, m)),
                    "text_len": n, "patterns_per_gpu": npat, "pattern_len": m,
                    "parallelism": "patterns sharded x%d, index replicated" % world,
                    "index_bytes": index.heap_size(), "build_ms": round(build_ms, 1),
@@ -208,7 +222,7 @@ def main():
         found_src[hit_pat[d_pos[:total_hits] == pos[hit_pat]]] = True
         assert bool(found_src.all()), "source position missing from locate output"
         kavg = sum(kms) / len(kms) / 1e3
-        lbytes = lf_steps * 3 * 64 + total_hits * 64   # steps*L*64 + 64 per hit
+        lbytes = lf_steps * Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
         out["locate"] = {"hits_per_s": total_hits * lsteps / ldt, "hits": total_hits,
                          "lf_steps": lf_steps, "level": args.level,
                          "ms_per_batch": ldt / lsteps * 1e3,
@@ -224,7 +238,7 @@ def main():
         t0 = time.time()
         bwt = index.export_bwt()
         cs = index.export_cs()
-        oi = O.OracleIndex.from_bwt(bwt, cs, 4, native=True)
+        oi = O.OracleIndex.from_bwt(bwt, cs, maxc, native=True)
         del bwt
         t_ob = time.time() - t0
         cores = os.cpu_count() or 1
@@ -242,12 +256,16 @@ def main():
         k = int(min(npat, max(k0, k0 * args.cpu_seconds / max(t_probe, 1e-6))))
         t_all, so, eo = cpu_run(k, cores)
         assert (so == s_h[:k]).all() and (eo == e_h[:k]).all(), "GPU != oracle on the CPU sample"
+        times = [t_all]
+        while sum(times) < args.cpu_seconds and len(times) < 25:   # ~10-30 s of CPU work in total
+            times.append(cpu_run(k, cores)[0])
+        t_all = sorted(times)[len(times) // 2]
         k1 = max(1024, k // cores)
         t_one, _, _ = cpu_run(k1, 1)
         out["cpu_baseline"] = {"value": k * m / t_all, "unit": "pattern-chars/s", "cores": cores,
                                "kind": "port",
                                "sample": "first %d of the %d patterns (same text, same index), "
-                                         "%.1f s; GPU (s,e) bit-identical on the sample" % (k, npat, t_all),
+                                         "median of %d runs of %.2f s; GPU (s,e) bit-identical on the sample" % (k, npat, len(times), t_all),
                                "single_thread_value": k1 * m / t_one,
                                "oracle_build_s": round(t_ob, 1)}
         oi.close()

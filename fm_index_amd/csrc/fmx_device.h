@@ -248,8 +248,8 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
                                                  uint32_t &e, uint32_t g) {
   if (KIND == FMX_KIND_FM) {
     uint32_t rs, re;
+    const uint32_t kc = ix.K[c];  // issued ahead of the record loads
     fmx_mwm_rank2(ix.bw, c, s, e, g, rs, re);
-    uint32_t kc = ix.K[c];
     s = kc + rs;  // fm_index.rs:93-95
     e = kc + re;
   } else {

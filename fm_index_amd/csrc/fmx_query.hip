@@ -48,6 +48,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
   uint64_t pbeg = 0;         // first symbol of the pattern
   uint32_t j = 0;            // symbols still to consume (from the back)
   uint32_t s = 0, e = 0;
+  uint32_t c = 0;            // symbol of the coming step (loaded one step ahead)
   uint32_t nsteps = 0;
 
   while (active) {
@@ -61,17 +62,20 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
         s = 0;
         e = ix.n;
       }
+      c = j ? pat[pbeg + j - 1] : 0u;                  // pattern.iter().rev()  wrapper.rs:108
       fresh = false;
     }
     bool done = (j == 0);
     if (!done) {
-      uint32_t c = pat[pbeg + j - 1];                 // pattern.iter().rev()  wrapper.rs:108
-      j--;
       if (c > ix.max_character) {                      // reference: panic on cs[c]
         if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_SYMBOL_RANGE);
         s = 0; e = 0; done = true;
       } else {
+        // the next symbol rides along with this step's record loads
+        const uint32_t cn = j > 1 ? pat[pbeg + j - 2] : 0u;
         fmx_lf_map2_pair<KIND>(ix, c, s, e, g);        // wrapper.rs:109-110
+        c = cn;
+        j--;
         nsteps++;
         if (s == e || j == 0) done = true;             // wrapper.rs:111-113
       }
@@ -88,7 +92,6 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
     }
   }
   if (steps_out) {
-    // one add per group leader; wave-reduced by the compiler's atomic coalescing
     if (g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
   }
 }
@@ -318,6 +321,87 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3_kernel(
         steps++;
         nsteps++;
       }
+    }
+  }
+  if (steps_out && g == 0 && nsteps)
+    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// locate walk v2: a WAVE owns a contiguous chunk of hits and hands them to its 8 groups
+// dynamically (ballot + prefix popcount, no atomics), so the wave runs sum(work)/8 iterations
+// instead of max over its groups of their statically assigned work.  The rows of the next 64
+// hits sit in a register window (one coalesced load per 56 hits); a finishing group takes its
+// next row from the window with a ds_bpermute -- no dependent memory access to start a walk.
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
+    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
+    uint32_t sa_level, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lmask = (1u << sa_level) - 1u;
+  const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
+  uint64_t w0 = wave * hits_per_wave;
+  if (w0 >= total) return;                          // wave-uniform
+  uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
+
+  uint64_t win_base = w0;
+  uint32_t win = rows[win_base + lane < total ? win_base + lane : total - 1];
+  uint64_t h = w0 + grp;
+  bool active = h < w1;
+  uint32_t row = (uint32_t)__shfl((int)win, (int)grp);
+  uint64_t next = w0 + 8 < w1 ? w0 + 8 : w1;
+  uint32_t steps = 0, nsteps = 0;
+  bool pending = false;
+  uint64_t pend_h = 0, pend_v = 0;
+  while (__any(active || pending)) {
+    if (next + 8 > win_base + 64 && next < w1) {    // wave-uniform window refill
+      win_base = next;
+      win = rows[win_base + lane < total ? win_base + lane : total - 1];
+    }
+    const bool flush = pending;
+    const uint64_t fl_h = pend_h, fl_v = pend_v;
+    pending = false;
+    bool fin = false;
+    if (!active) {
+      if (flush && g == 0) out_pos[fl_h] = fl_v;
+    } else {
+      const bool sampled = (row & lmask) == 0;
+      const uint32_t si = row >> sa_level;
+      const uint4 *addr = sampled ? (samp4 + (si >> 2)) : (rec + ((size_t)(row >> 8) * 8u + g));
+      const uint4 p = *addr;
+      if (flush && g == 0) out_pos[fl_h] = fl_v;   // behind this iteration's load (see above)
+      if (sampled) {
+        uint32_t w = si & 3u;
+        uint32_t sa = w == 0 ? p.x : (w == 1 ? p.y : (w == 2 ? p.z : p.w));
+        uint64_t v = (uint64_t)sa + steps;          // fm_index.rs:131-133: (sa + steps) % len
+        if (v >= n) v -= n;
+        pend_v = v;
+        pend_h = h;
+        pending = true;
+        fin = true;
+      } else {
+        const uint32_t off = row & 255u;
+        uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
+        row = fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));  // lf_map: counters are absolute
+        steps++;
+        nsteps++;
+      }
+    }
+    const unsigned long long fmask = __ballot(fin && g == 0);    // one bit per finishing group
+    if (fmask) {                                                  // wave-uniform
+      const uint32_t leader = lane & ~7u;
+      const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
+      const uint64_t h_new = next + my_rank;
+      const uint32_t r_new = (uint32_t)__shfl((int)win, (int)((h_new - win_base) & 63u));
+      if (fin) {
+        h = h_new;
+        active = h < w1;
+        row = r_new;
+        steps = 0;
+      }
+      next += (uint64_t)__popcll(fmask);
     }
   }
   if (steps_out && g == 0 && nsteps)
@@ -565,9 +649,18 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0,
                        st, d_s, d_e, d_off, npat, rows);
     fmx_time_begin(idx, st);
-    hipLaunchKernelGGL(fmx_locate_f3_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
-                       w.lv[0].rec, idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, rows, d_pos,
-                       steps);
+    if (fmx_variant() == 6) {
+      hipLaunchKernelGGL(fmx_locate_f3_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
+                         w.lv[0].rec, idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, rows,
+                         d_pos, steps);
+    } else {
+      uint64_t nwaves = (total + 7) / 8;
+      if (nwaves > (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64)) nwaves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
+      uint64_t hpw = (total + nwaves - 1) / nwaves;
+      unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+      hipLaunchKernelGGL(fmx_locate_f3w_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
+                         idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hpw, rows, d_pos, steps);
+    }
     fmx_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     FMX_HIP(hipFreeAsync(rows, st));

@@ -162,9 +162,18 @@ def main():
     # region at N=1 (launches are back to back on one stream); per-launch event at N>1
     avg_kernel_s = (ev_ms / 1e3) / args.steps if world == 1 else kernel_ms_single / 1e3
     achieved = chars_per_step_rank * bytes_per_char / avg_kernel_s / 1e9
+    # HBM-side bytes per launch: PMC counters of the same command, collected in separate
+    # rocprofv3 passes and corrected as profiles/README.md describes (None when not profiled)
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f).get("%s:%d:%d:%d" % (args.workload, npat, m, args.log2n), {})
+    except OSError:
+        pass
     roofline = {"bound": "hbm", "kernel": "fmx_count_kernel", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic.get("count", {}).get("bytes"),
+                "algorithmic_bytes_per_launch": chars_per_step_rank * bytes_per_char,
                 "algorithmic_bytes_per_char": bytes_per_char,
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
 
@@ -229,7 +238,8 @@ def main():
                          "roofline": {"bound": "hbm", "kernel": "fmx_locate_kernel",
                                       "achieved": round(lbytes / kavg / 1e9, 1), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(lbytes / kavg / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_kernel_ms": round(kavg * 1e3, 4), "traffic": None}}
+                                      "avg_kernel_ms": round(kavg * 1e3, 4),
+                                      "traffic": traffic.get("locate", {}).get("bytes")}}
         del hit_pat, chk, found_src
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's cores ----

@@ -135,6 +135,35 @@ __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint3
   }
 }
 
+// N positions of the same symbol at once: per level all N record loads are issued before the
+// first popcount (more lines in flight per group; equal lines are merged by the L1)
+template <int N>
+__device__ __forceinline__ void fmx_mwm_rankN(const FmxMwm &w, uint32_t c, uint32_t (&pos)[N],
+                                              uint32_t g, uint32_t (&r)[N]) {
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    const uint32_t code = (c >> L.shift) & L.mask;
+    uint4 p[N];
+    if (L.fmt == 3) {
+#pragma unroll
+      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<3>(L, pos[q], g);
+#pragma unroll
+      for (int q = 0; q < N; q++)
+        r[q] = fmx_group_sum(fmx_piece_rank<3>(p[q], fmx_off<3>(pos[q]), code, g));
+    } else {
+#pragma unroll
+      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<4>(L, pos[q], g);
+#pragma unroll
+      for (int q = 0; q < N; q++)
+        r[q] = fmx_group_sum(fmx_piece_rank<4>(p[q], fmx_off<4>(pos[q]), code, g));
+    }
+    if (l + 1 < w.nlevels) {
+#pragma unroll
+      for (int q = 0; q < N; q++) pos[q] = r[q];  // C_l[code] is folded into the counters
+    }
+  }
+}
+
 // access + rank along the same positions (fm_index.rs:82-91: get_l then rank of that
 // symbol): returns r with lf_map(i) = K[sym] + r and the symbol itself.
 __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, uint32_t g,
@@ -220,6 +249,40 @@ __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t 
   return lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
 }
 
+// two selects on the same vector, probes interleaved (hints, then records)
+__device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0, uint32_t k1,
+                                                 uint32_t g, uint32_t &out0, uint32_t &out1) {
+  const bool v0 = k0 < bv.ones, v1 = k1 < bv.ones;
+  const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
+  uint32_t lo0 = bv.sel[q0 / FMX_SEL_STEP], hi0 = bv.sel[q0 / FMX_SEL_STEP + 1];
+  uint32_t lo1 = bv.sel[q1 / FMX_SEL_STEP], hi1 = bv.sel[q1 / FMX_SEL_STEP + 1];
+  while (lo0 < hi0 || lo1 < hi1) {  // group-uniform binary searches over record bases
+    const uint32_t m0 = (lo0 + hi0 + 1u) >> 1, m1 = (lo1 + hi1 + 1u) >> 1;
+    const uint32_t x0 = bv.rec[(size_t)m0 * 8u].x, x1 = bv.rec[(size_t)m1 * 8u].x;
+    if (lo0 < hi0) { if (x0 <= q0) lo0 = m0; else hi0 = m0 - 1u; }
+    if (lo1 < hi1) { if (x1 <= q1) lo1 = m1; else hi1 = m1 - 1u; }
+  }
+  const uint4 a = bv.rec[(size_t)lo0 * 8u + g];
+  const uint4 b = bv.rec[(size_t)lo1 * 8u + g];
+  uint32_t res[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const uint4 pc = t ? b : a;
+    const uint32_t k = t ? q1 : q0, lo = t ? lo1 : lo0;
+    uint32_t p = fmx_group_sum(pc.x <= k ? 1u : 0u) - 1u;
+    uint32_t rem = k - pc.x;
+    uint32_t c0 = __popc(pc.y), c1 = __popc(pc.z);
+    uint32_t pos;
+    if (rem < c0) pos = fmx_select32(pc.y, rem);
+    else if (rem < c0 + c1) pos = 32u + fmx_select32(pc.z, rem - c0);
+    else pos = 64u + fmx_select32(pc.w, rem - c0 - c1);
+    pos = fmx_group_sum((g == p) ? pos : 0u);
+    res[t] = lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
+  }
+  out0 = v0 ? res[0] : bv.len;
+  out1 = v1 ? res[1] : bv.len;
+}
+
 // RLFMIndexBackend::lf_map2 (rlfmi.rs:135-143)
 __device__ __forceinline__ uint32_t fmx_rlfm_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i,
                                                      uint32_t g) {
@@ -242,6 +305,34 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i
   return fmx_bits_select(ix.bp, nr, g) + i - fmx_bits_select(ix.b, j, g);
 }
 
+// both interval ends of one backward-search step on the RLFM index, staged so that the
+// independent probes of the two ends overlap:  B ranks -> S ranks -> B' selects.
+// get_l(i) == c (rlfmi.rs:138) is decided WITHOUT the wavelet access: with lo = b.rank1(i+1)-1
+// (the run holding row i) it is  s.rank(lo+1, c) - s.rank(lo, c) == 1, and b.rank1(i) is lo or
+// lo+1, so one rank chain over the adjacent positions {lo, lo+1} yields nr and the comparison
+// from the same cache lines.
+__device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
+                                                      uint32_t &e, uint32_t g) {
+  const uint32_t kc = ix.K[c];
+  uint32_t bs, be;
+  const uint32_t js = fmx_bits_rank(ix.b, s, g, bs);  // b.rank1(i)        rlfmi.rs:136
+  const uint32_t je = fmx_bits_rank(ix.b, e, g, be);
+  const uint32_t los = js - 1u + bs, loe = je - 1u + be;  // b.rank1(i+1) - 1   rlfmi.rs:124
+  uint32_t pos[4] = {los, los + 1u, loe, loe + 1u};
+  uint32_t r[4];
+  fmx_mwm_rankN<4>(ix.bw, c, pos, g, r);
+  const uint32_t nrs = kc + (bs ? r[0] : r[1]);       // cs[c] + s.rank(j, c)   rlfmi.rs:137,139
+  const uint32_t nre = kc + (be ? r[2] : r[3]);
+  const bool eqs = (r[1] - r[0]) == 1u;               // get_l(i) == c          rlfmi.rs:138
+  const bool eqe = (r[3] - r[2]) == 1u;
+  uint32_t ns, ne;
+  fmx_bits_select2(ix.bp, nrs, nre, g, ns, ne);       // bp.select1(cs[c] + nr)
+  if (eqs) ns = ns + s - fmx_bits_select(ix.b, js, g);  // + i - b.select1(j)   rlfmi.rs:141
+  if (eqe) ne = ne + e - fmx_bits_select(ix.b, je, g);
+  s = ns;
+  e = ne;
+}
+
 // kind-dispatching forms used by the kernels
 template <int KIND>
 __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
@@ -253,8 +344,7 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
     s = kc + rs;  // fm_index.rs:93-95
     e = kc + re;
   } else {
-    s = fmx_rlfm_lf_map2(ix, c, s, g);
-    e = fmx_rlfm_lf_map2(ix, c, e, g);
+    fmx_rlfm_lf_map2_pair(ix, c, s, e, g);
   }
 }
 template <int KIND>

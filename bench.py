@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm"],
                     help="dna = config 2/3 (headline); bytes-fm / bytes-rlfm = config 4 text "
                          "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex")
+    ap.add_argument("--pair-index", action="store_true",
+                    help="also build the opt-in 2-step index (FMX_FLAG_PAIR_INDEX) and report its "
+                         "count rate in an extra 'pair_index' object (the headline stays 1-step)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real path) | gloo (single-GPU rehearsal of the N>1 code "
                          "path: all ranks share cuda:0 and gather through host memory)")
@@ -192,6 +195,35 @@ def main():
                    "textgen_s": round(t_gen, 2)},
         "roofline": roofline,
     }
+
+    # ---- opt-in 2-step index: same patterns, results asserted identical ----
+    if args.pair_index and dna:
+        pidx = F.FMIndex.from_device_text(text.data_ptr(), n, maxc, device=local, pair_index=True)
+        assert pidx.has_pair_index()
+        ps = torch.empty(npat, dtype=torch.int64, device=dev)
+        pe = torch.empty(npat, dtype=torch.int64, device=dev)
+
+        def pstep():
+            rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(pat.data_ptr()),
+                                         C.c_void_p(off.data_ptr()), npat, None,
+                                         C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
+            assert rc == 0
+        for _ in range(args.warmup):
+            pstep()
+        torch.cuda.synchronize()
+        p0 = torch.cuda.Event(enable_timing=True)
+        p1 = torch.cuda.Event(enable_timing=True)
+        p0.record(stream)
+        for _ in range(args.steps):
+            pstep()
+        p1.record(stream)
+        torch.cuda.synchronize()
+        pms = p0.elapsed_time(p1) / args.steps
+        assert bool((ps == d_s).all()) and bool((pe == d_e).all()), "pair index != 1-step index"
+        out["pair_index"] = {"value": chars_per_step_rank / (pms / 1e3), "unit": "pattern-chars/s",
+                             "ms_per_step": pms, "index_bytes": pidx.heap_size(),
+                             "note": "opt-in FMX_FLAG_PAIR_INDEX; (s,e) identical to the 1-step run"}
+        pidx.close()
 
     # ---- locate leg (config 3), rank 0 reports ----
     if level is not None:

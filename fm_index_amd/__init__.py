@@ -79,7 +79,7 @@ class Text:
 class _Index:
     _kind = L.KIND_FM
 
-    def __init__(self, text, level=None, device=0, keep_sa=False):
+    def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -87,19 +87,21 @@ class _Index:
         t = text.text()
         lvl = L.NO_LOCATE if level is None else int(level)
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), 1, text.max_character(),
-                                 self._kind, lvl, L.FLAG_KEEP_SA if keep_sa else 0, device,
-                                 C.byref(self._h))
+                                 self._kind, lvl, (L.FLAG_KEEP_SA if keep_sa else 0) |
+                                 (L.FLAG_PAIR_INDEX if pair_index else 0), device, C.byref(self._h))
         _check(rc)
 
     @classmethod
-    def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False):
+    def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
+                         pair_index=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
         self._h = C.c_void_p()
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, 1, max_character, cls._kind, lvl,
-                                       L.FLAG_KEEP_SA if keep_sa else 0, device,
+                                       (L.FLAG_KEEP_SA if keep_sa else 0) |
+                                       (L.FLAG_PAIR_INDEX if pair_index else 0), device,
                                        C.byref(self._h)))
         return self
 
@@ -187,6 +189,9 @@ class _Index:
         _check(self._lib.fmx_verify_sa(self._h, C.byref(v)))
         return int(v.value)
 
+    def has_pair_index(self):
+        return bool(self._lib.fmx_has_pair_index(self._h))
+
     def level(self):
         lv = int(self._lib.fmx_level(self._h))
         return None if lv == L.NO_LOCATE else lv
@@ -210,16 +215,16 @@ class FMIndex(_Index):
     """FMIndex::new(&text) (frontend.rs:195-203) -- count only."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, device=0, keep_sa=False):
-        super().__init__(text, None, device, keep_sa)
+    def __init__(self, text, device=0, keep_sa=False, pair_index=False):
+        super().__init__(text, None, device, keep_sa, pair_index)
 
 
 class FMIndexWithLocate(_Index):
     """FMIndexWithLocate::new(&text, level) (frontend.rs:205-221)."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, level, device=0, keep_sa=False):
-        super().__init__(text, level, device, keep_sa)
+    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False):
+        super().__init__(text, level, device, keep_sa, pair_index)
 
 
 class RLFMIndex(_Index):

@@ -20,6 +20,7 @@ KIND_FM = 0
 KIND_RLFM = 1
 NO_LOCATE = 0xFFFFFFFF
 FLAG_KEEP_SA = 1
+FLAG_PAIR_INDEX = 2
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
@@ -64,6 +65,7 @@ SYMBOLS = [
     ("fmx_export_sa", _I, [_V, _V]),
     ("fmx_verify_sa", _I, [_V, C.POINTER(_U64)]),
     ("fmx_num_runs", _U64, [_V]),
+    ("fmx_has_pair_index", _I, [_V]),
 ]
 
 

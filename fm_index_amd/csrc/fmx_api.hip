@@ -145,6 +145,7 @@ uint32_t fmx_level(const fmx_index *idx) { return idx ? idx->dev.sa_level : FMX_
 int fmx_device(const fmx_index *idx) { return idx ? idx->device : -1; }
 uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0; }
 uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
+int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
 void fmx_set_timing(fmx_index *idx, int enabled) {

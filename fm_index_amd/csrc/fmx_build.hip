@@ -149,6 +149,24 @@ __global__ __launch_bounds__(BLK) void k_samples(const uint32_t *__restrict__ sa
   if (j < nsamp) out[j] = sa[j << level];  // sample.rs:35-37
 }
 
+// 2-gram BWT for the opt-in pair index: code = (T[p-2]-1)*4 + (T[p-1]-1), p = SA[i] >= 2.
+// The two rows with p < 2 have no 2-gram: they are stored as code 0 and reported in
+// special[] so the query subtracts them from rank_0.
+__global__ __launch_bounds__(BLK) void k_bwt2(const uint8_t *__restrict__ t,
+                                               const uint32_t *__restrict__ sa, uint32_t n,
+                                               uint8_t *__restrict__ out,
+                                               uint32_t *__restrict__ special) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t p = sa[i];
+  if (p >= 2) {
+    out[i] = (uint8_t)((t[p - 2] - 1u) * 4u + (t[p - 1] - 1u));
+  } else {
+    out[i] = 0;
+    special[p] = (uint32_t)i;
+  }
+}
+
 // ---- multi-ary wavelet matrix levels --------------------------------------------
 // one thread per 16-B piece; planes written now, counters after the scan
 template <int FMT>
@@ -745,6 +763,36 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
     hipLaunchKernelGGL(k_bwt_cyclic, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
     FMX_HIP(hipDeviceSynchronize());
     if (int rc = build_rlfm(idx, d_bwt, n, L, pool)) return rc;
+  }
+
+  // -- opt-in pair index (FMX_FLAG_PAIR_INDEX): sigma <= 4, the terminator is the only zero --
+  if ((idx->flags & FMX_FLAG_PAIR_INDEX) && idx->kind == FMX_KIND_FM && maxc <= 4 && n >= 4 &&
+      st.hist[0] == 1 && dv.bw.nlevels == 1) {
+    // K2[c1c2] = LF(c1, LF(c2, 0)) = lf_map2(c1, cs[c2])   (fm_index.rs:93-95 applied twice)
+    uint64_t hc[16], hi[16], k2[16];
+    for (uint32_t code = 0; code < 16; code++) {
+      uint32_t c1 = code / 4 + 1, c2 = code % 4 + 1;
+      hc[code] = c1 <= maxc ? c1 : 1;
+      hi[code] = c2 <= maxc ? idx->h_cs[c2] : 0;
+    }
+    uint64_t *d_q;
+    FMX_HIP(pool.get(&d_q, 48));
+    FMX_HIP(hipMemcpy(d_q, hc, sizeof hc, hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(d_q + 16, hi, sizeof hi, hipMemcpyHostToDevice));
+    if (int rc = fmx_launch_scalar(idx, 2, d_q, d_q + 16, 16, d_q + 32, 0)) return rc;
+    FMX_HIP(hipMemcpy(k2, d_q + 32, sizeof k2, hipMemcpyDeviceToHost));
+    uint8_t *d_b2;
+    uint32_t *d_sp;
+    FMX_HIP(pool.get(&d_b2, n));
+    FMX_HIP(pool.get(&d_sp, 2));
+    hipLaunchKernelGGL(k_bwt2, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_b2, d_sp);
+    uint32_t sp[2];
+    FMX_HIP(hipMemcpy(sp, d_sp, sizeof sp, hipMemcpyDeviceToHost));
+    FmxMwm pw;
+    if (int rc = build_mwm(idx, &pw, d_b2, n, 4, pool, k2, 16)) return rc;
+    dv.pair_rec = pw.lv[0].rec;
+    dv.pair_row0 = sp[0];
+    dv.pair_row1 = sp[1];
   }
 
   if (idx->flags & FMX_FLAG_KEEP_SA) {

@@ -67,6 +67,8 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   uint32_t sa_level;    // effective level; FMX_NO_LOCATE when absent
   uint32_t kind;
   FmxBits b, bp;        // RLFM only
+  const uint4 *pair_rec;  // FMX_FLAG_PAIR_INDEX: fmt-4 records over the 2-gram BWT, absolute counters
+  uint32_t pair_row0, pair_row1;  // the two rows (SA = 0, 1) that have no 2-gram; stored as code 0
   const uint32_t *cs;   // RLFM only: run-based C array (rlfmi.rs:72-76)
 };
 

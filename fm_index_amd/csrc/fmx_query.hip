@@ -203,6 +203,105 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// count with the opt-in pair index (FMX_FLAG_PAIR_INDEX): while at least two symbols remain
+// (both in 1..4) one probe of the 2-gram records per interval end advances TWO pattern symbols:
+//     LF(c1, LF(c2, i)) = cnt2[c1c2] + popcount            (absolute counters hold K2)
+// The reference's early exit (wrapper.rs:111-113) is reproduced exactly: when the pair step
+// collapses the interval, the single step for the LAST symbol decides whether the reference
+// would have stopped after one symbol (then ITS (s, e) is returned) or after two.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
+    const uint4 *__restrict__ rec1, const uint4 *__restrict__ rec2, uint32_t n,
+    uint32_t max_character, uint32_t row0, uint32_t row1, uint32_t *status,
+    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+
+  uint64_t k = gid;
+  bool active = k < npat, fresh = true;
+  uint64_t pbeg = 0;
+  uint32_t j = 0, s = 0, e = 0;
+  uint32_t c2 = 0, c1 = 0;   // c2 = last unread symbol, c1 = the one before it
+  uint32_t nsteps = 0;
+  while (active) {
+    if (fresh) {
+      pbeg = off[k];
+      j = (uint32_t)(off[k + 1] - pbeg);
+      if (s0e0) {
+        s = (uint32_t)s0e0[2 * k];
+        e = (uint32_t)s0e0[2 * k + 1];
+      } else {
+        s = 0;
+        e = n;
+      }
+      c2 = j ? pat[pbeg + j - 1] : 0u;
+      c1 = j > 1 ? pat[pbeg + j - 2] : 0u;
+      fresh = false;
+    }
+    bool done = (j == 0);
+    if (!done) {
+      if (c2 > max_character) {                        // reference: panic on cs[c]
+        if (g == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
+        s = 0; e = 0; done = true;
+      } else {
+        const bool pair = j >= 2 && (c2 - 1u) < 4u && (c1 - 1u) < 4u;
+        // the two symbols after these ride along with the record loads
+        const uint32_t n1 = j > 2 ? pat[pbeg + j - 3] : 0u;
+        const uint32_t n2 = j > 3 ? pat[pbeg + j - 4] : 0u;
+        uint32_t used;
+        if (pair) {
+          const uint32_t code = (c1 - 1u) * 4u + (c2 - 1u);
+          const uint4 a = rec2[(size_t)(s >> 7) * 8u + g];
+          const uint4 b = rec2[(size_t)(e >> 7) * 8u + g];
+          uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(a, s & 127u, code, g));
+          uint32_t ne = fmx_group_sum(fmx_piece_rank<4>(b, e & 127u, code, g));
+          if (code == 0u) {  // the two rows without a 2-gram are stored as code 0
+            ns -= (uint32_t)(s > row0) + (uint32_t)(s > row1);
+            ne -= (uint32_t)(e > row0) + (uint32_t)(e > row1);
+          }
+          used = 2;
+          if (ns == ne) {
+            // would the reference already have stopped after the last symbol alone?
+            const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
+            const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
+            const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));
+            const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(b1, e & 255u, c2, g));
+            if (s1 == e1) { ns = s1; ne = e1; used = 1; }
+          }
+          s = ns; e = ne;
+        } else {
+          const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
+          const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
+          const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));  // wrapper.rs:109
+          const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(b1, e & 255u, c2, g));  // wrapper.rs:110
+          s = s1; e = e1;
+          used = 1;
+        }
+        nsteps += used;
+        j -= used;
+        if (used == 2) { c2 = n1; c1 = n2; } else { c2 = c1; c1 = n1; }
+        if (s == e || j == 0) done = true;             // wrapper.rs:111-113
+      }
+    }
+    if (done) {
+      if (g == 0) {
+        if (out_s) out_s[k] = s;
+        if (out_e) out_e[k] = e;
+        if (out_cnt) out_cnt[k] = (uint64_t)(e - s);
+      }
+      k += ngroups;
+      active = k < npat;
+      fresh = true;
+    }
+  }
+  if (steps_out && g == 0 && nsteps)
+    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---------------------------------------------------------------------------
 // locate
 // ---------------------------------------------------------------------------
 // exclusive offsets -> rows: out_pos[off[k] + j] = s[k] + j   (wrapper.rs:203-217: i = s..e-1
@@ -597,7 +696,12 @@ int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t 
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   const FmxMwm &w = idx->dev.bw;
   int variant = fmx_variant();
-  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && variant != 0) {
+  if (idx->dev.pair_rec && variant != 0 && variant != 7) {
+    hipLaunchKernelGGL(fmx_count_pair_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
+                       idx->dev.pair_rec, idx->dev.n, idx->dev.max_character, idx->dev.pair_row0,
+                       idx->dev.pair_row1, idx->dev.status, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt,
+                       steps);
+  } else if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && variant != 0) {
 #define FMX_F3_LAUNCH(PPG, SKIP)                                                                   \
   hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP>), dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), \
                      dim3(FMX_BLOCK), 0, st, w.lv[0].rec, idx->dev.n, idx->dev.max_character,        \

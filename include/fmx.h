@@ -57,6 +57,12 @@ typedef struct fmx_index fmx_index;
 
 /* build flags */
 #define FMX_FLAG_KEEP_SA 1u /* keep text + full suffix array in HBM (tests / export) */
+/* opt-in 2-step acceleration of count for sigma <= 4 texts (max_character <= 4, no interior
+ * zeros): a second rank structure over the 2-gram BWT lets one record probe consume TWO pattern
+ * symbols (LF(c1, LF(c2, i)) = K2[c1c2] + rank_{c1c2}(BWT2, i)).  Results -- including the
+ * (s, e) pair left by the early exit of wrapper.rs:111-113 -- are bit-identical to the 1-step
+ * path; +1 byte per text symbol of HBM.  Ignored (1-step index only) when not applicable. */
+#define FMX_FLAG_PAIR_INDEX 2u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
@@ -158,6 +164,7 @@ int fmx_export_sa(const fmx_index *idx, uint32_t *host_out);         /* needs FM
  * indices not hit exactly once (0 = the array IS the suffix array) */
 int fmx_verify_sa(const fmx_index *idx, uint64_t *violations);
 uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r (rlfmi.rs:43) */
+int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
 
 #ifdef __cplusplus
 }

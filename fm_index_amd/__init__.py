@@ -40,29 +40,43 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def _u8(x):
+_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
+
+
+def _sym(x, dtype=None):
+    """symbols as a contiguous array: bytes/str -> u8; arrays keep their unsigned width
+    (Character = u8 / u16 / u32 / u64, character.rs:38-42) unless `dtype` is given."""
     if isinstance(x, str):
         x = x.encode("latin-1")
     if isinstance(x, (bytes, bytearray, memoryview)):
-        return np.frombuffer(bytes(x), dtype=np.uint8)
-    return np.ascontiguousarray(x, dtype=np.uint8)
+        x = np.frombuffer(bytes(x), dtype=np.uint8)
+    x = np.asarray(x)
+    if dtype is None:
+        dtype = x.dtype if (x.dtype.kind == "u" and x.dtype.itemsize in _DTYPES) else np.uint8
+    return np.ascontiguousarray(x, dtype=dtype)
 
 
-def pack_patterns(patterns):
-    """list of byte strings -> (flat u8, offsets u64[npat+1])."""
-    pats = [_u8(p) for p in patterns]
+def _u8(x):
+    return _sym(x, np.uint8)
+
+
+def pack_patterns(patterns, dtype=np.uint8):
+    """list of symbol strings -> (flat symbols of `dtype`, offsets u64[npat+1])."""
+    pats = [_sym(p, dtype) for p in patterns]
     off = np.zeros(len(pats) + 1, dtype=np.uint64)
     if pats:
         off[1:] = np.cumsum([len(p) for p in pats], dtype=np.uint64)
-    flat = np.concatenate(pats) if pats and int(off[-1]) else np.zeros(1, dtype=np.uint8)
-    return np.ascontiguousarray(flat, dtype=np.uint8), off
+    flat = np.concatenate(pats) if pats and int(off[-1]) else np.zeros(1, dtype=dtype)
+    return np.ascontiguousarray(flat, dtype=dtype), off
 
 
 class Text:
     """Text (text.rs:11-64): the symbols INCLUDING the trailing 0, plus max_character."""
 
-    def __init__(self, text, max_character=255):  # Text::new: max_value of u8
-        self._t = _u8(text)
+    def __init__(self, text, max_character=None):
+        self._t = _sym(text)
+        if max_character is None:  # Text::new: C::max_value() (text.rs:28-33); the engine caps
+            max_character = min(int(np.iinfo(self._t.dtype).max), (1 << 26) - 1)  # tables at 2^26
         self._max = int(max_character)
 
     @classmethod
@@ -85,21 +99,24 @@ class _Index:
         self._lib = L.lib()
         self._h = C.c_void_p()
         t = text.text()
+        self._dtype = t.dtype
         lvl = L.NO_LOCATE if level is None else int(level)
-        rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), 1, text.max_character(),
+        rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
+                                 text.max_character(),
                                  self._kind, lvl, (L.FLAG_KEEP_SA if keep_sa else 0) |
                                  (L.FLAG_PAIR_INDEX if pair_index else 0), device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
-                         pair_index=False):
+                         pair_index=False, sym_bytes=1):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
         self._h = C.c_void_p()
+        self._dtype = np.dtype(_DTYPES[sym_bytes])
         lvl = L.NO_LOCATE if level is None else int(level)
-        _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, 1, max_character, cls._kind, lvl,
+        _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
                                        (L.FLAG_KEEP_SA if keep_sa else 0) |
                                        (L.FLAG_PAIR_INDEX if pair_index else 0), device,
                                        C.byref(self._h)))
@@ -121,8 +138,8 @@ class _Index:
     def search_many(self, patterns=None, flat=None, off=None, s0e0=None):
         """count for a batch: returns SearchBatch (s, e, counts as numpy u64)."""
         if flat is None:
-            flat, off = pack_patterns(patterns)
-        flat = _u8(flat)
+            flat, off = pack_patterns(patterns, self._dtype)
+        flat = _sym(flat, self._dtype)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         npat = len(off) - 1
         s = np.zeros(max(npat, 1), dtype=np.uint64)
@@ -165,7 +182,7 @@ class _Index:
 
     # -- export / checks --
     def export_bwt(self):
-        out = np.zeros(max(self.len(), 1), dtype=np.uint8)
+        out = np.zeros(max(self.len(), 1), dtype=_DTYPES[int(self._lib.fmx_sym_bytes(self._h))])
         _check(self._lib.fmx_export_bwt(self._h, _p(out)))
         return out[:self.len()]
 
@@ -252,7 +269,7 @@ class Search:
         self._e = e
 
     def search(self, pattern):  # wrapper.rs:103-124: prepends `pattern`
-        flat, off = pack_patterns([pattern])
+        flat, off = pack_patterns([pattern], self._ix._dtype)
         se = None if self._s is None else np.array([self._s, self._e], dtype=np.uint64)
         b = self._ix.search_many(flat=flat, off=off, s0e0=se)
         return Search(self._ix, int(b.s[0]), int(b.e[0]))

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("fmx_export_sa", _I, [_V, _V]),
     ("fmx_verify_sa", _I, [_V, C.POINTER(_U64)]),
     ("fmx_num_runs", _U64, [_V]),
+    ("fmx_sym_bytes", _U32, [_V]),
     ("fmx_has_pair_index", _I, [_V]),
 ]
 

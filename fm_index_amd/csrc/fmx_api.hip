@@ -77,8 +77,17 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
                         int device, fmx_index **out) {
   if (!out) return fail(FMX_ERR_ARG, "out is NULL");
   *out = nullptr;
-  if (sym_bytes != 1) return fail(FMX_ERR_UNSUPPORTED, "only sym_bytes == 1 (u8 text) is implemented");
-  if (max_character == 0 || max_character > 255) return fail(FMX_ERR_ARG, "max_character must be in 1..=255 for u8 text");
+  if (sym_bytes != 1 && sym_bytes != 2 && sym_bytes != 4 && sym_bytes != 8)
+    return fail(FMX_ERR_ARG, "sym_bytes must be 1, 2, 4 or 8 (Character = u8/u16/u32/u64)");
+  if (sym_bytes == 8 && text_on_device)
+    return fail(FMX_ERR_UNSUPPORTED, "u64 symbols are narrowed on the host: use fmx_build");
+  const uint64_t type_max = sym_bytes == 1 ? 0xFFull : (sym_bytes == 2 ? 0xFFFFull : 0xFFFFFFFFull);
+  if (max_character == 0 || (sym_bytes != 8 && max_character > type_max))
+    return fail(FMX_ERR_ARG, "max_character must be in 1..=MAX of the symbol type");
+  // the C array / K table have max_character+1 entries (the reference allocates the same,
+  // sais.rs:16): keep them to a sane size
+  if (max_character >= (1ull << 26))
+    return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM) return fail(FMX_ERR_ARG, "unknown kind");
   if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
@@ -88,6 +97,7 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   idx->device = device;
   idx->n = n;
   idx->sym_bytes = sym_bytes;
+  idx->sym_bytes_abi = sym_bytes;
   idx->max_character = max_character;
   idx->kind = kind;
   idx->level_requested = level;
@@ -109,10 +119,25 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
 
     if (text_on_device) {
       d_text = (uint8_t *)text;
-    } else {
-      if ((e = hipMalloc((void **)&d_text, n ? n : 1)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+    } else if (sym_bytes == 8) {
+      // Character = u64/usize: narrow to u32 (every symbol must be <= max_character < 2^26)
+      std::string narrow((size_t)(n ? n : 1) * 4, '\0');
+      uint32_t *dst = (uint32_t *)&narrow[0];
+      const uint64_t *src = (const uint64_t *)text;
+      bool bad = false;
+      for (uint64_t i = 0; i < n; i++) {
+        if (src[i] > max_character) bad = true;
+        dst[i] = (uint32_t)src[i];
+      }
+      if (bad) { rc = fail(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character"); break; }
+      idx->sym_bytes = 4;
+      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
       own_text = true;
-      if (n && (e = hipMemcpy(d_text, text, n, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
+      if (n && (e = hipMemcpy(d_text, dst, n * 4, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
+    } else {
+      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * sym_bytes)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      own_text = true;
+      if (n && (e = hipMemcpy(d_text, text, n * sym_bytes, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
     }
     rc = fmx_build_impl(idx, d_text);
   } while (0);
@@ -145,6 +170,7 @@ uint32_t fmx_level(const fmx_index *idx) { return idx ? idx->dev.sa_level : FMX_
 int fmx_device(const fmx_index *idx) { return idx ? idx->device : -1; }
 uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0; }
 uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
+uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
@@ -194,7 +220,7 @@ int fmx_count_batch_dev(const fmx_index *idx, const void *d_pat, const uint64_t 
                         uint64_t *d_out_e, uint64_t *d_out_count, void *stream) {
   CHECK_IDX(idx);
   if (npat && (!d_pat_off)) return fail(FMX_ERR_ARG, "pat_off is NULL");
-  return fmx_launch_count(idx, (const uint8_t *)d_pat, d_pat_off, npat, d_s0e0, d_out_s, d_out_e,
+  return fmx_launch_count(idx, d_pat, d_pat_off, npat, d_s0e0, d_out_s, d_out_e,
                           d_out_count, (hipStream_t)stream);
 }
 int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
@@ -250,22 +276,32 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   if (npat == 0) return FMX_OK;
   if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
   uint64_t total = pat_off[npat];
+  const uint32_t sb = idx->sym_bytes;  // device symbol width
   Scratch sc;
   void *d_pat, *d_off, *d_se = nullptr, *d_s, *d_e, *d_c;
-  FMX_HIP(sc.get(&d_pat, total));
+  FMX_HIP(sc.get(&d_pat, total * sb));
   FMX_HIP(sc.get(&d_off, (npat + 1) * 8));
   FMX_HIP(sc.get(&d_s, npat * 8));
   FMX_HIP(sc.get(&d_e, npat * 8));
   FMX_HIP(sc.get(&d_c, npat * 8));
-  if (total) FMX_HIP(hipMemcpy(d_pat, pat, total, hipMemcpyHostToDevice));
+  if (total) {
+    if (idx->sym_bytes_abi == 8) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
+      std::string narrow((size_t)total * 4, '\0');
+      uint32_t *dst = (uint32_t *)&narrow[0];
+      const uint64_t *src = (const uint64_t *)pat;
+      for (uint64_t i = 0; i < total; i++) dst[i] = src[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)src[i];
+      FMX_HIP(hipMemcpy(d_pat, dst, total * 4, hipMemcpyHostToDevice));
+    } else {
+      FMX_HIP(hipMemcpy(d_pat, pat, total * sb, hipMemcpyHostToDevice));
+    }
+  }
   FMX_HIP(hipMemcpy(d_off, pat_off, (npat + 1) * 8, hipMemcpyHostToDevice));
   if (s0e0) {
     FMX_HIP(sc.get(&d_se, npat * 16));
     FMX_HIP(hipMemcpy(d_se, s0e0, npat * 16, hipMemcpyHostToDevice));
   }
-  if (int rc = fmx_launch_count(idx, (const uint8_t *)d_pat, (const uint64_t *)d_off, npat,
-                                (const uint64_t *)d_se, (uint64_t *)d_s, (uint64_t *)d_e,
-                                (uint64_t *)d_c, 0))
+  if (int rc = fmx_launch_count(idx, d_pat, (const uint64_t *)d_off, npat, (const uint64_t *)d_se,
+                                (uint64_t *)d_s, (uint64_t *)d_e, (uint64_t *)d_c, 0))
     return rc;
   FMX_HIP(hipDeviceSynchronize());
   if (out_s) FMX_HIP(hipMemcpy(out_s, d_s, npat * 8, hipMemcpyDeviceToHost));
@@ -342,10 +378,10 @@ int fmx_export_bwt(const fmx_index *idx, void *host_out) {
   if (idx->n == 0) return FMX_OK;
   Scratch sc;
   void *d;
-  FMX_HIP(sc.get(&d, idx->n));
-  if (int rc = fmx_launch_export_l(idx, (uint8_t *)d, 0)) return rc;
+  FMX_HIP(sc.get(&d, idx->n * idx->sym_bytes));
+  if (int rc = fmx_launch_export_l(idx, d, 0)) return rc;
   FMX_HIP(hipDeviceSynchronize());
-  FMX_HIP(hipMemcpy(host_out, d, idx->n, hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(host_out, d, idx->n * idx->sym_bytes, hipMemcpyDeviceToHost));
   return FMX_OK;
 }
 int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {

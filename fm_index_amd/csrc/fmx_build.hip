@@ -54,26 +54,41 @@ struct TextStats {
   unsigned long long last_nonzero_plus1;  // 0 when every symbol is zero
   unsigned long long max_sym;
 };
-__global__ __launch_bounds__(BLK) void k_text_stats(const uint8_t *__restrict__ t, uint64_t n,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_text_stats(const T *__restrict__ t, uint64_t n,
                                                      TextStats *st) {
   __shared__ unsigned int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long last = 0;
+  unsigned long long last = 0, mx = 0;
   const uint64_t stride = (uint64_t)gridDim.x * BLK;
   for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-    uint32_t c = t[i];
-    atomicAdd(&h[c], 1u);
+    uint32_t c = (uint32_t)t[i];
+    if (c < 256u) atomicAdd(&h[c], 1u);
     if (c) last = i + 1;
+    if (c > mx) mx = c;
   }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
   if (last) atomicMax(&st->last_nonzero_plus1, last);
+  if (mx) atomicMax(&st->max_sym, mx);
+}
+// large alphabets (max_character > 255): histogram straight into global memory
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_hist_global(const T *__restrict__ t, uint64_t n,
+                                                      uint32_t maxc,
+                                                      unsigned long long *__restrict__ hist) {
+  const uint64_t stride = (uint64_t)gridDim.x * BLK;
+  for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    uint32_t c = (uint32_t)t[i];
+    if (c <= maxc) atomicAdd(&hist[c], 1ull);
+  }
 }
 
 // ---- suffix sorting by prefix doubling -----------------------------------------
 // initial key: the first `k` symbols, `bits` bits each, zero-padded past the end
-__global__ __launch_bounds__(BLK) void k_init_keys(const uint8_t *__restrict__ t, uint32_t n,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_init_keys(const T *__restrict__ t, uint32_t n,
                                                     uint32_t bits, uint32_t k,
                                                     uint64_t *__restrict__ keys,
                                                     uint32_t *__restrict__ idx) {
@@ -126,18 +141,20 @@ __global__ __launch_bounds__(BLK) void k_double_keys(const uint32_t *__restrict_
 }
 
 // ---- BWT + samples -------------------------------------------------------------
-__global__ __launch_bounds__(BLK) void k_bwt(const uint8_t *__restrict__ t,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_bwt(const T *__restrict__ t,
                                               const uint32_t *__restrict__ sa, uint32_t n,
-                                              uint8_t *__restrict__ bwt) {
+                                              T *__restrict__ bwt) {
   uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (p >= n) return;
   uint32_t k = sa[p];
-  bwt[p] = k > 0 ? t[k - 1] : (uint8_t)0;  // fm_index.rs:50-55
+  bwt[p] = k > 0 ? t[k - 1] : (T)0;  // fm_index.rs:50-55
 }
 // RLFM: c_i = T[SA[i]-1], or T[n-1] when SA[i] == 0  (rlfmi.rs:48-53)
-__global__ __launch_bounds__(BLK) void k_bwt_cyclic(const uint8_t *__restrict__ t,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_bwt_cyclic(const T *__restrict__ t,
                                                      const uint32_t *__restrict__ sa, uint32_t n,
-                                                     uint8_t *__restrict__ bwt) {
+                                                     T *__restrict__ bwt) {
   uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (p >= n) return;
   uint32_t k = sa[p];
@@ -169,8 +186,8 @@ __global__ __launch_bounds__(BLK) void k_bwt2(const uint8_t *__restrict__ t,
 
 // ---- multi-ary wavelet matrix levels --------------------------------------------
 // one thread per 16-B piece; planes written now, counters after the scan
-template <int FMT>
-__global__ __launch_bounds__(BLK) void k_mwm_pieces(const uint8_t *__restrict__ cur, uint32_t n,
+template <int FMT, typename T>
+__global__ __launch_bounds__(BLK) void k_mwm_pieces(const T *__restrict__ cur, uint32_t n,
                                                      uint32_t shift, uint32_t mask, uint32_t nrec,
                                                      uint4 *__restrict__ rec,
                                                      uint32_t *__restrict__ hist) {
@@ -183,17 +200,19 @@ __global__ __launch_bounds__(BLK) void k_mwm_pieces(const uint8_t *__restrict__ 
   const uint64_t base = t * PER;
   uint32_t pl[4] = {0, 0, 0, 0};
   uint32_t valid = 0;
-  alignas(16) uint8_t sy[PER];
-  if (base + PER <= n) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(cur + base);  // base % 16 == 0
-    for (int q = 0; q < PER / 16; q++) *reinterpret_cast<uint4 *>(&sy[q * 16]) = src[q];
+  uint32_t sy[PER];
+  if (sizeof(T) == 1 && base + PER <= n) {
+    alignas(16) uint8_t raw[PER];
+    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(cur) + base);
+    for (int q = 0; q < PER / 16; q++) *reinterpret_cast<uint4 *>(&raw[q * 16]) = src[q];
+    for (int j = 0; j < PER; j++) sy[j] = raw[j];
   } else {
-    for (int j = 0; j < PER; j++) sy[j] = (base + j < n) ? cur[base + j] : (uint8_t)0;
+    for (int j = 0; j < PER; j++) sy[j] = (base + j < n) ? (uint32_t)cur[base + j] : 0u;
   }
   for (int j = 0; j < PER; j++) {
     uint64_t p = base + j;
     if (p < n) {
-      uint32_t code = ((uint32_t)sy[j] >> shift) & mask;
+      uint32_t code = (sy[j] >> shift) & mask;
       valid |= 1u << j;
       pl[0] |= (code & 1u) << j;
       pl[1] |= ((code >> 1) & 1u) << j;
@@ -258,11 +277,12 @@ __global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict
 
 // ---- RLFM construction (rlfmi.rs:30-96) --------------------------------------------
 // run starts: c0 starts at 0, a run begins wherever c != c0  (rlfmi.rs:41, 56-59)
-__global__ __launch_bounds__(BLK) void k_run_flags(const uint8_t *__restrict__ L, uint32_t n,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_run_flags(const T *__restrict__ L, uint32_t n,
                                                     uint8_t *__restrict__ flags) {
   uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  uint8_t prev = i ? L[i - 1] : (uint8_t)0;
+  T prev = i ? L[i - 1] : (T)0;
   flags[i] = L[i] != prev ? 1 : 0;
 }
 __global__ __launch_bounds__(BLK) void k_iota(uint32_t *out, uint32_t n) {
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(BLK) void k_select_hints(const uint4 *__restrict__ 
 }
 
 // ---- verification (FMX_FLAG_KEEP_SA) ---------------------------------------------
-__global__ __launch_bounds__(BLK) void k_verify_sa(const uint8_t *__restrict__ t,
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_verify_sa(const T *__restrict__ t,
                                                     const uint32_t *__restrict__ sa, uint32_t n,
                                                     uint32_t *__restrict__ mark,
                                                     unsigned long long *bad) {
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(BLK) void k_verify_sa(const uint8_t *__restrict__ t
     uint64_t pa = a + j, pb = b + j;
     if (pa >= n) return;                     // a ended first: ok
     if (pb >= n) { atomicAdd(bad, 1ull); return; }
-    uint8_t ca = t[pa], cb = t[pb];
+    T ca = t[pa], cb = t[pb];
     if (ca < cb) return;
     if (ca > cb) { atomicAdd(bad, 1ull); return; }
   }
@@ -370,7 +391,8 @@ void split_levels(uint32_t L, uint32_t *nlv, uint32_t *bits) {
 }
 
 // suffix array of d_text[0..n) into d_sa (u32) -- prefix doubling
-int suffix_sort(const uint8_t *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, DevPool &pool) {
+template <typename T>
+int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, DevPool &pool) {
   uint64_t *keys_a, *keys_b;
   uint32_t *vals_b, *rank, *head;
   unsigned int *d_ng;
@@ -396,7 +418,7 @@ int suffix_sort(const uint8_t *d_text, uint32_t n, uint32_t sym_bits, uint32_t *
   uint8_t *tmp;
   FMX_HIP(pool.get(&tmp, tmp_bytes));
 
-  hipLaunchKernelGGL(k_init_keys, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
+  hipLaunchKernelGGL(k_init_keys<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
                      d_sa);
   uint64_t *keys_cur = keys_a, *keys_alt = keys_b;
   uint32_t *sa_cur = d_sa, *sa_alt = vals_b;
@@ -438,7 +460,8 @@ int suffix_sort(const uint8_t *d_text, uint32_t n, uint32_t sym_bits, uint32_t *
 
 // builds the multi-ary wavelet matrix over d_seq[0..len) (u8 symbols of `L` bits).
 // d_seq is consumed (sorted in place between levels).
-int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t L, DevPool &pool,
+template <typename T>
+int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, DevPool &pool,
               const uint64_t *single_level_add = nullptr, uint32_t nadd = 0) {
   uint32_t nlv, bits[FMX_MAX_LEVELS];
   split_levels(L, &nlv, bits);
@@ -446,7 +469,7 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
   w->nlevels = nlv;
   w->bits = L;
   w->len = len;
-  uint8_t *cur = d_seq, *alt = nullptr;
+  T *cur = d_seq, *alt = nullptr;
   if (nlv > 1) FMX_HIP(pool.get(&alt, len));
   uint32_t shift = L;
   for (uint32_t l = 0; l < nlv; l++) {
@@ -469,10 +492,10 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
     FMX_HIP(pool.get(&scan, nh));
     unsigned grid = nblocks((uint64_t)lv.nrec * 8);
     if (lv.fmt == 3)
-      hipLaunchKernelGGL(k_mwm_pieces<3>, dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
+      hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
                          lv.nrec, rec, hist);
     else
-      hipLaunchKernelGGL(k_mwm_pieces<4>, dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
+      hipLaunchKernelGGL((k_mwm_pieces<4, T>), dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
                          lv.nrec, rec, hist);
     size_t tb = 0;
     FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, scan, nh, (hipStream_t)0));
@@ -507,7 +530,7 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
                                                 (int)(lv.shift + bits[l]), (hipStream_t)0));
       FMX_HIP(hipDeviceSynchronize());
       pool.release(stmp);
-      uint8_t *x = cur; cur = alt; alt = x;
+      T *x = cur; cur = alt; alt = x;
     }
     FMX_HIP(hipDeviceSynchronize());
     pool.release(hist); pool.release(scan); pool.release(tmp);
@@ -515,6 +538,35 @@ int build_mwm(fmx_index *idx, FmxMwm *w, uint8_t *d_seq, uint32_t len, uint32_t 
   return FMX_OK;
 }
 
+
+// histogram of a device symbol array over 0..=maxc (host result), plus the TextStats
+// (last non-zero index, maximum symbol) used by the validation
+template <typename T>
+int symbol_histogram(const T *d_sym, uint64_t count, uint32_t maxc, std::vector<uint64_t> &hist,
+                     TextStats *st_out, DevPool &pool) {
+  TextStats *d_st;
+  FMX_HIP(pool.get(&d_st, 1));
+  FMX_HIP(hipMemset(d_st, 0, sizeof(TextStats)));
+  unsigned grid = nblocks(count, BLK * 16);
+  if (grid > 4096) grid = 4096;
+  if (count) hipLaunchKernelGGL(k_text_stats<T>, dim3(grid), dim3(BLK), 0, 0, d_sym, count, d_st);
+  TextStats st;
+  FMX_HIP(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
+  pool.release(d_st);
+  hist.assign((size_t)maxc + 1, 0);
+  if (maxc <= 255) {
+    for (uint32_t c = 0; c <= maxc; c++) hist[c] = st.hist[c];
+  } else {
+    unsigned long long *d_h;
+    FMX_HIP(pool.get(&d_h, (size_t)maxc + 1));
+    FMX_HIP(hipMemset(d_h, 0, ((size_t)maxc + 1) * 8));
+    if (count) hipLaunchKernelGGL(k_hist_global<T>, dim3(grid), dim3(BLK), 0, 0, d_sym, count, maxc, d_h);
+    FMX_HIP(hipMemcpy(hist.data(), d_h, ((size_t)maxc + 1) * 8, hipMemcpyDeviceToHost));
+    pool.release(d_h);
+  }
+  if (st_out) *st_out = st;
+  return FMX_OK;
+}
 
 // FmxBits (rank/select records + select hints) from one flag byte per bit
 int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, DevPool &pool) {
@@ -556,16 +608,18 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
 }
 
 // RLFMIndexBackend::new (rlfmi.rs:30-96) from the L column (d_L is consumed)
-int build_rlfm(fmx_index *idx, uint8_t *d_L, uint32_t n, uint32_t L, DevPool &pool) {
+template <typename T>
+int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   FmxDev &dv = idx->dev;
   const uint32_t maxc = (uint32_t)idx->max_character;
-  uint8_t *flags, *heads;
+  uint8_t *flags;
+  T *heads;
   uint32_t *starts, *d_num;
   FMX_HIP(pool.get(&flags, n));
   FMX_HIP(pool.get(&heads, n));
   FMX_HIP(pool.get(&starts, n));
   FMX_HIP(pool.get(&d_num, 1));
-  hipLaunchKernelGGL(k_run_flags, dim3(nblocks(n)), dim3(BLK), 0, 0, d_L, n, flags);
+  hipLaunchKernelGGL(k_run_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_L, n, flags);
   // S = run heads (rlfmi.rs:57), starts = first row of every run
   size_t t1 = 0, t2 = 0;
   hipcub::CountingInputIterator<uint32_t> rows(0);
@@ -585,24 +639,15 @@ int build_rlfm(fmx_index *idx, uint8_t *d_L, uint32_t n, uint32_t L, DevPool &po
   // B (rlfmi.rs:46, 58, 61, 85)
   if (int rc = build_bits(idx, &dv.b, flags, n, pool)) return rc;
   // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
-  TextStats *d_st;
-  FMX_HIP(pool.get(&d_st, 1));
-  FMX_HIP(hipMemset(d_st, 0, sizeof(TextStats)));
-  {
-    unsigned grid = nblocks(r, BLK * 16);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_text_stats, dim3(grid), dim3(BLK), 0, 0, heads, (uint64_t)r, d_st);
-  }
-  TextStats st;
-  FMX_HIP(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
-  std::vector<uint64_t> rcs(maxc + 1);
+  std::vector<uint64_t> rcs;
+  if (int rc = symbol_histogram<T>(heads, r, maxc, rcs, nullptr, pool)) return rc;
   {
     uint64_t acc = 0;
-    for (uint32_t c = 0; c <= maxc; c++) { rcs[c] = acc; acc += st.hist[c]; }
+    for (uint32_t c = 0; c <= maxc; c++) { uint64_t v = rcs[c]; rcs[c] = acc; acc += v; }
   }
   // B' (rlfmi.rs:71-83): runs in (head, row) order, each 1 0^{len-1}
   uint32_t *order, *order2, *lens, *fpos;
-  uint8_t *hk2;
+  T *hk2;
   FMX_HIP(pool.get(&order, r));
   FMX_HIP(pool.get(&order2, r));
   FMX_HIP(pool.get(&lens, r));
@@ -610,11 +655,11 @@ int build_rlfm(fmx_index *idx, uint8_t *d_L, uint32_t n, uint32_t L, DevPool &po
   FMX_HIP(pool.get(&hk2, r));
   hipLaunchKernelGGL(k_iota, dim3(nblocks(r)), dim3(BLK), 0, 0, order, r);
   size_t sb = 0;
-  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0, 8,
+  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0, (int)L,
                                              (hipStream_t)0));
   uint8_t *stmp;
   FMX_HIP(pool.get(&stmp, sb));
-  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0, 8,
+  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0, (int)L,
                                              (hipStream_t)0));
   hipLaunchKernelGGL(k_sorted_run_lens, dim3(nblocks(r)), dim3(BLK), 0, 0, starts, order2, r, n, lens);
   size_t eb = 0;
@@ -655,8 +700,15 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   FMX_HIP(hipMalloc((void **)&bad, 8));
   FMX_HIP(hipMemset(mark, 0, (size_t)n * 4));
   FMX_HIP(hipMemset(bad, 0, 8));
-  hipLaunchKernelGGL(k_verify_sa, dim3(nblocks(n)), dim3(BLK), 0, 0, idx->d_text, idx->d_sa, n, mark,
-                     bad);
+  if (idx->sym_bytes == 1)
+    hipLaunchKernelGGL(k_verify_sa<uint8_t>, dim3(nblocks(n)), dim3(BLK), 0, 0,
+                       (const uint8_t *)idx->d_text, idx->d_sa, n, mark, bad);
+  else if (idx->sym_bytes == 2)
+    hipLaunchKernelGGL(k_verify_sa<uint16_t>, dim3(nblocks(n)), dim3(BLK), 0, 0,
+                       (const uint16_t *)idx->d_text, idx->d_sa, n, mark, bad);
+  else
+    hipLaunchKernelGGL(k_verify_sa<uint32_t>, dim3(nblocks(n)), dim3(BLK), 0, 0,
+                       (const uint32_t *)idx->d_text, idx->d_sa, n, mark, bad);
   hipLaunchKernelGGL(k_count_not_one, dim3(nblocks(n)), dim3(BLK), 0, 0, mark, n, bad);
   unsigned long long hb = 0;
   FMX_HIP(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
@@ -666,7 +718,8 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   return FMX_OK;
 }
 
-int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
+template <typename T>
+static int build_impl_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
   DevPool pool;
   const uint32_t n = (uint32_t)idx->n;
@@ -674,24 +727,16 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);  // text.rs:61-63
 
   // -- statistics + validation (sais.rs:115-139) --
-  TextStats *d_st;
-  FMX_HIP(pool.get(&d_st, 1));
-  FMX_HIP(hipMemset(d_st, 0, sizeof(TextStats)));
-  if (n) {
-    unsigned grid = nblocks(n, BLK * 16);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_text_stats, dim3(grid), dim3(BLK), 0, 0, d_text, (uint64_t)n, d_st);
-  }
+  std::vector<uint64_t> hist;
   TextStats st;
-  FMX_HIP(hipMemcpy(&st, d_st, sizeof st, hipMemcpyDeviceToHost));
-  for (uint32_t c = maxc + 1; c < 256; c++)
-    if (st.hist[c]) {  // count_chars would index out of bounds (sais.rs:18)
-      fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
-      return FMX_ERR_SYMBOL_RANGE;
-    }
+  if (int rc = symbol_histogram<T>(d_text, n, maxc, hist, &st, pool)) return rc;
+  if (st.max_sym > maxc) {  // count_chars would index out of bounds (sais.rs:18)
+    fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
+    return FMX_ERR_SYMBOL_RANGE;
+  }
   if (n >= 2) {  // lengths 0 and 1 bypass validation (sais.rs:121-126)
-    uint8_t first = 0;
-    FMX_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
+    T first = 0;
+    FMX_HIP(hipMemcpy(&first, d_text, sizeof(T), hipMemcpyDeviceToHost));
     if (first == 0) {
       fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
       return FMX_ERR_TEXT_START_ZERO;
@@ -702,17 +747,17 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
     }
   }
   // -- C array (sais.rs:9-32) --
-  idx->h_cs = (uint64_t *)calloc(maxc + 1, sizeof(uint64_t));
+  idx->h_cs = (uint64_t *)calloc((size_t)maxc + 1, sizeof(uint64_t));
   {
     uint64_t sum = 0;
-    for (uint32_t c = 0; c <= maxc; c++) { idx->h_cs[c] = sum; sum += st.hist[c]; }
+    for (uint32_t c = 0; c <= maxc; c++) { idx->h_cs[c] = sum; sum += hist[c]; }
   }
 
   // -- suffix array --
   uint32_t *d_sa;
   FMX_HIP(pool.get(&d_sa, n));
   if (n) {
-    if (int rc = suffix_sort(d_text, n, L, d_sa, pool)) return rc;
+    if (int rc = suffix_sort<T>(d_text, n, L, d_sa, pool)) return rc;
   }
 
   // -- SA samples (sample.rs:21-44) --
@@ -720,6 +765,7 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
   dv.n = n;
   dv.max_character = maxc;
   dv.kind = idx->kind;
+  dv.sym_bytes = (uint32_t)sizeof(T);
   dv.sa_level = FMX_NO_LOCATE;
   if (idx->level_requested != FMX_NO_LOCATE && n > 0) {
     uint32_t level = idx->level_requested;
@@ -737,21 +783,21 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
   }
 
   // -- BWT (fm_index.rs:44-58) --
-  uint8_t *d_bwt;
+  T *d_bwt;
   FMX_HIP(pool.get(&d_bwt, n));
-  if (n) hipLaunchKernelGGL(k_bwt, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+  if (n) hipLaunchKernelGGL(k_bwt<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
   FMX_HIP(hipGetLastError());
 
   if (idx->kind == FMX_KIND_FM) {
     FMX_HIP(hipDeviceSynchronize());
-    if (int rc = build_mwm(idx, &dv.bw, d_bwt, n, L, pool, idx->h_cs, maxc + 1)) return rc;
+    if (int rc = build_mwm<T>(idx, &dv.bw, d_bwt, n, L, pool, idx->h_cs, maxc + 1)) return rc;
     // K[c] = cs[c] - S_c (all zero when cs[] was folded into a single level)
     uint64_t *d_cs;
     uint32_t *d_K;
-    FMX_HIP(pool.get(&d_cs, maxc + 1));
-    FMX_HIP(hipMemcpy(d_cs, idx->h_cs, (maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    FMX_HIP(hipMalloc((void **)&d_K, (maxc + 1) * sizeof(uint32_t)));
-    if (int rc = keep(idx, d_K, (maxc + 1) * 4)) return rc;
+    FMX_HIP(pool.get(&d_cs, (size_t)maxc + 1));
+    FMX_HIP(hipMemcpy(d_cs, idx->h_cs, ((size_t)maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * sizeof(uint32_t)));
+    if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 4)) return rc;
     if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
     dv.K = d_K;
   } else {
@@ -760,14 +806,14 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
       return FMX_ERR_UNSUPPORTED;
     }
     // c_i = T[SA[i]-1], or T[n-1] when SA[i] == 0 (rlfmi.rs:48-53)
-    hipLaunchKernelGGL(k_bwt_cyclic, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+    hipLaunchKernelGGL(k_bwt_cyclic<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
     FMX_HIP(hipDeviceSynchronize());
-    if (int rc = build_rlfm(idx, d_bwt, n, L, pool)) return rc;
+    if (int rc = build_rlfm<T>(idx, d_bwt, n, L, pool)) return rc;
   }
 
   // -- opt-in pair index (FMX_FLAG_PAIR_INDEX): sigma <= 4, the terminator is the only zero --
-  if ((idx->flags & FMX_FLAG_PAIR_INDEX) && idx->kind == FMX_KIND_FM && maxc <= 4 && n >= 4 &&
-      st.hist[0] == 1 && dv.bw.nlevels == 1) {
+  if ((idx->flags & FMX_FLAG_PAIR_INDEX) && idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= 4 &&
+      n >= 4 && hist[0] == 1 && dv.bw.nlevels == 1) {
     // K2[c1c2] = LF(c1, LF(c2, 0)) = lf_map2(c1, cs[c2])   (fm_index.rs:93-95 applied twice)
     uint64_t hc[16], hi[16], k2[16];
     for (uint32_t code = 0; code < 16; code++) {
@@ -785,22 +831,23 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
     uint32_t *d_sp;
     FMX_HIP(pool.get(&d_b2, n));
     FMX_HIP(pool.get(&d_sp, 2));
-    hipLaunchKernelGGL(k_bwt2, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_b2, d_sp);
+    hipLaunchKernelGGL(k_bwt2, dim3(nblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)d_text, d_sa, n, d_b2,
+                       d_sp);
     uint32_t sp[2];
     FMX_HIP(hipMemcpy(sp, d_sp, sizeof sp, hipMemcpyDeviceToHost));
     FmxMwm pw;
-    if (int rc = build_mwm(idx, &pw, d_b2, n, 4, pool, k2, 16)) return rc;
+    if (int rc = build_mwm<uint8_t>(idx, &pw, d_b2, n, 4, pool, k2, 16)) return rc;
     dv.pair_rec = pw.lv[0].rec;
     dv.pair_row0 = sp[0];
     dv.pair_row1 = sp[1];
   }
 
   if (idx->flags & FMX_FLAG_KEEP_SA) {
-    uint8_t *kt;
-    FMX_HIP(hipMalloc((void **)&kt, n ? n : 1));
-    if (n) FMX_HIP(hipMemcpy(kt, d_text, n, hipMemcpyDeviceToDevice));
-    if (int rc = keep(idx, kt, n)) return rc;
-    idx->d_text = kt;
+    T *kt;
+    FMX_HIP(hipMalloc((void **)&kt, (n ? n : 1) * sizeof(T)));
+    if (n) FMX_HIP(hipMemcpy(kt, d_text, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice));
+    if (int rc = keep(idx, kt, (uint64_t)n * sizeof(T))) return rc;
+    idx->d_text = (uint8_t *)kt;
     // hand the SA over to the index instead of freeing it
     for (size_t i = 0; i < pool.v.size(); i++)
       if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
@@ -811,4 +858,16 @@ int fmx_build_impl(fmx_index *idx, const uint8_t *d_text) {
   idx->build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return FMX_OK;
+}
+
+// Character = u8 / u16 / u32 (character.rs:38-42); u64 texts are narrowed by the caller
+int fmx_build_impl(fmx_index *idx, const void *d_text) {
+  switch (idx->sym_bytes) {
+    case 1: return build_impl_t<uint8_t>(idx, (const uint8_t *)d_text);
+    case 2: return build_impl_t<uint16_t>(idx, (const uint16_t *)d_text);
+    case 4: return build_impl_t<uint32_t>(idx, (const uint32_t *)d_text);
+    default:
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "sym_bytes must be 1, 2 or 4 on the device");
+      return FMX_ERR_UNSUPPORTED;
+  }
 }

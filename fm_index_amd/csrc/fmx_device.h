@@ -11,6 +11,13 @@
 
 #define FMX_GROUP 8
 
+// pattern / text symbol i of a buffer whose symbols are sb bytes wide (Character, character.rs)
+__device__ __forceinline__ uint32_t fmx_load_sym(const void *p, uint32_t sb, uint64_t i) {
+  if (sb == 1) return ((const uint8_t *)p)[i];
+  if (sb == 2) return ((const uint16_t *)p)[i];
+  return ((const uint32_t *)p)[i];
+}
+
 __device__ __forceinline__ uint32_t fmx_dpp_xor1(uint32_t v) {  // quad_perm [1,0,3,2]
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }

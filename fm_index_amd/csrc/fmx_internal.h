@@ -66,6 +66,7 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   uint32_t max_character;
   uint32_t sa_level;    // effective level; FMX_NO_LOCATE when absent
   uint32_t kind;
+  uint32_t sym_bytes;   // width of text / pattern symbols (1, 2 or 4)
   FmxBits b, bp;        // RLFM only
   const uint4 *pair_rec;  // FMX_FLAG_PAIR_INDEX: fmt-4 records over the 2-gram BWT, absolute counters
   uint32_t pair_row0, pair_row1;  // the two rows (SA = 0, 1) that have no 2-gram; stored as code 0
@@ -76,7 +77,8 @@ struct fmx_index {
   FmxDev dev;
   int device;
   uint64_t n;
-  uint32_t sym_bytes;
+  uint32_t sym_bytes;      // width on the device (1, 2, 4)
+  uint32_t sym_bytes_abi;  // width the caller uses (8 = u64 narrowed to u32 on the host)
   uint64_t max_character;
   uint32_t kind;
   uint32_t level_requested;
@@ -107,9 +109,9 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
     if (_e != hipSuccess) return fmx_hip_fail(_e, #x, __LINE__); \
   } while (0)
 
-int fmx_build_impl(fmx_index *idx, const uint8_t *d_text);
+int fmx_build_impl(fmx_index *idx, const void *d_text);
 
-int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t *d_off,
+int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
                      uint64_t *d_cnt, hipStream_t st);
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
@@ -121,7 +123,7 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st);
 // K[c] for every symbol, from the finished wavelet levels (used by the builder)
-int fmx_launch_export_l(const fmx_index *idx, uint8_t *d_out, hipStream_t st);
+int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
 int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations);
 int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,
                          uint32_t max_character, hipStream_t st);

@@ -35,7 +35,7 @@ static inline unsigned fmx_grid_for_groups(uint64_t units) {
 // ---------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
-    FmxDev ix, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
         s = 0;
         e = ix.n;
       }
-      c = j ? pat[pbeg + j - 1] : 0u;                  // pattern.iter().rev()  wrapper.rs:108
+      c = j ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 1) : 0u;  // pattern.iter().rev()  wrapper.rs:108
       fresh = false;
     }
     bool done = (j == 0);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
         s = 0; e = 0; done = true;
       } else {
         // the next symbol rides along with this step's record loads
-        const uint32_t cn = j > 1 ? pat[pbeg + j - 2] : 0u;
+        const uint32_t cn = j > 1 ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
         fmx_lf_map2_pair<KIND>(ix, c, s, e, g);        // wrapper.rs:109-110
         c = cn;
         j--;
@@ -635,17 +635,21 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
 
 // export: L column of rows [0, n) as one byte per row (get_l, fm_index.rs:82-84)
 template <int KIND>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, uint8_t *__restrict__ out) {
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, void *__restrict__ out) {
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   for (uint64_t q = gid; q < ix.n; q += ngroups) {
     uint32_t sym;
     (void)fmx_lf_map_any<KIND>(ix, (uint32_t)q, g, sym);
-    if (g == 0) out[q] = (uint8_t)sym;
+    if (g == 0) {
+      if (ix.sym_bytes == 1) ((uint8_t *)out)[q] = (uint8_t)sym;
+      else if (ix.sym_bytes == 2) ((uint16_t *)out)[q] = (uint16_t)sym;
+      else ((uint32_t *)out)[q] = sym;
+    }
   }
 }
-int fmx_launch_export_l(const fmx_index *idx, uint8_t *d_out, hipStream_t st) {
+int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   if (idx->n == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(idx->n)),
@@ -687,7 +691,7 @@ static void fmx_time_end(const fmx_index *idx, hipStream_t st) {
   }
 }
 
-int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t *d_off,
+int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
                      uint64_t *d_cnt, hipStream_t st) {
   if (npat == 0) return FMX_OK;
@@ -696,16 +700,18 @@ int fmx_launch_count(const fmx_index *idx, const uint8_t *d_pat, const uint64_t 
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   const FmxMwm &w = idx->dev.bw;
   int variant = fmx_variant();
-  if (idx->dev.pair_rec && variant != 0 && variant != 7) {
+  const uint8_t *d_pat8 = (const uint8_t *)d_pat;
+  if (idx->dev.pair_rec && idx->sym_bytes == 1 && variant != 0 && variant != 7) {
     hipLaunchKernelGGL(fmx_count_pair_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
                        idx->dev.pair_rec, idx->dev.n, idx->dev.max_character, idx->dev.pair_row0,
-                       idx->dev.pair_row1, idx->dev.status, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt,
+                       idx->dev.pair_row1, idx->dev.status, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt,
                        steps);
-  } else if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && variant != 0) {
+  } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
+             variant != 0) {
 #define FMX_F3_LAUNCH(PPG, SKIP)                                                                   \
   hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP>), dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), \
                      dim3(FMX_BLOCK), 0, st, w.lv[0].rec, idx->dev.n, idx->dev.max_character,        \
-                     idx->dev.status, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+                     idx->dev.status, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
     switch (variant) {
       case 2: FMX_F3_LAUNCH(2, false); break;
       case 3: FMX_F3_LAUNCH(1, true); break;

@@ -14,7 +14,10 @@
  * Conventions
  *  - rows / positions / counts are uint64_t (= Rust usize); the engine keeps
  *    uint32_t internally and rejects texts with n >= 2^32 (FMX_ERR_UNSUPPORTED).
- *  - symbols are `sym_bytes` wide (only 1 = u8 is implemented this round).
+ *  - symbols are `sym_bytes` wide: Character = u8 / u16 / u32 / u64 (character.rs:38-42) =
+ *    1 / 2 / 4 / 8.  u64 texts and patterns are narrowed to u32 on the host (host-pointer entry
+ *    points only); the *_dev entry points take 1-, 2- or 4-byte symbols (fmx_sym_bytes()).
+ *    max_character < 2^26.
  *  - `*_dev` entry points take DEVICE pointers and are asynchronous on `stream`
  *    (a hipStream_t passed as void*; NULL = the default stream).  The plain
  *    variants take HOST pointers, copy, run the same kernels, and synchronise.
@@ -155,7 +158,7 @@ double fmx_last_kernel_ms(const fmx_index *idx);
 /* LF steps executed by the last count / locate call when timing is enabled (else 0) */
 uint64_t fmx_last_steps(const fmx_index *idx);
 double fmx_build_ms(const fmx_index *idx);
-int fmx_export_bwt(const fmx_index *idx, void *host_out);            /* n symbols (fm_index.rs:50-55) */
+int fmx_export_bwt(const fmx_index *idx, void *host_out);            /* n symbols of fmx_sym_bytes() */
 int fmx_export_cs(const fmx_index *idx, uint64_t *host_out);         /* max_character+1 (sais.rs:9-32) */
 int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out); /* ((n-1)>>level)+1 */
 uint64_t fmx_num_samples(const fmx_index *idx);
@@ -164,6 +167,7 @@ int fmx_export_sa(const fmx_index *idx, uint32_t *host_out);         /* needs FM
  * indices not hit exactly once (0 = the array IS the suffix array) */
 int fmx_verify_sa(const fmx_index *idx, uint64_t *violations);
 uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r (rlfmi.rs:43) */
+uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol width in HBM / *_dev */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
 
 #ifdef __cplusplus

@@ -211,55 +211,58 @@ uint64_t orc_rsvec_select1(const orc_rsvec *v, uint64_t k) {
 /* ------------------------------------------------------------------ */
 /* WaveletMatrix                                                       */
 /* ------------------------------------------------------------------ */
-void orc_wm_build(orc_wm *w, const uint8_t *vals, uint64_t n, uint32_t bits) {
-  w->bits = bits;
-  w->len = n;
-  w->lv = (orc_rsvec *)calloc(bits, sizeof(orc_rsvec));
-  w->zeros = (uint64_t *)calloc(bits, sizeof(uint64_t));
-  uint8_t *cur = (uint8_t *)malloc(n ? n : 1), *nxt = (uint8_t *)malloc(n ? n : 1);
-  memcpy(cur, vals, n);
-  uint64_t nwords = (n + 63) / 64;
-  int nt = orc_max_threads();
-  uint64_t *zc = (uint64_t *)calloc((size_t)nt + 1, sizeof(uint64_t));
-  for (uint32_t l = 0; l < bits; l++) {
-    uint32_t sh = bits - 1 - l;
-    uint64_t *words = (uint64_t *)calloc(nwords + BLK_WORDS, sizeof(uint64_t));
-    /* chunk boundaries are multiples of 64 so word writes never race */
-    uint64_t chunk = ((n / (uint64_t)nt) / 64 + 1) * 64;
-#pragma omp parallel for schedule(static, 1)
-    for (int t = 0; t < nt; t++) {
-      uint64_t a = (uint64_t)t * chunk, b = a + chunk;
-      if (a > n) a = n;
-      if (b > n) b = n;
-      uint64_t z = 0;
-      for (uint64_t i = a; i < b; i++) {
-        uint64_t bit = (cur[i] >> sh) & 1u;
-        words[i >> 6] |= bit << (i & 63);
-        z += bit ^ 1u;
-      }
-      zc[t + 1] = z;
-    }
-    for (int t = 0; t < nt; t++) zc[t + 1] += zc[t];
-    uint64_t zeros = zc[nt];
-#pragma omp parallel for schedule(static, 1)
-    for (int t = 0; t < nt; t++) {
-      uint64_t a = (uint64_t)t * chunk, b = a + chunk;
-      if (a > n) a = n;
-      if (b > n) b = n;
-      uint64_t pz = zc[t], po = zeros + (a - zc[t]);
-      for (uint64_t i = a; i < b; i++) {
-        if ((cur[i] >> sh) & 1u) nxt[po++] = cur[i]; else nxt[pz++] = cur[i];
-      }
-    }
-    zc[0] = 0;
-    w->zeros[l] = zeros;
-    orc_rsvec_build(&w->lv[l], words, n);
-    uint8_t *tmp = cur; cur = nxt; nxt = tmp;
-  }
-  free(zc);
-  free(cur);
-  free(nxt);
+#define ORC_DEFINE_WM_BUILD(NAME, T) \
+void NAME(orc_wm *w, const T *vals, uint64_t n, uint32_t bits) { \
+  w->bits = bits; \
+  w->len = n; \
+  w->lv = (orc_rsvec *)calloc(bits, sizeof(orc_rsvec)); \
+  w->zeros = (uint64_t *)calloc(bits, sizeof(uint64_t)); \
+  T *cur = (T *)malloc((n ? n : 1) * sizeof(T)), *nxt = (T *)malloc((n ? n : 1) * sizeof(T)); \
+  memcpy(cur, vals, n * sizeof(T)); \
+  uint64_t nwords = (n + 63) / 64; \
+  int nt = orc_max_threads(); \
+  uint64_t *zc = (uint64_t *)calloc((size_t)nt + 1, sizeof(uint64_t)); \
+  for (uint32_t l = 0; l < bits; l++) { \
+    uint32_t sh = bits - 1 - l; \
+    uint64_t *words = (uint64_t *)calloc(nwords + BLK_WORDS, sizeof(uint64_t)); \
+    /* chunk boundaries are multiples of 64 so word writes never race */ \
+    uint64_t chunk = ((n / (uint64_t)nt) / 64 + 1) * 64; \
+_Pragma("omp parallel for schedule(static, 1)") \
+    for (int t = 0; t < nt; t++) { \
+      uint64_t a = (uint64_t)t * chunk, b = a + chunk; \
+      if (a > n) a = n; \
+      if (b > n) b = n; \
+      uint64_t z = 0; \
+      for (uint64_t i = a; i < b; i++) { \
+        uint64_t bit = ((uint64_t)cur[i] >> sh) & 1u; \
+        words[i >> 6] |= bit << (i & 63); \
+        z += bit ^ 1u; \
+      } \
+      zc[t + 1] = z; \
+    } \
+    for (int t = 0; t < nt; t++) zc[t + 1] += zc[t]; \
+    uint64_t zeros = zc[nt]; \
+_Pragma("omp parallel for schedule(static, 1)") \
+    for (int t = 0; t < nt; t++) { \
+      uint64_t a = (uint64_t)t * chunk, b = a + chunk; \
+      if (a > n) a = n; \
+      if (b > n) b = n; \
+      uint64_t pz = zc[t], po = zeros + (a - zc[t]); \
+      for (uint64_t i = a; i < b; i++) { \
+        if (((uint64_t)cur[i] >> sh) & 1u) nxt[po++] = cur[i]; else nxt[pz++] = cur[i]; \
+      } \
+    } \
+    zc[0] = 0; \
+    w->zeros[l] = zeros; \
+    orc_rsvec_build(&w->lv[l], words, n); \
+    T *tmp = cur; cur = nxt; nxt = tmp; \
+  } \
+  free(zc); \
+  free(cur); \
+  free(nxt); \
 }
+ORC_DEFINE_WM_BUILD(orc_wm_build, uint8_t)
+ORC_DEFINE_WM_BUILD(orc_wm_build_w, uint32_t)
 void orc_wm_free(orc_wm *w) {
   for (uint32_t l = 0; l < w->bits; l++) orc_rsvec_free(&w->lv[l]);
   free(w->lv); free(w->zeros);
@@ -617,6 +620,221 @@ uint64_t orc_naive_search(const uint8_t *text, uint64_t n, const uint8_t *pat, u
   if (m > n) return 0;
   for (uint64_t i = 0; i + m <= n; i++) {
     if (memcmp(text + i, pat, m) == 0) {
+      if (cnt < cap) out[cnt] = i;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+/* ------------------------------------------------------------------ */
+/* wide symbols (u16 / u32 texts as uint32_t arrays)                    */
+/* ------------------------------------------------------------------ */
+int orc_validate_text_w(const uint32_t *text, uint64_t n) { /* sais.rs:115-139 */
+  if (n == 0 || n == 1) return ORC_OK;
+  if (text[0] == 0) return ORC_ERR_START_ZERO;
+  int64_t last = -1;
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--)
+    if (text[i] != 0) { last = i; break; }
+  if (last != (int64_t)n - 2) return ORC_ERR_END_ZERO;
+  return ORC_OK;
+}
+typedef struct { const uint32_t *t; uint64_t n; } naive_ctx_w;
+static int naive_cmp_w(const void *a, const void *b, void *c) {
+  const naive_ctx_w *x = (const naive_ctx_w *)c;
+  uint64_t i = *(const uint32_t *)a, j = *(const uint32_t *)b;
+  while (i < x->n && j < x->n) {
+    if (x->t[i] != x->t[j]) return x->t[i] < x->t[j] ? -1 : 1;
+    i++; j++;
+  }
+  return i >= x->n ? (j >= x->n ? 0 : -1) : 1; /* the suffix that ends first is smaller */
+}
+void orc_suffix_array_naive_w(const uint32_t *text, uint64_t n, uint32_t *sa) {
+  for (uint64_t i = 0; i < n; i++) sa[i] = (uint32_t)i;
+  naive_ctx_w c = {text, n};
+  qsort_r(sa, n, sizeof(uint32_t), naive_cmp_w, &c);
+}
+static int sym_cmp_w(const void *a, const void *b, void *c) {
+  const uint32_t *t = (const uint32_t *)c;
+  uint32_t x = t[*(const uint32_t *)a], y = t[*(const uint32_t *)b];
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+void orc_suffix_array_w(const uint32_t *text, uint64_t n, uint32_t *sa) {
+  if (n == 0) return;
+  uint32_t *rank = (uint32_t *)malloc(n * sizeof(uint32_t));
+  uint32_t *nrank = (uint32_t *)malloc(n * sizeof(uint32_t));
+  for (uint64_t i = 0; i < n; i++) sa[i] = (uint32_t)i;
+  qsort_r(sa, n, sizeof(uint32_t), sym_cmp_w, (void *)text);
+  uint64_t head = 0;
+  for (uint64_t p = 0; p < n; p++) {
+    if (p > 0 && text[sa[p]] != text[sa[p - 1]]) head = p;
+    rank[sa[p]] = (uint32_t)head;
+  }
+  for (uint64_t h = 1;; h *= 2) {
+    dbl_ctx ctx = {rank, h, n};
+    int any = 0;
+    uint64_t g0 = 0;
+    while (g0 < n) {
+      uint64_t g1 = g0 + 1;
+      uint32_t r = rank[sa[g0]];
+      while (g1 < n && rank[sa[g1]] == r) g1++;
+      if (g1 - g0 > 1) {
+        any = 1;
+        qsort_r(sa + g0, g1 - g0, sizeof(uint32_t), dbl_cmp, &ctx);
+        uint64_t hd = g0;
+        for (uint64_t p = g0; p < g1; p++) {
+          if (p > g0 && dbl_cmp(&sa[p - 1], &sa[p], &ctx) != 0) hd = p;
+          nrank[sa[p]] = (uint32_t)hd;
+        }
+      } else {
+        nrank[sa[g0]] = (uint32_t)g0;
+      }
+      g0 = g1;
+    }
+    memcpy(rank, nrank, n * sizeof(uint32_t));
+    if (!any) break;
+  }
+  free(rank);
+  free(nrank);
+}
+static int check_symbols_w(const uint32_t *text, uint64_t n, uint64_t max_character) {
+  for (uint64_t i = 0; i < n; i++)
+    if (text[i] > max_character) return ORC_ERR_SYMBOL_RANGE;
+  return ORC_OK;
+}
+static void bucket_start_w(const uint32_t *text, uint64_t n, uint64_t max_character, uint64_t *cs) {
+  uint64_t m = max_character + 1;
+  uint64_t *occ = (uint64_t *)calloc(m, sizeof(uint64_t));
+  for (uint64_t i = 0; i < n; i++) occ[text[i]]++;
+  uint64_t sum = 0;
+  for (uint64_t c = 0; c < m; c++) { cs[c] = sum; sum += occ[c]; }
+  free(occ);
+}
+int orc_fm_new_w(orc_fm **out, const uint32_t *text, uint64_t n, uint64_t max_character, int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 0xFFFFFFFFull) return ORC_ERR_ARG;
+  int rc = check_symbols_w(text, n, max_character);
+  if (rc) return rc;
+  rc = orc_validate_text_w(text, n);
+  if (rc) return rc;
+  orc_fm *f = (orc_fm *)calloc(1, sizeof(orc_fm));
+  f->max_character = max_character;
+  f->cs = (uint64_t *)calloc(max_character + 1, sizeof(uint64_t));
+  bucket_start_w(text, n, max_character, f->cs);             /* fm_index.rs:32 */
+  uint32_t *sa = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_suffix_array_w(text, n, sa);                           /* fm_index.rs:33 */
+  uint32_t *bwt = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  for (uint64_t i = 0; i < n; i++) bwt[i] = sa[i] > 0 ? text[sa[i] - 1] : 0; /* fm_index.rs:50-55 */
+  orc_wm_build_w(&f->bw, bwt, n, orc_max_bits(max_character));
+  if (level >= 0) {
+    orc_ssa_sample(&f->ssa, sa, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  free(bwt);
+  free(sa);
+  *out = f;
+  return ORC_OK;
+}
+int orc_rlfm_new_w(orc_rlfm **out, const uint32_t *text, uint64_t n, uint64_t max_character,
+                   int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 0xFFFFFFFFull) return ORC_ERR_ARG;
+  int rc = check_symbols_w(text, n, max_character);
+  if (rc) return rc;
+  rc = orc_validate_text_w(text, n);
+  if (rc) return rc;
+  orc_rlfm *f = (orc_rlfm *)calloc(1, sizeof(orc_rlfm));
+  uint64_t m = max_character + 1;
+  f->len = n;
+  f->max_character = max_character;
+  uint32_t *sa = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_suffix_array_w(text, n, sa);
+  uint64_t nw = (n + 63) / 64 + BLK_WORDS;
+  uint64_t *bw = (uint64_t *)calloc(nw, 8), *bpw = (uint64_t *)calloc(nw, 8);
+  uint32_t *heads = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  uint64_t *run_len = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+  uint64_t *runs_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t r = 0, c0 = 0;
+  for (uint64_t i = 0; i < n; i++) {                            /* rlfmi.rs:48-68 */
+    uint32_t k = sa[i];
+    uint64_t c = k > 0 ? text[k - 1] : text[n - 1];
+    if (c0 != c) {
+      heads[r] = (uint32_t)c; run_len[r] = 1; r++;
+      bits_set(bw, i);
+      runs_of[c]++;
+    } else {
+      run_len[r - 1]++;
+    }
+    c0 = c;
+  }
+  f->runs = r;
+  orc_wm_build_w(&f->s, heads, r, orc_max_bits(max_character));
+  f->cs = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t acc = 0;
+  for (uint64_t c = 0; c < m; c++) { f->cs[c] = acc; acc += runs_of[c]; }
+  uint64_t *start_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  {
+    uint64_t *chars_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+    for (uint64_t k = 0; k < r; k++) chars_of[heads[k]] += run_len[k];
+    uint64_t a = 0;
+    for (uint64_t c = 0; c < m; c++) { start_of[c] = a; a += chars_of[c]; }
+    free(chars_of);
+  }
+  for (uint64_t k = 0; k < r; k++) {
+    uint64_t c = heads[k];
+    bits_set(bpw, start_of[c]);
+    start_of[c] += run_len[k];
+  }
+  orc_rsvec_build(&f->b, bw, n);
+  orc_rsvec_build(&f->bp, bpw, n);
+  if (level >= 0) {
+    orc_ssa_sample(&f->ssa, sa, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  free(start_of); free(runs_of); free(run_len); free(heads); free(sa);
+  *out = f;
+  return ORC_OK;
+}
+static int orc_search_w(const orc_backend *b, const uint32_t *pat, uint64_t m, uint64_t *ps,
+                        uint64_t *pe, uint64_t *steps) {       /* wrapper.rs:103-124 */
+  uint64_t s = *ps, e = *pe, k = 0;
+  for (uint64_t j = m; j-- > 0;) {
+    uint64_t c = pat[j];
+    if (c > b->max_character) return ORC_ERR_SYMBOL_RANGE;
+    s = b->lf_map2(b->self, c, s);
+    e = b->lf_map2(b->self, c, e);
+    k++;
+    if (s == e) break;
+  }
+  *ps = s; *pe = e;
+  if (steps) *steps = k;
+  return ORC_OK;
+}
+int orc_count_batch_w(const orc_backend *b, const uint32_t *pat, const uint64_t *off,
+                      uint64_t npat, const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e,
+                      uint64_t *out_steps, int nthreads) {
+  int err = 0;
+  uint64_t n = b->len(b->self);
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (int64_t k = 0; k < (int64_t)npat; k++) {
+    uint64_t s = s0e0 ? s0e0[2 * k] : 0, e = s0e0 ? s0e0[2 * k + 1] : n, st = 0;
+    int rc = orc_search_w(b, pat + off[k], off[k + 1] - off[k], &s, &e, &st);
+    if (rc) {
+#pragma omp atomic write
+      err = rc;
+    }
+    out_s[k] = s; out_e[k] = e;
+    if (out_steps) out_steps[k] = st;
+  }
+  return err;
+}
+uint64_t orc_naive_search_w(const uint32_t *text, uint64_t n, const uint32_t *pat, uint64_t m,
+                            uint64_t *out, uint64_t cap) {      /* tests/testutil/mod.rs:62-86 */
+  uint64_t cnt = 0;
+  if (m > n) return 0;
+  for (uint64_t i = 0; i + m <= n; i++) {
+    if (memcmp(text + i, pat, m * sizeof(uint32_t)) == 0) {
       if (cnt < cap) out[cnt] = i;
       cnt++;
     }

@@ -172,6 +172,21 @@ uint64_t orc_naive_search(const uint8_t *text, uint64_t n, const uint8_t *pat, u
 
 int orc_max_threads(void);
 
+/* ---- wide symbols: Character = u16 / u32 (character.rs:38-42) as uint32_t arrays ------ */
+/* Same algorithms as above with 32-bit symbols; max_character < 2^32, bits = max_bits. */
+int orc_validate_text_w(const uint32_t *text, uint64_t n);
+void orc_suffix_array_naive_w(const uint32_t *text, uint64_t n, uint32_t *sa);
+void orc_suffix_array_w(const uint32_t *text, uint64_t n, uint32_t *sa);
+void orc_wm_build_w(orc_wm *w, const uint32_t *vals, uint64_t n, uint32_t bits);
+int orc_fm_new_w(orc_fm **out, const uint32_t *text, uint64_t n, uint64_t max_character, int level);
+int orc_rlfm_new_w(orc_rlfm **out, const uint32_t *text, uint64_t n, uint64_t max_character,
+                   int level);
+int orc_count_batch_w(const orc_backend *b, const uint32_t *pat, const uint64_t *pat_off,
+                      uint64_t npat, const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e,
+                      uint64_t *out_steps, int nthreads);
+uint64_t orc_naive_search_w(const uint32_t *text, uint64_t n, const uint32_t *pat, uint64_t m,
+                            uint64_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,16 @@ def _bind(lib):
     lib.orc_naive_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_uint64]
     lib.orc_max_threads.restype = C.c_int
+    # wide symbols (u16 / u32 texts as uint32 arrays)
+    lib.orc_suffix_array_naive_w.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_suffix_array_w.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_fm_new_w.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    lib.orc_rlfm_new_w.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    lib.orc_count_batch_w.argtypes = [bp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_naive_search_w.restype = C.c_uint64
+    lib.orc_naive_search_w.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                       C.c_uint64]
     return lib
 
 
@@ -105,6 +115,14 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _is_wide(a):
+    return isinstance(a, np.ndarray) and a.dtype.itemsize > 1
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
 def pack_patterns(patterns):
     """list of byte strings -> (flat u8, offsets u64[npat+1])."""
     off = np.zeros(len(patterns) + 1, dtype=np.uint64)
@@ -117,6 +135,11 @@ def pack_patterns(patterns):
 
 
 def suffix_array(text, naive=False):
+    if _is_wide(text):
+        t = _u32(text)
+        sa = np.zeros(max(len(t), 1), dtype=np.uint32)
+        (lib().orc_suffix_array_naive_w if naive else lib().orc_suffix_array_w)(_p(t), len(t), _p(sa))
+        return sa[:len(t)]
     t = _u8(text)
     sa = np.zeros(max(len(t), 1), dtype=np.uint32)
     (lib().orc_suffix_array_naive if naive else lib().orc_suffix_array)(_p(t), len(t), _p(sa))
@@ -140,6 +163,12 @@ def bwt(text, sa):
 
 def naive_search(text, pattern):
     """NaiveSearchIndex::search (tests/testutil/mod.rs:62-86): ascending positions."""
+    if _is_wide(text):
+        t, p = _u32(text), _u32(pattern)
+        cap = max(len(t), 1)
+        out = np.zeros(cap, dtype=np.uint64)
+        k = lib().orc_naive_search_w(_p(t), len(t), _p(p), len(p), _p(out), cap)
+        return out[:k].copy()
     t, p = _u8(text), _u8(pattern)
     cap = max(len(t), 1)
     out = np.zeros(cap, dtype=np.uint64)
@@ -153,6 +182,7 @@ class OracleIndex:
     def __init__(self, text=None, max_character=255, level=None, kind="fm", _lib=None,
                  _from_bwt=None):
         self._l = _lib or lib()
+        self.wide = False
         self.kind = kind
         self.max_character = int(max_character)
         h = C.c_void_p()
@@ -164,6 +194,12 @@ class OracleIndex:
             sp = _p(np.ascontiguousarray(samples, dtype=np.uint32)) if samples is not None else None
             rc = self._l.orc_fm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, _p(cs),
                                          sp, lvl)
+        elif _is_wide(text):
+            t = _u32(text)
+            self._text_keep = t
+            self.wide = True
+            new = self._l.orc_fm_new_w if kind == "fm" else self._l.orc_rlfm_new_w
+            rc = new(C.byref(h), _p(t), len(t), self.max_character, lvl)
         else:
             t = _u8(text)
             self._text_keep = t
@@ -196,14 +232,15 @@ class OracleIndex:
 
     # --- batched driver -------------------------------------------------
     def count_batch(self, flat, off, s0e0=None, nthreads=1, want_steps=False):
-        flat = _u8(flat)
+        flat = _u32(flat) if self.wide else _u8(flat)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         npat = len(off) - 1
         s = np.zeros(max(npat, 1), dtype=np.uint64)
         e = np.zeros(max(npat, 1), dtype=np.uint64)
         st = np.zeros(max(npat, 1), dtype=np.uint64)
         se = None if s0e0 is None else np.ascontiguousarray(s0e0, dtype=np.uint64)
-        rc = self._l.orc_count_batch(C.byref(self._b), _p(flat), _p(off), npat,
+        fn = self._l.orc_count_batch_w if self.wide else self._l.orc_count_batch
+        rc = fn(C.byref(self._b), _p(flat), _p(off), npat,
                                      None if se is None else _p(se), _p(s), _p(e), _p(st),
                                      nthreads)
         if rc != 0:
@@ -224,7 +261,11 @@ class OracleIndex:
 
     # --- reference-shaped convenience ------------------------------------
     def search(self, pattern, s0e0=None):
-        flat, off = pack_patterns([pattern])
+        if self.wide:
+            flat = _u32(pattern) if len(pattern) else np.zeros(1, dtype=np.uint32)
+            off = np.array([0, len(pattern)], dtype=np.uint64)
+        else:
+            flat, off = pack_patterns([pattern])
         se = None if s0e0 is None else np.array(s0e0, dtype=np.uint64)
         s, e = self.count_batch(flat, off, se)
         return int(s[0]), int(e[0])

@@ -79,6 +79,32 @@ def build_library(force=False):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, the soname libfmx.so needs).  If torch is imported first, libfmx binds to
+    that copy and everything -- including torch streams handed to the *_dev entry points -- lives
+    in one runtime.  If libfmx were loaded first it would pull /opt/rocm's copy and a later
+    `import torch` would bring up a second runtime (which then finds no device).  So when a torch
+    wheel with a bundled runtime is installed, load that copy first (torch itself is NOT
+    imported).  FMX_HIP_RUNTIME=<path> overrides; FMX_HIP_RUNTIME=system skips this."""
+    forced = os.environ.get("FMX_HIP_RUNTIME")
+    if forced == "system":
+        return
+    path = forced
+    if not path:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec and spec.submodule_search_locations:
+                cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+                if os.path.exists(cand):
+                    path = cand
+        except Exception:  # noqa: BLE001
+            path = None
+    if path:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -86,6 +112,7 @@ def lib():
             raise RuntimeError(
                 "fm_index_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        _preload_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol

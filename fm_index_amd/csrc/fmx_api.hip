@@ -90,6 +90,8 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM) return fail(FMX_ERR_ARG, "unknown kind");
   if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
+  if (kind == FMX_KIND_RLFM && n >= (1ull << 31))
+    return fail(FMX_ERR_UNSUPPORTED, "RLFM: n >= 2^31 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
 
@@ -258,6 +260,13 @@ int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, 
 // host-pointer entry points (copy in, same kernels, copy out, synchronise)
 // ---------------------------------------------------------------------------
 namespace {
+// every host-pointer call runs on its own non-blocking stream: concurrent callers never share
+// the legacy default stream (or its stream-ordered allocations)
+struct CallStream {
+  hipStream_t st = nullptr;
+  hipError_t open() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
+  ~CallStream() { if (st) (void)hipStreamDestroy(st); }
+};
 struct Scratch {  // device buffers freed on scope exit
   void *p[12];
   int n = 0;
@@ -277,6 +286,8 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
   uint64_t total = pat_off[npat];
   const uint32_t sb = idx->sym_bytes;  // device symbol width
+  CallStream cs;
+  FMX_HIP(cs.open());
   Scratch sc;
   void *d_pat, *d_off, *d_se = nullptr, *d_s, *d_e, *d_c;
   FMX_HIP(sc.get(&d_pat, total * sb));
@@ -301,9 +312,9 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     FMX_HIP(hipMemcpy(d_se, s0e0, npat * 16, hipMemcpyHostToDevice));
   }
   if (int rc = fmx_launch_count(idx, d_pat, (const uint64_t *)d_off, npat, (const uint64_t *)d_se,
-                                (uint64_t *)d_s, (uint64_t *)d_e, (uint64_t *)d_c, 0))
+                                (uint64_t *)d_s, (uint64_t *)d_e, (uint64_t *)d_c, cs.st))
     return rc;
-  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipStreamSynchronize(cs.st));
   if (out_s) FMX_HIP(hipMemcpy(out_s, d_s, npat * 8, hipMemcpyDeviceToHost));
   if (out_e) FMX_HIP(hipMemcpy(out_e, d_e, npat * 8, hipMemcpyDeviceToHost));
   if (out_count) FMX_HIP(hipMemcpy(out_count, d_c, npat * 8, hipMemcpyDeviceToHost));
@@ -318,6 +329,8 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
   uint64_t total = out_off[npat];
   if (total == 0) return FMX_OK;
+  CallStream cs;
+  FMX_HIP(cs.open());
   Scratch sc;
   void *d_s, *d_e, *d_off, *d_pos;
   FMX_HIP(sc.get(&d_s, npat * 8));
@@ -328,9 +341,9 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
   FMX_HIP(hipMemcpy(d_off, out_off, (npat + 1) * 8, hipMemcpyHostToDevice));
   if (int rc = fmx_launch_locate(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat,
-                                 (const uint64_t *)d_off, total, (uint64_t *)d_pos, 0))
+                                 (const uint64_t *)d_off, total, (uint64_t *)d_pos, cs.st))
     return rc;
-  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipStreamSynchronize(cs.st));
   FMX_HIP(hipMemcpy(out_pos, d_pos, total * 8, hipMemcpyDeviceToHost));
   return fmx_stream_status(idx);
 }
@@ -340,6 +353,8 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
   CHECK_IDX(idx);
   if (op == 3 && idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   if (k == 0) return FMX_OK;
+  CallStream cs;
+  FMX_HIP(cs.open());
   Scratch sc;
   void *d_c = nullptr, *d_i, *d_o;
   FMX_HIP(sc.get(&d_i, k * 8));
@@ -350,9 +365,9 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
     FMX_HIP(hipMemcpy(d_c, c, k * 8, hipMemcpyHostToDevice));
   }
   if (int rc = fmx_launch_scalar(idx, op, (const uint64_t *)d_c, (const uint64_t *)d_i, k,
-                                 (uint64_t *)d_o, 0))
+                                 (uint64_t *)d_o, cs.st))
     return rc;
-  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipStreamSynchronize(cs.st));
   FMX_HIP(hipMemcpy(out, d_o, k * 8, hipMemcpyDeviceToHost));
   return fmx_stream_status(idx);
 }

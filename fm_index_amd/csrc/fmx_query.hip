@@ -19,8 +19,11 @@
 
 // kernel variant selector for experiments (FMX_VARIANT=0 forces the generic kernels)
 static inline int fmx_variant() {
-  const char *v = getenv("FMX_VARIANT");
-  return v ? atoi(v) : 1;
+  static const int cached = [] {
+    const char *v = getenv("FMX_VARIANT");
+    return v ? atoi(v) : 1;
+  }();
+  return cached;
 }
 
 static inline unsigned fmx_grid_for_groups(uint64_t units) {

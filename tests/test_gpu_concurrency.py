@@ -1,0 +1,90 @@
+"""Thread-safety promise of the ABI (include/fmx.h): a handle is immutable after build, so any
+number of host threads may query it concurrently; *_dev calls honour the caller's stream."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import fm_index_amd as F
+from fm_index_amd import _lib as L
+from fm_index_amd import workload as W
+from oracle import fm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_queries_on_one_handle():
+    t = W.dna_text_np(1 << 18, 1)
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    oi = O.OracleIndex(t, 4, level=2)
+    jobs = []
+    for k in range(8):
+        flat, off, _ = W.substring_patterns_np(t, 3000, 10 + k, 100 + k)
+        s, e = oi.count_batch(flat, off, nthreads=4)
+        ooff, opos = oi.locate_batch(s, e, nthreads=4)
+        jobs.append((flat, off, s, e, opos))
+    errors = []
+
+    def worker(job):
+        flat, off, s, e, opos = job
+        try:
+            for _ in range(5):
+                b = gi.search_many(flat=flat, off=off)
+                assert (b.s == s).all() and (b.e == e).all()
+                _, pos = b.locate()
+                assert (pos == opos).all()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
+def test_dev_entry_points_on_a_side_stream():
+    import torch
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    t = W.dna_text_np(1 << 18, 2)
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 1)
+    oi = O.OracleIndex(t, 4, level=1)
+    flat, off, _ = W.substring_patterns_np(t, 5000, 9, 3)
+    s0, e0 = oi.count_batch(flat, off, nthreads=4)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        d_pat = torch.from_numpy(flat).to(dev, non_blocking=False)
+        d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+        npat = len(off) - 1
+        d_s = torch.empty(npat, dtype=torch.int64, device=dev)
+        d_e = torch.empty(npat, dtype=torch.int64, device=dev)
+        d_c = torch.empty(npat, dtype=torch.int64, device=dev)
+        sp = C.c_void_p(side.cuda_stream)
+        h = gi.handle()
+        assert lib.fmx_count_batch_dev(h, C.c_void_p(d_pat.data_ptr()), C.c_void_p(d_off.data_ptr()),
+                                       npat, None, C.c_void_p(d_s.data_ptr()),
+                                       C.c_void_p(d_e.data_ptr()), C.c_void_p(d_c.data_ptr()), sp) == 0
+        d_o = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+        assert lib.fmx_offsets_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                   C.c_void_p(d_o.data_ptr()), sp) == 0
+        side.synchronize()
+        total = int(d_o[-1].item())
+        d_p = torch.empty(total, dtype=torch.int64, device=dev)
+        assert lib.fmx_locate_batch_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                        C.c_void_p(d_o.data_ptr()), total,
+                                        C.c_void_p(d_p.data_ptr()), sp) == 0
+        side.synchronize()
+    assert lib.fmx_stream_status(h) == 0
+    assert (d_s.cpu().numpy().view(np.uint64) == s0).all()
+    assert (d_e.cpu().numpy().view(np.uint64) == e0).all()
+    _, opos = oi.locate_batch(s0, e0, nthreads=4)
+    assert (d_p.cpu().numpy().view(np.uint64) == opos).all()
+    # ragged + refinement through the device entry points
+    flat2, off2 = W.ragged_patterns_np(4000, 7, 4, 8)
+    se = np.stack([s0[:4000], e0[:4000]], axis=1).reshape(-1)
+    s2, e2 = oi.count_batch(flat2, off2, se)
+    b = gi.search_many(flat=flat2, off=off2, s0e0=se)
+    assert (b.s == s2).all() and (b.e == e2).all()

@@ -122,6 +122,20 @@ class _Index:
                                        C.byref(self._h)))
         return self
 
+    def save(self, path):
+        """write the flat index file (header + HBM arrays)."""
+        _check(self._lib.fmx_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """upload a saved index to `device` without rebuilding."""
+        self = cls.__new__(cls)
+        self._lib = L.lib()
+        self._h = C.c_void_p()
+        _check(self._lib.fmx_load(str(path).encode(), device, C.byref(self._h)))
+        self._dtype = np.dtype(_DTYPES[int(self._lib.fmx_sym_bytes(self._h))])
+        return self
+
     # -- SearchIndex (frontend.rs:26-44) --
     def search(self, pattern):
         return Search(self, None, None).search(pattern)

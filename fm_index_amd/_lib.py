@@ -30,6 +30,8 @@ SYMBOLS = [
     ("fmx_build", _I, [_V, _U64, _U32, _U64, _U32, _U32, _U32, _I, C.POINTER(_V)]),
     ("fmx_build_dev", _I, [_V, _U64, _U32, _U64, _U32, _U32, _U32, _I, C.POINTER(_V)]),
     ("fmx_free", None, [_V]),
+    ("fmx_save", _I, [_V, C.c_char_p]),
+    ("fmx_load", _I, [C.c_char_p, _I, C.POINTER(_V)]),
     ("fmx_len", _U64, [_V]),
     ("fmx_index_bytes", _U64, [_V]),
     ("fmx_max_character", _U64, [_V]),

@@ -421,3 +421,119 @@ int fmx_verify_sa(const fmx_index *idx, uint64_t *violations) {
   if (!idx->d_sa || !idx->d_text) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
   return fmx_verify_sa_impl(idx, violations);
 }
+
+// ---------------------------------------------------------------------------
+// flat index file (the reference has no public on-disk format: its serde derives sit on
+// private backend structs only, fm_index.rs:13 / rlfmi.rs:15 / sample.rs:12)
+//   header | FmxDev (pointers are rewritten on load) | cs[] | device arrays in a fixed order
+// ---------------------------------------------------------------------------
+namespace {
+struct FileHeader {
+  char magic[8];           // "FMXIDX01"
+  uint32_t version, dev_struct_bytes;
+  uint64_t n, max_character, nsamples, runs, bytes;
+  uint32_t sym_bytes, sym_bytes_abi, kind, level_requested;
+};
+struct Blob { const void **field; uint64_t bytes; };
+// every device array the query path reads, in file order
+int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
+  int k = 0;
+  for (uint32_t l = 0; l < d.bw.nlevels; l++) {
+    out[k++] = {(const void **)&d.bw.lv[l].rec, (uint64_t)d.bw.lv[l].nrec * 128};
+    out[k++] = {(const void **)&d.bw.lv[l].C, 64};
+  }
+  out[k++] = {(const void **)&d.K, ((uint64_t)d.max_character + 1) * 4};
+  if (d.sa_level != FMX_NO_LOCATE) out[k++] = {(const void **)&d.samples, (nsamples + 4) * 4};
+  if (d.kind == FMX_KIND_RLFM) {
+    out[k++] = {(const void **)&d.b.rec, (uint64_t)d.b.nrec * 128};
+    out[k++] = {(const void **)&d.b.sel, (uint64_t)d.b.nsel * 4};
+    out[k++] = {(const void **)&d.bp.rec, (uint64_t)d.bp.nrec * 128};
+    out[k++] = {(const void **)&d.bp.sel, (uint64_t)d.bp.nsel * 4};
+  }
+  if (d.pair_rec) out[k++] = {(const void **)&d.pair_rec, ((uint64_t)d.n / 128 + 1) * 128};
+  return k;
+}
+const size_t kChunk = 64u << 20;
+}  // namespace
+
+int fmx_save(const fmx_index *idx, const char *path) {
+  CHECK_IDX(idx);
+  if (!path) return fail(FMX_ERR_ARG, "path is NULL");
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(FMX_ERR_ARG, "cannot open file for writing");
+  FileHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "FMXIDX01", 8);
+  h.version = 1;
+  h.dev_struct_bytes = (uint32_t)sizeof(FmxDev);
+  h.n = idx->n; h.max_character = idx->max_character; h.nsamples = idx->nsamples;
+  h.runs = idx->runs; h.bytes = idx->bytes;
+  h.sym_bytes = idx->sym_bytes; h.sym_bytes_abi = idx->sym_bytes_abi; h.kind = idx->kind;
+  h.level_requested = idx->level_requested;
+  FmxDev d = idx->dev;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&d, sizeof d, 1, f) == 1 &&
+            fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
+  Blob blobs[40];
+  int nb = enumerate_blobs(d, idx->nsamples, blobs);
+  std::string buf(kChunk, '\0');
+  for (int b = 0; ok && b < nb; b++) {
+    const uint8_t *src = (const uint8_t *)*blobs[b].field;
+    for (uint64_t o = 0; ok && o < blobs[b].bytes; o += kChunk) {
+      size_t m = (size_t)(blobs[b].bytes - o < kChunk ? blobs[b].bytes - o : kChunk);
+      if (hipMemcpy(&buf[0], src + o, m, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+      ok = fwrite(&buf[0], 1, m, f) == m;
+    }
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? FMX_OK : fail(FMX_ERR_ARG, "write failed");
+}
+
+int fmx_load(const char *path, int device, fmx_index **out) {
+  if (!out || !path) return fail(FMX_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (int rc = select_device(device)) return rc;
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(FMX_ERR_ARG, "cannot open index file");
+  FileHeader h;
+  fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
+  int rc = FMX_OK;
+  do {
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "FMXIDX01", 8) != 0 || h.version != 1 ||
+        h.dev_struct_bytes != sizeof(FmxDev)) { rc = fail(FMX_ERR_ARG, "not an fmx index file (or another version)"); break; }
+    if (fread(&idx->dev, sizeof(FmxDev), 1, f) != 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
+    idx->device = device;
+    idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = h.nsamples; idx->runs = h.runs;
+    idx->sym_bytes = h.sym_bytes; idx->sym_bytes_abi = h.sym_bytes_abi; idx->kind = h.kind;
+    idx->level_requested = h.level_requested;
+    idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
+    if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
+    Blob blobs[40];
+    int nb = enumerate_blobs(idx->dev, idx->nsamples, blobs);
+    for (int b = 0; b < nb; b++) *blobs[b].field = nullptr;  // stale pointers of the saving process
+    idx->dev.status = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&idx->dev.status, 4)) != hipSuccess || (e = hipMalloc((void **)&idx->d_steps, 8)) != hipSuccess ||
+        (e = hipMemset(idx->dev.status, 0, 4)) != hipSuccess || (e = hipMemset(idx->d_steps, 0, 8)) != hipSuccess ||
+        (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess) {
+      rc = fmx_hip_fail(e, "handle resources", __LINE__);
+      break;
+    }
+    std::string buf(kChunk, '\0');
+    for (int b = 0; rc == FMX_OK && b < nb; b++) {
+      void *p = nullptr;
+      if ((e = hipMalloc(&p, blobs[b].bytes ? blobs[b].bytes : 8)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
+      if ((rc = fmx_keep(idx, p, blobs[b].bytes)) != FMX_OK) { (void)hipFree(p); break; }
+      *blobs[b].field = p;
+      for (uint64_t o = 0; o < blobs[b].bytes; o += kChunk) {
+        size_t m = (size_t)(blobs[b].bytes - o < kChunk ? blobs[b].bytes - o : kChunk);
+        if (fread(&buf[0], 1, m, f) != m) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
+        if ((e = hipMemcpy((uint8_t *)p + o, &buf[0], m, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
+      }
+    }
+  } while (0);
+  fclose(f);
+  if (rc != FMX_OK) { fmx_free(idx); return rc; }
+  idx->bytes = h.bytes;  // as reported by the index that was saved
+  *out = idx;
+  return FMX_OK;
+}

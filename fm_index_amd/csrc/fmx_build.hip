@@ -373,12 +373,7 @@ __global__ __launch_bounds__(BLK) void k_count_not_one(const uint32_t *mark, uin
 }
 
 // ---- helpers ---------------------------------------------------------------------
-int keep(fmx_index *idx, void *p, uint64_t bytes) {
-  if (idx->nalloc >= 64) return FMX_ERR_ARG;
-  idx->d_alloc[idx->nalloc++] = p;
-  idx->bytes += bytes;
-  return FMX_OK;
-}
+int keep(fmx_index *idx, void *p, uint64_t bytes) { return fmx_keep(idx, p, bytes); }
 
 // level split: fewest levels (<= 4 bits each), widths as even as possible, wide ones first
 // L=3 -> [3]; 5 -> [3,2]; 7 -> [4,3]; 8 -> [4,4]; 9 -> [3,3,3]

@@ -110,6 +110,13 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// registers a device allocation owned by the index (freed by fmx_free, counted in index bytes)
+static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
+  if (idx->nalloc >= 64) return FMX_ERR_ARG;
+  idx->d_alloc[idx->nalloc++] = p;
+  idx->bytes += bytes;
+  return FMX_OK;
+}
 
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,

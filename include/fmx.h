@@ -85,6 +85,10 @@ int fmx_build(const void *text, uint64_t n, uint32_t sym_bytes, uint64_t max_cha
 int fmx_build_dev(const void *d_text, uint64_t n, uint32_t sym_bytes, uint64_t max_character,
                   uint32_t kind, uint32_t level, uint32_t flags, int device, fmx_index **out);
 void fmx_free(fmx_index *idx); /* Drop */
+/* flat index file: header + the HBM arrays as they are (the reference has no public on-disk
+ * format).  fmx_load uploads it to `device` without rebuilding. */
+int fmx_save(const fmx_index *idx, const char *path);
+int fmx_load(const char *path, int device, fmx_index **out);
 
 /* ---- SearchIndex (frontend.rs:26-44) ------------------------------------ */
 uint64_t fmx_len(const fmx_index *idx);         /* SearchIndexBackend::len, backend.rs:25 */

@@ -194,6 +194,12 @@ class _Index:
     def get_sa(self, i):
         return self._scalar(self._lib.fmx_get_sa_batch, i)
 
+    def get_f(self, i):
+        return self._scalar(self._lib.fmx_get_f_batch, i)
+
+    def fl_map(self, i):
+        return self._scalar(self._lib.fmx_fl_map_batch, i)
+
     # -- export / checks --
     def export_bwt(self):
         out = np.zeros(max(self.len(), 1), dtype=_DTYPES[int(self._lib.fmx_sym_bytes(self._h))])
@@ -317,6 +323,13 @@ class Match:
         if v == 0xFFFFFFFFFFFFFFFF:
             raise Error(L.ERR_NO_LOCATE, lib.fmx_last_error().decode())
         return v
+
+    def iter_chars_forward(self):  # wrapper.rs:175-183: get_f then fl_map
+        i = self._i
+        lib = self._ix._lib
+        while True:
+            yield int(lib.fmx_get_f(self._ix._h, i))
+            i = int(lib.fmx_fl_map(self._ix._h, i))
 
     def iter_chars_backward(self):  # wrapper.rs:154-161: get_l then lf_map
         i = self._i

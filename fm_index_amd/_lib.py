@@ -42,14 +42,20 @@ SYMBOLS = [
     ("fmx_lf_map", _U64, [_V, _U64]),
     ("fmx_lf_map2", _U64, [_V, _U64, _U64]),
     ("fmx_get_sa", _U64, [_V, _U64]),
+    ("fmx_get_f", _U64, [_V, _U64]),
+    ("fmx_fl_map", _U64, [_V, _U64]),
     ("fmx_get_l_batch_dev", _I, [_V, _V, _U64, _V, _V]),
     ("fmx_lf_map_batch_dev", _I, [_V, _V, _U64, _V, _V]),
     ("fmx_lf_map2_batch_dev", _I, [_V, _V, _V, _U64, _V, _V]),
     ("fmx_get_sa_batch_dev", _I, [_V, _V, _U64, _V, _V]),
+    ("fmx_get_f_batch_dev", _I, [_V, _V, _U64, _V, _V]),
+    ("fmx_fl_map_batch_dev", _I, [_V, _V, _U64, _V, _V]),
     ("fmx_get_l_batch", _I, [_V, _V, _U64, _V]),
     ("fmx_lf_map_batch", _I, [_V, _V, _U64, _V]),
     ("fmx_lf_map2_batch", _I, [_V, _V, _V, _U64, _V]),
     ("fmx_get_sa_batch", _I, [_V, _V, _U64, _V]),
+    ("fmx_get_f_batch", _I, [_V, _V, _U64, _V]),
+    ("fmx_fl_map_batch", _I, [_V, _V, _U64, _V]),
     ("fmx_count_batch_dev", _I, [_V, _V, _V, _U64, _V, _V, _V, _V, _V]),
     ("fmx_count_batch", _I, [_V, _V, _V, _U64, _V, _V, _V, _V]),
     ("fmx_stream_status", _I, [_V]),

@@ -250,6 +250,14 @@ int fmx_lf_map2_batch_dev(const fmx_index *idx, const uint64_t *d_c, const uint6
   CHECK_IDX(idx);
   return fmx_launch_scalar(idx, 2, d_c, d_i, k, d_out, (hipStream_t)stream);
 }
+int fmx_get_f_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_scalar(idx, 4, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
+int fmx_fl_map_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_scalar(idx, 5, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
 int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
@@ -378,11 +386,15 @@ int fmx_lf_map2_batch(const fmx_index *idx, const uint64_t *c, const uint64_t *i
   return scalar_host(idx, 2, c, i, k, out);
 }
 int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 3, nullptr, i, k, out); }
+int fmx_get_f_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 4, nullptr, i, k, out); }
+int fmx_fl_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 5, nullptr, i, k, out); }
 
 // one trait method per call
 uint64_t fmx_get_l(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_l_batch(idx, &i, 1, &o) ? ~0ull : o; }
 uint64_t fmx_lf_map(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_lf_map_batch(idx, &i, 1, &o) ? ~0ull : o; }
 uint64_t fmx_lf_map2(const fmx_index *idx, uint64_t c, uint64_t i) { uint64_t o = ~0ull; return fmx_lf_map2_batch(idx, &c, &i, 1, &o) ? ~0ull : o; }
+uint64_t fmx_get_f(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_f_batch(idx, &i, 1, &o) ? ~0ull : o; }
+uint64_t fmx_fl_map(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_fl_map_batch(idx, &i, 1, &o) ? ~0ull : o; }
 uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_sa_batch(idx, &i, 1, &o) ? ~0ull : o; }
 
 // ---------------------------------------------------------------------------
@@ -443,6 +455,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     out[k++] = {(const void **)&d.bw.lv[l].C, 64};
   }
   out[k++] = {(const void **)&d.K, ((uint64_t)d.max_character + 1) * 4};
+  out[k++] = {(const void **)&d.cs, ((uint64_t)d.max_character + 1) * 4};
   if (d.sa_level != FMX_NO_LOCATE) out[k++] = {(const void **)&d.samples, (nsamples + 4) * 4};
   if (d.kind == FMX_KIND_RLFM) {
     out[k++] = {(const void **)&d.b.rec, (uint64_t)d.b.nrec * 128};

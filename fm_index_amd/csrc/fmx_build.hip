@@ -679,6 +679,15 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   if (int rc = keep(idx, d_K, (maxc + 1) * 4)) return rc;
   if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
   dv.K = d_K;
+  {  // run-based C array as u32 for get_f / fl_map (rlfmi.rs:145-169)
+    std::vector<uint32_t> c32((size_t)maxc + 1);
+    for (uint32_t c = 0; c <= maxc; c++) c32[c] = (uint32_t)rcs[c];
+    uint32_t *d_c32;
+    FMX_HIP(hipMalloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
+    if (int rc = keep(idx, d_c32, ((uint64_t)maxc + 1) * 4)) return rc;
+    FMX_HIP(hipMemcpy(d_c32, c32.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
+    dv.cs = d_c32;
+  }
   (void)d_L;
   return FMX_OK;
 }
@@ -795,6 +804,15 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 4)) return rc;
     if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
     dv.K = d_K;
+    {  // C array as u32 for get_f / fl_map
+      std::vector<uint32_t> c32((size_t)maxc + 1);
+      for (uint32_t c = 0; c <= maxc; c++) c32[c] = (uint32_t)idx->h_cs[c];
+      uint32_t *d_c32;
+      FMX_HIP(hipMalloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
+      if (int rc = keep(idx, d_c32, ((uint64_t)maxc + 1) * 4)) return rc;
+      FMX_HIP(hipMemcpy(d_c32, c32.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
+      dv.cs = d_c32;
+    }
   } else {
     if (n < 2) {  // the reference hits unreachable!() (rlfmi.rs:62-65) / has nothing to index
       fmx_set_error(FMX_ERR_UNSUPPORTED, "RLFM index needs a text of at least 2 symbols");

@@ -197,6 +197,69 @@ __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, ui
   return r;
 }
 
+// position of the r-th (0-based) set bit of w; r < popc(w)
+__device__ __forceinline__ uint32_t fmx_select32(uint32_t w, uint32_t r) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (int sh = 16; sh; sh >>= 1) {
+    uint32_t c = __popc((w >> pos) & ((1u << sh) - 1u));
+    if (r >= c) { r -= c; pos += sh; }
+  }
+  return pos;
+}
+// ---------------------------------------------------------------------------
+// select on the wavelet levels (extract path: get_f / fl_map, fm_index.rs:97-120).
+// Not on the count/locate hot path: a plain binary search over the record counters.
+// ---------------------------------------------------------------------------
+// counter of `code` at the start of record r (same units as fmx_level_rank's result)
+__device__ __forceinline__ uint32_t fmx_level_counter(const FmxLevel &L, uint32_t r, uint32_t code) {
+  if (L.fmt == 3) return L.rec[(size_t)r * 8u + code].x;
+  const uint4 p = L.rec[(size_t)r * 8u + (code >> 1)];
+  return (code & 1u) ? p.y : p.x;
+}
+// position p of the entry with level code `code` whose fmx_level_rank(L, p, code) == target
+__device__ __forceinline__ uint32_t fmx_level_select(const FmxLevel &L, uint32_t code,
+                                                     uint32_t target, uint32_t g) {
+  uint32_t lo = 0, hi = L.nrec - 1u;
+  while (lo < hi) {  // last record whose counter <= target
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (fmx_level_counter(L, mid, code) <= target) lo = mid; else hi = mid - 1u;
+  }
+  const uint32_t rem = target - fmx_level_counter(L, lo, code);  // rem-th match inside the record
+  uint32_t m, per;
+  if (L.fmt == 3) { m = fmx_piece_match<3>(L.rec[(size_t)lo * 8u + g], code); per = 32u; }
+  else { m = fmx_piece_match<4>(L.rec[(size_t)lo * 8u + g], code); per = 16u; }
+  const uint32_t mine = __popc(m);
+  // exclusive prefix of the per-piece counts over the 8 lanes of the group
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < FMX_GROUP; q++) {
+    const uint32_t cq = fmx_group_sum(g == q ? mine : 0u);
+    before += (q < g) ? cq : 0u;
+  }
+  const bool here = rem >= before && rem < before + mine;
+  const uint32_t pos = here ? g * per + fmx_select32(m, rem - before) : 0u;
+  return lo * (L.fmt == 3 ? 256u : 128u) + fmx_group_sum(pos);
+}
+// WaveletMatrix::select_u64_unchecked(k, c): position of the k-th (0-based) c
+__device__ __forceinline__ uint32_t fmx_mwm_select(const FmxMwm &w, uint32_t c, uint32_t k,
+                                                   uint32_t g) {
+  // down: the start chain of c, in counter units of the last level
+  uint32_t pos = 0, r = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    r = fmx_level_rank(L, pos, (c >> L.shift) & L.mask, g);
+    pos = r;
+  }
+  // up: invert the level mappings
+  uint32_t target = r + k;
+  for (uint32_t l = w.nlevels; l-- > 0;) {
+    const FmxLevel &L = w.lv[l];
+    target = fmx_level_select(L, (c >> L.shift) & L.mask, target, g);
+  }
+  return target;
+}
+
 // ===========================================================================
 // RLFM (rlfmi.rs): bit vectors B / B' with rank1 / select1, and the LF formulas
 // ===========================================================================
@@ -223,16 +286,6 @@ __device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i,
   uint32_t mine = (g == p) ? 1u : 0u;
   bit_i = fmx_group_sum(mine * ((word >> (bit & 31u)) & 1u));
   return fmx_group_sum(mine * (pc.x + c));
-}
-// position of the r-th (0-based) set bit of w; r < popc(w)
-__device__ __forceinline__ uint32_t fmx_select32(uint32_t w, uint32_t r) {
-  uint32_t pos = 0;
-#pragma unroll
-  for (int sh = 16; sh; sh >>= 1) {
-    uint32_t c = __popc((w >> pos) & ((1u << sh) - 1u));
-    if (r >= c) { r -= c; pos += sh; }
-  }
-  return pos;
 }
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
@@ -338,6 +391,34 @@ __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t
   if (eqe) ne = ne + e - fmx_bits_select(ix.b, je, g);
   s = ns;
   e = ne;
+}
+
+// greatest c with cs[c] <= v  (get_f's binary search, fm_index.rs:97-112)
+__device__ __forceinline__ uint32_t fmx_cs_upper(const uint32_t *cs, uint32_t max_character,
+                                                 uint32_t v) {
+  uint32_t s = 0, e = max_character + 1u;
+  while (e - s > 1u) {
+    const uint32_t m = s + (e - s) / 2u;
+    if (cs[m] <= v) s = m; else e = m;
+  }
+  return s;
+}
+// get_f + fl_map (fm_index.rs:97-120, rlfmi.rs:145-169); returns fl_map(i), sets sym = get_f(i)
+template <int KIND>
+__device__ __forceinline__ uint32_t fmx_fl_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
+                                                   uint32_t &sym) {
+  if (KIND == FMX_KIND_FM) {
+    sym = fmx_cs_upper(ix.cs, ix.max_character, i);
+    return fmx_mwm_select(ix.bw, sym, i - ix.cs[sym], g);   // bw.select(i - cs[c], c)
+  } else {
+    uint32_t bit;
+    const uint32_t j = fmx_bits_rank(ix.bp, i + 1u, g, bit) - 1u;   // bp.rank1(i+1) - 1
+    sym = fmx_cs_upper(ix.cs, ix.max_character, j);
+    const uint32_t p = fmx_bits_select(ix.bp, j, g);                // bp.select1(j)
+    const uint32_t m = fmx_mwm_select(ix.bw, sym, j - ix.cs[sym], g);  // s.select(j - cs[c], c)
+    const uint32_t nn = fmx_bits_select(ix.b, m, g);                // b.select1(m)
+    return nn + i - p;
+  }
 }
 
 // kind-dispatching forms used by the kernels

@@ -70,7 +70,8 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   FmxBits b, bp;        // RLFM only
   const uint4 *pair_rec;  // FMX_FLAG_PAIR_INDEX: fmt-4 records over the 2-gram BWT, absolute counters
   uint32_t pair_row0, pair_row1;  // the two rows (SA = 0, 1) that have no 2-gram; stored as code 0
-  const uint32_t *cs;   // RLFM only: run-based C array (rlfmi.rs:72-76)
+  const uint32_t *cs;   // C array on the device for get_f / fl_map: characters (FM, sais.rs:9-32)
+                        // or runs (RLFM, rlfmi.rs:72-76)
 };
 
 struct fmx_index {
@@ -126,7 +127,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                       hipStream_t st);
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
                        hipStream_t st);
-// op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa
+// op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st);
 // K[c] for every symbol, from the finished wavelet levels (used by the builder)

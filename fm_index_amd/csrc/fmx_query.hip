@@ -620,6 +620,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
       uint32_t sym;
       uint32_t r = fmx_lf_map_any<KIND>(ix, (uint32_t)i64, g, sym);
       res = op == 0 ? (uint64_t)sym : (uint64_t)r;
+    } else if (op == 4 || op == 5) {  // get_f / fl_map (fm_index.rs:97-120, rlfmi.rs:145-169)
+      uint32_t sym;
+      uint32_t r = fmx_fl_map_any<KIND>(ix, (uint32_t)i64, g, sym);
+      res = op == 4 ? (uint64_t)sym : (uint64_t)r;
     } else {  // get_sa (fm_index.rs:127-140)
       uint32_t row = (uint32_t)i64, steps = 0;
       const uint32_t lmask = (1u << ix.sa_level) - 1u;

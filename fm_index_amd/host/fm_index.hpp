@@ -51,6 +51,9 @@ class Match {  // frontend.rs:86-98
   Match(const Index *ix, uint64_t i) : ix_(ix), i_(i) {}
   uint64_t locate() const;  // wrapper.rs:238-242
   uint64_t row() const { return i_; }
+  // iter_chars_forward().take(k) / iter_chars_backward().take(k)  (wrapper.rs:142-183)
+  std::vector<uint64_t> chars_forward(size_t k) const;
+  std::vector<uint64_t> chars_backward(size_t k) const;
 
  private:
   const Index *ix_;
@@ -138,6 +141,24 @@ inline std::vector<uint64_t> Search::locate_all() const {
   std::vector<uint64_t> pos(e_ - s_);
   check(fmx_locate_batch(ix_->handle(), &s_, &e_, 1, off, pos.data()));
   return pos;
+}
+inline std::vector<uint64_t> Match::chars_forward(size_t k) const {
+  std::vector<uint64_t> out;
+  uint64_t i = i_;
+  for (size_t t = 0; t < k; t++) {           // get_f then fl_map  (wrapper.rs:175-183)
+    out.push_back(fmx_get_f(ix_->handle(), i));
+    i = fmx_fl_map(ix_->handle(), i);
+  }
+  return out;
+}
+inline std::vector<uint64_t> Match::chars_backward(size_t k) const {
+  std::vector<uint64_t> out;
+  uint64_t i = i_;
+  for (size_t t = 0; t < k; t++) {           // get_l then lf_map  (wrapper.rs:154-161)
+    out.push_back(fmx_get_l(ix_->handle(), i));
+    i = fmx_lf_map(ix_->handle(), i);
+  }
+  return out;
 }
 inline uint64_t Match::locate() const {
   uint64_t v = fmx_get_sa(ix_->handle(), i_);

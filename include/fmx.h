@@ -105,6 +105,10 @@ uint64_t fmx_get_l(const fmx_index *idx, uint64_t i);              /* fm_index.r
 uint64_t fmx_lf_map(const fmx_index *idx, uint64_t i);             /* fm_index.rs:86-91  */
 uint64_t fmx_lf_map2(const fmx_index *idx, uint64_t c, uint64_t i); /* fm_index.rs:93-95 */
 uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i);             /* fm_index.rs:127-140 */
+/* the remaining two trait methods (backend.rs:17-19): the extract path behind
+ * Match::iter_chars_forward (wrapper.rs:175-183).  fl_map is always Some for FM / RLFM. */
+uint64_t fmx_get_f(const fmx_index *idx, uint64_t i);              /* fm_index.rs:97-112  */
+uint64_t fmx_fl_map(const fmx_index *idx, uint64_t i);             /* fm_index.rs:114-120 */
 
 /* batched forms of the same four methods (device pointers, async) */
 int fmx_get_l_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
@@ -115,12 +119,18 @@ int fmx_lf_map2_batch_dev(const fmx_index *idx, const uint64_t *d_c, const uint6
                           uint64_t k, uint64_t *d_out, void *stream);
 int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
                          void *stream);
+int fmx_get_f_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                        void *stream);
+int fmx_fl_map_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                         void *stream);
 /* host-pointer forms */
 int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
 int fmx_lf_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
 int fmx_lf_map2_batch(const fmx_index *idx, const uint64_t *c, const uint64_t *i, uint64_t k,
                       uint64_t *out);
 int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+int fmx_get_f_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+int fmx_fl_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
 
 /* ---- Search::search(..).count()  (wrapper.rs:37-42, 103-134) -------------- */
 /* For pattern k = pat[pat_off[k] .. pat_off[k+1]):

@@ -295,6 +295,17 @@ uint64_t orc_wm_rank(const orc_wm *w, uint64_t i, uint64_t c) {
   return e - s;
 }
 
+/* select_u64_unchecked(k, c): position of the k-th (0-based) c, by definition
+ * (smallest p with rank(p+1, c) == k+1) -- a binary search over rank is enough for a checker */
+uint64_t orc_wm_select(const orc_wm *w, uint64_t k, uint64_t c) {
+  uint64_t lo = 0, hi = w->len; /* answer in [lo, hi) */
+  while (hi - lo > 1) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (orc_wm_rank(w, mid, c) <= k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 /* ------------------------------------------------------------------ */
 /* SOSampledSuffixArray                                                */
 /* ------------------------------------------------------------------ */
@@ -366,9 +377,26 @@ static uint64_t fm_get_sa(const void *p, uint64_t i) {                          
     steps++;
   }
 }
+static uint64_t cs_upper(const uint64_t *cs, uint64_t m, uint64_t v) { /* fm_index.rs:97-112 */
+  uint64_t s = 0, e = m;
+  while (e - s > 1) {
+    uint64_t mid = s + (e - s) / 2;
+    if (cs[mid] <= v) s = mid; else e = mid;
+  }
+  return s;
+}
+static uint64_t fm_get_f(const void *p, uint64_t i) {                           /* fm_index.rs:97-112 */
+  const orc_fm *f = (const orc_fm *)p;
+  return cs_upper(f->cs, f->max_character + 1, i);
+}
+static uint64_t fm_fl_map(const void *p, uint64_t i) {                          /* fm_index.rs:114-120 */
+  const orc_fm *f = (const orc_fm *)p;
+  uint64_t c = fm_get_f(p, i);
+  return orc_wm_select(&f->bw, i - f->cs[c], c);
+}
 orc_backend orc_fm_backend(orc_fm *f) {
   orc_backend b = {f, fm_get_l, fm_lf_map, fm_lf_map2, fm_len,
-                   f->has_locate ? fm_get_sa : NULL, f->max_character};
+                   f->has_locate ? fm_get_sa : NULL, fm_get_f, fm_fl_map, f->max_character};
   return b;
 }
 static int check_symbols(const uint8_t *text, uint64_t n, uint64_t max_character) {
@@ -468,9 +496,23 @@ static uint64_t rl_get_sa(const void *p, uint64_t i) {                       /* 
     steps++;
   }
 }
+static uint64_t rl_get_f(const void *p, uint64_t i) {                        /* rlfmi.rs:145-158 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  uint64_t r = orc_rsvec_rank1(&f->bp, i + 1) - 1;
+  return cs_upper(f->cs, f->max_character + 1, r);
+}
+static uint64_t rl_fl_map(const void *p, uint64_t i) {                       /* rlfmi.rs:160-169 */
+  const orc_rlfm *f = (const orc_rlfm *)p;
+  uint64_t c = rl_get_f(p, i);
+  uint64_t j = orc_rsvec_rank1(&f->bp, i + 1) - 1;
+  uint64_t pp = orc_rsvec_select1(&f->bp, j);
+  uint64_t m = orc_wm_select(&f->s, j - f->cs[c], c);
+  uint64_t nn = orc_rsvec_select1(&f->b, m);
+  return nn + i - pp;
+}
 orc_backend orc_rlfm_backend(orc_rlfm *f) {
   orc_backend b = {f, rl_get_l, rl_lf_map, rl_lf_map2, rl_len,
-                   f->has_locate ? rl_get_sa : NULL, f->max_character};
+                   f->has_locate ? rl_get_sa : NULL, rl_get_f, rl_fl_map, f->max_character};
   return b;
 }
 static void bits_set(uint64_t *w, uint64_t i) { w[i >> 6] |= 1ull << (i & 63); }
@@ -611,6 +653,12 @@ void orc_get_l_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64
 }
 void orc_get_sa_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
   for (uint64_t j = 0; j < k; j++) out[j] = b->get_sa(b->self, i[j]);
+}
+void orc_get_f_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->get_f(b->self, i[j]);
+}
+void orc_fl_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->fl_map(b->self, i[j]);
 }
 
 /* tests/testutil/mod.rs:62-86 with match_prefix_only = match_suffix_only = false */

@@ -83,6 +83,7 @@ void orc_wm_build(orc_wm *w, const uint8_t *vals, uint64_t n, uint32_t bits);
 void orc_wm_free(orc_wm *w);
 uint64_t orc_wm_get(const orc_wm *w, uint64_t i);               /* get_u64_unchecked  */
 uint64_t orc_wm_rank(const orc_wm *w, uint64_t i, uint64_t c);  /* rank_u64_unchecked */
+uint64_t orc_wm_select(const orc_wm *w, uint64_t k, uint64_t c); /* select_u64_unchecked */
 
 /* ---- SOSampledSuffixArray (suffix_array/sample.rs:21-60) ---- */
 typedef struct orc_ssa {
@@ -104,6 +105,8 @@ typedef struct orc_backend {
   uint64_t (*lf_map2)(const void *self, uint64_t c, uint64_t i);
   uint64_t (*len)(const void *self);
   uint64_t (*get_sa)(const void *self, uint64_t i); /* HasPosition; may be NULL */
+  uint64_t (*get_f)(const void *self, uint64_t i);
+  uint64_t (*fl_map)(const void *self, uint64_t i); /* always Some for FM / RLFM */
   uint64_t max_character;
 } orc_backend;
 
@@ -164,6 +167,8 @@ void orc_lf_map2_batch(const orc_backend *b, const uint64_t *c, const uint64_t *
 void orc_lf_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_get_l_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_get_sa_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
+void orc_get_f_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
+void orc_fl_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 
 /* NaiveSearchIndex::search (tests/testutil/mod.rs:62-86): positions ascending;
  * returns the number of matches, writes at most cap of them */

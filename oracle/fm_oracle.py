@@ -22,7 +22,7 @@ _u8p = C.POINTER(C.c_uint8)
 class _Backend(C.Structure):
     _fields_ = [("self", C.c_void_p), ("get_l", C.c_void_p), ("lf_map", C.c_void_p),
                 ("lf_map2", C.c_void_p), ("len", C.c_void_p), ("get_sa", C.c_void_p),
-                ("max_character", C.c_uint64)]
+                ("get_f", C.c_void_p), ("fl_map", C.c_void_p), ("max_character", C.c_uint64)]
 
 
 def build(native=False):
@@ -66,6 +66,8 @@ def _bind(lib):
     lib.orc_lf_map_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_get_l_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_get_sa_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_get_f_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_fl_map_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_naive_search.restype = C.c_uint64
     lib.orc_naive_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_uint64]
@@ -306,4 +308,16 @@ class OracleIndex:
         i = np.ascontiguousarray(i, dtype=np.uint64)
         out = np.zeros(max(len(i), 1), dtype=np.uint64)
         self._l.orc_get_sa_batch(C.byref(self._b), _p(i), len(i), _p(out))
+        return out[:len(i)]
+
+    def get_f(self, i):
+        i = np.ascontiguousarray(i, dtype=np.uint64)
+        out = np.zeros(max(len(i), 1), dtype=np.uint64)
+        self._l.orc_get_f_batch(C.byref(self._b), _p(i), len(i), _p(out))
+        return out[:len(i)]
+
+    def fl_map(self, i):
+        i = np.ascontiguousarray(i, dtype=np.uint64)
+        out = np.zeros(max(len(i), 1), dtype=np.uint64)
+        self._l.orc_fl_map_batch(C.byref(self._b), _p(i), len(i), _p(out))
         return out[:len(i)]

@@ -18,6 +18,13 @@ int main(int argc, char **argv) {
     std::printf("positions");
     for (auto &m : search.iter_matches()) std::printf(" %llu", (unsigned long long)m.locate());
     std::printf("\n");
+    auto ms = search.iter_matches();
+    std::printf("forward ");
+    for (auto c : ms[3].chars_forward(20)) std::printf("%c", (char)c);       // README.md:78-85
+    std::printf("\nbackward ");
+    auto back = ms[0].chars_backward(16);                                    // README.md:67-76
+    for (size_t t = back.size(); t-- > 0;) std::printf("%c", (char)back[t]);
+    std::printf("\n");
     auto refined = index.search(std::string("lor")).search(std::string("do"));
     std::printf("refined %llu\n", (unsigned long long)refined.count());
     try {

@@ -17,5 +17,7 @@ def test_readme_example_cpp(golden, tmp_path):
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "count 4"
     assert lines[1] == "positions 246 12 300 103"          # README.md:64, in this order
-    assert lines[2] == "refined 4"
-    assert lines[3] == "error invalid text: the given text must end with exactly one zero character"
+    assert lines[2] == "forward " + golden["readme"]["forward_20_from_match_3"]
+    assert lines[3] == "backward " + golden["readme"]["backward_16_from_first_match"]
+    assert lines[4] == "refined 4"
+    assert lines[5] == "error invalid text: the given text must end with exactly one zero character"

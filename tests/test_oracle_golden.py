@@ -244,3 +244,20 @@ def test_symbol_out_of_range_is_error():
         fm.search(bytes([5]))
     with pytest.raises(O.OracleError):
         O.OracleIndex(np.array([1, 9, 0], dtype=np.uint8), 4)
+
+
+@pytest.mark.parametrize("kind", ["fm", "rlfm"])
+def test_fl_map_and_get_f_known_answers(golden, kind):
+    """fm_index.rs:163-173 / rlfmi.rs:329-351: fl_map table and get_f = sorted text."""
+    g = golden["mississippi"]
+    idx = O.OracleIndex(b(g["text"]), 255, kind=kind)
+    assert idx.fl_map(np.arange(12)).tolist() == g["fl_map"]["expected"]
+    assert bytes(int(x) for x in idx.get_f(np.arange(12))) == bytes(sorted(b(g["text"])))
+    r = golden["readme"]
+    idx = O.OracleIndex(b(r["text"]), 255, level=2, kind=kind)
+    s, e = idx.search(b(r["pattern"]))
+    i, out = s + 3, []          # iter_matches().nth(3).iter_chars_forward().take(20)
+    for _ in range(20):
+        out.append(int(idx.get_f([i])[0]))
+        i = int(idx.fl_map([i])[0])
+    assert bytes(out) == b(r["forward_20_from_match_3"])

@@ -104,23 +104,52 @@ def main():
     del idx2d
     d_s = torch.empty(npat, dtype=torch.int64, device=dev)
     d_e = torch.empty(npat, dtype=torch.int64, device=dev)
-    d_c = torch.empty(npat, dtype=torch.int64, device=dev)
     from fm_index_amd import sharding
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     h = index.handle()
 
+    # N > 1 (config 5): the per-pattern counts of every rank are all-gathered over RCCL/xGMI.
+    # The gather of step k overlaps the search kernel of step k+1: two result buffers alternate,
+    # the collective is issued async (it runs on RCCL's stream once the kernel that produced its
+    # input has finished) and a buffer is only reused after its gather has completed.  Counts
+    # travel as int32 (n < 2^32): 4 MiB per rank per step instead of 8.
+    pipelined = world > 1 and args.dist_backend == "nccl" and not os.environ.get("FMX_BENCH_SYNC_GATHER")
+    nbuf = 2 if pipelined else 1
+    d_cs = [torch.empty(npat, dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    d_c32 = [torch.empty(npat, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    g_out = [torch.empty(total_pat, dtype=torch.int32, device=dev) for _ in range(nbuf)] if world > 1 else []
+    pending = [None] * nbuf
+    d_c = d_cs[0]
+    step_no = [0]
+
     def step():
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        if pending[b] is not None:          # this buffer's previous gather must be done
+            pending[b].wait()
+            pending[b] = None
         rc = lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat,
                                      None, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
-                                     C.c_void_p(d_c.data_ptr()), sp)
+                                     C.c_void_p(d_cs[b].data_ptr()), sp)
         if rc != 0:
             raise RuntimeError(lib.fmx_last_error().decode())
-        if world > 1:   # config 5: RCCL all-gather of the per-pattern counts over xGMI
-            if args.dist_backend == "gloo":
-                return sharding.gather_counts(d_c.cpu(), total_pat)
-            return sharding.gather_counts(d_c, total_pat)
-        return d_c
+        if world > 1:
+            if args.dist_backend == "gloo":     # single-GPU rehearsal of the control flow
+                return sharding.gather_counts(d_cs[b].cpu(), total_pat)
+            d_c32[b].copy_(d_cs[b])
+            if pipelined:
+                pending[b] = dist.all_gather_into_tensor(g_out[b], d_c32[b], async_op=True)
+            else:
+                dist.all_gather_into_tensor(g_out[b], d_c32[b])
+            return g_out[b]
+        return d_cs[b]
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def barrier():
         if world > 1:
@@ -129,6 +158,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     # kernel-only time over the timed region: HIP events on the launch stream
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -137,6 +167,7 @@ def main():
     ev0.record(stream)
     for k in range(args.steps):
         step()
+    drain()                      # every gather of the timed steps has completed
     ev1.record(stream)
     barrier()
     dt = time.perf_counter() - t0
@@ -150,8 +181,13 @@ def main():
 
     # ---- validation + step census (outside the timed region) ----
     lib.fmx_set_timing(h, 1)
-    step()
+    step_no[0] = 0
+    last = step()
+    drain()
     torch.cuda.synchronize()
+    if world > 1 and args.dist_backend == "nccl":
+        # gathered counts: this rank's shard sits at [rank*npat, (rank+1)*npat) and equals its own
+        assert bool((last[rank * npat:(rank + 1) * npat].to(torch.int64) == d_cs[0]).all())
     kernel_ms_single = lib.fmx_last_kernel_ms(h)
     steps_exec = int(lib.fmx_last_steps(h))
     lib.fmx_set_timing(h, 0)

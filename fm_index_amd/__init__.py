@@ -20,7 +20,8 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["Text", "Error", "FMIndex", "FMIndexWithLocate", "RLFMIndex", "RLFMIndexWithLocate",
-           "Search", "Match", "SearchBatch", "pack_patterns"]
+           "FMIndexMultiPieces", "FMIndexMultiPiecesWithLocate", "Search", "Match", "SearchBatch",
+           "pack_patterns"]
 
 
 class Error(Exception):
@@ -139,6 +140,18 @@ class _Index:
     # -- SearchIndex (frontend.rs:26-44) --
     def search(self, pattern):
         return Search(self, None, None).search(pattern)
+
+    def match_rows_many(self, s, e, prefix_only=False):
+        """rows iter_matches() visits for every [s, e): (offsets, rows) (wrapper.rs:203-217)."""
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        e = np.ascontiguousarray(e, dtype=np.uint64)
+        cnt = np.zeros(max(len(s), 1), dtype=np.uint64)
+        _check(self._lib.fmx_match_counts(self._h, _p(s), _p(e), len(s), int(prefix_only), _p(cnt)))
+        off = np.zeros(len(s) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(cnt[:len(s)], dtype=np.uint64)
+        rows = np.zeros(max(int(off[-1]), 1), dtype=np.uint64)
+        _check(self._lib.fmx_match_rows(self._h, _p(s), _p(e), len(s), int(prefix_only), _p(off), _p(rows)))
+        return off, rows[:int(off[-1])]
 
     def len(self):
         return int(self._lib.fmx_len(self._h))
@@ -280,19 +293,51 @@ class RLFMIndexWithLocate(_Index):
         super().__init__(text, level, device, keep_sa)
 
 
+class FMIndexMultiPieces(_Index):
+    """FMIndexMultiPieces::new(&text) (frontend.rs:245-253): several \\0-separated pieces."""
+    _kind = L.KIND_MULTI
+
+    def __init__(self, text, device=0, keep_sa=False):
+        super().__init__(text, None, device, keep_sa)
+
+    def piece_id(self, i):
+        return self._scalar(self._lib.fmx_piece_id_batch, i)
+
+    def pieces_count(self):
+        return int(self._lib.fmx_pieces_count(self._h))
+
+    # SearchIndexWithMultiPieces (frontend.rs:46-68; wrapper.rs:57-82)
+    def search_prefix(self, pattern):
+        return Search(self, None, None, True).search(pattern)
+
+    def search_suffix(self, pattern):
+        return Search(self, 0, self.pieces_count(), False).search(pattern)
+
+    def search_exact(self, pattern):
+        return Search(self, 0, self.pieces_count(), True).search(pattern)
+
+
+class FMIndexMultiPiecesWithLocate(FMIndexMultiPieces):
+    """FMIndexMultiPiecesWithLocate::new(&text, level) (frontend.rs:255-267)."""
+
+    def __init__(self, text, level, device=0, keep_sa=False):
+        _Index.__init__(self, text, level, device, keep_sa)
+
+
 class Search:
     """Search (frontend.rs:70-84): an SA interval [s, e) that can be refined."""
 
-    def __init__(self, index, s, e):
+    def __init__(self, index, s, e, match_prefix_only=False):
         self._ix = index
         self._s = s
         self._e = e
+        self._prefix = match_prefix_only     # wrapper.rs:22, 208
 
     def search(self, pattern):  # wrapper.rs:103-124: prepends `pattern`
         flat, off = pack_patterns([pattern], self._ix._dtype)
         se = None if self._s is None else np.array([self._s, self._e], dtype=np.uint64)
         b = self._ix.search_many(flat=flat, off=off, s0e0=se)
-        return Search(self._ix, int(b.s[0]), int(b.e[0]))
+        return Search(self._ix, int(b.s[0]), int(b.e[0]), self._prefix)
 
     def count(self):  # wrapper.rs:132-134
         return self._e - self._s
@@ -301,13 +346,26 @@ class Search:
         return (self._s, self._e)
 
     def iter_matches(self):  # wrapper.rs:137-139, 203-217: rows s..e-1 ascending
-        for i in range(self._s, self._e):
-            yield Match(self._ix, i)
+        if not self._prefix:
+            for i in range(self._s, self._e):
+                yield Match(self._ix, i)
+        else:  # match_prefix_only: only rows whose L symbol is the end marker (wrapper.rs:208)
+            _, rows = self._ix.match_rows_many([self._s], [self._e], True)
+            for i in rows:
+                yield Match(self._ix, int(i))
 
     def locate_all(self):
         """iter_matches().map(|m| m.locate()).collect() in one kernel launch."""
+        if self._prefix:
+            _, rows = self._ix.match_rows_many([self._s], [self._e], True)
+            return [int(x) for x in self._ix.get_sa(rows)]
         _, pos = self._ix.locate_many([self._s], [self._e])
         return [int(x) for x in pos]
+
+    def piece_ids(self):
+        """iter_matches().map(|m| m.piece_id()).collect() (multi-pieces index)."""
+        _, rows = self._ix.match_rows_many([self._s], [self._e], self._prefix)
+        return [int(x) for x in self._ix.piece_id(rows)]
 
 
 class Match:
@@ -324,12 +382,18 @@ class Match:
             raise Error(L.ERR_NO_LOCATE, lib.fmx_last_error().decode())
         return v
 
-    def iter_chars_forward(self):  # wrapper.rs:175-183: get_f then fl_map
+    def piece_id(self):  # MatchWithPieceId::piece_id (frontend.rs:100-104)
+        return int(self._ix._lib.fmx_piece_id(self._ix._h, self._i))
+
+    def iter_chars_forward(self):  # wrapper.rs:175-183: get_f then fl_map (stops at None)
         i = self._i
         lib = self._ix._lib
         while True:
-            yield int(lib.fmx_get_f(self._ix._h, i))
+            c = int(lib.fmx_get_f(self._ix._h, i))
             i = int(lib.fmx_fl_map(self._ix._h, i))
+            if i == 0xFFFFFFFFFFFFFFFF:      # fl_map -> None: `?` ends the iterator (wrapper.rs:180)
+                return
+            yield c
 
     def iter_chars_backward(self):  # wrapper.rs:154-161: get_l then lf_map
         i = self._i

@@ -18,6 +18,7 @@ ERR_HIP = 6
 ERR_NO_LOCATE = 7
 KIND_FM = 0
 KIND_RLFM = 1
+KIND_MULTI = 2
 NO_LOCATE = 0xFFFFFFFF
 FLAG_KEEP_SA = 1
 FLAG_PAIR_INDEX = 2
@@ -73,6 +74,14 @@ SYMBOLS = [
     ("fmx_export_sa", _I, [_V, _V]),
     ("fmx_verify_sa", _I, [_V, C.POINTER(_U64)]),
     ("fmx_num_runs", _U64, [_V]),
+    ("fmx_pieces_count", _U64, [_V]),
+    ("fmx_piece_id", _U64, [_V, _U64]),
+    ("fmx_piece_id_batch_dev", _I, [_V, _V, _U64, _V, _V]),
+    ("fmx_piece_id_batch", _I, [_V, _V, _U64, _V]),
+    ("fmx_match_counts_dev", _I, [_V, _V, _V, _U64, _I, _V, _V]),
+    ("fmx_match_counts", _I, [_V, _V, _V, _U64, _I, _V]),
+    ("fmx_match_rows_dev", _I, [_V, _V, _V, _U64, _I, _V, _V, _V]),
+    ("fmx_match_rows", _I, [_V, _V, _V, _U64, _I, _V, _V]),
     ("fmx_sym_bytes", _U32, [_V]),
     ("fmx_has_pair_index", _I, [_V]),
 ]

@@ -88,7 +88,8 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   // sais.rs:16): keep them to a sane size
   if (max_character >= (1ull << 26))
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
-  if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM) return fail(FMX_ERR_ARG, "unknown kind");
+  if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
+    return fail(FMX_ERR_ARG, "unknown kind");
   if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
   if (kind == FMX_KIND_RLFM && n >= (1ull << 31))
     return fail(FMX_ERR_UNSUPPORTED, "RLFM: n >= 2^31 is not supported");
@@ -398,6 +399,74 @@ uint64_t fmx_fl_map(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; retu
 uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_sa_batch(idx, &i, 1, &o) ? ~0ull : o; }
 
 // ---------------------------------------------------------------------------
+// multi-pieces (multi_pieces.rs)
+// ---------------------------------------------------------------------------
+uint64_t fmx_pieces_count(const fmx_index *idx) { return idx && idx->kind == FMX_KIND_MULTI ? idx->dev.doc_count : 0; }
+int fmx_piece_id_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
+  CHECK_IDX(idx);
+  if (idx->kind != FMX_KIND_MULTI) return fail(FMX_ERR_ARG, "piece_id needs a multi-pieces index");
+  return fmx_launch_scalar(idx, 6, nullptr, d_i, k, d_out, (hipStream_t)stream);
+}
+int fmx_piece_id_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) {
+  if (idx && idx->kind != FMX_KIND_MULTI) return fail(FMX_ERR_ARG, "piece_id needs a multi-pieces index");
+  return scalar_host(idx, 6, nullptr, i, k, out);
+}
+uint64_t fmx_piece_id(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_piece_id_batch(idx, &i, 1, &o) ? ~0ull : o; }
+int fmx_match_counts_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                         int prefix_only, uint64_t *d_out_count, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_match_counts(idx, d_s, d_e, npat, prefix_only, d_out_count, (hipStream_t)stream);
+}
+int fmx_match_rows_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                       int prefix_only, const uint64_t *d_out_off, uint64_t *d_out_rows, void *stream) {
+  CHECK_IDX(idx);
+  return fmx_launch_match_rows(idx, d_s, d_e, npat, prefix_only, d_out_off, d_out_rows, (hipStream_t)stream);
+}
+int fmx_match_counts(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                     int prefix_only, uint64_t *out_count) {
+  CHECK_IDX(idx);
+  if (npat == 0) return FMX_OK;
+  CallStream cs;
+  FMX_HIP(cs.open());
+  Scratch sc;
+  void *d_s, *d_e, *d_c;
+  FMX_HIP(sc.get(&d_s, npat * 8));
+  FMX_HIP(sc.get(&d_e, npat * 8));
+  FMX_HIP(sc.get(&d_c, npat * 8));
+  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
+  if (int rc = fmx_launch_match_counts(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat,
+                                       prefix_only, (uint64_t *)d_c, cs.st))
+    return rc;
+  FMX_HIP(hipStreamSynchronize(cs.st));
+  FMX_HIP(hipMemcpy(out_count, d_c, npat * 8, hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                   int prefix_only, const uint64_t *out_off, uint64_t *out_rows) {
+  CHECK_IDX(idx);
+  if (npat == 0 || out_off[npat] == 0) return FMX_OK;
+  uint64_t total = out_off[npat];
+  CallStream cs;
+  FMX_HIP(cs.open());
+  Scratch sc;
+  void *d_s, *d_e, *d_o, *d_r;
+  FMX_HIP(sc.get(&d_s, npat * 8));
+  FMX_HIP(sc.get(&d_e, npat * 8));
+  FMX_HIP(sc.get(&d_o, (npat + 1) * 8));
+  FMX_HIP(sc.get(&d_r, total * 8));
+  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_o, out_off, (npat + 1) * 8, hipMemcpyHostToDevice));
+  if (int rc = fmx_launch_match_rows(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat, prefix_only,
+                                     (const uint64_t *)d_o, (uint64_t *)d_r, cs.st))
+    return rc;
+  FMX_HIP(hipStreamSynchronize(cs.st));
+  FMX_HIP(hipMemcpy(out_rows, d_r, total * 8, hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // export / verification
 // ---------------------------------------------------------------------------
 int fmx_export_bwt(const fmx_index *idx, void *host_out) {
@@ -456,6 +525,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   }
   out[k++] = {(const void **)&d.K, ((uint64_t)d.max_character + 1) * 4};
   out[k++] = {(const void **)&d.cs, ((uint64_t)d.max_character + 1) * 4};
+  if (d.kind == FMX_KIND_MULTI) out[k++] = {(const void **)&d.doc, (uint64_t)d.doc_count * 4};
   if (d.sa_level != FMX_NO_LOCATE) out[k++] = {(const void **)&d.samples, (nsamples + 4) * 4};
   if (d.kind == FMX_KIND_RLFM) {
     out[k++] = {(const void **)&d.b.rec, (uint64_t)d.b.nrec * 128};

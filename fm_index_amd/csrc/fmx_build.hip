@@ -342,6 +342,30 @@ __global__ __launch_bounds__(BLK) void k_select_hints(const uint4 *__restrict__ 
   for (; m < b1; m += FMX_SEL_STEP) sel[m / FMX_SEL_STEP] = (uint32_t)r;
 }
 
+// ---- multi-pieces: doc[] and sa_idx_first_text (multi_pieces.rs:57-85) ----------------
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_zero_flags(const T *__restrict__ a, uint32_t n,
+                                                     uint32_t *__restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) flags[i] = a[i] == 0 ? 1u : 0u;
+}
+// for the k-th end marker of L (row p): doc[k] = number of end markers before text position
+// (SA[p] - 1) mod n; the row whose marker is the LAST of the text is sa_idx_first_text
+__global__ __launch_bounds__(BLK) void k_doc(const uint32_t *__restrict__ sa,
+                                              const uint32_t *__restrict__ zl_flag,
+                                              const uint32_t *__restrict__ zl_rank,
+                                              const uint32_t *__restrict__ zt_rank, uint32_t n,
+                                              uint32_t pieces, uint32_t *__restrict__ doc,
+                                              uint32_t *__restrict__ first_row) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n || !zl_flag[p]) return;
+  uint32_t k = sa[p];
+  uint32_t pos = k > 0 ? k - 1 : n - 1;   // modular_sub(sa[p], 1, n)
+  uint32_t piece = zt_rank[pos];          // end_marker_flags.rank1(end_marker_idx)
+  doc[zl_rank[p]] = piece;
+  if (piece == pieces - 1) *first_row = (uint32_t)p;
+}
+
 // ---- verification (FMX_FLAG_KEEP_SA) ---------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_verify_sa(const T *__restrict__ t,
@@ -792,7 +816,39 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
   if (n) hipLaunchKernelGGL(k_bwt<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
   FMX_HIP(hipGetLastError());
 
-  if (idx->kind == FMX_KIND_FM) {
+  if (idx->kind == FMX_KIND_MULTI && n > 0) {
+    // doc[] before the BWT buffer is consumed by the wavelet builder
+    const uint32_t pieces = (uint32_t)hist[0];
+    uint32_t *zl, *zlr, *zt, *ztr, *d_doc, *d_first;
+    FMX_HIP(pool.get(&zl, n));
+    FMX_HIP(pool.get(&zlr, n));
+    FMX_HIP(pool.get(&zt, n));
+    FMX_HIP(pool.get(&ztr, n));
+    FMX_HIP(pool.get(&d_first, 1));
+    FMX_HIP(hipMemset(d_first, 0, 4));
+    FMX_HIP(hipMalloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
+    if (int rc = keep(idx, d_doc, (uint64_t)pieces * 4)) return rc;
+    hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_bwt, n, zl);
+    hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, zt);
+    size_t tb = 0;
+    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, zl, zlr, (size_t)n, (hipStream_t)0));
+    uint8_t *tmp;
+    FMX_HIP(pool.get(&tmp, tb));
+    size_t t1 = tb;
+    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, t1, zl, zlr, (size_t)n, (hipStream_t)0));
+    t1 = tb;
+    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, t1, zt, ztr, (size_t)n, (hipStream_t)0));
+    hipLaunchKernelGGL(k_doc, dim3(nblocks(n)), dim3(BLK), 0, 0, d_sa, zl, zlr, ztr, n, pieces, d_doc,
+                       d_first);
+    uint32_t first = 0;
+    FMX_HIP(hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost));
+    dv.doc = d_doc;
+    dv.doc_count = pieces;
+    dv.first_row = first;
+    pool.release(zl); pool.release(zlr); pool.release(zt); pool.release(ztr); pool.release(tmp);
+    pool.release(d_first);
+  }
+  if (idx->kind == FMX_KIND_FM || idx->kind == FMX_KIND_MULTI) {
     FMX_HIP(hipDeviceSynchronize());
     if (int rc = build_mwm<T>(idx, &dv.bw, d_bwt, n, L, pool, idx->h_cs, maxc + 1)) return rc;
     // K[c] = cs[c] - S_c (all zero when cs[] was folded into a single level)

@@ -407,8 +407,9 @@ __device__ __forceinline__ uint32_t fmx_cs_upper(const uint32_t *cs, uint32_t ma
 template <int KIND>
 __device__ __forceinline__ uint32_t fmx_fl_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
                                                    uint32_t &sym) {
-  if (KIND == FMX_KIND_FM) {
+  if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
     sym = fmx_cs_upper(ix.cs, ix.max_character, i);
+    if (KIND == FMX_KIND_MULTI && sym == 0u) return 0xFFFFFFFFu;   // fl_map: None (multi_pieces.rs:176-178)
     return fmx_mwm_select(ix.bw, sym, i - ix.cs[sym], g);   // bw.select(i - cs[c], c)
   } else {
     uint32_t bit;
@@ -422,13 +423,23 @@ __device__ __forceinline__ uint32_t fmx_fl_map_any(const FmxDev &ix, uint32_t i,
 }
 
 // kind-dispatching forms used by the kernels
+// FMIndexMultiPiecesBackend::lf_map2 for c == 0 (multi_pieces.rs:147-153): the end markers are
+// ordered by piece, the LAST one (row sa_idx_first_text) maps to row 0
+__device__ __forceinline__ uint32_t fmx_multi_zero(const FmxDev &ix, uint32_t i, uint32_t rank0) {
+  return i < ix.first_row ? rank0 + 1u : (i == ix.first_row ? 0u : rank0);
+}
 template <int KIND>
 __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                  uint32_t &e, uint32_t g) {
-  if (KIND == FMX_KIND_FM) {
+  if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
     uint32_t rs, re;
     const uint32_t kc = ix.K[c];  // issued ahead of the record loads
     fmx_mwm_rank2(ix.bw, c, s, e, g, rs, re);
+    if (KIND == FMX_KIND_MULTI && c == 0u) {
+      s = fmx_multi_zero(ix, s, kc + rs);
+      e = fmx_multi_zero(ix, e, kc + re);
+      return;
+    }
     s = kc + rs;  // fm_index.rs:93-95
     e = kc + re;
   } else {
@@ -438,9 +449,11 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
 template <int KIND>
 __device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
                                                    uint32_t &sym) {
-  if (KIND == FMX_KIND_FM) {
+  if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
     uint32_t r = fmx_mwm_lf(ix.bw, i, g, sym);
-    return ix.K[sym] + r;  // fm_index.rs:86-91
+    r += ix.K[sym];  // fm_index.rs:86-91
+    if (KIND == FMX_KIND_MULTI && sym == 0u) r = fmx_multi_zero(ix, i, r);  // multi_pieces.rs:131-137
+    return r;
   } else {
     return fmx_rlfm_lf_map(ix, i, g, sym);
   }

@@ -68,6 +68,9 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   uint32_t kind;
   uint32_t sym_bytes;   // width of text / pattern symbols (1, 2 or 4)
   FmxBits b, bp;        // RLFM only
+  const uint32_t *doc;    // MULTI: piece id of the k-th end marker in L order (multi_pieces.rs:57-85)
+  uint32_t doc_count;     // MULTI: number of pieces
+  uint32_t first_row;     // MULTI: sa_idx_first_text (multi_pieces.rs:21-22)
   const uint4 *pair_rec;  // FMX_FLAG_PAIR_INDEX: fmt-4 records over the 2-gram BWT, absolute counters
   uint32_t pair_row0, pair_row1;  // the two rows (SA = 0, 1) that have no 2-gram; stored as code 0
   const uint32_t *cs;   // C array on the device for get_f / fl_map: characters (FM, sais.rs:9-32)
@@ -127,10 +130,15 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                       hipStream_t st);
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
                        hipStream_t st);
-// op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
+// op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map, 6 piece_id
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st);
 // K[c] for every symbol, from the finished wavelet levels (used by the builder)
+int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                            uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st);
+int fmx_launch_match_rows(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                          uint64_t npat, int prefix_only, const uint64_t *d_off, uint64_t *d_rows,
+                          hipStream_t st);
 int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
 int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations);
 int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,

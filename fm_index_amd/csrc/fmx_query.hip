@@ -620,10 +620,22 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
       uint32_t sym;
       uint32_t r = fmx_lf_map_any<KIND>(ix, (uint32_t)i64, g, sym);
       res = op == 0 ? (uint64_t)sym : (uint64_t)r;
+    } else if (op == 6) {  // HasMultiPieces::piece_id (multi_pieces.rs:206-219)
+      uint32_t row = (uint32_t)i64;
+      for (;;) {
+        uint32_t sym;
+        uint32_t raw = fmx_mwm_lf(ix.bw, row, g, sym);
+        if (sym == 0u) {  // doc[bw.rank(i, 0)] + 1 mod pieces
+          uint32_t prev = ix.doc[ix.K[0] + raw];
+          res = (uint64_t)((prev + 1u) % ix.doc_count);
+          break;
+        }
+        row = ix.K[sym] + raw;
+      }
     } else if (op == 4 || op == 5) {  // get_f / fl_map (fm_index.rs:97-120, rlfmi.rs:145-169)
       uint32_t sym;
       uint32_t r = fmx_fl_map_any<KIND>(ix, (uint32_t)i64, g, sym);
-      res = op == 4 ? (uint64_t)sym : (uint64_t)r;
+      res = op == 4 ? (uint64_t)sym : (r == 0xFFFFFFFFu && KIND == FMX_KIND_MULTI ? ~0ull : (uint64_t)r);
     } else {  // get_sa (fm_index.rs:127-140)
       uint32_t row = (uint32_t)i64, steps = 0;
       const uint32_t lmask = (1u << ix.sa_level) - 1u;
@@ -658,12 +670,68 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, void
 }
 int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   if (idx->n == 0) return FMX_OK;
-  if (idx->kind == FMX_KIND_FM)
+  if (idx->kind == FMX_KIND_FM || idx->kind == FMX_KIND_MULTI)
     hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(idx->n)),
                        dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
   else
     hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(idx->n)),
                        dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// ---- iter_matches() bookkeeping (wrapper.rs:203-217) incl. the match_prefix_only filter ------
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_match_counts_kernel(
+    FmxDev ix, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, uint64_t npat,
+    int prefix_only, uint64_t *__restrict__ out) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t k = gid; k < npat; k += ngroups) {
+    uint64_t a = s[k], b = e[k], cnt = b > a ? b - a : 0;
+    if (prefix_only && cnt) {  // rows of [a, b) whose L symbol is the end marker
+      uint32_t ra = fmx_mwm_rank(ix.bw, 0u, (uint32_t)a, g);
+      uint32_t rb = fmx_mwm_rank(ix.bw, 0u, (uint32_t)b, g);
+      cnt = rb - ra;
+    }
+    if (g == 0) out[k] = cnt;
+  }
+}
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_match_rows_kernel(
+    FmxDev ix, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
+    const uint64_t *__restrict__ off, uint64_t npat, int prefix_only, uint64_t *__restrict__ rows) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t k = gid; k < npat; k += ngroups) {
+    uint64_t a = s[k], b = e[k], o = off[k];
+    uint64_t cnt = b > a ? b - a : 0;
+    if (!prefix_only) {
+      for (uint64_t t = g; t < cnt; t += FMX_GROUP) rows[o + t] = a + t;
+    } else if (cnt) {
+      uint32_t ra = fmx_mwm_rank(ix.bw, 0u, (uint32_t)a, g);
+      uint32_t rb = fmx_mwm_rank(ix.bw, 0u, (uint32_t)b, g);
+      for (uint32_t j = 0; j < rb - ra; j++) {   // the j-th end marker of L at or after row a
+        uint32_t row = fmx_mwm_select(ix.bw, 0u, ix.K[0] + ra + j, g);
+        if (g == 0) rows[o + j] = row;
+      }
+    }
+  }
+}
+int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                            uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st) {
+  if (npat == 0) return FMX_OK;
+  hipLaunchKernelGGL(fmx_match_counts_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
+                     idx->dev, d_s, d_e, npat, prefix_only, d_cnt);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+int fmx_launch_match_rows(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                          uint64_t npat, int prefix_only, const uint64_t *d_off, uint64_t *d_rows,
+                          hipStream_t st) {
+  if (npat == 0) return FMX_OK;
+  hipLaunchKernelGGL(fmx_match_rows_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
+                     idx->dev, d_s, d_e, d_off, npat, prefix_only, d_rows);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -729,6 +797,9 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   } else if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
                        d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
+  else if (idx->kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_MULTI>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
   else
     hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_RLFM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
                        d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
@@ -789,6 +860,9 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(total)),
                        dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
+  else if (idx->kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_MULTI>, dim3(fmx_grid_for_groups(total)),
+                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
   else
     hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(total)),
                        dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
@@ -802,6 +876,9 @@ int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const u
   if (k == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK),
+                       0, st, idx->dev, op, d_c, d_i, k, d_out);
+  else if (idx->kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_MULTI>, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK),
                        0, st, idx->dev, op, d_c, d_i, k, d_out);
   else
     hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(k)),

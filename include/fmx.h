@@ -56,6 +56,8 @@ typedef struct fmx_index fmx_index;
 /* ---- index kinds (frontend.rs:110-193) ---------------------------------- */
 #define FMX_KIND_FM 0   /* FMIndex / FMIndexWithLocate     (src/fm_index.rs) */
 #define FMX_KIND_RLFM 1 /* RLFMIndex / RLFMIndexWithLocate (src/rlfmi.rs)    */
+#define FMX_KIND_MULTI 2 /* FMIndexMultiPieces / ...WithLocate (src/multi_pieces.rs): several
+                          * \0-separated pieces in one text */
 #define FMX_NO_LOCATE 0xFFFFFFFFu /* `level` value for the count-only types */
 
 /* build flags */
@@ -163,6 +165,32 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
 /* exclusive scan helper on the device: d_out_off[k] = sum_{j<k}(e[j]-s[j]), k = 0..npat */
 int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
                     uint64_t *d_out_off, void *stream);
+
+/* ---- multi-pieces index (src/multi_pieces.rs, frontend.rs:46-68, 100-104) --- */
+/* SearchIndexWithMultiPieces::search_prefix / search_suffix / search_exact are the same
+ * backward search with a different start and a filter (wrapper.rs:57-82):
+ *   search_suffix / search_exact start from (0, pieces_count) -> pass that pair as s0e0;
+ *   search_prefix / search_exact keep only matches whose row has L == 0 (wrapper.rs:208)
+ *   -> prefix_only = 1 below.  count() stays e - s in the reference (wrapper.rs:132-134). */
+uint64_t fmx_pieces_count(const fmx_index *idx);               /* HasMultiPieces::pieces_count */
+/* HasMultiPieces::piece_id (multi_pieces.rs:206-219) for SA rows */
+uint64_t fmx_piece_id(const fmx_index *idx, uint64_t i);
+int fmx_piece_id_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out,
+                           void *stream);
+int fmx_piece_id_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
+/* number of matches iter_matches() yields for [s, e): e - s, or with prefix_only the rows of
+ * the range whose L symbol is 0 (MatchIteratorWrapper::next, wrapper.rs:203-217) */
+int fmx_match_counts_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                         uint64_t npat, int prefix_only, uint64_t *d_out_count, void *stream);
+int fmx_match_counts(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                     int prefix_only, uint64_t *out_count);
+/* the SA rows iter_matches() visits, in its order: out_rows[out_off[k] + j] (out_off = exclusive
+ * scan of the match counts).  Feed them to fmx_get_sa_batch / fmx_piece_id_batch. */
+int fmx_match_rows_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                       uint64_t npat, int prefix_only, const uint64_t *d_out_off,
+                       uint64_t *d_out_rows, void *stream);
+int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                   int prefix_only, const uint64_t *out_off, uint64_t *out_rows);
 
 /* ---- instrumentation / export (tests, bench, checkers) -------------------- */
 /* milliseconds the last *_dev query kernel of each type took, measured with HIP

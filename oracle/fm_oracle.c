@@ -396,7 +396,7 @@ static uint64_t fm_fl_map(const void *p, uint64_t i) {                          
 }
 orc_backend orc_fm_backend(orc_fm *f) {
   orc_backend b = {f, fm_get_l, fm_lf_map, fm_lf_map2, fm_len,
-                   f->has_locate ? fm_get_sa : NULL, fm_get_f, fm_fl_map, f->max_character};
+                   f->has_locate ? fm_get_sa : NULL, fm_get_f, fm_fl_map, NULL, 0, f->max_character};
   return b;
 }
 static int check_symbols(const uint8_t *text, uint64_t n, uint64_t max_character) {
@@ -512,7 +512,7 @@ static uint64_t rl_fl_map(const void *p, uint64_t i) {                       /* 
 }
 orc_backend orc_rlfm_backend(orc_rlfm *f) {
   orc_backend b = {f, rl_get_l, rl_lf_map, rl_lf_map2, rl_len,
-                   f->has_locate ? rl_get_sa : NULL, rl_get_f, rl_fl_map, f->max_character};
+                   f->has_locate ? rl_get_sa : NULL, rl_get_f, rl_fl_map, NULL, 0, f->max_character};
   return b;
 }
 static void bits_set(uint64_t *w, uint64_t i) { w[i >> 6] |= 1ull << (i & 63); }
@@ -592,6 +592,107 @@ void orc_rlfm_free(orc_rlfm *f) {
 }
 
 /* ------------------------------------------------------------------ */
+/* FMIndexMultiPiecesBackend (multi_pieces.rs)                          */
+/* ------------------------------------------------------------------ */
+static uint64_t mp_len(const void *p) { return ((const orc_multi *)p)->bw.len; }
+static uint64_t mp_get_l(const void *p, uint64_t i) { return orc_wm_get(&((const orc_multi *)p)->bw, i); }
+static uint64_t mp_zero(const orc_multi *f, uint64_t i, uint64_t rank) { /* multi_pieces.rs:131-137 */
+  if (i < f->sa_idx_first_text) return rank + 1;
+  if (i == f->sa_idx_first_text) return 0;
+  return rank;
+}
+static uint64_t mp_lf_map2(const void *p, uint64_t c, uint64_t i) {      /* multi_pieces.rs:145-157 */
+  const orc_multi *f = (const orc_multi *)p;
+  uint64_t rank = orc_wm_rank(&f->bw, i, c);
+  return c == 0 ? mp_zero(f, i, rank) : rank + f->cs[c];
+}
+static uint64_t mp_lf_map(const void *p, uint64_t i) {                   /* multi_pieces.rs:128-143 */
+  return mp_lf_map2(p, mp_get_l(p, i), i);
+}
+static uint64_t mp_get_f(const void *p, uint64_t i) {                    /* multi_pieces.rs:159-174 */
+  const orc_multi *f = (const orc_multi *)p;
+  return cs_upper(f->cs, f->max_character + 1, i);
+}
+static uint64_t mp_fl_map(const void *p, uint64_t i) {                   /* multi_pieces.rs:176-187 */
+  const orc_multi *f = (const orc_multi *)p;
+  uint64_t c = mp_get_f(p, i);
+  if (c == 0) return UINT64_MAX; /* None */
+  return orc_wm_select(&f->bw, i - f->cs[c], c);
+}
+static uint64_t mp_get_sa(const void *p, uint64_t i) {                   /* multi_pieces.rs:194-207 */
+  const orc_multi *f = (const orc_multi *)p;
+  uint64_t steps = 0, sa;
+  for (;;) {
+    if (orc_ssa_get(&f->ssa, i, &sa)) return (sa + steps) % f->bw.len;
+    i = mp_lf_map(p, i);
+    steps++;
+  }
+}
+static uint64_t mp_piece_id(const void *p, uint64_t i) {                 /* multi_pieces.rs:213-224 */
+  const orc_multi *f = (const orc_multi *)p;
+  for (;;) {
+    if (mp_get_l(p, i) == 0) {
+      uint64_t prev = f->doc[orc_wm_rank(&f->bw, i, 0)];
+      return (prev + 1) % f->doc_len; /* modular_add */
+    }
+    i = mp_lf_map(p, i);
+  }
+}
+orc_backend orc_multi_backend(orc_multi *f) {
+  orc_backend b = {f, mp_get_l, mp_lf_map, mp_lf_map2, mp_len, f->has_locate ? mp_get_sa : NULL,
+                   mp_get_f, mp_fl_map, mp_piece_id, f->doc_len, f->max_character};
+  return b;
+}
+int orc_multi_new(orc_multi **out, const uint8_t *text, uint64_t n, uint64_t max_character,
+                  int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  int rc = check_symbols(text, n, max_character);
+  if (rc) return rc;
+  rc = orc_validate_text(text, n);
+  if (rc) return rc;
+  orc_multi *f = (orc_multi *)calloc(1, sizeof(orc_multi));
+  f->max_character = max_character;
+  f->cs = (uint64_t *)calloc(max_character + 1, sizeof(uint64_t));
+  orc_bucket_start(text, n, max_character, f->cs);           /* multi_pieces.rs:39 */
+  uint32_t *sa = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_suffix_array(text, n, sa);                              /* multi_pieces.rs:40 */
+  uint8_t *bwt = (uint8_t *)malloc(n ? n : 1);
+  orc_bwt(text, n, sa, bwt);                                  /* multi_pieces.rs:87-103 */
+  orc_wm_build(&f->bw, bwt, n, orc_max_bits(max_character));
+  /* doc (multi_pieces.rs:57-85) */
+  uint64_t count = 0;
+  for (uint64_t i = 0; i < n; i++) count += text[i] == 0;
+  f->doc = (uint64_t *)calloc(count ? count : 1, sizeof(uint64_t));
+  f->doc_len = count;
+  uint64_t k = 0;
+  for (uint64_t p = 0; p < n; p++) { /* bw.select_u64(k, 0) enumerates the zeros of L in order */
+    if (bwt[p] != 0) continue;
+    uint64_t idx = sa[p] >= 1 ? sa[p] - 1 : n - 1;            /* modular_sub(sa[p], 1, n) */
+    uint64_t piece = 0;
+    for (uint64_t q = 0; q < idx; q++) piece += text[q] == 0; /* end_marker_flags.rank1(idx) */
+    if (piece == count - 1) f->sa_idx_first_text = p;
+    f->doc[k++] = piece;
+  }
+  if (level >= 0) {
+    orc_ssa_sample(&f->ssa, sa, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  free(bwt);
+  free(sa);
+  *out = f;
+  return ORC_OK;
+}
+void orc_multi_free(orc_multi *f) {
+  if (!f) return;
+  orc_wm_free(&f->bw);
+  orc_ssa_free(&f->ssa);
+  free(f->cs);
+  free(f->doc);
+  free(f);
+}
+
+/* ------------------------------------------------------------------ */
 /* driver (wrapper.rs)                                                 */
 /* ------------------------------------------------------------------ */
 int orc_search(const orc_backend *b, const uint8_t *pat, uint64_t m, uint64_t *ps,
@@ -653,6 +754,20 @@ void orc_get_l_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64
 }
 void orc_get_sa_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
   for (uint64_t j = 0; j < k; j++) out[j] = b->get_sa(b->self, i[j]);
+}
+uint64_t orc_match_rows(const orc_backend *b, uint64_t s, uint64_t e, int match_prefix_only,
+                        uint64_t *out, uint64_t cap) {            /* wrapper.rs:203-217 */
+  uint64_t cnt = 0;
+  for (uint64_t i = s; i < e; i++) {
+    if (!match_prefix_only || b->get_l(b->self, i) == 0) {
+      if (cnt < cap) out[cnt] = i;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+void orc_piece_id_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
+  for (uint64_t j = 0; j < k; j++) out[j] = b->piece_id(b->self, i[j]);
 }
 void orc_get_f_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out) {
   for (uint64_t j = 0; j < k; j++) out[j] = b->get_f(b->self, i[j]);

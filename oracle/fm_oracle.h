@@ -106,7 +106,9 @@ typedef struct orc_backend {
   uint64_t (*len)(const void *self);
   uint64_t (*get_sa)(const void *self, uint64_t i); /* HasPosition; may be NULL */
   uint64_t (*get_f)(const void *self, uint64_t i);
-  uint64_t (*fl_map)(const void *self, uint64_t i); /* always Some for FM / RLFM */
+  uint64_t (*fl_map)(const void *self, uint64_t i); /* UINT64_MAX = None (multi-pieces, c == 0) */
+  uint64_t (*piece_id)(const void *self, uint64_t i); /* HasMultiPieces; NULL otherwise */
+  uint64_t pieces_count;
   uint64_t max_character;
 } orc_backend;
 
@@ -146,6 +148,22 @@ int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_c
 void orc_rlfm_free(orc_rlfm *f);
 orc_backend orc_rlfm_backend(orc_rlfm *f);
 
+/* ---- FMIndexMultiPiecesBackend (multi_pieces.rs) ---- */
+typedef struct orc_multi {
+  orc_wm bw;
+  uint64_t *cs;
+  uint64_t max_character;
+  orc_ssa ssa;
+  int has_locate;
+  uint64_t *doc;            /* multi_pieces.rs:20 */
+  uint64_t doc_len;
+  uint64_t sa_idx_first_text; /* multi_pieces.rs:22 */
+} orc_multi;
+int orc_multi_new(orc_multi **out, const uint8_t *text, uint64_t n, uint64_t max_character,
+                  int level);
+void orc_multi_free(orc_multi *f);
+orc_backend orc_multi_backend(orc_multi *f);
+
 /* ---- driver (wrapper.rs) ---- */
 /* SearchWrapper::search, wrapper.rs:103-124; (s,e) in/out. returns ORC_ERR_SYMBOL_RANGE
  * where the reference would panic on cs[c]. *steps (nullable) = executed iterations */
@@ -167,6 +185,10 @@ void orc_lf_map2_batch(const orc_backend *b, const uint64_t *c, const uint64_t *
 void orc_lf_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_get_l_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_get_sa_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
+/* MatchIteratorWrapper::next (wrapper.rs:203-217): rows of [s,e) it yields; returns their number */
+uint64_t orc_match_rows(const orc_backend *b, uint64_t s, uint64_t e, int match_prefix_only,
+                        uint64_t *out, uint64_t cap);
+void orc_piece_id_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_get_f_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 void orc_fl_map_batch(const orc_backend *b, const uint64_t *i, uint64_t k, uint64_t *out);
 

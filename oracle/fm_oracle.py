@@ -22,7 +22,8 @@ _u8p = C.POINTER(C.c_uint8)
 class _Backend(C.Structure):
     _fields_ = [("self", C.c_void_p), ("get_l", C.c_void_p), ("lf_map", C.c_void_p),
                 ("lf_map2", C.c_void_p), ("len", C.c_void_p), ("get_sa", C.c_void_p),
-                ("get_f", C.c_void_p), ("fl_map", C.c_void_p), ("max_character", C.c_uint64)]
+                ("get_f", C.c_void_p), ("fl_map", C.c_void_p), ("piece_id", C.c_void_p),
+                ("pieces_count", C.c_uint64), ("max_character", C.c_uint64)]
 
 
 def build(native=False):
@@ -67,6 +68,13 @@ def _bind(lib):
     lib.orc_get_l_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_get_sa_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_get_f_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_piece_id_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_match_rows.restype = C.c_uint64
+    lib.orc_match_rows.argtypes = [bp, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+    lib.orc_multi_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    lib.orc_multi_free.argtypes = [C.c_void_p]
+    lib.orc_multi_backend.restype = _Backend
+    lib.orc_multi_backend.argtypes = [C.c_void_p]
     lib.orc_fl_map_batch.argtypes = [bp, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_naive_search.restype = C.c_uint64
     lib.orc_naive_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
@@ -205,12 +213,14 @@ class OracleIndex:
         else:
             t = _u8(text)
             self._text_keep = t
-            new = self._l.orc_fm_new if kind == "fm" else self._l.orc_rlfm_new
+            new = {"fm": self._l.orc_fm_new, "rlfm": self._l.orc_rlfm_new,
+                   "multi": self._l.orc_multi_new}[kind]
             rc = new(C.byref(h), _p(t), len(t), self.max_character, lvl)
         if rc != 0:
             raise OracleError(rc, self._l.orc_error_message(rc).decode())
         self._h = h
-        self._b = (self._l.orc_fm_backend if kind == "fm" else self._l.orc_rlfm_backend)(h)
+        self._b = {"fm": self._l.orc_fm_backend, "rlfm": self._l.orc_rlfm_backend,
+                   "multi": self._l.orc_multi_backend}[kind](h)
         self.has_locate = level is not None
 
     @classmethod
@@ -220,7 +230,8 @@ class OracleIndex:
 
     def close(self):
         if getattr(self, "_h", None):
-            (self._l.orc_fm_free if self.kind == "fm" else self._l.orc_rlfm_free)(self._h)
+            {"fm": self._l.orc_fm_free, "rlfm": self._l.orc_rlfm_free,
+             "multi": self._l.orc_multi_free}[self.kind](self._h)
             self._h = None
 
     def __del__(self):
@@ -321,3 +332,19 @@ class OracleIndex:
         out = np.zeros(max(len(i), 1), dtype=np.uint64)
         self._l.orc_fl_map_batch(C.byref(self._b), _p(i), len(i), _p(out))
         return out[:len(i)]
+
+    # --- multi-pieces (multi_pieces.rs) ---
+    def pieces_count(self):
+        return int(self._b.pieces_count)
+
+    def piece_id(self, i):
+        i = np.ascontiguousarray(i, dtype=np.uint64)
+        out = np.zeros(max(len(i), 1), dtype=np.uint64)
+        self._l.orc_piece_id_batch(C.byref(self._b), _p(i), len(i), _p(out))
+        return out[:len(i)]
+
+    def match_rows(self, s, e, prefix_only=False):
+        cap = max(int(e) - int(s), 1)
+        out = np.zeros(cap, dtype=np.uint64)
+        k = self._l.orc_match_rows(C.byref(self._b), int(s), int(e), int(prefix_only), _p(out), cap)
+        return out[:k].copy()

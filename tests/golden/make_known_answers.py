@@ -17,6 +17,16 @@ LOREM = (
     "Excepteur sint occaecat cupidatat non proident, sunt in culpa qui officia deserunt mollit anim id est laborum."
 )
 
+TWINKLE = (
+    "Twinkle, twinkle, little star,\n" "How I wonder what you are!\n" "Up above the world so high,\n"
+    "Like a diamond in the sky.\n" "Twinkle, twinkle, little star,\n" "How I wonder what you are!\n" + Z +
+    "When the blazing sun is gone,\n" "When he nothing shines upon,\n" "Then you show your little light,\n"
+    "Twinkle, twinkle, all the night.\n" "Twinkle, twinkle, little star,\n" "How I wonder what you are!\n" + Z +
+    "Then the traveller in the dark,\n" "Thanks you for your tiny spark;\n"
+    "He could not see which way to go,\n" "If you did not twinkle so.\n" "Twinkle, twinkle, little star,\n"
+    "How I wonder what you are!\n" + Z
+)
+
 G = {
     "_comment": "Known answers harvested from the reference's own tests (inputs + expected outputs).",
     "mississippi": {
@@ -68,6 +78,21 @@ G = {
         "source": "src/suffix_array/sais.rs:427-466",
     },
     "len": {"text": "text" + Z, "expected": 5, "source": "tests/test_api.rs:13-67"},
+    "multi_pieces_example": {
+        "text": TWINKLE, "level": 2,
+        "count_star": 4,
+        "piece_ids_how_i_wonder_sorted": [0, 0, 1, 2],
+        "backward_until_space_from_in_the_dark": ["rellevart"],
+        "forward_until_comma_from_ing": ["ing shines upon", "ing sun is gone"],
+        "prefix_twinkle_piece_ids_sorted": [0],
+        "suffix_what_you_are_piece_ids_sorted": [0, 1, 2],
+        "source": "examples/multi_pieces.rs:4-88",
+    },
+    "multi_pieces_small": {"text": "a" + Z, "level": 2, "count": 1, "positions": [0], "piece_ids": [0],
+                           "source": "tests/test_multi_pieces.rs:7-41"},
+    "multi_pieces_foo_bar_baz": {"text": "foo" + Z + "bar" + Z + "baz" + Z,
+                                 "rule": "piece_id(row of SA value p) == number of zeros in text[..p]",
+                                 "source": "src/multi_pieces.rs:277-297"},
     "log2": {"cases": [[2, 1], [3, 1], [4, 2], [5, 2], [6, 2], [7, 2], [8, 3]], "source": "src/util.rs:9-18"},
 }
 

@@ -36,9 +36,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-locate", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm"],
+    ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm", "rep-fm", "rep-rlfm"],
                     help="dna = config 2/3 (headline); bytes-fm / bytes-rlfm = config 4 text "
-                         "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex")
+                         "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex; rep-* = config 4b: "
+                         "1 MiB random block repeated with 1 % point mutations (the case RLFM exists for)")
     ap.add_argument("--pair-index", action="store_true",
                     help="also build the opt-in 2-step index (FMX_FLAG_PAIR_INDEX) and report its "
                          "count rate in an extra 'pair_index' object (the headline stays 1-step)")
@@ -80,14 +81,20 @@ def main():
     maxc = 4 if dna else 255
     Lbits = 3 if dna else 8
     # 2 endpoints x L levels x 64 B (FM); 2 x (2L+4) probes x 64 B (RLFM)
-    bytes_per_char = 2 * (2 * Lbits + 4) * 64 if args.workload == "bytes-rlfm" else 2 * Lbits * 64
+    rlfm = args.workload.endswith("rlfm")
+    bytes_per_char = 2 * (2 * Lbits + 4) * 64 if rlfm else 2 * Lbits * 64
     # ---- synthetic inputs: text seed 1, patterns seed 3 / 7 ----
     t0 = time.time()
-    text = W.dna_text_torch(n, 1, dev) if dna else W.byte_text_torch(n, 4, dev)
+    if dna:
+        text = W.dna_text_torch(n, 1, dev)
+    elif args.workload.startswith("rep"):
+        text = W.repetitive_text_torch(n, 5, dev, base_len=1 << 20)
+    else:
+        text = W.byte_text_torch(n, 4, dev)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     level = None if args.no_locate else args.level
-    if args.workload == "bytes-rlfm":
+    if rlfm:
         cls = F.RLFMIndexWithLocate if level is not None else F.RLFMIndex
     else:
         cls = F.FMIndexWithLocate if level is not None else F.FMIndex

@@ -323,40 +323,62 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
   }
 }
 
-// in place: out_pos[h] holds SA row i on entry and get_sa(i) on exit.
+// generic locate walk (any kind / any number of levels): same wave-level dynamic hit assignment
+// and register row window as fmx_locate_f3w_kernel below; one LF step = fmx_lf_map_any (several
+// dependent probes), the sample read is a plain dependent load.
 template <int KIND>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(FmxDev ix, uint64_t total,
-                                                                uint64_t *__restrict__ out_pos,
-                                                                uint64_t *__restrict__ steps_out) {
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
+    FmxDev ix, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
-
-  uint64_t h = gid;
-  bool active = h < total;
-  bool fresh = true;
-  uint32_t row = 0, steps = 0, nsteps = 0;
-  while (active) {
-    if (fresh) {
-      row = (uint32_t)out_pos[h];
-      steps = 0;
-      fresh = false;
+  uint64_t w0 = wave * hits_per_wave;
+  if (w0 >= total) return;                          // wave-uniform
+  uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
+  uint64_t win_base = w0;
+  uint32_t win = rows[win_base + lane < total ? win_base + lane : total - 1];
+  uint64_t h = w0 + grp;
+  bool active = h < w1;
+  uint32_t row = (uint32_t)__shfl((int)win, (int)grp);
+  uint64_t next = w0 + 8 < w1 ? w0 + 8 : w1;
+  uint32_t steps = 0, nsteps = 0;
+  while (__any(active)) {
+    if (next + 8 > win_base + 64 && next < w1) {    // wave-uniform window refill
+      win_base = next;
+      win = rows[win_base + lane < total ? win_base + lane : total - 1];
     }
-    if ((row & lmask) == 0) {
-      // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
-      uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
-      if (v >= ix.n) v -= ix.n;  // steps < n, sa < n
-      if (g == 0) out_pos[h] = v;
-      h += ngroups;
-      active = h < total;
-      fresh = true;
-    } else {
-      // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
-      uint32_t sym;
-      row = fmx_lf_map_any<KIND>(ix, row, g, sym);
-      steps++;
-      nsteps++;
+    bool fin = false;
+    if (active) {
+      if ((row & lmask) == 0) {
+        // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
+        uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
+        if (v >= ix.n) v -= ix.n;  // steps < n, sa < n
+        if (g == 0) out_pos[h] = v;
+        fin = true;
+      } else {
+        // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
+        uint32_t sym;
+        row = fmx_lf_map_any<KIND>(ix, row, g, sym);
+        steps++;
+        nsteps++;
+      }
+    }
+    const unsigned long long fmask = __ballot(fin && g == 0);
+    if (fmask) {                                                  // wave-uniform
+      const uint32_t leader = lane & ~7u;
+      const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
+      const uint64_t h_new = next + my_rank;
+      const uint32_t r_new = (uint32_t)__shfl((int)win, (int)((h_new - win_base) & 63u));
+      if (fin) {
+        h = h_new;
+        active = h < w1;
+        row = r_new;
+        steps = 0;
+      }
+      next += (uint64_t)__popcll(fmask);
     }
   }
   if (steps_out && g == 0 && nsteps)
@@ -830,44 +852,39 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   if (npat == 0 || total == 0) return FMX_OK;
   const FmxMwm &w = idx->dev.bw;
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
-  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && fmx_variant() != 0) {
-    // rows in their own read-only buffer: the walk's loads never alias its stores
-    uint32_t *rows = nullptr;
-    FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0,
-                       st, d_s, d_e, d_off, npat, rows);
-    fmx_time_begin(idx, st);
-    if (fmx_variant() == 6) {
+  // rows in their own read-only buffer: the walk's loads never alias its stores
+  uint32_t *rows = nullptr;
+  FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0,
+                     st, d_s, d_e, d_off, npat, rows);
+  uint64_t nwaves = (total + 7) / 8;
+  const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
+  if (nwaves > max_waves) nwaves = max_waves;
+  const uint64_t hpw = (total + nwaves - 1) / nwaves;
+  const unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+  fmx_time_begin(idx, st);
+  if (idx->kind == FMX_KIND_FM && idx->sym_bytes >= 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
+      fmx_variant() != 0) {
+    if (fmx_variant() == 6)
       hipLaunchKernelGGL(fmx_locate_f3_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
                          w.lv[0].rec, idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, rows,
                          d_pos, steps);
-    } else {
-      uint64_t nwaves = (total + 7) / 8;
-      if (nwaves > (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64)) nwaves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
-      uint64_t hpw = (total + nwaves - 1) / nwaves;
-      unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+    else
       hipLaunchKernelGGL(fmx_locate_f3w_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
                          idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hpw, rows, d_pos, steps);
-    }
-    fmx_time_end(idx, st);
-    FMX_HIP(hipGetLastError());
-    FMX_HIP(hipFreeAsync(rows, st));
-    return FMX_OK;
+  } else if (idx->kind == FMX_KIND_FM) {
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       total, hpw, rows, d_pos, steps);
+  } else if (idx->kind == FMX_KIND_MULTI) {
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_MULTI>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       total, hpw, rows, d_pos, steps);
+  } else {
+    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_RLFM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
+                       total, hpw, rows, d_pos, steps);
   }
-  hipLaunchKernelGGL(fmx_expand_kernel<uint64_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
-                     d_s, d_e, d_off, npat, d_pos);
-  fmx_time_begin(idx, st);
-  if (idx->kind == FMX_KIND_FM)
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(total)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
-  else if (idx->kind == FMX_KIND_MULTI)
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_MULTI>, dim3(fmx_grid_for_groups(total)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
-  else
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(total)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, total, d_pos, steps);
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
+  FMX_HIP(hipFreeAsync(rows, st));
   return FMX_OK;
 }
 

@@ -145,3 +145,21 @@ def substring_patterns_torch(text, npat, m, seed):
     flat = text[idx].reshape(-1).contiguous()
     off = torch.arange(npat + 1, dtype=torch.int64, device=text.device) * m
     return flat, off, pos
+
+
+def repetitive_text_torch(n, seed, device, base_len=1 << 12, mut_per_1024=10):
+    """same text as repetitive_text_np, generated on `device`."""
+    import torch
+    base = byte_text_torch(base_len + 1, seed, device)[:base_len]
+    t = base.repeat(n // base_len + 1)[:n].contiguous()
+    step = 1 << 26
+    for a in range(0, n, step):
+        k = min(step, n - a)
+        r = splitmix64_torch(seed + 1, a, k, device)
+        mut = (r & 1023) < mut_per_1024
+        hi = (r >> 16) & ((1 << 48) - 1)            # logical shift of the 64-bit pattern
+        val = (umod_torch(hi, 255) + 1).to(torch.uint8)
+        seg = t[a:a + k]
+        seg[mut] = val[mut]
+    t[n - 1] = 0
+    return t

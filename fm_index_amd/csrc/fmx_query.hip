@@ -17,7 +17,13 @@
 #define FMX_BLOCK 256
 #define FMX_MAX_BLOCKS 2048  // 256 CUs x 8 resident 256-thread blocks
 
-// kernel variant selector for experiments (FMX_VARIANT=0 forces the generic kernels)
+// Kernel variant selector (environment FMX_VARIANT, read once), kept so the measured
+// alternatives of DESIGN.md section 4.1 stay reproducible:
+//   unset / 1  single-level fast paths (count: 1 chain per group, both record loads issued)
+//   0          force the generic kernels (any kind / any number of levels)
+//   2, 5       count with 2 / 4 independent chains per group          (slower: 0.78 / 1.00 ms)
+//   3, 4       count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
+//   7          ignore the pair index even when it was built
 static inline int fmx_variant() {
   static const int cached = [] {
     const char *v = getenv("FMX_VARIANT");
@@ -385,77 +391,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// locate walk, single 3-bit level (DNA).  Every iteration a group issues exactly ONE 16-B
-// load per lane whose address depends on its state -- a record piece while walking
-// (fm_index.rs:134-137) or the aligned chunk holding its SA sample once the row is sampled
-// (sample.rs:46-60) -- so walking and finishing groups of one wave overlap their latencies
-// instead of serialising two branches.  The next hit's row is prefetched a walk ahead.
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3_kernel(
-    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
-    uint32_t sa_level, uint64_t total, const uint32_t *__restrict__ rows,
-    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  const uint32_t lmask = (1u << sa_level) - 1u;
-  const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
-
-  uint64_t h = gid;
-  bool active = h < total;
-  uint32_t row = active ? rows[h] : 0u;
-  uint64_t hn = h + ngroups;                       // next hit of this group
-  uint32_t steps = 0, nsteps = 0;
-  // a finished position is stored one iteration late, right BEHIND that iteration's loads: the
-  // single vmcnt(0) that waits for the loads then also covers the store (vmcnt is in order), so
-  // the store's completion is never waited for on its own
-  bool pending = false;
-  uint64_t pend_h = 0, pend_v = 0;
-  while (active || pending) {
-    const bool flush = pending;
-    const uint64_t fl_h = pend_h, fl_v = pend_v;
-    pending = false;
-    if (!active) {
-      if (flush && g == 0) out_pos[fl_h] = fl_v;
-    } else {
-      const bool sampled = (row & lmask) == 0;
-      const uint32_t si = row >> sa_level;
-      const uint4 *addr = sampled ? (samp4 + (si >> 2)) : (rec + ((size_t)(row >> 8) * 8u + g));
-      const uint4 p = *addr;
-      // the next hit's row rides along with every probe (an L1/L2 hit after its first touch), so
-      // starting the next walk never waits on a dependent load of its own
-      const uint32_t row_next = (hn < total) ? rows[hn] : 0u;
-      if (flush && g == 0) out_pos[fl_h] = fl_v;   // issued behind this iteration's loads
-      if (sampled) {
-        uint32_t w = si & 3u;
-        uint32_t sa = w == 0 ? p.x : (w == 1 ? p.y : (w == 2 ? p.z : p.w));
-        uint64_t v = (uint64_t)sa + steps;          // fm_index.rs:131-133: (sa + steps) % len
-        if (v >= n) v -= n;
-        pend_v = v;
-        pend_h = h;
-        pending = true;
-        h = hn;
-        active = h < total;
-        row = row_next;
-        steps = 0;
-        hn = h + ngroups;
-      } else {
-        const uint32_t off = row & 255u;
-        uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
-        row = fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));  // lf_map: counters are absolute
-        steps++;
-        nsteps++;
-      }
-    }
-  }
-  if (steps_out && g == 0 && nsteps)
-    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-
-// locate walk v2: a WAVE owns a contiguous chunk of hits and hands them to its 8 groups
-// dynamically (ballot + prefix popcount, no atomics), so the wave runs sum(work)/8 iterations
-// instead of max over its groups of their statically assigned work.  The rows of the next 64
-// hits sit in a register window (one coalesced load per 56 hits); a finishing group takes its
-// next row from the window with a ds_bpermute -- no dependent memory access to start a walk.
+// locate walk, single 3-bit level (DNA).  A WAVE owns a contiguous chunk of hits and hands them
+// to its 8 groups dynamically (ballot + prefix popcount, no atomics), so the wave runs
+// sum(work)/8 iterations instead of max over its groups of their statically assigned work.  The
+// rows of the next 64 hits sit in a register window (one coalesced load per 56 hits); a finishing
+// group takes its next row from the window with a ds_bpermute -- no dependent memory access to
+// start a walk.  Every iteration a group issues exactly ONE 16-B load per lane whose address
+// depends on its state -- a record piece while walking (fm_index.rs:134-137) or the aligned
+// chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking and
+// finishing groups of one wave overlap their latencies instead of serialising two branches.
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
     uint32_t sa_level, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
@@ -863,15 +807,10 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const uint64_t hpw = (total + nwaves - 1) / nwaves;
   const unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
   fmx_time_begin(idx, st);
-  if (idx->kind == FMX_KIND_FM && idx->sym_bytes >= 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
+  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 &&
       fmx_variant() != 0) {
-    if (fmx_variant() == 6)
-      hipLaunchKernelGGL(fmx_locate_f3_kernel, dim3(fmx_grid_for_groups(total)), dim3(FMX_BLOCK), 0, st,
-                         w.lv[0].rec, idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, rows,
-                         d_pos, steps);
-    else
-      hipLaunchKernelGGL(fmx_locate_f3w_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
-                         idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hpw, rows, d_pos, steps);
+    hipLaunchKernelGGL(fmx_locate_f3w_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
+                       idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hpw, rows, d_pos, steps);
   } else if (idx->kind == FMX_KIND_FM) {
     hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
                        total, hpw, rows, d_pos, steps);

@@ -400,10 +400,14 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 // depends on its state -- a record piece while walking (fm_index.rs:134-137) or the aligned
 // chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking and
 // finishing groups of one wave overlap their latencies instead of serialising two branches.
+template <int Q>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
     uint32_t sa_level, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  // Q independent walks per group: Q record loads in flight per lane, and the wave needs
+  // sum(work) / (8 Q) iterations for the bulk of its chunk (the longest single walk of the batch
+  // still bounds the kernel from below).
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane & (FMX_GROUP - 1);
   const uint32_t grp = lane >> 3;
@@ -414,62 +418,104 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
   if (w0 >= total) return;                          // wave-uniform
   uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
 
+  // register window over the next 128 rows of this wave's chunk
   uint64_t win_base = w0;
-  uint32_t win = rows[win_base + lane < total ? win_base + lane : total - 1];
-  uint64_t h = w0 + grp;
-  bool active = h < w1;
-  uint32_t row = (uint32_t)__shfl((int)win, (int)grp);
-  uint64_t next = w0 + 8 < w1 ? w0 + 8 : w1;
-  uint32_t steps = 0, nsteps = 0;
-  bool pending = false;
-  uint64_t pend_h = 0, pend_v = 0;
-  while (__any(active || pending)) {
-    if (next + 8 > win_base + 64 && next < w1) {    // wave-uniform window refill
-      win_base = next;
-      win = rows[win_base + lane < total ? win_base + lane : total - 1];
+  auto load_win = [&](uint64_t base) -> uint32_t {
+    uint64_t x = base + lane;
+    return rows[x < total ? x : total - 1];
+  };
+  uint32_t win0 = load_win(win_base), win1 = load_win(win_base + 64);
+  auto window = [&](uint64_t hh) -> uint32_t {
+    const uint32_t rel = (uint32_t)(hh - win_base);
+    uint32_t v = (uint32_t)__shfl((int)win0, (int)(rel & 63u));
+    if (__any(rel >= 64u)) {
+      const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(rel & 63u));
+      v = rel >= 64u ? v1 : v;
     }
-    const bool flush = pending;
-    const uint64_t fl_h = pend_h, fl_v = pend_v;
-    pending = false;
-    bool fin = false;
-    if (!active) {
-      if (flush && g == 0) out_pos[fl_h] = fl_v;
-    } else {
-      const bool sampled = (row & lmask) == 0;
-      const uint32_t si = row >> sa_level;
-      const uint4 *addr = sampled ? (samp4 + (si >> 2)) : (rec + ((size_t)(row >> 8) * 8u + g));
-      const uint4 p = *addr;
-      if (flush && g == 0) out_pos[fl_h] = fl_v;   // behind this iteration's load (see above)
-      if (sampled) {
-        uint32_t w = si & 3u;
-        uint32_t sa = w == 0 ? p.x : (w == 1 ? p.y : (w == 2 ? p.z : p.w));
-        uint64_t v = (uint64_t)sa + steps;          // fm_index.rs:131-133: (sa + steps) % len
-        if (v >= n) v -= n;
-        pend_v = v;
-        pend_h = h;
-        pending = true;
-        fin = true;
-      } else {
-        const uint32_t off = row & 255u;
-        uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
-        row = fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));  // lf_map: counters are absolute
-        steps++;
-        nsteps++;
+    return v;
+  };
+
+  uint64_t h[Q], pend_h[Q], pend_v[Q];
+  uint32_t row[Q], steps[Q];
+  bool active[Q], pending[Q];
+  uint64_t next = w0;
+  uint32_t nsteps = 0;
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    h[q] = next + grp;
+    active[q] = h[q] < w1;
+    row[q] = window(active[q] ? h[q] : win_base);
+    next = next + 8 < w1 ? next + 8 : w1;
+    steps[q] = 0;
+    pending[q] = false;
+    pend_h[q] = 0;
+    pend_v[q] = 0;
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < Q; q++) any |= active[q] || pending[q];
+    if (!__any(any)) break;
+    // issue every load of this round
+    uint4 p[Q];
+    bool sampled[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      sampled[q] = (row[q] & lmask) == 0;
+      p[q] = make_uint4(0u, 0u, 0u, 0u);
+      if (active[q]) {
+        const uint32_t si = row[q] >> sa_level;
+        const uint4 *addr = sampled[q] ? (samp4 + (si >> 2)) : (rec + ((size_t)(row[q] >> 8) * 8u + g));
+        p[q] = *addr;
       }
     }
-    const unsigned long long fmask = __ballot(fin && g == 0);    // one bit per finishing group
-    if (fmask) {                                                  // wave-uniform
-      const uint32_t leader = lane & ~7u;
-      const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
-      const uint64_t h_new = next + my_rank;
-      const uint32_t r_new = (uint32_t)__shfl((int)win, (int)((h_new - win_base) & 63u));
-      if (fin) {
-        h = h_new;
-        active = h < w1;
-        row = r_new;
-        steps = 0;
+    // positions finished in the previous round are stored behind these loads
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (pending[q] && g == 0) out_pos[pend_h[q]] = pend_v[q];
+      pending[q] = false;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      bool fin = false;
+      if (active[q]) {
+        if (sampled[q]) {
+          const uint32_t w = (row[q] >> sa_level) & 3u;
+          const uint32_t sa = w == 0 ? p[q].x : (w == 1 ? p[q].y : (w == 2 ? p[q].z : p[q].w));
+          uint64_t v = (uint64_t)sa + steps[q];     // fm_index.rs:131-133: (sa + steps) % len
+          if (v >= n) v -= n;
+          pend_v[q] = v;
+          pend_h[q] = h[q];
+          pending[q] = true;
+          fin = true;
+        } else {
+          const uint32_t off = row[q] & 255u;
+          const uint32_t sym =
+              fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
+          row[q] = fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));  // lf_map (absolute counters)
+          steps[q]++;
+          nsteps++;
+        }
       }
-      next += (uint64_t)__popcll(fmask);
+      const unsigned long long fmask = __ballot(fin && g == 0);  // one bit per finishing group
+      if (fmask) {                                                // wave-uniform
+        if (next >= win_base + 64) {                              // slide the row window
+          win_base += 64;
+          win0 = win1;
+          win1 = load_win(win_base + 64);
+        }
+        const uint32_t leader = lane & ~7u;
+        const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
+        const uint64_t h_new = next + my_rank;
+        const uint32_t r_new = window(h_new < w1 ? h_new : win_base);
+        if (fin) {
+          h[q] = h_new;
+          active[q] = h_new < w1;
+          row[q] = r_new;
+          steps[q] = 0;
+        }
+        next += (uint64_t)__popcll(fmask);
+      }
     }
   }
   if (steps_out && g == 0 && nsteps)
@@ -809,8 +855,21 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   fmx_time_begin(idx, st);
   if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 &&
       fmx_variant() != 0) {
-    hipLaunchKernelGGL(fmx_locate_f3w_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
-                       idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hpw, rows, d_pos, steps);
+    // walks per group: 4 when the batch is large enough to keep every group busy with them
+    const int v = fmx_variant();
+    const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (total >= (1u << 16) ? 4 : 1);
+    uint64_t nw = (total + 8 * q - 1) / (8 * q);
+    // measured (profiles/README.md): the loop is instruction-issue bound at 8 waves/SIMD, so
+    // mid-size batches finish sooner on 4 waves/SIMD with 4 walks per group
+    uint64_t cap = total < (4u << 20) ? max_waves / 2 : max_waves;
+    if (const char *e = getenv("FMX_LOC_WAVES")) cap = (uint64_t)atoll(e);
+    if (nw > cap) nw = cap;
+    const uint64_t hp = (total + nw - 1) / nw;
+    const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+#define FMX_LOC_LAUNCH(Q)                                                                          \
+  hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
+                     idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hp, rows, d_pos, steps)
+    if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
   } else if (idx->kind == FMX_KIND_FM) {
     hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
                        total, hpw, rows, d_pos, steps);

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
   fill<<<(unsigned)((bytes / 16 + 255) / 256), 256>>>(buf, bytes / 16);
   CK(hipDeviceSynchronize());
   int steps = 256;
-  for (int blocks : {512, 1024, 2048}) {
+  for (int blocks : {1, 16, 256, 512, 1024, 2048}) {
     run<8, 1>(buf, bytes, blocks, steps, out);
     run<8, 2>(buf, bytes, blocks, steps, out);
     run<8, 4>(buf, bytes, blocks, steps, out);

@@ -50,6 +50,7 @@ class Match {  // frontend.rs:86-98
  public:
   Match(const Index *ix, uint64_t i) : ix_(ix), i_(i) {}
   uint64_t locate() const;  // wrapper.rs:238-242
+  uint64_t piece_id() const;  // MatchWithPieceId (frontend.rs:100-104)
   uint64_t row() const { return i_; }
   // iter_chars_forward().take(k) / iter_chars_backward().take(k)  (wrapper.rs:142-183)
   std::vector<uint64_t> chars_forward(size_t k) const;
@@ -62,22 +63,21 @@ class Match {  // frontend.rs:86-98
 
 class Search {  // frontend.rs:70-84
  public:
-  Search(const Index *ix, uint64_t s, uint64_t e, bool fresh) : ix_(ix), s_(s), e_(e), fresh_(fresh) {}
+  Search(const Index *ix, uint64_t s, uint64_t e, bool fresh, bool prefix_only = false)
+      : ix_(ix), s_(s), e_(e), fresh_(fresh), prefix_(prefix_only) {}
   Search search(const std::vector<uint8_t> &pattern) const;   // wrapper.rs:103-124 (prepends)
   Search search(const std::string &p) const { return search(std::vector<uint8_t>(p.begin(), p.end())); }
   uint64_t count() const { return e_ - s_; }                  // wrapper.rs:132-134
   std::pair<uint64_t, uint64_t> get_range() const { return {s_, e_}; }
-  std::vector<Match> iter_matches() const {                   // wrapper.rs:203-217
-    std::vector<Match> m;
-    for (uint64_t i = s_; i < e_; i++) m.emplace_back(ix_, i);
-    return m;
-  }
+  std::vector<Match> iter_matches() const;                    // wrapper.rs:203-217
   std::vector<uint64_t> locate_all() const;                   // iter_matches().map(locate)
+  std::vector<uint64_t> piece_ids() const;                    // iter_matches().map(piece_id)
 
  private:
+  std::vector<uint64_t> rows() const;
   const Index *ix_;
   uint64_t s_, e_;
-  bool fresh_;
+  bool fresh_, prefix_;
 };
 
 class Index {
@@ -126,6 +126,21 @@ struct RLFMIndex : Index {
 struct RLFMIndexWithLocate : Index {
   RLFMIndexWithLocate(const Text &t, uint32_t level, int device = 0) : Index(t, FMX_KIND_RLFM, level, device) {}
 };
+// FMIndexMultiPieces / ...WithLocate (frontend.rs:245-267): SearchIndexWithMultiPieces
+struct FMIndexMultiPieces : Index {
+  explicit FMIndexMultiPieces(const Text &t, uint32_t level = FMX_NO_LOCATE, int device = 0)
+      : Index(t, FMX_KIND_MULTI, level, device) {}
+  uint64_t pieces_count() const { return fmx_pieces_count(handle()); }
+  Search search_prefix(const std::string &p) const {          // wrapper.rs:57-63
+    return Search(this, 0, 0, true, true).search(p);
+  }
+  Search search_suffix(const std::string &p) const {          // wrapper.rs:66-72
+    return Search(this, 0, pieces_count(), false, false).search(p);
+  }
+  Search search_exact(const std::string &p) const {           // wrapper.rs:75-81
+    return Search(this, 0, pieces_count(), false, true).search(p);
+  }
+};
 
 inline Search Search::search(const std::vector<uint8_t> &pattern) const {
   uint64_t off[2] = {0, pattern.size()};
@@ -134,12 +149,40 @@ inline Search Search::search(const std::vector<uint8_t> &pattern) const {
   uint8_t dummy = 0;
   check(fmx_count_batch(ix_->handle(), pattern.empty() ? &dummy : pattern.data(), off, 1,
                         fresh_ ? nullptr : se, &s, &e, nullptr));
-  return Search(ix_, s, e, false);
+  return Search(ix_, s, e, false, prefix_);
+}
+inline std::vector<uint64_t> Search::rows() const {
+  uint64_t cnt = 0, off[2] = {0, 0};
+  check(fmx_match_counts(ix_->handle(), &s_, &e_, 1, prefix_ ? 1 : 0, &cnt));
+  off[1] = cnt;
+  std::vector<uint64_t> r(cnt);
+  if (cnt) check(fmx_match_rows(ix_->handle(), &s_, &e_, 1, prefix_ ? 1 : 0, off, r.data()));
+  return r;
+}
+inline std::vector<Match> Search::iter_matches() const {
+  std::vector<Match> m;
+  for (uint64_t i : rows()) m.emplace_back(ix_, i);
+  return m;
+}
+inline std::vector<uint64_t> Search::piece_ids() const {
+  std::vector<uint64_t> r = rows(), out(r.size());
+  if (!r.empty()) check(fmx_piece_id_batch(ix_->handle(), r.data(), r.size(), out.data()));
+  return out;
+}
+inline uint64_t Match::piece_id() const {
+  uint64_t v = fmx_piece_id(ix_->handle(), i_);
+  if (v == ~0ull) throw Error(FMX_ERR_ARG, fmx_last_error());
+  return v;
 }
 inline std::vector<uint64_t> Search::locate_all() const {
+  if (prefix_) {
+    std::vector<uint64_t> r = rows(), pos(r.size());
+    if (!r.empty()) check(fmx_get_sa_batch(ix_->handle(), r.data(), r.size(), pos.data()));
+    return pos;
+  }
   uint64_t off[2] = {0, e_ - s_};
   std::vector<uint64_t> pos(e_ - s_);
-  check(fmx_locate_batch(ix_->handle(), &s_, &e_, 1, off, pos.data()));
+  if (e_ > s_) check(fmx_locate_batch(ix_->handle(), &s_, &e_, 1, off, pos.data()));
   return pos;
 }
 inline std::vector<uint64_t> Match::chars_forward(size_t k) const {

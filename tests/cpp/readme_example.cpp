@@ -1,5 +1,6 @@
 // The reference's README example (README.md:35-64) written against the C++ host mirror.
 // Built by tests/test_abi_cpu.py (compile + link only on CPU) and run by the -m gpu tests.
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <iterator>
@@ -27,6 +28,20 @@ int main(int argc, char **argv) {
     std::printf("\n");
     auto refined = index.search(std::string("lor")).search(std::string("do"));
     std::printf("refined %llu\n", (unsigned long long)refined.count());
+    if (argc > 2) {  // examples/multi_pieces.rs on the C++ mirror
+      std::ifstream f2(argv[2], std::ios::binary);
+      std::vector<uint8_t> b2((std::istreambuf_iterator<char>(f2)), std::istreambuf_iterator<char>());
+      fmx::FMIndexMultiPieces mp(fmx::Text(b2), 2);
+      std::printf("star %llu\n", (unsigned long long)mp.search(std::string("star")).count());
+      auto ids = mp.search_suffix(std::string("what you are!\n")).piece_ids();
+      std::sort(ids.begin(), ids.end());
+      std::printf("suffix");
+      for (auto v : ids) std::printf(" %llu", (unsigned long long)v);
+      auto pre = mp.search_prefix(std::string("Twinkle")).piece_ids();
+      std::printf("\nprefix");
+      for (auto v : pre) std::printf(" %llu", (unsigned long long)v);
+      std::printf("\n");
+    }
     try {
       fmx::FMIndex bad(fmx::Text(std::vector<uint8_t>{'n', 'o'}));
     } catch (const fmx::Error &e) {

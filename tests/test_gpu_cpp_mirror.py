@@ -12,7 +12,9 @@ def test_readme_example_cpp(golden, tmp_path):
     exe = build_readme_example(tmp_path)
     txt = tmp_path / "lorem.bin"
     txt.write_bytes(golden["readme"]["text"].encode("latin-1"))
-    out = subprocess.run([exe, str(txt)], capture_output=True, text=True, timeout=300)
+    mp = tmp_path / "twinkle.bin"
+    mp.write_bytes(golden["multi_pieces_example"]["text"].encode("latin-1"))
+    out = subprocess.run([exe, str(txt), str(mp)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "count 4"
@@ -20,4 +22,7 @@ def test_readme_example_cpp(golden, tmp_path):
     assert lines[2] == "forward " + golden["readme"]["forward_20_from_match_3"]
     assert lines[3] == "backward " + golden["readme"]["backward_16_from_first_match"]
     assert lines[4] == "refined 4"
-    assert lines[5] == "error invalid text: the given text must end with exactly one zero character"
+    assert lines[5] == "star 4"                             # examples/multi_pieces.rs:33
+    assert lines[6] == "suffix 0 1 2"                       # examples/multi_pieces.rs:80-87
+    assert lines[7] == "prefix 0"                           # examples/multi_pieces.rs:70-77
+    assert lines[8] == "error invalid text: the given text must end with exactly one zero character"

@@ -264,3 +264,13 @@ def test_tiny_texts():
         for p in (b"a", b"b", b"ab", b"aa", b""):
             assert gi.search(p).get_range() == oi.search(p), (raw, p)
             assert gi.search(p).locate_all() == oi.locate(p)
+
+
+def test_empty_text():
+    """sais.rs:121-123: a 0-length text builds; every search is the empty interval."""
+    for cls in (F.FMIndex, lambda t: F.FMIndexWithLocate(t, 2)):
+        gi = cls(F.Text(b""))
+        assert gi.len() == 0
+        for p in (b"a", b"", b"ab"):
+            s = gi.search(p)
+            assert s.get_range() == (0, 0) and s.count() == 0

@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmx.so")
+# FMX_LIB=<path> selects another build of the same ABI (e.g. the range-checked libfmx_debug.so)
+LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(_HERE, "libfmx.so")
 _lib = None
 
 OK = 0

@@ -806,6 +806,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (int rc = keep(idx, d_samp, nsamp * 4)) return rc;
     hipLaunchKernelGGL(k_samples, dim3(nblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
     dv.samples = d_samp;
+    dv.nsamples = (uint32_t)nsamp;
     dv.sa_level = level;
     idx->nsamples = nsamp;
   }

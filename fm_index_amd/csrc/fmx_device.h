@@ -11,6 +11,14 @@
 
 #define FMX_GROUP 8
 
+// Debug build (make debug -> libfmx_debug.so, -DFMX_DEBUG_BOUNDS): every index into the HBM arrays
+// is range-checked and a violation traps the kernel (the GPU pool has no address sanitizer).
+#ifdef FMX_DEBUG_BOUNDS
+#define FMX_CHECK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define FMX_CHECK(cond) do { } while (0)
+#endif
+
 // pattern / text symbol i of a buffer whose symbols are sb bytes wide (Character, character.rs)
 __device__ __forceinline__ uint32_t fmx_load_sym(const void *p, uint32_t sb, uint64_t i) {
   if (sb == 1) return ((const uint8_t *)p)[i];
@@ -82,6 +90,7 @@ __device__ __forceinline__ uint32_t fmx_piece_rank(const uint4 &p, uint32_t off,
 template <int FMT>
 __device__ __forceinline__ uint4 fmx_load_piece(const FmxLevel &L, uint32_t pos, uint32_t g) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
+  FMX_CHECK((pos >> SH) < L.nrec);
   return L.rec[(size_t)(pos >> SH) * 8u + g];
 }
 template <int FMT>
@@ -213,6 +222,7 @@ __device__ __forceinline__ uint32_t fmx_select32(uint32_t w, uint32_t r) {
 // ---------------------------------------------------------------------------
 // counter of `code` at the start of record r (same units as fmx_level_rank's result)
 __device__ __forceinline__ uint32_t fmx_level_counter(const FmxLevel &L, uint32_t r, uint32_t code) {
+  FMX_CHECK(r < L.nrec);
   if (L.fmt == 3) return L.rec[(size_t)r * 8u + code].x;
   const uint4 p = L.rec[(size_t)r * 8u + (code >> 1)];
   return (code & 1u) ? p.y : p.x;
@@ -278,6 +288,7 @@ __device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i,
   uint32_t within = i - rec * FMX_BITS_PER_REC;
   uint32_t p = fmx_div3(within >> 5);         // within / 96
   uint32_t bit = within - p * FMX_BITS_PER_PIECE;
+  FMX_CHECK(rec < bv.nrec);
   uint4 pc = bv.rec[(size_t)rec * 8u + g];
   uint32_t c = __popc(pc.y & fmx_lowmask(bit < 32u ? bit : 32u));
   if (bit > 32u) c += __popc(pc.z & fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u));
@@ -291,7 +302,9 @@ __device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i,
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
   uint32_t h = k / FMX_SEL_STEP;
+  FMX_CHECK(h + 1 < bv.nsel);
   uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
+  FMX_CHECK(lo < bv.nrec && hi < bv.nrec);
   while (lo < hi) {  // group-uniform binary search over record bases
     uint32_t mid = (lo + hi + 1u) >> 1;
     uint32_t x = bv.rec[(size_t)mid * 8u].x;
@@ -314,8 +327,10 @@ __device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0,
                                                  uint32_t g, uint32_t &out0, uint32_t &out1) {
   const bool v0 = k0 < bv.ones, v1 = k1 < bv.ones;
   const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
+  FMX_CHECK(q0 / FMX_SEL_STEP + 1 < bv.nsel && q1 / FMX_SEL_STEP + 1 < bv.nsel);
   uint32_t lo0 = bv.sel[q0 / FMX_SEL_STEP], hi0 = bv.sel[q0 / FMX_SEL_STEP + 1];
   uint32_t lo1 = bv.sel[q1 / FMX_SEL_STEP], hi1 = bv.sel[q1 / FMX_SEL_STEP + 1];
+  FMX_CHECK(hi0 < bv.nrec && hi1 < bv.nrec);
   while (lo0 < hi0 || lo1 < hi1) {  // group-uniform binary searches over record bases
     const uint32_t m0 = (lo0 + hi0 + 1u) >> 1, m1 = (lo1 + hi1 + 1u) >> 1;
     const uint32_t x0 = bv.rec[(size_t)m0 * 8u].x, x1 = bv.rec[(size_t)m1 * 8u].x;

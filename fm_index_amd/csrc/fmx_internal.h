@@ -67,6 +67,7 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   uint32_t sa_level;    // effective level; FMX_NO_LOCATE when absent
   uint32_t kind;
   uint32_t sym_bytes;   // width of text / pattern symbols (1, 2 or 4)
+  uint32_t nsamples;    // entries of samples[] (bounds checks of the debug build)
   FmxBits b, bp;        // RLFM only
   const uint32_t *doc;    // MULTI: piece id of the k-th end marker in L order (multi_pieces.rs:57-85)
   uint32_t doc_count;     // MULTI: number of pieces

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  [[maybe_unused]] const uint32_t nrec = n / 256u + 1u;
 
   uint64_t k[PPG], pbeg[PPG];
   uint32_t j[PPG], s[PPG], e[PPG], c[PPG];
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
       cn[q] = 0;
       if (stepping[q]) {
         uint32_t rs = s[q] >> 8, re = e[q] >> 8;
+        FMX_CHECK(rs < nrec && re < nrec);
         a[q] = rec[(size_t)rs * 8u + g];
         if (SKIP) {
           b[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
         uint32_t used;
         if (pair) {
           const uint32_t code = (c1 - 1u) * 4u + (c2 - 1u);
+          FMX_CHECK((s >> 7) < n / 128u + 1u && (e >> 7) < n / 128u + 1u);
           const uint4 a = rec2[(size_t)(s >> 7) * 8u + g];
           const uint4 b = rec2[(size_t)(e >> 7) * 8u + g];
           uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(a, s & 127u, code, g));
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
           used = 2;
           if (ns == ne) {
             // would the reference already have stopped after the last symbol alone?
+            FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
             const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
             const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
             const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
           }
           s = ns; e = ne;
         } else {
+          FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
           const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
           const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
           const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));  // wrapper.rs:109
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
     if (active) {
       if ((row & lmask) == 0) {
         // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
+        FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
         uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
         if (v >= ix.n) v -= ix.n;  // steps < n, sa < n
         if (g == 0) out_pos[h] = v;
@@ -465,6 +471,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
       p[q] = make_uint4(0u, 0u, 0u, 0u);
       if (active[q]) {
         const uint32_t si = row[q] >> sa_level;
+        FMX_CHECK(row[q] < n && (row[q] >> 8) < n / 256u + 1u);
+        FMX_CHECK(!sampled[q] || (uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
         const uint4 *addr = sampled[q] ? (samp4 + (si >> 2)) : (rec + ((size_t)(row[q] >> 8) * 8u + g));
         p[q] = *addr;
       }
@@ -638,6 +646,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
         uint32_t sym;
         uint32_t raw = fmx_mwm_lf(ix.bw, row, g, sym);
         if (sym == 0u) {  // doc[bw.rank(i, 0)] + 1 mod pieces
+          FMX_CHECK(ix.K[0] + raw < ix.doc_count);
           uint32_t prev = ix.doc[ix.K[0] + raw];
           res = (uint64_t)((prev + 1u) % ix.doc_count);
           break;
@@ -656,6 +665,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
         row = fmx_lf_map_any<KIND>(ix, row, g, sym);
         steps++;
       }
+      FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
       uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
       if (v >= ix.n) v -= ix.n;
       res = v;

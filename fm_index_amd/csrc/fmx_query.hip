@@ -24,6 +24,7 @@
 //   2, 5       count with 2 / 4 independent chains per group          (slower: 0.78 / 1.00 ms)
 //   3, 4       count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
 //   7          ignore the pair index even when it was built
+//   8, 9       measurement only: lane-per-pattern / wavefront-per-pattern count kernels
 static inline int fmx_variant() {
   static const int cached = [] {
     const char *v = getenv("FMX_VARIANT");
@@ -211,6 +212,84 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
   }
   if (steps_out && g == 0 && nsteps)
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---------------------------------------------------------------------------
+// Measurement-only alternatives to the 8-lane-group shape (selected
+// with FMX_VARIANT=8 / 9, never used by default):
+//   fmx_count_f3_lane_kernel  -- one LANE owns one pattern and reads both 128-B records itself
+//                                (8 dwordx4 loads per record, no cross-lane traffic)
+//   fmx_count_f3_wave_kernel  -- one WAVEFRONT owns one pattern (lanes 0-7 fetch the record of s,
+//                                lanes 8-15 the record of e, the other 48 lanes idle)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fmx_rank_whole_record(const uint4 *__restrict__ r, uint32_t off,
+                                                          uint32_t c) {
+  uint32_t acc = r[c].x;  // absolute counter of symbol c
+#pragma unroll
+  for (uint32_t g = 0; g < 8; g++) {
+    const uint4 p = r[g];
+    int nb = (int)off - (int)(g * 32);
+    nb = nb < 0 ? 0 : (nb > 32 ? 32 : nb);
+    acc += __popc(fmx_piece_match<3>(p, c) & (uint32_t)((1ull << nb) - 1ull));
+  }
+  return acc;
+}
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_lane_kernel(
+    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
+    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt,
+    uint64_t *__restrict__ steps_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t nsteps = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < npat; k += stride) {
+    const uint64_t pbeg = off[k];
+    uint32_t j = (uint32_t)(off[k + 1] - pbeg), s = 0, e = n;
+    while (j) {
+      nsteps++;
+      const uint32_t c = pat[pbeg + --j];
+      if (c > max_character) { atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE); s = e = 0; break; }
+      s = fmx_rank_whole_record(rec + (size_t)(s >> 8) * 8u, s & 255u, c);
+      e = fmx_rank_whole_record(rec + (size_t)(e >> 8) * 8u, e & 255u, c);
+      if (s == e) break;
+    }
+    if (out_s) out_s[k] = s;
+    if (out_e) out_e[k] = e;
+    if (out_cnt) out_cnt[k] = (uint64_t)(e - s);
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_wave_kernel(
+    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
+    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt,
+    uint64_t *__restrict__ steps_out) {
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u;
+  if (lane >= 16u) return;                 // 48 of the 64 lanes have nothing to fetch
+  const bool is_e = lane >= 8u;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint32_t nsteps = 0;
+  for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < npat; k += nwaves) {
+    const uint64_t pbeg = off[k];
+    uint32_t j = (uint32_t)(off[k + 1] - pbeg);
+    uint32_t v = is_e ? n : 0u;            // lanes 0-7 carry s, lanes 8-15 carry e
+    bool dead = false;
+    while (j && !dead) {
+      const uint32_t c = pat[pbeg + --j];
+      if (c > max_character) { if (lane == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE); v = 0; break; }
+      const uint4 p = rec[(size_t)(v >> 8) * 8u + g];
+      v = fmx_group_sum(fmx_piece_rank<3>(p, v & 255u, c, g));
+      const uint32_t other = (uint32_t)__shfl((int)v, (int)(lane ^ 8u));
+      dead = (v == other);
+      nsteps++;
+    }
+    if (g == 0) {
+      if (!is_e && out_s) out_s[k] = v;
+      if (is_e && out_e) out_e[k] = v;
+    }
+    const uint32_t sv = (uint32_t)__shfl((int)v, (int)(lane & 7u));
+    if (lane == 8 && out_cnt) out_cnt[k] = (uint64_t)(v - sv);
+  }
+  if (steps_out && lane == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // ---------------------------------------------------------------------------
@@ -810,6 +889,18 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
                      dim3(FMX_BLOCK), 0, st, w.lv[0].rec, idx->dev.n, idx->dev.max_character,        \
                      idx->dev.status, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
     switch (variant) {
+      case 8:  // measurement only: lane per pattern
+        if (d_s0e0) return FMX_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(fmx_count_f3_lane_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
+                           w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, d_pat8, d_off,
+                           npat, d_s, d_e, d_cnt, steps);
+        break;
+      case 9:  // measurement only: wavefront per pattern
+        if (d_s0e0) return FMX_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(fmx_count_f3_wave_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
+                           w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, d_pat8, d_off,
+                           npat, d_s, d_e, d_cnt, steps);
+        break;
       case 2: FMX_F3_LAUNCH(2, false); break;
       case 3: FMX_F3_LAUNCH(1, true); break;
       case 4: FMX_F3_LAUNCH(2, true); break;

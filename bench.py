@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=30, help="text length 2^k incl. terminator")
     ap.add_argument("--npat", type=int, default=1 << 20, help="patterns per GPU")
     ap.add_argument("--plen", type=int, default=32)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""One-off scale check: a text of 3 * 2^30 symbols (rows and positions beyond 2^31) -- build,
+count, locate, and verify every located position against the text.  ~120 GB of builder scratch."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import fm_index_amd as F
+    from fm_index_amd import _lib as L
+    from fm_index_amd import workload as W
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3 << 30
+    text = W.dna_text_torch(n, 1, dev)
+    t0 = time.time()
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=3, keep_sa=False)
+    t_build = time.time() - t0
+    npat, m = 1 << 18, 40
+    pat, off, pos = W.substring_patterns_torch(text, npat, m, 3)
+    s = torch.empty(npat, dtype=torch.int64, device=dev)
+    e = torch.empty(npat, dtype=torch.int64, device=dev)
+    c = torch.empty(npat, dtype=torch.int64, device=dev)
+    h = index.handle()
+    assert lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                   C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()),
+                                   C.c_void_p(c.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert bool((c >= 1).all())
+    o = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+    lib.fmx_offsets_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat, C.c_void_p(o.data_ptr()), None)
+    total = int(o[-1].item())
+    p = torch.empty(total, dtype=torch.int64, device=dev)
+    assert lib.fmx_locate_batch_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                                    C.c_void_p(o.data_ptr()), total, C.c_void_p(p.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    hit = torch.repeat_interleave(torch.arange(npat, device=dev), c)
+    ok = torch.ones(total, dtype=torch.bool, device=dev)
+    for j in range(m):
+        ok &= text[p + j] == pat.view(npat, m)[hit, j]
+    found = torch.zeros(npat, dtype=torch.bool, device=dev)
+    found[hit[p == pos[hit]]] = True
+    print(json.dumps({"n": n, "build_s": round(t_build, 2), "index_bytes": index.heap_size(),
+                      "hits": total, "max_row": int(e.max().item()), "max_pos": int(p.max().item()),
+                      "all_positions_hold_pattern": bool(ok.all()),
+                      "all_sources_found": bool(found.all()),
+                      "rows_beyond_2^31": int((e > (1 << 31)).sum().item())}))
+
+
+if __name__ == "__main__":
+    main()

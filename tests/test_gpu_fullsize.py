@@ -91,11 +91,31 @@ def test_config4_rlfm_byte_text_1gb():
     text = W.byte_text_torch(N, 4, dev)
     npat, m = 1 << 20, 16
     pat, off, pos = W.substring_patterns_torch(text, npat, m, 6)
-    rl = F.RLFMIndex.from_device_text(text.data_ptr(), N, 255)
+    lib = L.lib()
+    rl = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), N, 255, level=3)
     s, e, c = _count_dev(rl, pat, off, npat)
     assert bool((c >= 1).all())
-    runs = int(L.lib().fmx_num_runs(rl.handle()))
+    runs = int(lib.fmx_num_runs(rl.handle()))
     assert 0.99 * N < runs <= N
+    # RLFM locate (rlfmi.rs:127-133, 176-189) at full size: positions verified against the text
+    k = 1 << 16
+    d_off = torch.empty(k + 1, dtype=torch.int64, device=dev)
+    assert lib.fmx_offsets_dev(rl.handle(), C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), k,
+                               C.c_void_p(d_off.data_ptr()), None) == 0
+    total = int(d_off[-1].item())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    assert lib.fmx_locate_batch_dev(rl.handle(), C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), k,
+                                    C.c_void_p(d_off.data_ptr()), total, C.c_void_p(d_pos.data_ptr()),
+                                    None) == 0
+    torch.cuda.synchronize()
+    hit_pat = torch.repeat_interleave(torch.arange(k, device=dev), c[:k])
+    ok = torch.ones(total, dtype=torch.bool, device=dev)
+    for j in range(m):
+        ok &= text[d_pos + j] == pat.view(npat, m)[hit_pat, j]
+    assert bool(ok.all())
+    found = torch.zeros(k, dtype=torch.bool, device=dev)
+    found[hit_pat[d_pos == pos[hit_pat]]] = True
+    assert bool(found.all())
     rl.close()
     fm = F.FMIndex.from_device_text(text.data_ptr(), N, 255)
     s2, e2, c2 = _count_dev(fm, pat, off, npat)

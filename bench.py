@@ -216,7 +216,9 @@ def main():
             traffic = json.load(f).get("%s:%d:%d:%d" % (args.workload, npat, m, args.log2n), {})
     except OSError:
         pass
-    roofline = {"bound": "hbm", "kernel": "fmx_count_kernel", "achieved": round(achieved, 1),
+    kname = "fmx_count_f3_kernel<1,false>" if dna else \
+        ("fmx_count_kernel<FMX_KIND_RLFM>" if rlfm else "fmx_count_kernel<FMX_KIND_FM>")
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("count", {}).get("bytes"),
                 "algorithmic_bytes_per_launch": chars_per_step_rank * bytes_per_char,
@@ -318,7 +320,10 @@ def main():
         out["locate"] = {"hits_per_s": total_hits * lsteps / ldt, "hits": total_hits,
                          "lf_steps": lf_steps, "level": args.level,
                          "ms_per_batch": ldt / lsteps * 1e3,
-                         "roofline": {"bound": "hbm", "kernel": "fmx_locate_kernel",
+                         "roofline": {"bound": "hbm",
+                                      "kernel": "fmx_locate_f3w_kernel<4>" if dna else
+                                      ("fmx_locate_kernel<FMX_KIND_RLFM>" if rlfm else
+                                       "fmx_locate_kernel<FMX_KIND_FM>"),
                                       "achieved": round(lbytes / kavg / 1e9, 1), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(lbytes / kavg / 1e9 / HBM_PEAK_GBS, 4),
                                       "avg_kernel_ms": round(kavg * 1e3, 4),

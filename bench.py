@@ -146,7 +146,11 @@ def main():
                 return sharding.gather_counts(d_cs[b].cpu(), total_pat)
             d_c32[b].copy_(d_cs[b])
             if pipelined:
-                pending[b] = dist.all_gather_into_tensor(g_out[b], d_c32[b], async_op=True)
+                try:
+                    pending[b] = dist.all_gather_into_tensor(g_out[b], d_c32[b], async_op=True)
+                except Exception:   # noqa: BLE001 -- fall back to the blocking collective
+                    pending[b] = None
+                    dist.all_gather_into_tensor(g_out[b], d_c32[b])
             else:
                 dist.all_gather_into_tensor(g_out[b], d_c32[b])
             return g_out[b]

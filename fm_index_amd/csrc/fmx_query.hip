@@ -397,19 +397,37 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
 // ---------------------------------------------------------------------------
 // locate
 // ---------------------------------------------------------------------------
-// exclusive offsets -> rows: out_pos[off[k] + j] = s[k] + j   (wrapper.rs:203-217: i = s..e-1
-// ascending).  One 8-lane group per pattern, lanes stride over its rows.
+// exclusive offsets -> rows: rows[off[k] + j] = s[k] + j   (wrapper.rs:203-217: i = s..e-1
+// ascending).  One LANE per pattern writes short ranges itself; ranges longer than 32 rows are
+// written by the whole wave, one after the other (ballot over the lanes that hold one).
 template <typename T>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
     const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos) {
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  for (uint64_t k = gid; k < npat; k += ngroups) {
-    uint64_t a = s[k], b = e[k], o = off[k];
-    uint64_t cnt = b > a ? b - a : 0;
-    for (uint64_t t = g; t < cnt; t += FMX_GROUP) out_pos[o + t] = (T)(a + t);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t base = first - lane; base < npat; base += stride) {   // wave-uniform trip count
+    const uint64_t k = base + lane;
+    uint64_t a = 0, o = 0, cnt = 0;
+    if (k < npat) {
+      a = s[k];
+      const uint64_t b = e[k];
+      o = off[k];
+      cnt = b > a ? b - a : 0;
+    }
+    if (cnt <= 32) {
+      for (uint64_t t = 0; t < cnt; t++) out_pos[o + t] = (T)(a + t);
+    }
+    unsigned long long big = __ballot(cnt > 32);
+    while (big) {
+      const int l = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const uint64_t A = ((uint64_t)(uint32_t)__shfl((int)(a >> 32), l) << 32) | (uint32_t)__shfl((int)a, l);
+      const uint64_t O = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), l) << 32) | (uint32_t)__shfl((int)o, l);
+      const uint64_t N = ((uint64_t)(uint32_t)__shfl((int)(cnt >> 32), l) << 32) | (uint32_t)__shfl((int)cnt, l);
+      for (uint64_t t = lane; t < N; t += 64) out_pos[O + t] = (T)(A + t);
+    }
   }
 }
 
@@ -946,8 +964,12 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   // rows in their own read-only buffer: the walk's loads never alias its stores
   uint32_t *rows = nullptr;
   FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0,
-                     st, d_s, d_e, d_off, npat, rows);
+  {
+    uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
+    if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
+    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
+                       d_off, npat, rows);
+  }
   uint64_t nwaves = (total + 7) / 8;
   const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
   if (nwaves > max_waves) nwaves = max_waves;

@@ -23,6 +23,7 @@
 //   0          force the generic kernels (any kind / any number of levels)
 //   2, 5       count with 2 / 4 independent chains per group          (slower: 0.78 / 1.00 ms)
 //   3, 4       count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
+//   (non-temporal loads for the deep steps were also measured: 0.80 ms, removed)
 //   7          ignore the pair index even when it was built
 //   8, 9       measurement only: lane-per-pattern / wavefront-per-pattern count kernels
 static inline int fmx_variant() {
@@ -166,11 +167,12 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
       if (stepping[q]) {
         uint32_t rs = s[q] >> 8, re = e[q] >> 8;
         FMX_CHECK(rs < nrec && re < nrec);
-        a[q] = rec[(size_t)rs * 8u + g];
         if (SKIP) {
+          a[q] = rec[(size_t)rs * 8u + g];
           b[q] = make_uint4(0u, 0u, 0u, 0u);
           if (re != rs) b[q] = rec[(size_t)re * 8u + g];
         } else {
+          a[q] = rec[(size_t)rs * 8u + g];
           b[q] = rec[(size_t)re * 8u + g];
         }
         if (j[q] > 1) cn[q] = pat[pbeg[q] + j[q] - 2];

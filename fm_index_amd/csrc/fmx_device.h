@@ -112,25 +112,33 @@ __device__ __forceinline__ uint32_t fmx_level_rank(const FmxLevel &L, uint32_t p
 
 // rank_c(i) over the whole multi-ary wavelet matrix, minus the symbol-only start
 // chain (folded into K[c]): the value r with lf_map2(c,i) = K[c] + r  (fm_index.rs:93-95)
+// NL > 0 fixes the number of levels at compile time: the loops unroll and the level descriptors
+// stay in SGPRs instead of being re-read from the kernel arguments inside the search loop.
+template <int NL = 0>
 __device__ __forceinline__ uint32_t fmx_mwm_rank(const FmxMwm &w, uint32_t c, uint32_t pos,
                                                  uint32_t g) {
   uint32_t r = 0;
-  for (uint32_t l = 0; l < w.nlevels; l++) {
+  const uint32_t nl = NL ? (uint32_t)NL : w.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = w.lv[l];
     uint32_t code = (c >> L.shift) & L.mask;
     r = fmx_level_rank(L, pos, code, g);
-    if (l + 1 < w.nlevels) pos = r;  // C_l[code] is folded into the counters
+    if (l + 1 < nl) pos = r;  // C_l[code] is folded into the counters
   }
   return r;
 }
 
 // both endpoints of one backward-search step, loads issued together
+template <int NL = 0>
 __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint32_t ps,
                                               uint32_t pe, uint32_t g, uint32_t &rs,
                                               uint32_t &re) {
   rs = 0;
   re = 0;
-  for (uint32_t l = 0; l < w.nlevels; l++) {
+  const uint32_t nl = NL ? (uint32_t)NL : w.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = w.lv[l];
     uint32_t code = (c >> L.shift) & L.mask;
     if (L.fmt == 3) {
@@ -144,7 +152,7 @@ __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint3
       rs = fmx_group_sum(fmx_piece_rank<4>(a, fmx_off<4>(ps), code, g));
       re = fmx_group_sum(fmx_piece_rank<4>(b, fmx_off<4>(pe), code, g));
     }
-    if (l + 1 < w.nlevels) {  // C_l[code] is folded into the counters
+    if (l + 1 < nl) {  // C_l[code] is folded into the counters
       ps = rs;
       pe = re;
     }
@@ -153,10 +161,12 @@ __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint3
 
 // N positions of the same symbol at once: per level all N record loads are issued before the
 // first popcount (more lines in flight per group; equal lines are merged by the L1)
-template <int N>
+template <int N, int NL = 0>
 __device__ __forceinline__ void fmx_mwm_rankN(const FmxMwm &w, uint32_t c, uint32_t (&pos)[N],
                                               uint32_t g, uint32_t (&r)[N]) {
-  for (uint32_t l = 0; l < w.nlevels; l++) {
+  const uint32_t nl = NL ? (uint32_t)NL : w.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = w.lv[l];
     const uint32_t code = (c >> L.shift) & L.mask;
     uint4 p[N];
@@ -173,7 +183,7 @@ __device__ __forceinline__ void fmx_mwm_rankN(const FmxMwm &w, uint32_t c, uint3
       for (int q = 0; q < N; q++)
         r[q] = fmx_group_sum(fmx_piece_rank<4>(p[q], fmx_off<4>(pos[q]), code, g));
     }
-    if (l + 1 < w.nlevels) {
+    if (l + 1 < nl) {
 #pragma unroll
       for (int q = 0; q < N; q++) pos[q] = r[q];  // C_l[code] is folded into the counters
     }
@@ -182,11 +192,14 @@ __device__ __forceinline__ void fmx_mwm_rankN(const FmxMwm &w, uint32_t c, uint3
 
 // access + rank along the same positions (fm_index.rs:82-91: get_l then rank of that
 // symbol): returns r with lf_map(i) = K[sym] + r and the symbol itself.
+template <int NL = 0>
 __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, uint32_t g,
                                                uint32_t &sym) {
   uint32_t r = 0;
   sym = 0;
-  for (uint32_t l = 0; l < w.nlevels; l++) {
+  const uint32_t nl = NL ? (uint32_t)NL : w.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = w.lv[l];
     uint32_t code;
     if (L.fmt == 3) {
@@ -201,7 +214,7 @@ __device__ __forceinline__ uint32_t fmx_mwm_lf(const FmxMwm &w, uint32_t pos, ui
       r = fmx_group_sum(fmx_piece_rank<4>(p, off, code, g));
     }
     sym |= code << L.shift;
-    if (l + 1 < w.nlevels) pos = r;  // C_l[code] folded
+    if (l + 1 < nl) pos = r;  // C_l[code] folded
   }
   return r;
 }
@@ -371,12 +384,13 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map2(const FmxDev &ix, uint32_t 
   return r;
 }
 // RLFMIndexBackend::get_l + lf_map (rlfmi.rs:122-133)
+template <int NL = 0>
 __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i, uint32_t g,
                                                     uint32_t &sym) {
   uint32_t bi;
   uint32_t j = fmx_bits_rank(ix.b, i, g, bi);
-  (void)fmx_mwm_lf(ix.bw, j - 1u + bi, g, sym);
-  uint32_t nr = ix.K[sym] + fmx_mwm_rank(ix.bw, sym, j, g);
+  (void)fmx_mwm_lf<NL>(ix.bw, j - 1u + bi, g, sym);
+  uint32_t nr = ix.K[sym] + fmx_mwm_rank<NL>(ix.bw, sym, j, g);
   return fmx_bits_select(ix.bp, nr, g) + i - fmx_bits_select(ix.b, j, g);
 }
 
@@ -386,6 +400,7 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i
 // (the run holding row i) it is  s.rank(lo+1, c) - s.rank(lo, c) == 1, and b.rank1(i) is lo or
 // lo+1, so one rank chain over the adjacent positions {lo, lo+1} yields nr and the comparison
 // from the same cache lines.
+template <int NL = 0>
 __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                       uint32_t &e, uint32_t g) {
   const uint32_t kc = ix.K[c];
@@ -395,7 +410,7 @@ __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t
   const uint32_t los = js - 1u + bs, loe = je - 1u + be;  // b.rank1(i+1) - 1   rlfmi.rs:124
   uint32_t pos[4] = {los, los + 1u, loe, loe + 1u};
   uint32_t r[4];
-  fmx_mwm_rankN<4>(ix.bw, c, pos, g, r);
+  fmx_mwm_rankN<4, NL>(ix.bw, c, pos, g, r);
   const uint32_t nrs = kc + (bs ? r[0] : r[1]);       // cs[c] + s.rank(j, c)   rlfmi.rs:137,139
   const uint32_t nre = kc + (be ? r[2] : r[3]);
   const bool eqs = (r[1] - r[0]) == 1u;               // get_l(i) == c          rlfmi.rs:138
@@ -443,13 +458,13 @@ __device__ __forceinline__ uint32_t fmx_fl_map_any(const FmxDev &ix, uint32_t i,
 __device__ __forceinline__ uint32_t fmx_multi_zero(const FmxDev &ix, uint32_t i, uint32_t rank0) {
   return i < ix.first_row ? rank0 + 1u : (i == ix.first_row ? 0u : rank0);
 }
-template <int KIND>
+template <int KIND, int NL = 0>
 __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                  uint32_t &e, uint32_t g) {
   if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
     uint32_t rs, re;
     const uint32_t kc = ix.K[c];  // issued ahead of the record loads
-    fmx_mwm_rank2(ix.bw, c, s, e, g, rs, re);
+    fmx_mwm_rank2<NL>(ix.bw, c, s, e, g, rs, re);
     if (KIND == FMX_KIND_MULTI && c == 0u) {
       s = fmx_multi_zero(ix, s, kc + rs);
       e = fmx_multi_zero(ix, e, kc + re);
@@ -458,18 +473,18 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
     s = kc + rs;  // fm_index.rs:93-95
     e = kc + re;
   } else {
-    fmx_rlfm_lf_map2_pair(ix, c, s, e, g);
+    fmx_rlfm_lf_map2_pair<NL>(ix, c, s, e, g);
   }
 }
-template <int KIND>
+template <int KIND, int NL = 0>
 __device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
                                                    uint32_t &sym) {
   if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
-    uint32_t r = fmx_mwm_lf(ix.bw, i, g, sym);
+    uint32_t r = fmx_mwm_lf<NL>(ix.bw, i, g, sym);
     r += ix.K[sym];  // fm_index.rs:86-91
     if (KIND == FMX_KIND_MULTI && sym == 0u) r = fmx_multi_zero(ix, i, r);  // multi_pieces.rs:131-137
     return r;
   } else {
-    return fmx_rlfm_lf_map(ix, i, g, sym);
+    return fmx_rlfm_lf_map<NL>(ix, i, g, sym);
   }
 }

@@ -44,7 +44,7 @@ static inline unsigned fmx_grid_for_groups(uint64_t units) {
 // ---------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, int NL>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
     FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
       } else {
         // the next symbol rides along with this step's record loads
         const uint32_t cn = j > 1 ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
-        fmx_lf_map2_pair<KIND>(ix, c, s, e, g);        // wrapper.rs:109-110
+        fmx_lf_map2_pair<KIND, NL>(ix, c, s, e, g);    // wrapper.rs:109-110
         c = cn;
         j--;
         nsteps++;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
 // generic locate walk (any kind / any number of levels): same wave-level dynamic hit assignment
 // and register row window as fmx_locate_f3w_kernel below; one LF step = fmx_lf_map_any (several
 // dependent probes), the sample read is a plain dependent load.
-template <int KIND>
+template <int KIND, int NL>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
     FmxDev ix, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
       } else {
         // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
         uint32_t sym;
-        row = fmx_lf_map_any<KIND>(ix, row, g, sym);
+        row = fmx_lf_map_any<KIND, NL>(ix, row, g, sym);
         steps++;
         nsteps++;
       }
@@ -927,15 +927,21 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
       case 5: FMX_F3_LAUNCH(4, false); break;
       default: FMX_F3_LAUNCH(1, false); break;
     }
-  } else if (idx->kind == FMX_KIND_FM)
-    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
-  else if (idx->kind == FMX_KIND_MULTI)
-    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_MULTI>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
-  else
-    hipLaunchKernelGGL(fmx_count_kernel<FMX_KIND_RLFM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);
+  } else {
+    // number of wavelet levels fixed at compile time for the common cases (1, 2), runtime otherwise
+#define FMX_COUNT_LAUNCH(KIND, NL)                                                                  \
+  hipLaunchKernelGGL((fmx_count_kernel<KIND, NL>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, d_pat, \
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+#define FMX_COUNT_KIND(KIND)                                                                        \
+  do {                                                                                              \
+    if (w.nlevels == 1) FMX_COUNT_LAUNCH(KIND, 1);                                                  \
+    else if (w.nlevels == 2) FMX_COUNT_LAUNCH(KIND, 2);                                             \
+    else FMX_COUNT_LAUNCH(KIND, 0);                                                                 \
+  } while (0)
+    if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM);
+    else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI);
+    else FMX_COUNT_KIND(FMX_KIND_RLFM);
+  }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -995,15 +1001,19 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
                      idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hp, rows, d_pos, steps)
     if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
-  } else if (idx->kind == FMX_KIND_FM) {
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_FM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       total, hpw, rows, d_pos, steps);
-  } else if (idx->kind == FMX_KIND_MULTI) {
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_MULTI>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       total, hpw, rows, d_pos, steps);
   } else {
-    hipLaunchKernelGGL(fmx_locate_kernel<FMX_KIND_RLFM>, dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev,
-                       total, hpw, rows, d_pos, steps);
+#define FMX_LOCATE_LAUNCH(KIND, NL)                                                                 \
+  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, total, \
+                     hpw, rows, d_pos, steps)
+#define FMX_LOCATE_KIND(KIND)                                                                       \
+  do {                                                                                              \
+    if (w.nlevels == 1) FMX_LOCATE_LAUNCH(KIND, 1);                                                 \
+    else if (w.nlevels == 2) FMX_LOCATE_LAUNCH(KIND, 2);                                            \
+    else FMX_LOCATE_LAUNCH(KIND, 0);                                                                \
+  } while (0)
+    if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM);
+    else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI);
+    else FMX_LOCATE_KIND(FMX_KIND_RLFM);
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());

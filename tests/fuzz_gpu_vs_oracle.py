@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Differential soak test: random texts / alphabets / index kinds / levels / flags, random and
+substring patterns, every result compared with the CPU oracle (bit-exact (s,e), ordered locate
+sequences, every trait method on sampled rows).  Usage: python tests/fuzz_gpu_vs_oracle.py [seconds] [seed]
+(the oracle is the checker here, exactly as in tests/)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import numpy as np
+    import fm_index_amd as F
+    from fm_index_amd import workload as W
+    from oracle import fm_oracle as O
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    it = 0
+    stats = {"fm": 0, "rlfm": 0, "multi": 0, "pair": 0, "wide": 0}
+    while time.time() < t_end:
+        it += 1
+        kind = rng.choice(["fm", "fm", "rlfm", "multi"])
+        n = int(rng.choice([2, 3, 5, 17, 64, 255, 256, 257, 700, 1023, 1024, 1025, 3000, 9000]))
+        wide = kind != "multi" and rng.random() < 0.2
+        if wide:
+            alpha = int(rng.choice([3, 40, 300, 5000]))
+            maxc = int(rng.choice([alpha, alpha + 7, 2 * alpha, 65535]))
+            dtype = np.uint16 if maxc <= 65535 and rng.random() < 0.5 else np.uint32
+        else:
+            alpha = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 100, 255]))
+            maxc = int(rng.choice([alpha, min(255, alpha + 1), 255]))
+            dtype = np.uint8
+        style = rng.choice(["random", "repetitive", "runs"])
+        if style == "random":
+            t = rng.integers(1, alpha + 1, size=n)
+        elif style == "repetitive":
+            blk = rng.integers(1, alpha + 1, size=max(1, int(rng.integers(1, 40))))
+            t = np.tile(blk, n // len(blk) + 1)[:n]
+            mut = rng.random(n) < 0.02
+            t[mut] = rng.integers(1, alpha + 1, size=int(mut.sum()))
+        else:
+            t = np.repeat(rng.integers(1, alpha + 1, size=n), rng.integers(1, 9, size=n))[:n]
+        t = t.astype(dtype)
+        if kind == "multi" and n > 4:
+            z = rng.random(n) < 0.05
+            z[0] = False
+            z[1:] &= ~z[:-1]          # no double zeros
+            z[n - 2] = False
+            t[z] = 0
+        t[n - 1] = 0
+        level = None if rng.random() < 0.2 else int(rng.integers(0, 6))
+        pair = kind == "fm" and not wide and maxc <= 4 and rng.random() < 0.5
+        t_or = t if dtype == np.uint8 else t.astype(np.uint32)
+        try:
+            oi = O.OracleIndex(t_or, maxc, level=level, kind=kind)
+        except O.OracleError:
+            continue
+        text = F.Text.with_max_character(t, maxc)
+        if kind == "fm":
+            gi = F.FMIndexWithLocate(text, level, pair_index=pair) if level is not None else \
+                F.FMIndex(text, pair_index=pair)
+        elif kind == "rlfm":
+            if n < 2:
+                continue
+            gi = F.RLFMIndexWithLocate(text, level) if level is not None else F.RLFMIndex(text)
+        else:
+            gi = F.FMIndexMultiPiecesWithLocate(text, level) if level is not None else F.FMIndexMultiPieces(text)
+        stats[kind] += 1
+        stats["pair"] += int(pair)
+        stats["wide"] += int(wide)
+        # patterns: random ragged + substrings (+ occasional zero symbol)
+        npat = 200
+        lens = rng.integers(0, 12, size=npat)
+        pats = []
+        for k in range(npat):
+            m = int(lens[k])
+            if rng.random() < 0.5 and n > 2:
+                a = int(rng.integers(0, n - 1))
+                p = t[a:min(n - 1, a + m)].copy()
+            else:
+                p = rng.integers(0 if rng.random() < 0.1 else 1, alpha + 1, size=m).astype(dtype)
+            pats.append(p)
+        flat, off = F.pack_patterns(pats, dtype)
+        se = None
+        if rng.random() < 0.3:
+            a = rng.integers(0, n + 1, size=npat)
+            b2 = rng.integers(0, n + 1, size=npat)
+            se = np.stack([np.minimum(a, b2), np.maximum(a, b2)], axis=1).reshape(-1).astype(np.uint64)
+        gb = gi.search_many(flat=flat, off=off, s0e0=se)
+        os_, oe = oi.count_batch(flat.astype(np.uint32) if dtype != np.uint8 else flat, off, se)
+        assert (gb.s == os_).all() and (gb.e == oe).all(), ("count", it, kind, n, maxc, level, pair, style)
+        if level is not None:
+            small = (oe - os_) < 2000
+            goff, gpos = gi.locate_many(gb.s[small], gb.e[small])
+            ooff, opos = oi.locate_batch(os_[small], oe[small])
+            assert (goff == ooff).all() and (gpos == opos).all(), ("locate", it, kind, n, maxc, level)
+        rows = rng.integers(0, n, size=min(n, 64)).astype(np.uint64)
+        assert (gi.get_l(rows) == oi.get_l(rows)).all(), ("get_l", it, kind)
+        assert (gi.lf_map(rows) == oi.lf_map(rows)).all(), ("lf_map", it, kind)
+        assert (gi.get_f(rows) == oi.get_f(rows)).all(), ("get_f", it, kind)
+        assert (gi.fl_map(rows) == oi.fl_map(rows)).all(), ("fl_map", it, kind)
+        if level is not None:
+            assert (gi.get_sa(rows) == oi.get_sa(rows)).all(), ("get_sa", it, kind)
+        if kind == "multi":
+            assert (gi.piece_id(rows) == oi.piece_id(rows)).all(), ("piece_id", it)
+        cs = rng.integers(0, maxc + 1, size=64).astype(np.uint64)
+        ii = rng.integers(0, n + 1, size=64).astype(np.uint64)
+        assert (gi.lf_map2(cs, ii) == oi.lf_map2(cs, ii)).all(), ("lf_map2", it, kind, n, maxc)
+        gi.close()
+        oi.close()
+    print("fuzz ok: %d iterations in %.0f s, seed %d, %s" % (it, budget, seed, stats))
+
+
+if __name__ == "__main__":
+    main()

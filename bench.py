@@ -94,6 +94,8 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     level = None if args.no_locate else args.level
+    # a throw-away 4 KiB build first: runtime / code-object initialisation is not index construction
+    F.FMIndex(F.Text.with_max_character(W.dna_text_np(4096, 9), 4), device=local).close()
     if rlfm:
         cls = F.RLFMIndexWithLocate if level is not None else F.RLFMIndex
     else:

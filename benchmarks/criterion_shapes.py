@@ -24,6 +24,11 @@ PUBLISHED_US = {  # CHANGES.md v0.2.0 table: default build / target-cpu=native
     ("locate", "FMIndex", 1): (3200.0, 2700.0), ("locate", "FMIndex", 2): (8300.0, 7100.0),
     ("locate", "FMIndex", 3): (18200.0, 15600.0), ("locate", "RLFMIndex", 1): (8900.0, 5200.0),
     ("locate", "RLFMIndex", 2): (24900.0, 14100.0), ("locate", "RLFMIndex", 3): (57700.0, 31900.0),
+    # benches/construction.rs (CHANGES.md:42-49 / 69-76): time of one ::new(&text), default / native
+    ("construction", "FMIndex", 1000): (45.4, 44.2), ("construction", "FMIndex", 10000): (647.8, 635.5),
+    ("construction", "FMIndex", 100000): (7800.0, 7100.0), ("construction", "FMIndex", 1000000): (101800.0, 76700.0),
+    ("construction", "RLFMIndex", 1000): (52.7, 48.2), ("construction", "RLFMIndex", 10000): (686.2, 680.5),
+    ("construction", "RLFMIndex", 100000): (8000.0, 7700.0), ("construction", "RLFMIndex", 1000000): (101800.0, 93700.0),
 }
 
 
@@ -44,10 +49,24 @@ def main():
     d_o = torch.empty(257, dtype=torch.int64, device=dev)
     reps = 200
 
-    def text(prob, seed=0):
-        r = W.splitmix64_np(seed, 0, 50000).astype(np.float64) / 2.0 ** 64
+    def text(prob, seed=0, n=50000):
+        r = W.splitmix64_np(seed, 0, n).astype(np.float64) / 2.0 ** 64
         t = np.where(r < prob, ord("0"), ord("1")).astype(np.uint8)
         return np.concatenate([t, np.zeros(1, dtype=np.uint8)])
+
+    # benches/construction.rs: one ::new(&text) from a HOST text (H2D copy included), warm process
+    F.FMIndex(F.Text.with_max_character(text(0.5, n=1000), ord("1"))).close()
+    for n in (1000, 10000, 100000, 1000000):
+        tx = F.Text.with_max_character(text(0.5, n=n), ord("1"))
+        for name, cls in (("FMIndex", F.FMIndex), ("RLFMIndex", F.RLFMIndex)):
+            cls(tx).close()
+            k = 20
+            t0 = time.perf_counter()
+            for _ in range(k):
+                cls(tx).close()
+            us = (time.perf_counter() - t0) / k * 1e6
+            print(json.dumps({"bench": "construction", "index": name, "n": n, "gpu_us_per_build": round(us, 1),
+                              "reference_published_us": PUBLISHED_US[("construction", name, n)]}))
 
     def time_batches(fn):
         fn()

@@ -276,6 +276,50 @@ struct CallStream {
   hipError_t open() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
   ~CallStream() { if (st) (void)hipStreamDestroy(st); }
 };
+// Small calls (the one-element trait shims, short batches) reuse a per-thread, per-device context:
+// a stream, a pinned staging buffer and a device buffer of the same layout -- no hipMalloc /
+// hipFree / stream creation per call, one H2D, one launch, one D2H, one synchronise.
+const size_t kSmallCap = 256u << 10;
+struct SmallCtx {
+  hipStream_t st = nullptr;
+  uint8_t *h = nullptr, *d = nullptr;
+};
+struct SmallCtxSet {  // released when the owning thread exits
+  SmallCtx ctx[16];
+  ~SmallCtxSet() {
+    for (int dvc = 0; dvc < 16; dvc++) {
+      SmallCtx &c = ctx[dvc];
+      if (!c.st) continue;
+      if (hipSetDevice(dvc) != hipSuccess) continue;
+      (void)hipStreamDestroy(c.st);
+      (void)hipHostFree(c.h);
+      (void)hipFree(c.d);
+      c.st = nullptr;
+    }
+  }
+};
+SmallCtx *small_ctx(int device) {
+  static thread_local SmallCtxSet set;
+  if (device < 0 || device >= 16) return nullptr;
+  SmallCtx &c = set.ctx[device];
+  if (!c.st) {
+    if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) != hipSuccess) { c.st = nullptr; return nullptr; }
+    if (hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c.d, kSmallCap) != hipSuccess) {
+      (void)hipStreamDestroy(c.st);
+      c.st = nullptr;
+      return nullptr;
+    }
+  }
+  return &c;
+}
+struct Arena {  // bump allocator over the two mirrored buffers
+  SmallCtx *c;
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 15) & ~size_t(15); return o; }
+  template <typename T> T *host(size_t o) const { return (T *)(c->h + o); }
+  template <typename T> T *dev(size_t o) const { return (T *)(c->d + o); }
+};
 struct Scratch {  // device buffers freed on scope exit
   void *p[12];
   int n = 0;
@@ -295,6 +339,29 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
   uint64_t total = pat_off[npat];
   const uint32_t sb = idx->sym_bytes;  // device symbol width
+  if (total * sb + npat * 48 + 128 <= kSmallCap && idx->sym_bytes_abi != 8) {
+    if (SmallCtx *sx = small_ctx(idx->device)) {
+      Arena a{sx};
+      const size_t op = a.take(total * sb ? total * sb : 1), oo = a.take((npat + 1) * 8);
+      const size_t ose = a.take(s0e0 ? npat * 16 : 0), in_end = a.off;
+      const size_t os = a.take(npat * 8), oe = a.take(npat * 8), oc = a.take(npat * 8), ost = a.take(4);
+      if (total) memcpy(a.host<uint8_t>(op), pat, total * sb);
+      memcpy(a.host<uint8_t>(oo), pat_off, (npat + 1) * 8);
+      if (s0e0) memcpy(a.host<uint8_t>(ose), s0e0, npat * 16);
+      FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
+      if (int rc = fmx_launch_count(idx, a.dev<uint8_t>(op), a.dev<uint64_t>(oo), npat,
+                                    s0e0 ? a.dev<uint64_t>(ose) : nullptr, a.dev<uint64_t>(os),
+                                    a.dev<uint64_t>(oe), a.dev<uint64_t>(oc), sx->st))
+        return rc;
+      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), a.dev<uint8_t>(os), (size_t)(ost - os), hipMemcpyDeviceToHost, sx->st));
+      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(ost), idx->dev.status, 4, hipMemcpyDeviceToHost, sx->st));
+      FMX_HIP(hipStreamSynchronize(sx->st));
+      if (out_s) memcpy(out_s, a.host<uint8_t>(os), npat * 8);
+      if (out_e) memcpy(out_e, a.host<uint8_t>(oe), npat * 8);
+      if (out_count) memcpy(out_count, a.host<uint8_t>(oc), npat * 8);
+      return *a.host<uint32_t>(ost) ? fmx_stream_status(idx) : FMX_OK;
+    }
+  }
   CallStream cs;
   FMX_HIP(cs.open());
   Scratch sc;
@@ -362,6 +429,24 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
   CHECK_IDX(idx);
   if (op == 3 && idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   if (k == 0) return FMX_OK;
+  if (k * 24 + 64 <= kSmallCap) {
+    if (SmallCtx *sx = small_ctx(idx->device)) {
+      Arena a{sx};
+      const size_t oi = a.take(k * 8), oc = a.take(c ? k * 8 : 0), in_end = a.off;
+      const size_t oo = a.take(k * 8), os = a.take(4);
+      memcpy(a.host<uint8_t>(oi), i, k * 8);
+      if (c) memcpy(a.host<uint8_t>(oc), c, k * 8);
+      FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
+      if (int rc = fmx_launch_scalar(idx, op, c ? a.dev<uint64_t>(oc) : nullptr, a.dev<uint64_t>(oi), k,
+                                     a.dev<uint64_t>(oo), sx->st))
+        return rc;
+      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(oo), a.dev<uint8_t>(oo), k * 8, hipMemcpyDeviceToHost, sx->st));
+      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), idx->dev.status, 4, hipMemcpyDeviceToHost, sx->st));
+      FMX_HIP(hipStreamSynchronize(sx->st));
+      memcpy(out, a.host<uint8_t>(oo), k * 8);
+      return *a.host<uint32_t>(os) ? fmx_stream_status(idx) : FMX_OK;
+    }
+  }
   CallStream cs;
   FMX_HIP(cs.open());
   Scratch sc;

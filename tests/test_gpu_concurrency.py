@@ -88,3 +88,42 @@ def test_dev_entry_points_on_a_side_stream():
     s2, e2 = oi.count_batch(flat2, off2, se)
     b = gi.search_many(flat=flat2, off=off2, s0e0=se)
     assert (b.s == s2).all() and (b.e == e2).all()
+
+
+def test_count_dev_is_graph_capturable():
+    """fmx_count_batch_dev launches kernels only (no allocation, no synchronisation), so a caller
+    can capture it into a hipGraph and replay it (launch-bound small batches)."""
+    import torch
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    t = W.dna_text_np(1 << 16, 5)
+    gi = F.FMIndex(F.Text.with_max_character(t, 4))
+    oi = O.OracleIndex(t, 4)
+    flat, off, _ = W.substring_patterns_np(t, 256, 8, 3)
+    s0, e0 = oi.count_batch(flat, off)
+    d_pat = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_s = torch.zeros(256, dtype=torch.int64, device=dev)
+    d_e = torch.zeros(256, dtype=torch.int64, device=dev)
+    h = gi.handle()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sp = C.c_void_p(side.cuda_stream)
+        assert lib.fmx_count_batch_dev(h, C.c_void_p(d_pat.data_ptr()), C.c_void_p(d_off.data_ptr()), 256,
+                                       None, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
+                                       None, sp) == 0      # warm-up outside the capture
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            cap = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = lib.fmx_count_batch_dev(h, C.c_void_p(d_pat.data_ptr()), C.c_void_p(d_off.data_ptr()),
+                                         256, None, C.c_void_p(d_s.data_ptr()),
+                                         C.c_void_p(d_e.data_ptr()), None, cap)
+        assert rc == 0
+        d_s.zero_()
+        d_e.zero_()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+    assert (d_s.cpu().numpy().view(np.uint64) == s0).all()
+    assert (d_e.cpu().numpy().view(np.uint64) == e0).all()

@@ -8,7 +8,7 @@ from fm_index_amd import workload as W
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["fm", "fm_pair", "rlfm", "fm_bytes", "fm_u16"])
+@pytest.mark.parametrize("kind", ["fm", "fm_pair", "rlfm", "fm_bytes", "fm_u16", "multi"])
 def test_save_load_roundtrip(tmp_path, kind):
     if kind in ("fm", "fm_pair"):
         t = W.dna_text_np(50000, 3)
@@ -18,6 +18,11 @@ def test_save_load_roundtrip(tmp_path, kind):
         t = W.repetitive_text_np(50000, 5, base_len=256)
         idx = F.RLFMIndexWithLocate(F.Text(t), 3)
         flat, off, _ = W.substring_patterns_np(t, 2000, 9, 6)
+    elif kind == "multi":
+        t = W.byte_text_np(30000, 4)
+        t[np.arange(500, 29000, 977)] = 0            # several pieces
+        idx = F.FMIndexMultiPiecesWithLocate(F.Text(t), 2)
+        flat, off, _ = W.substring_patterns_np(t, 1500, 3, 9)
     elif kind == "fm_bytes":
         t = W.byte_text_np(50000, 4)
         idx = F.FMIndexWithLocate(F.Text(t), 1)
@@ -33,7 +38,8 @@ def test_save_load_roundtrip(tmp_path, kind):
     aoff, apos = a.locate()
     path = tmp_path / "index.fmx"
     idx.save(path)
-    cls = F.RLFMIndexWithLocate if kind == "rlfm" else F.FMIndexWithLocate
+    cls = F.RLFMIndexWithLocate if kind == "rlfm" else \
+        (F.FMIndexMultiPiecesWithLocate if kind == "multi" else F.FMIndexWithLocate)
     idx2 = cls.load(path)
     assert idx2.len() == idx.len() and idx2.level() == idx.level()
     assert idx2.heap_size() == idx.heap_size()
@@ -45,6 +51,9 @@ def test_save_load_roundtrip(tmp_path, kind):
     rows = np.arange(0, idx.len(), 97)
     assert (idx.lf_map(rows) == idx2.lf_map(rows)).all()
     assert (idx.export_cs() == idx2.export_cs()).all()
+    if kind == "multi":
+        assert idx2.pieces_count() == idx.pieces_count() > 5
+        assert (idx.piece_id(rows) == idx2.piece_id(rows)).all()
 
 
 def test_load_rejects_garbage(tmp_path):

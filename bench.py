@@ -249,6 +249,31 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- config 2b: uniform random patterns -> the early exit of wrapper.rs:111-113 ----
+    if dna and rank == 0:
+        rflat = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)
+        rs_ = torch.empty(npat, dtype=torch.int64, device=dev)
+        re_ = torch.empty(npat, dtype=torch.int64, device=dev)
+
+        def rstep():
+            rc = lib.fmx_count_batch_dev(h, C.c_void_p(rflat.data_ptr()), C.c_void_p(off.data_ptr()), npat,
+                                         None, C.c_void_p(rs_.data_ptr()), C.c_void_p(re_.data_ptr()), None, sp)
+            assert rc == 0
+        rstep()
+        torch.cuda.synchronize()
+        lib.fmx_set_timing(h, 1)
+        rstep()
+        torch.cuda.synchronize()
+        rms = lib.fmx_last_kernel_ms(h)
+        rsteps = int(lib.fmx_last_steps(h))
+        lib.fmx_set_timing(h, 0)
+        out["early_exit"] = {"workload": "config 2b: %d uniform random len-%d patterns" % (npat, m),
+                             "executed_steps": rsteps, "offered_chars": npat * m,
+                             "mean_steps_per_pattern": round(rsteps / npat, 2),
+                             "executed_steps_per_s": rsteps / (rms / 1e3), "kernel_ms": round(rms, 4),
+                             "nonzero_counts": int((re_ > rs_).sum().item())}
+        del rflat, rs_, re_
+
     # ---- opt-in 2-step index: same patterns, results asserted identical ----
     if args.pair_index and dna:
         pidx = F.FMIndex.from_device_text(text.data_ptr(), n, maxc, device=local, pair_index=True)

@@ -71,6 +71,19 @@ def test_config2_config3_dna_1gb():
     # hits of one pattern are distinct
     key = hit_pat * N + d_pos
     assert int(torch.unique(key).numel()) == total
+    # structural invariant of the whole rank structure: LF is a permutation of the rows
+    marks = torch.zeros(N, dtype=torch.uint8, device=dev)
+    chunk = 1 << 26
+    for a in range(0, N, chunk):
+        rows_ = torch.arange(a, a + chunk, dtype=torch.int64, device=dev)
+        outp = torch.empty(chunk, dtype=torch.int64, device=dev)
+        assert lib.fmx_lf_map_batch_dev(index.handle(), C.c_void_p(rows_.data_ptr()), chunk,
+                                        C.c_void_p(outp.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        assert int(outp.max().item()) < N and int(outp.min().item()) >= 0
+        marks.index_add_(0, outp, torch.ones(chunk, dtype=torch.uint8, device=dev))
+    assert bool((marks == 1).all())
+    del marks, rows_, outp
     # oracle (independent rank structure + driver) on a sample, from the exported BWT
     oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4,
                                 samples=index.export_sa_samples(), level=2)

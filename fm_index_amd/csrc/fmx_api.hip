@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "fmx_internal.h"
 
 // ---------------------------------------------------------------------------
@@ -269,20 +270,17 @@ int fmx_get_sa_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, 
 // host-pointer entry points (copy in, same kernels, copy out, synchronise)
 // ---------------------------------------------------------------------------
 namespace {
-// every host-pointer call runs on its own non-blocking stream: concurrent callers never share
-// the legacy default stream (or its stream-ordered allocations)
-struct CallStream {
-  hipStream_t st = nullptr;
-  hipError_t open() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
-  ~CallStream() { if (st) (void)hipStreamDestroy(st); }
-};
-// Small calls (the one-element trait shims, short batches) reuse a per-thread, per-device context:
-// a stream, a pinned staging buffer and a device buffer of the same layout -- no hipMalloc /
-// hipFree / stream creation per call, one H2D, one launch, one D2H, one synchronise.
+// Host-pointer calls run on per-thread, per-device contexts: two non-blocking streams (concurrent
+// callers never share the legacy default stream), a pinned staging buffer + device mirror for
+// small calls, and a grow-only device scratch for batches -- no hipMalloc / hipFree / stream
+// creation per call.  Everything is released when the owning thread exits.
 const size_t kSmallCap = 256u << 10;
+const size_t kRetainCap = 1ull << 30;   // larger batch scratch is allocated and freed per call
 struct SmallCtx {
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;
   uint8_t *h = nullptr, *d = nullptr;
+  uint8_t *big = nullptr;
+  size_t big_cap = 0;
 };
 struct SmallCtxSet {  // released when the owning thread exits
   SmallCtx ctx[16];
@@ -292,8 +290,10 @@ struct SmallCtxSet {  // released when the owning thread exits
       if (!c.st) continue;
       if (hipSetDevice(dvc) != hipSuccess) continue;
       (void)hipStreamDestroy(c.st);
+      (void)hipStreamDestroy(c.st2);
       (void)hipHostFree(c.h);
       (void)hipFree(c.d);
+      if (c.big) (void)hipFree(c.big);
       c.st = nullptr;
     }
   }
@@ -304,15 +304,57 @@ SmallCtx *small_ctx(int device) {
   SmallCtx &c = set.ctx[device];
   if (!c.st) {
     if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) != hipSuccess) { c.st = nullptr; return nullptr; }
+    if (hipStreamCreateWithFlags(&c.st2, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipStreamDestroy(c.st);
+      c.st = nullptr;
+      return nullptr;
+    }
     if (hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c.d, kSmallCap) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
+      (void)hipStreamDestroy(c.st2);
       c.st = nullptr;
       return nullptr;
     }
   }
   return &c;
 }
+// device scratch of one batch call, carved from the thread's retained buffer
+struct HostCall {
+  SmallCtx *sx = nullptr;
+  uint8_t *base = nullptr;
+  size_t off = 0, cap = 0;
+  bool temp = false;
+  ~HostCall() { if (temp && base) (void)hipFree(base); }
+  static size_t pad(size_t b) { return (b + 255) & ~size_t(255); }
+  hipError_t open(int device, size_t bytes) {
+    sx = small_ctx(device);
+    if (!sx) return hipErrorInvalidDevice;
+    if (bytes > kRetainCap) {
+      temp = true;
+      cap = bytes;
+      return hipMalloc((void **)&base, bytes);
+    }
+    if (bytes > sx->big_cap) {
+      if (sx->big) (void)hipFree(sx->big);
+      sx->big = nullptr;
+      sx->big_cap = 0;
+      size_t want = bytes + bytes / 4;
+      if (want > kRetainCap) want = kRetainCap;
+      hipError_t e = hipMalloc((void **)&sx->big, want);
+      if (e != hipSuccess) return e;
+      sx->big_cap = want;
+    }
+    base = sx->big;
+    cap = sx->big_cap;
+    return hipSuccess;
+  }
+  template <typename T> T *take(size_t bytes) {
+    T *p = (T *)(base + off);
+    off += pad(bytes ? bytes : 8);
+    return p;
+  }
+};
 struct Arena {  // bump allocator over the two mirrored buffers
   SmallCtx *c;
   size_t off = 0;
@@ -362,38 +404,65 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       return *a.host<uint32_t>(ost) ? fmx_stream_status(idx) : FMX_OK;
     }
   }
-  CallStream cs;
-  FMX_HIP(cs.open());
-  Scratch sc;
-  void *d_pat, *d_off, *d_se = nullptr, *d_s, *d_e, *d_c;
-  FMX_HIP(sc.get(&d_pat, total * sb));
-  FMX_HIP(sc.get(&d_off, (npat + 1) * 8));
-  FMX_HIP(sc.get(&d_s, npat * 8));
-  FMX_HIP(sc.get(&d_e, npat * 8));
-  FMX_HIP(sc.get(&d_c, npat * 8));
-  if (total) {
-    if (idx->sym_bytes_abi == 8) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
-      std::string narrow((size_t)total * 4, '\0');
-      uint32_t *dst = (uint32_t *)&narrow[0];
-      const uint64_t *src = (const uint64_t *)pat;
-      for (uint64_t i = 0; i < total; i++) dst[i] = src[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)src[i];
-      FMX_HIP(hipMemcpy(d_pat, dst, total * 4, hipMemcpyHostToDevice));
-    } else {
-      FMX_HIP(hipMemcpy(d_pat, pat, total * sb, hipMemcpyHostToDevice));
+  // batches: pattern bytes go in and (s, e, count) come out in chunks that alternate between the
+  // context's two streams, so chunk k's kernel runs under chunk k+1's upload and chunk k-1's
+  // download
+  std::vector<uint32_t> narrow;
+  const uint8_t *src = (const uint8_t *)pat;
+  if (idx->sym_bytes_abi == 8 && total) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
+    narrow.resize((size_t)total);
+    const uint64_t *p64 = (const uint64_t *)pat;
+    for (uint64_t i = 0; i < total; i++) narrow[i] = p64[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p64[i];
+    src = (const uint8_t *)narrow.data();
+  }
+  const size_t b_pat = (size_t)total * sb, b_off = (size_t)(npat + 1) * 8, b_out = (size_t)npat * 8;
+  HostCall hc;
+  FMX_HIP(hc.open(idx->device, HostCall::pad(b_pat ? b_pat : 8) + HostCall::pad(b_off) +
+                                   (s0e0 ? HostCall::pad(2 * b_out) : 0) + 3 * HostCall::pad(b_out)));
+  uint8_t *d_pat = hc.take<uint8_t>(b_pat);
+  uint64_t *d_off = hc.take<uint64_t>(b_off);
+  uint64_t *d_se = s0e0 ? hc.take<uint64_t>(2 * b_out) : nullptr;
+  uint64_t *d_s = hc.take<uint64_t>(b_out), *d_e = hc.take<uint64_t>(b_out), *d_c = hc.take<uint64_t>(b_out);
+  hipStream_t st[2] = {hc.sx->st, hc.sx->st2};
+  // two halves: every pageable copy has a fixed cost of 50-80 us on this runtime, so more, smaller
+  // chunks lose (measured at 2^20 x 32: 1 chunk 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13)
+  uint64_t nch = (npat >= (1u << 17) && !idx->timing) ? 2 : 1;
+  // all offsets first (every chunk's kernel reads its own slice plus one entry)
+  FMX_HIP(hipMemcpyAsync(d_off, pat_off, b_off, hipMemcpyHostToDevice, st[0]));
+  FMX_HIP(hipStreamSynchronize(st[0]));
+  auto download = [&](uint64_t k) -> hipError_t {
+    const uint64_t a = npat * k / nch, b = npat * (k + 1) / nch;
+    hipStream_t S = st[k & 1];
+    hipError_t e = hipSuccess;
+    if (out_s && e == hipSuccess) e = hipMemcpyAsync(out_s + a, d_s + a, (b - a) * 8, hipMemcpyDeviceToHost, S);
+    if (out_e && e == hipSuccess) e = hipMemcpyAsync(out_e + a, d_e + a, (b - a) * 8, hipMemcpyDeviceToHost, S);
+    if (out_count && e == hipSuccess) e = hipMemcpyAsync(out_count + a, d_c + a, (b - a) * 8, hipMemcpyDeviceToHost, S);
+    return e;
+  };
+  for (uint64_t k = 0; k < nch; k++) {
+    const uint64_t a = npat * k / nch, b = npat * (k + 1) / nch;
+    const uint64_t pa = pat_off[a], pb = pat_off[b];
+    if (pb < pa || pb > total) {
+      (void)hipStreamSynchronize(st[0]);
+      (void)hipStreamSynchronize(st[1]);
+      return fail(FMX_ERR_ARG, "pat_off is not non-decreasing");
     }
+    hipStream_t S = st[k & 1];
+    if (pb > pa)
+      FMX_HIP(hipMemcpyAsync(d_pat + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, S));
+    if (s0e0)
+      FMX_HIP(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, S));
+    if (int rc = fmx_launch_count(idx, d_pat, d_off + a, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a,
+                                  d_e + a, d_c + a, S)) {
+      (void)hipStreamSynchronize(st[0]);
+      (void)hipStreamSynchronize(st[1]);
+      return rc;
+    }
+    if (k) FMX_HIP(download(k - 1));
   }
-  FMX_HIP(hipMemcpy(d_off, pat_off, (npat + 1) * 8, hipMemcpyHostToDevice));
-  if (s0e0) {
-    FMX_HIP(sc.get(&d_se, npat * 16));
-    FMX_HIP(hipMemcpy(d_se, s0e0, npat * 16, hipMemcpyHostToDevice));
-  }
-  if (int rc = fmx_launch_count(idx, d_pat, (const uint64_t *)d_off, npat, (const uint64_t *)d_se,
-                                (uint64_t *)d_s, (uint64_t *)d_e, (uint64_t *)d_c, cs.st))
-    return rc;
-  FMX_HIP(hipStreamSynchronize(cs.st));
-  if (out_s) FMX_HIP(hipMemcpy(out_s, d_s, npat * 8, hipMemcpyDeviceToHost));
-  if (out_e) FMX_HIP(hipMemcpy(out_e, d_e, npat * 8, hipMemcpyDeviceToHost));
-  if (out_count) FMX_HIP(hipMemcpy(out_count, d_c, npat * 8, hipMemcpyDeviceToHost));
+  FMX_HIP(download(nch - 1));
+  FMX_HIP(hipStreamSynchronize(st[0]));
+  FMX_HIP(hipStreamSynchronize(st[1]));
   return fmx_stream_status(idx);
 }
 
@@ -405,22 +474,21 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
   uint64_t total = out_off[npat];
   if (total == 0) return FMX_OK;
-  CallStream cs;
-  FMX_HIP(cs.open());
-  Scratch sc;
-  void *d_s, *d_e, *d_off, *d_pos;
-  FMX_HIP(sc.get(&d_s, npat * 8));
-  FMX_HIP(sc.get(&d_e, npat * 8));
-  FMX_HIP(sc.get(&d_off, (npat + 1) * 8));
-  FMX_HIP(sc.get(&d_pos, total * 8));
-  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
-  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
-  FMX_HIP(hipMemcpy(d_off, out_off, (npat + 1) * 8, hipMemcpyHostToDevice));
-  if (int rc = fmx_launch_locate(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat,
-                                 (const uint64_t *)d_off, total, (uint64_t *)d_pos, cs.st))
+  HostCall hc;
+  const size_t b_in = (size_t)npat * 8, b_pos = (size_t)total * 8;
+  FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(b_in) + HostCall::pad(b_in + 8) + HostCall::pad(b_pos)));
+  uint64_t *d_s = hc.take<uint64_t>(b_in), *d_e = hc.take<uint64_t>(b_in);
+  uint64_t *d_off = hc.take<uint64_t>(b_in + 8), *d_pos = hc.take<uint64_t>(b_pos);
+  hipStream_t S = hc.sx->st;
+  FMX_HIP(hipMemcpyAsync(d_s, s, b_in, hipMemcpyHostToDevice, S));
+  FMX_HIP(hipMemcpyAsync(d_e, e, b_in, hipMemcpyHostToDevice, S));
+  FMX_HIP(hipMemcpyAsync(d_off, out_off, b_in + 8, hipMemcpyHostToDevice, S));
+  if (int rc = fmx_launch_locate(idx, d_s, d_e, npat, d_off, total, d_pos, S)) {
+    (void)hipStreamSynchronize(S);
     return rc;
-  FMX_HIP(hipStreamSynchronize(cs.st));
-  FMX_HIP(hipMemcpy(out_pos, d_pos, total * 8, hipMemcpyDeviceToHost));
+  }
+  FMX_HIP(hipMemcpyAsync(out_pos, d_pos, b_pos, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipStreamSynchronize(S));
   return fmx_stream_status(idx);
 }
 
@@ -447,22 +515,19 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
       return *a.host<uint32_t>(os) ? fmx_stream_status(idx) : FMX_OK;
     }
   }
-  CallStream cs;
-  FMX_HIP(cs.open());
-  Scratch sc;
-  void *d_c = nullptr, *d_i, *d_o;
-  FMX_HIP(sc.get(&d_i, k * 8));
-  FMX_HIP(sc.get(&d_o, k * 8));
-  FMX_HIP(hipMemcpy(d_i, i, k * 8, hipMemcpyHostToDevice));
-  if (c) {
-    FMX_HIP(sc.get(&d_c, k * 8));
-    FMX_HIP(hipMemcpy(d_c, c, k * 8, hipMemcpyHostToDevice));
-  }
-  if (int rc = fmx_launch_scalar(idx, op, (const uint64_t *)d_c, (const uint64_t *)d_i, k,
-                                 (uint64_t *)d_o, cs.st))
+  HostCall hc;
+  const size_t bk = (size_t)k * 8;
+  FMX_HIP(hc.open(idx->device, 3 * HostCall::pad(bk)));
+  uint64_t *d_i = hc.take<uint64_t>(bk), *d_o = hc.take<uint64_t>(bk), *d_c = c ? hc.take<uint64_t>(bk) : nullptr;
+  hipStream_t S = hc.sx->st;
+  FMX_HIP(hipMemcpyAsync(d_i, i, bk, hipMemcpyHostToDevice, S));
+  if (c) FMX_HIP(hipMemcpyAsync(d_c, c, bk, hipMemcpyHostToDevice, S));
+  if (int rc = fmx_launch_scalar(idx, op, d_c, d_i, k, d_o, S)) {
+    (void)hipStreamSynchronize(S);
     return rc;
-  FMX_HIP(hipStreamSynchronize(cs.st));
-  FMX_HIP(hipMemcpy(out, d_o, k * 8, hipMemcpyDeviceToHost));
+  }
+  FMX_HIP(hipMemcpyAsync(out, d_o, bk, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipStreamSynchronize(S));
   return fmx_stream_status(idx);
 }
 int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 0, nullptr, i, k, out); }
@@ -511,20 +576,19 @@ int fmx_match_counts(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
                      int prefix_only, uint64_t *out_count) {
   CHECK_IDX(idx);
   if (npat == 0) return FMX_OK;
-  CallStream cs;
-  FMX_HIP(cs.open());
-  Scratch sc;
-  void *d_s, *d_e, *d_c;
-  FMX_HIP(sc.get(&d_s, npat * 8));
-  FMX_HIP(sc.get(&d_e, npat * 8));
-  FMX_HIP(sc.get(&d_c, npat * 8));
-  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
-  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
-  if (int rc = fmx_launch_match_counts(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat,
-                                       prefix_only, (uint64_t *)d_c, cs.st))
+  HostCall hc;
+  const size_t bk = (size_t)npat * 8;
+  FMX_HIP(hc.open(idx->device, 3 * HostCall::pad(bk)));
+  uint64_t *d_s = hc.take<uint64_t>(bk), *d_e = hc.take<uint64_t>(bk), *d_c = hc.take<uint64_t>(bk);
+  hipStream_t S = hc.sx->st;
+  FMX_HIP(hipMemcpyAsync(d_s, s, bk, hipMemcpyHostToDevice, S));
+  FMX_HIP(hipMemcpyAsync(d_e, e, bk, hipMemcpyHostToDevice, S));
+  if (int rc = fmx_launch_match_counts(idx, d_s, d_e, npat, prefix_only, d_c, S)) {
+    (void)hipStreamSynchronize(S);
     return rc;
-  FMX_HIP(hipStreamSynchronize(cs.st));
-  FMX_HIP(hipMemcpy(out_count, d_c, npat * 8, hipMemcpyDeviceToHost));
+  }
+  FMX_HIP(hipMemcpyAsync(out_count, d_c, bk, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipStreamSynchronize(S));
   return FMX_OK;
 }
 int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
@@ -532,22 +596,21 @@ int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, u
   CHECK_IDX(idx);
   if (npat == 0 || out_off[npat] == 0) return FMX_OK;
   uint64_t total = out_off[npat];
-  CallStream cs;
-  FMX_HIP(cs.open());
-  Scratch sc;
-  void *d_s, *d_e, *d_o, *d_r;
-  FMX_HIP(sc.get(&d_s, npat * 8));
-  FMX_HIP(sc.get(&d_e, npat * 8));
-  FMX_HIP(sc.get(&d_o, (npat + 1) * 8));
-  FMX_HIP(sc.get(&d_r, total * 8));
-  FMX_HIP(hipMemcpy(d_s, s, npat * 8, hipMemcpyHostToDevice));
-  FMX_HIP(hipMemcpy(d_e, e, npat * 8, hipMemcpyHostToDevice));
-  FMX_HIP(hipMemcpy(d_o, out_off, (npat + 1) * 8, hipMemcpyHostToDevice));
-  if (int rc = fmx_launch_match_rows(idx, (const uint64_t *)d_s, (const uint64_t *)d_e, npat, prefix_only,
-                                     (const uint64_t *)d_o, (uint64_t *)d_r, cs.st))
+  HostCall hc;
+  const size_t bk = (size_t)npat * 8, br = (size_t)total * 8;
+  FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(bk) + HostCall::pad(bk + 8) + HostCall::pad(br)));
+  uint64_t *d_s = hc.take<uint64_t>(bk), *d_e = hc.take<uint64_t>(bk);
+  uint64_t *d_o = hc.take<uint64_t>(bk + 8), *d_r = hc.take<uint64_t>(br);
+  hipStream_t S = hc.sx->st;
+  FMX_HIP(hipMemcpyAsync(d_s, s, bk, hipMemcpyHostToDevice, S));
+  FMX_HIP(hipMemcpyAsync(d_e, e, bk, hipMemcpyHostToDevice, S));
+  FMX_HIP(hipMemcpyAsync(d_o, out_off, bk + 8, hipMemcpyHostToDevice, S));
+  if (int rc = fmx_launch_match_rows(idx, d_s, d_e, npat, prefix_only, d_o, d_r, S)) {
+    (void)hipStreamSynchronize(S);
     return rc;
-  FMX_HIP(hipStreamSynchronize(cs.st));
-  FMX_HIP(hipMemcpy(out_rows, d_r, total * 8, hipMemcpyDeviceToHost));
+  }
+  FMX_HIP(hipMemcpyAsync(out_rows, d_r, br, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipStreamSynchronize(S));
   return FMX_OK;
 }
 

@@ -127,3 +127,38 @@ def test_count_dev_is_graph_capturable():
         torch.cuda.synchronize()
     assert (d_s.cpu().numpy().view(np.uint64) == s0).all()
     assert (d_e.cpu().numpy().view(np.uint64) == e0).all()
+
+
+def test_large_host_pointer_batch_is_chunked_consistently():
+    """Host-pointer batches >= 2^17 patterns are uploaded / searched / downloaded in two
+    overlapping halves; the answers must equal the same patterns asked in small batches,
+    with ragged (incl. empty) patterns and with refinement from given (s, e)."""
+    t = W.dna_text_np(200000, 21)
+    idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    npat = (1 << 17) + 12345
+    flat, off = W.ragged_patterns_np(npat, 9, 4, 31)
+    big = idx.search_many(flat=flat, off=off)
+    step = 40000
+    for a in range(0, npat, step):
+        b = min(npat, a + step)
+        sub_off = off[a:b + 1] - off[a]
+        sub = idx.search_many(flat=flat[int(off[a]):int(off[b])], off=sub_off)
+        assert (sub.s == big.s[a:b]).all() and (sub.e == big.e[a:b]).all()
+        assert (sub.counts == big.counts[a:b]).all()
+    # refinement: prepend one more symbol to every (s, e)
+    se = np.stack([big.s, big.e], axis=1).reshape(-1).copy()
+    one = np.full(npat, 2, dtype=np.uint8)
+    off1 = np.arange(npat + 1, dtype=np.uint64)
+    ref = idx.search_many(flat=one, off=off1, s0e0=se)
+    j = np.arange(0, npat, 997)
+    for k in j:
+        pat = bytes([2]) + bytes(flat[int(off[k]):int(off[k + 1])])
+        assert ref.counts[k] == idx.search(pat).count()
+    # offsets that go backwards are refused, not dereferenced
+    bad = off.copy()
+    bad[npat // 2] = off[-1] + np.uint64(5)
+    with pytest.raises(F.Error):
+        idx.search_many(flat=flat, off=bad)
+    # and the handle still works afterwards
+    again = idx.search_many(flat=flat, off=off)
+    assert (again.counts == big.counts).all()

@@ -213,6 +213,22 @@ class _Index:
     def fl_map(self, i):
         return self._scalar(self._lib.fmx_fl_map_batch, i)
 
+    def extract_many(self, rows, length, forward=False):
+        """iter_chars_backward / iter_chars_forward for many rows in one launch (wrapper.rs:142-183):
+        (syms[nrows, length], lens[nrows], next_rows[nrows]).  Forward on a multi-pieces index ends
+        at the piece end: lens < length there, the unused slots are 0 and next is 2^64-1."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        k, length = len(rows), int(length)
+        dt = _DTYPES[int(self._lib.fmx_sym_bytes(self._h))]
+        syms = np.zeros((max(k, 1), max(length, 1)), dtype=dt)
+        lens = np.zeros(max(k, 1), dtype=np.uint64)
+        nxt = np.zeros(max(k, 1), dtype=np.uint64)
+        if length:
+            syms = np.zeros((max(k, 1), length), dtype=dt)
+        _check(self._lib.fmx_extract_batch(self._h, _p(rows), k, length, 1 if forward else 0,
+                                           _p(syms), _p(lens), _p(nxt)))
+        return syms[:k, :length], lens[:k], nxt[:k]
+
     # -- export / checks --
     def export_bwt(self):
         out = np.zeros(max(self.len(), 1), dtype=_DTYPES[int(self._lib.fmx_sym_bytes(self._h))])
@@ -385,22 +401,25 @@ class Match:
     def piece_id(self):  # MatchWithPieceId::piece_id (frontend.rs:100-104)
         return int(self._ix._lib.fmx_piece_id(self._ix._h, self._i))
 
+    _CHUNK = 64  # characters fetched per launch by the iterators below
+
     def iter_chars_forward(self):  # wrapper.rs:175-183: get_f then fl_map (stops at None)
         i = self._i
-        lib = self._ix._lib
         while True:
-            c = int(lib.fmx_get_f(self._ix._h, i))
-            i = int(lib.fmx_fl_map(self._ix._h, i))
+            syms, lens, nxt = self._ix.extract_many([i], self._CHUNK, forward=True)
+            for c in syms[0, :int(lens[0])]:
+                yield int(c)
+            i = int(nxt[0])
             if i == 0xFFFFFFFFFFFFFFFF:      # fl_map -> None: `?` ends the iterator (wrapper.rs:180)
                 return
-            yield c
 
     def iter_chars_backward(self):  # wrapper.rs:154-161: get_l then lf_map
         i = self._i
-        lib = self._ix._lib
         while True:
-            yield int(lib.fmx_get_l(self._ix._h, i))
-            i = int(lib.fmx_lf_map(self._ix._h, i))
+            syms, _, nxt = self._ix.extract_many([i], self._CHUNK, forward=False)
+            for c in syms[0]:
+                yield int(c)
+            i = int(nxt[0])
 
 
 class SearchBatch:

@@ -58,6 +58,8 @@ SYMBOLS = [
     ("fmx_get_sa_batch", _I, [_V, _V, _U64, _V]),
     ("fmx_get_f_batch", _I, [_V, _V, _U64, _V]),
     ("fmx_fl_map_batch", _I, [_V, _V, _U64, _V]),
+    ("fmx_extract_batch_dev", _I, [_V, _V, _U64, _U64, _I, _V, _V, _V, _V]),
+    ("fmx_extract_batch", _I, [_V, _V, _U64, _U64, _I, _V, _V, _V]),
     ("fmx_count_batch_dev", _I, [_V, _V, _V, _U64, _V, _V, _V, _V, _V]),
     ("fmx_count_batch", _I, [_V, _V, _V, _U64, _V, _V, _V, _V]),
     ("fmx_stream_status", _I, [_V]),

@@ -540,6 +540,42 @@ int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64
 int fmx_get_f_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 4, nullptr, i, k, out); }
 int fmx_fl_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 5, nullptr, i, k, out); }
 
+// Match::iter_chars_backward / iter_chars_forward for many rows (wrapper.rs:142-183)
+int fmx_extract_batch_dev(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint64_t len,
+                          int forward, void *d_out_syms, uint64_t *d_out_len, uint64_t *d_out_next,
+                          void *stream) {
+  CHECK_IDX(idx);
+  if (len > 0xFFFFFFFFull) return fail(FMX_ERR_ARG, "len is too large");
+  if (nrows && (!d_rows || (len && !d_out_syms))) return fail(FMX_ERR_ARG, "NULL argument");
+  return fmx_launch_extract(idx, d_rows, nrows, (uint32_t)len, forward, d_out_syms, d_out_len,
+                            d_out_next, (hipStream_t)stream);
+}
+int fmx_extract_batch(const fmx_index *idx, const uint64_t *rows, uint64_t nrows, uint64_t len,
+                      int forward, void *out_syms, uint64_t *out_len, uint64_t *out_next) {
+  CHECK_IDX(idx);
+  if (len > 0xFFFFFFFFull) return fail(FMX_ERR_ARG, "len is too large");
+  if (nrows == 0) return FMX_OK;
+  if (!rows || (len && !out_syms)) return fail(FMX_ERR_ARG, "NULL argument");
+  HostCall hc;
+  const size_t b_rows = (size_t)nrows * 8, b_sym = (size_t)nrows * len * idx->sym_bytes;
+  FMX_HIP(hc.open(idx->device, 3 * HostCall::pad(b_rows) + HostCall::pad(b_sym ? b_sym : 8)));
+  uint64_t *d_rows = hc.take<uint64_t>(b_rows), *d_len = hc.take<uint64_t>(b_rows);
+  uint64_t *d_next = hc.take<uint64_t>(b_rows);
+  uint8_t *d_sym = hc.take<uint8_t>(b_sym);
+  hipStream_t S = hc.sx->st;
+  FMX_HIP(hipMemcpyAsync(d_rows, rows, b_rows, hipMemcpyHostToDevice, S));
+  if (b_sym) FMX_HIP(hipMemsetAsync(d_sym, 0, b_sym, S));   // slots past a piece end read as 0 on the host side
+  if (int rc = fmx_launch_extract(idx, d_rows, nrows, (uint32_t)len, forward, d_sym, d_len, d_next, S)) {
+    (void)hipStreamSynchronize(S);
+    return rc;
+  }
+  if (b_sym) FMX_HIP(hipMemcpyAsync(out_syms, d_sym, b_sym, hipMemcpyDeviceToHost, S));
+  if (out_len) FMX_HIP(hipMemcpyAsync(out_len, d_len, b_rows, hipMemcpyDeviceToHost, S));
+  if (out_next) FMX_HIP(hipMemcpyAsync(out_next, d_next, b_rows, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipStreamSynchronize(S));
+  return fmx_stream_status(idx);
+}
+
 // one trait method per call
 uint64_t fmx_get_l(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_get_l_batch(idx, &i, 1, &o) ? ~0ull : o; }
 uint64_t fmx_lf_map(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; return fmx_lf_map_batch(idx, &i, 1, &o) ? ~0ull : o; }

@@ -134,6 +134,9 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
 // op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map, 6 piece_id
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st);
+int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
+                       int forward, void *d_out, uint64_t *d_out_len, uint64_t *d_out_next,
+                       hipStream_t st);
 // K[c] for every symbol, from the finished wavelet levels (used by the builder)
 int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                             uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st);

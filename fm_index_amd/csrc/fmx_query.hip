@@ -773,6 +773,44 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
   }
 }
 
+// Match::iter_chars_backward / iter_chars_forward for many rows (wrapper.rs:154-183):
+//   backward: c = get_l(i); i = lf_map(i); yield c          (never ends)
+//   forward : c = get_f(i); i = fl_map(i)?; yield c         (ends, without yielding, at None)
+// one 8-lane group per row, `len` dependent steps each; symbols land row-major in out[r*len + t]
+template <int KIND, typename T>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_extract_kernel(FmxDev ix,
+                                                                 const uint64_t *__restrict__ rows,
+                                                                 uint64_t nrows, uint32_t len, int forward,
+                                                                 T *__restrict__ out,
+                                                                 uint64_t *__restrict__ out_len,
+                                                                 uint64_t *__restrict__ out_next) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t q = gid; q < nrows; q += ngroups) {
+    const uint64_t i64 = rows[q];
+    uint32_t t = 0;
+    uint64_t next = ~0ull;
+    if (i64 >= ix.n) {
+      if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+    } else {
+      uint32_t i = (uint32_t)i64;
+      T *dst = out + q * (uint64_t)len;
+      bool ended = false;
+      for (; t < len; t++) {
+        uint32_t sym;
+        const uint32_t nx = forward ? fmx_fl_map_any<KIND>(ix, i, g, sym) : fmx_lf_map_any<KIND>(ix, i, g, sym);
+        if (forward && KIND == FMX_KIND_MULTI && nx == 0xFFFFFFFFu) { ended = true; break; }
+        if (g == 0) dst[t] = (T)sym;
+        i = nx;
+      }
+      if (!ended) next = i;
+    }
+    if (g == 0 && out_len) out_len[q] = t;
+    if (g == 0 && out_next) out_next[q] = next;
+  }
+}
+
 // export: L column of rows [0, n) as one byte per row (get_l, fm_index.rs:82-84)
 template <int KIND>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, void *__restrict__ out) {
@@ -1035,6 +1073,31 @@ int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const u
                        dim3(FMX_BLOCK), 0, st, idx->dev, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
+}
+
+template <typename T>
+static int fmx_launch_extract_t(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
+                                int forward, T *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st) {
+  const dim3 grid(fmx_grid_for_groups(nrows)), block(FMX_BLOCK);
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_FM, T>), grid, block, 0, st, idx->dev, d_rows, nrows, len,
+                       forward, d_out, d_out_len, d_out_next);
+  else if (idx->kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_MULTI, T>), grid, block, 0, st, idx->dev, d_rows, nrows,
+                       len, forward, d_out, d_out_len, d_out_next);
+  else
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_RLFM, T>), grid, block, 0, st, idx->dev, d_rows, nrows,
+                       len, forward, d_out, d_out_len, d_out_next);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
+                       int forward, void *d_out, uint64_t *d_out_len, uint64_t *d_out_next,
+                       hipStream_t st) {
+  if (nrows == 0) return FMX_OK;
+  if (idx->sym_bytes == 1) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint8_t *)d_out, d_out_len, d_out_next, st);
+  if (idx->sym_bytes == 2) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint16_t *)d_out, d_out_len, d_out_next, st);
+  return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint32_t *)d_out, d_out_len, d_out_next, st);
 }
 
 int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <cstring>
 #include <vector>
 #include "fmx.h"
 
@@ -185,23 +186,25 @@ inline std::vector<uint64_t> Search::locate_all() const {
   if (e_ > s_) check(fmx_locate_batch(ix_->handle(), &s_, &e_, 1, off, pos.data()));
   return pos;
 }
-inline std::vector<uint64_t> Match::chars_forward(size_t k) const {
-  std::vector<uint64_t> out;
-  uint64_t i = i_;
-  for (size_t t = 0; t < k; t++) {           // get_f then fl_map  (wrapper.rs:175-183)
-    out.push_back(fmx_get_f(ix_->handle(), i));
-    i = fmx_fl_map(ix_->handle(), i);
+// one fmx_extract_batch launch: k steps of the iterator, symbols widened to u64
+inline std::vector<uint64_t> extract_one(const fmx_index *h, uint64_t row, size_t k, int forward) {
+  const uint32_t sb = fmx_sym_bytes(h);
+  std::vector<uint8_t> raw(k * sb + 8);
+  uint64_t len = 0;
+  check(fmx_extract_batch(h, &row, 1, k, forward, raw.data(), &len, nullptr));
+  std::vector<uint64_t> out((size_t)len);
+  for (size_t t = 0; t < (size_t)len; t++) {
+    uint64_t v = 0;
+    std::memcpy(&v, raw.data() + t * sb, sb);   // little-endian host
+    out[t] = v;
   }
   return out;
 }
-inline std::vector<uint64_t> Match::chars_backward(size_t k) const {
-  std::vector<uint64_t> out;
-  uint64_t i = i_;
-  for (size_t t = 0; t < k; t++) {           // get_l then lf_map  (wrapper.rs:154-161)
-    out.push_back(fmx_get_l(ix_->handle(), i));
-    i = fmx_lf_map(ix_->handle(), i);
-  }
-  return out;
+inline std::vector<uint64_t> Match::chars_forward(size_t k) const {    // wrapper.rs:175-183
+  return extract_one(ix_->handle(), i_, k, 1);
+}
+inline std::vector<uint64_t> Match::chars_backward(size_t k) const {   // wrapper.rs:154-161
+  return extract_one(ix_->handle(), i_, k, 0);
 }
 inline uint64_t Match::locate() const {
   uint64_t v = fmx_get_sa(ix_->handle(), i_);

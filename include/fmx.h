@@ -134,6 +134,22 @@ int fmx_get_sa_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64
 int fmx_get_f_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
 int fmx_fl_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out);
 
+/* ---- Match::iter_chars_backward / iter_chars_forward for many rows  (wrapper.rs:142-183) -- */
+/* For row r = rows[q] the iterator the reference would hand out is run for `len` items:
+ *     backward:  c = get_l(i); i = lf_map(i);  yield c            wrapper.rs:154-161 (never ends)
+ *     forward :  c = get_f(i); i = fl_map(i)?; yield c            wrapper.rs:175-183
+ * out_syms[q*len + t] = t-th yielded character (fmx_sym_bytes() wide, like fmx_export_bwt);
+ * out_len[q] (nullable) = number yielded: `len`, except forward on a multi-pieces index, where the
+ * iterator ends at the piece's end marker without yielding it (fl_map == None) and the rest of
+ * that row's slots are left untouched (dev form) or zero (host form).  out_next[q] (nullable) =
+ * the iterator's row after the last item, so a caller can resume in chunks (UINT64_MAX once a
+ * forward iterator has ended).  A row >= len() reports FMX_ERR_ARG (out_len = 0). */
+int fmx_extract_batch_dev(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint64_t len,
+                          int forward, void *d_out_syms, uint64_t *d_out_len, uint64_t *d_out_next,
+                          void *stream);
+int fmx_extract_batch(const fmx_index *idx, const uint64_t *rows, uint64_t nrows, uint64_t len,
+                      int forward, void *out_syms, uint64_t *out_len, uint64_t *out_next);
+
 /* ---- Search::search(..).count()  (wrapper.rs:37-42, 103-134) -------------- */
 /* For pattern k = pat[pat_off[k] .. pat_off[k+1]):
  *     (s,e) = s0e0 ? (s0e0[2k], s0e0[2k+1]) : (0, len)          wrapper.rs:41 / 105-106

@@ -42,3 +42,85 @@ def test_forward_every_row(maxc, alphabet, n, dtype, kind):
     assert (gi.fl_map(rows) == oi.fl_map(rows)).all()
     # FL is the inverse of LF
     assert (gi.lf_map(gi.fl_map(rows)) == rows).all()
+
+
+def _text_case(kind):
+    if kind == "fm":
+        t = W.dna_text_np(30000, 5)
+        return t, F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    if kind == "rlfm":
+        t = W.repetitive_text_np(30000, 7, base_len=128)
+        return t, F.RLFMIndexWithLocate(F.Text(t), 2)
+    if kind == "u16":
+        t = ((W.splitmix64_np(3, 0, 20000) % np.uint64(3000)) + np.uint64(1)).astype(np.uint16)
+        t[-1] = 0
+        return t, F.FMIndexWithLocate(F.Text.with_max_character(t, 3000), 1)
+    t = W.byte_text_np(30000, 9)
+    t[np.arange(700, 29000, 1499)] = 0
+    return t, F.FMIndexMultiPiecesWithLocate(F.Text(t), 2)
+
+
+@pytest.mark.parametrize("kind", ["fm", "rlfm", "u16", "multi"])
+def test_extract_many_is_the_text(kind):
+    """fmx_extract_batch = the char iterators run for many rows in one launch: the characters
+    must be the text read backward from p-1 / forward from p, where p = locate(row)."""
+    t, idx = _text_case(kind)
+    n = len(t)
+    rows = (W.splitmix64_np(77, 0, 500) % np.uint64(n)).astype(np.uint64)
+    pos = idx.get_sa(rows).astype(np.int64)
+    k = 23
+    back, blen, bnext = idx.extract_many(rows, k, forward=False)
+    fwd, flen, fnext = idx.extract_many(rows, k, forward=True)
+    assert back.dtype == t.dtype and (blen == k).all()
+    for r in range(len(rows)):
+        p = int(pos[r])
+        if kind == "multi":
+            # backward inside one piece only (the reference wraps to another piece at a marker
+            # through its own rule, covered by the scalar tests); forward ends at the piece end
+            want_b = []
+            q = p - 1
+            while len(want_b) < k and q >= 0 and t[q] != 0:
+                want_b.append(int(t[q])); q -= 1
+            assert back[r, :len(want_b)].tolist() == want_b
+            want_f = []
+            q = p
+            while len(want_f) < k and t[q] != 0:
+                want_f.append(int(t[q])); q += 1
+            if len(want_f) < k:
+                assert int(flen[r]) == len(want_f) and int(fnext[r]) == 2**64 - 1
+                assert (fwd[r, len(want_f):] == 0).all()
+            else:
+                assert int(flen[r]) == k
+            assert fwd[r, :len(want_f)].tolist() == want_f
+        else:
+            want_b = [int(t[(p - 1 - j) % n]) for j in range(k)]
+            want_f = [int(t[(p + j) % n]) for j in range(k)]
+            assert back[r].tolist() == want_b
+            assert fwd[r].tolist() == want_f and int(flen[r]) == k
+    # the scalar trait methods give the same characters and the same resume rows
+    j = np.arange(0, len(rows), 50)
+    cur = rows[j].copy()
+    for step in range(5):
+        assert (idx.get_l(cur) == back[j, step]).all()
+        cur = idx.lf_map(cur)
+    if kind != "multi":
+        cur2 = rows[j].copy()
+        for step in range(k):
+            cur2 = idx.lf_map(cur2)
+        assert (cur2 == bnext[j]).all()
+        # resuming from next continues the same stream
+        more, _, _ = idx.extract_many(bnext, 4, forward=False)
+        for r in range(0, len(rows), 37):
+            p = int(pos[r])
+            assert more[r].tolist() == [int(t[(p - 1 - k - jj) % n]) for jj in range(4)]
+    # a row outside the index is refused
+    with pytest.raises(F.Error):
+        idx.extract_many([n], 3)
+
+
+def test_extract_zero_length_and_empty():
+    t, idx = _text_case("fm")
+    s, l, nx = idx.extract_many([5, 6], 0)
+    assert s.shape == (2, 0) and l.tolist() == [0, 0] and nx.tolist() == [5, 6]
+    s, l, nx = idx.extract_many([], 4)
+    assert s.shape == (0, 4)

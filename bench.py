@@ -43,6 +43,16 @@ def main():
     ap.add_argument("--pair-index", action="store_true",
                     help="also build the opt-in 2-step index (FMX_FLAG_PAIR_INDEX) and report its "
                          "count rate in an extra 'pair_index' object (the headline stays 1-step)")
+    ap.add_argument("--kmer-table", action="store_true",
+                    help="also build the opt-in k-mer start table (FMX_FLAG_KMER_TABLE) and report "
+                         "its count rate in 'kmer_table' (and with --pair-index the combination in "
+                         "'kmer_table+pair_index'); the headline stays the plain index")
+    ap.add_argument("--no-accel", action="store_true",
+                    help="skip the extra legs that time the opt-in indexes (pair index, k-mer start table); "
+                         "by default they are built and reported next to the plain-index headline")
+    ap.add_argument("--no-early-exit", action="store_true",
+                    help="skip the config-2b (uniform random patterns) legs, so that a profile of this "
+                         "run holds only config-2 launches of the count kernels")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real path) | gloo (single-GPU rehearsal of the N>1 code "
                          "path: all ranks share cuda:0 and gather through host memory)")
@@ -222,7 +232,7 @@ def main():
             traffic = json.load(f).get("%s:%d:%d:%d" % (args.workload, npat, m, args.log2n), {})
     except OSError:
         pass
-    kname = "fmx_count_f3_kernel<1,false>" if dna else \
+    kname = "fmx_count_f3_kernel<1,false,false>" if dna else \
         ("fmx_count_kernel<FMX_KIND_RLFM>" if rlfm else "fmx_count_kernel<FMX_KIND_FM>")
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -250,7 +260,7 @@ def main():
     }
 
     # ---- config 2b: uniform random patterns -> the early exit of wrapper.rs:111-113 ----
-    if dna and rank == 0:
+    if dna and rank == 0 and not args.no_early_exit:
         rflat = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)
         rs_ = torch.empty(npat, dtype=torch.int64, device=dev)
         re_ = torch.empty(npat, dtype=torch.int64, device=dev)
@@ -274,34 +284,78 @@ def main():
                              "nonzero_counts": int((re_ > rs_).sum().item())}
         del rflat, rs_, re_
 
-    # ---- opt-in 2-step index: same patterns, results asserted identical ----
+    # ---- opt-in accelerators: same patterns, results asserted identical to the plain index ----
+    legs = []
+    if not args.no_accel:
+        args.pair_index = args.kmer_table = True
     if args.pair_index and dna:
-        pidx = F.FMIndex.from_device_text(text.data_ptr(), n, maxc, device=local, pair_index=True)
-        assert pidx.has_pair_index()
-        ps = torch.empty(npat, dtype=torch.int64, device=dev)
-        pe = torch.empty(npat, dtype=torch.int64, device=dev)
+        legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX"))
+    if args.kmer_table and dna:
+        legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE"))
+    if args.kmer_table and args.pair_index and dna:
+        legs.append(("kmer_table+pair_index", dict(kmer_table=True, pair_index=True),
+                     "FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX"))
+    for leg_name, leg_kw, leg_note in legs:
+        try:
+            pidx = F.FMIndex.from_device_text(text.data_ptr(), n, maxc, device=local, **leg_kw)
+            assert pidx.has_pair_index() == bool(leg_kw.get("pair_index"))
+            assert (pidx.kmer_k() > 0) == bool(leg_kw.get("kmer_table"))
+            ps = torch.empty(npat, dtype=torch.int64, device=dev)
+            pe = torch.empty(npat, dtype=torch.int64, device=dev)
 
-        def pstep():
-            rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(pat.data_ptr()),
-                                         C.c_void_p(off.data_ptr()), npat, None,
-                                         C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
-            assert rc == 0
-        for _ in range(args.warmup):
-            pstep()
-        torch.cuda.synchronize()
-        p0 = torch.cuda.Event(enable_timing=True)
-        p1 = torch.cuda.Event(enable_timing=True)
-        p0.record(stream)
-        for _ in range(args.steps):
-            pstep()
-        p1.record(stream)
-        torch.cuda.synchronize()
-        pms = p0.elapsed_time(p1) / args.steps
-        assert bool((ps == d_s).all()) and bool((pe == d_e).all()), "pair index != 1-step index"
-        out["pair_index"] = {"value": chars_per_step_rank / (pms / 1e3), "unit": "pattern-chars/s",
-                             "ms_per_step": pms, "index_bytes": pidx.heap_size(),
-                             "note": "opt-in FMX_FLAG_PAIR_INDEX; (s,e) identical to the 1-step run"}
-        pidx.close()
+            def pstep():
+                rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(pat.data_ptr()),
+                                             C.c_void_p(off.data_ptr()), npat, None,
+                                             C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
+                assert rc == 0
+            for _ in range(args.warmup):
+                pstep()
+            torch.cuda.synchronize()
+            p0 = torch.cuda.Event(enable_timing=True)
+            p1 = torch.cuda.Event(enable_timing=True)
+            p0.record(stream)
+            for _ in range(args.steps):
+                pstep()
+            p1.record(stream)
+            torch.cuda.synchronize()
+            pms = p0.elapsed_time(p1) / args.steps
+            assert bool((ps == d_s).all()) and bool((pe == d_e).all()), leg_name + " != plain index"
+            out[leg_name] = {"value": chars_per_step_rank / (pms / 1e3), "unit": "pattern-chars/s",
+                             "ms_per_step": pms, "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
+                             "build_ms": round(float(lib.fmx_build_ms(pidx.handle())), 1),
+                             "traffic": traffic.get(leg_name, {}).get("bytes"),
+                             "note": leg_note + "; (s,e) identical to the plain-index run"}
+            if not args.no_early_exit and "early_exit" in out:
+                # config 2b patterns (uniform random, mostly absent) through the same index
+                rflat2 = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)
+                lib.fmx_count_batch_dev(h, C.c_void_p(rflat2.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                        C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), None, sp)
+
+                def rstep():
+                    rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(rflat2.data_ptr()),
+                                                 C.c_void_p(off.data_ptr()), npat, None,
+                                                 C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
+                    assert rc == 0
+                for _ in range(args.warmup):
+                    rstep()
+                torch.cuda.synchronize()
+                p0.record(stream)
+                for _ in range(args.steps):
+                    rstep()
+                p1.record(stream)
+                torch.cuda.synchronize()
+                rms2 = p0.elapsed_time(p1) / args.steps
+                assert bool((ps == d_s).all()) and bool((pe == d_e).all()), leg_name + " != plain index (2b)"
+                out[leg_name]["early_exit_ms_per_step"] = rms2
+                out[leg_name]["early_exit_offered_chars_per_s"] = npat * m / (rms2 / 1e3)
+                # restore the config-2 (s, e) the locate leg starts from
+                lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                        C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), None, sp)
+                torch.cuda.synchronize()
+                del rflat2
+            pidx.close()
+        except Exception as ex:  # never lose the headline line to an optional leg
+            out[leg_name] = {"error": repr(ex)}
 
     # ---- locate leg (config 3), rank 0 reports ----
     if level is not None:

@@ -94,7 +94,7 @@ class Text:
 class _Index:
     _kind = L.KIND_FM
 
-    def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False):
+    def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -105,12 +105,13 @@ class _Index:
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
                                  text.max_character(),
                                  self._kind, lvl, (L.FLAG_KEEP_SA if keep_sa else 0) |
-                                 (L.FLAG_PAIR_INDEX if pair_index else 0), device, C.byref(self._h))
+                                 (L.FLAG_PAIR_INDEX if pair_index else 0) |
+                                 (L.FLAG_KMER_TABLE if kmer_table else 0), device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
-                         pair_index=False, sym_bytes=1):
+                         pair_index=False, sym_bytes=1, kmer_table=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -119,7 +120,8 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
                                        (L.FLAG_KEEP_SA if keep_sa else 0) |
-                                       (L.FLAG_PAIR_INDEX if pair_index else 0), device,
+                                       (L.FLAG_PAIR_INDEX if pair_index else 0) |
+                                       (L.FLAG_KMER_TABLE if kmer_table else 0), device,
                                        C.byref(self._h)))
         return self
 
@@ -258,6 +260,10 @@ class _Index:
     def has_pair_index(self):
         return bool(self._lib.fmx_has_pair_index(self._h))
 
+    def kmer_k(self):
+        """k of the opt-in k-mer start table (0 = none)."""
+        return int(self._lib.fmx_kmer_k(self._h))
+
     def level(self):
         lv = int(self._lib.fmx_level(self._h))
         return None if lv == L.NO_LOCATE else lv
@@ -281,16 +287,16 @@ class FMIndex(_Index):
     """FMIndex::new(&text) (frontend.rs:195-203) -- count only."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, device=0, keep_sa=False, pair_index=False):
-        super().__init__(text, None, device, keep_sa, pair_index)
+    def __init__(self, text, device=0, keep_sa=False, pair_index=False, kmer_table=False):
+        super().__init__(text, None, device, keep_sa, pair_index, kmer_table)
 
 
 class FMIndexWithLocate(_Index):
     """FMIndexWithLocate::new(&text, level) (frontend.rs:205-221)."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False):
-        super().__init__(text, level, device, keep_sa, pair_index)
+    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False):
+        super().__init__(text, level, device, keep_sa, pair_index, kmer_table)
 
 
 class RLFMIndex(_Index):

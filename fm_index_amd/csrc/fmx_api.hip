@@ -176,6 +176,7 @@ uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0;
 uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
 uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
+uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
 void fmx_set_timing(fmx_index *idx, int enabled) {
@@ -718,6 +719,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     out[k++] = {(const void **)&d.bp.sel, (uint64_t)d.bp.nsel * 4};
   }
   if (d.pair_rec) out[k++] = {(const void **)&d.pair_rec, ((uint64_t)d.n / 128 + 1) * 128};
+  if (d.kmer) out[k++] = {(const void **)&d.kmer, (1ull << (d.kmer_bits * d.kmer_k)) * 8};
   return k;
 }
 const size_t kChunk = 64u << 20;

@@ -912,6 +912,26 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     dv.pair_row1 = sp[1];
   }
 
+  // -- opt-in k-mer start table (FMX_FLAG_KMER_TABLE): one 3-bit level, u8 symbols --
+  if ((idx->flags & FMX_FLAG_KMER_TABLE) && idx->kind == FMX_KIND_FM && sizeof(T) == 1 &&
+      dv.bw.nlevels == 1 && dv.bw.lv[0].fmt == 3 && maxc >= 1) {
+    uint32_t bits = 1;
+    while ((1u << bits) < maxc) bits++;             // symbol c is coded c - 1 in 0..maxc-1
+    uint32_t kk = 24u / bits;                        // <= 2^24 entries (128 MiB)
+    if (kk > 16) kk = 16;                            // two symbols per lane of the 8-lane group
+    while (kk > 0 && (1ull << (bits * kk)) > (uint64_t)n / 16u) kk--;   // table <= n/2 bytes
+    if (kk >= 2) {
+      uint2 *d_tab;
+      const uint64_t tab_bytes = (1ull << (bits * kk)) * sizeof(uint2);
+      FMX_HIP(hipMalloc((void **)&d_tab, tab_bytes));
+      if (int rc = keep(idx, d_tab, tab_bytes)) return rc;
+      if (int rc = fmx_launch_kmer_build(idx, d_tab, kk, bits, 0)) return rc;
+      dv.kmer = d_tab;
+      dv.kmer_k = kk;
+      dv.kmer_bits = bits;
+    }
+  }
+
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
     FMX_HIP(hipMalloc((void **)&kt, (n ? n : 1) * sizeof(T)));

@@ -76,6 +76,9 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   uint32_t pair_row0, pair_row1;  // the two rows (SA = 0, 1) that have no 2-gram; stored as code 0
   const uint32_t *cs;   // C array on the device for get_f / fl_map: characters (FM, sais.rs:9-32)
                         // or runs (RLFM, rlfmi.rs:72-76)
+  const uint2 *kmer;    // FMX_FLAG_KMER_TABLE: (s, e) of searching each k-mer from (0, n)
+  uint32_t kmer_k;      // symbols per entry (0 = no table)
+  uint32_t kmer_bits;   // bits per symbol in the table index (symbol c is coded c - 1)
 };
 
 struct fmx_index {
@@ -131,6 +134,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                       hipStream_t st);
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
                        hipStream_t st);
+// fills table[code] for every k-mer code (FMX_FLAG_KMER_TABLE; the index must be complete)
+int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st);
 // op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map, 6 piece_id
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st);

@@ -24,6 +24,7 @@
 //   2, 5       count with 2 / 4 independent chains per group          (slower: 0.78 / 1.00 ms)
 //   3, 4       count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
 //   (non-temporal loads for the deep steps were also measured: 0.80 ms, removed)
+//   6          ignore the k-mer start table even when it was built
 //   7          ignore the pair index even when it was built
 //   8, 9       measurement only: lane-per-pattern / wavefront-per-pattern count kernels
 static inline int fmx_variant() {
@@ -108,6 +109,47 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// k-mer start table (FMX_FLAG_KMER_TABLE).  Entry `code` = the (s, e) SearchWrapper::search
+// leaves for the k-mer, early exit included, so a lookup replaces the first k steps exactly.
+// code: the symbol consumed FIRST (the pattern's last) sits in the top bits, each coded c - 1.
+// ---------------------------------------------------------------------------
+// the group's lanes read the last `kk` (<= 16) symbols of the pattern (two per lane) and combine
+// them; returns false when one of them is 0 or > max_character (then the stepwise path decides)
+__device__ __forceinline__ bool fmx_kmer_code(const uint8_t *__restrict__ pat, uint64_t pend, uint32_t kk,
+                                              uint32_t bits, uint32_t max_character, uint32_t g,
+                                              uint32_t &code) {
+  uint32_t part = 0, bad = 0;
+#pragma unroll
+  for (uint32_t h = 0; h < 2; h++) {
+    const uint32_t t = g + 8u * h;                      // t-th symbol from the back
+    if (t < kk) {
+      const uint32_t cc = pat[pend - 1u - t];
+      bad |= (uint32_t)((cc - 1u) >= max_character);
+      part |= ((cc - 1u) & ((1u << bits) - 1u)) << (bits * (kk - 1u - t));
+    }
+  }
+  code = fmx_group_sum(part);                           // disjoint bit fields: sum == or
+  return fmx_group_sum(bad) == 0u;
+}
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_kmer_build_kernel(FmxDev ix, uint2 *__restrict__ table,
+                                                                    uint32_t kk, uint32_t bits) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  const uint64_t ncodes = 1ull << (bits * kk);
+  for (uint64_t code = gid; code < ncodes; code += ngroups) {
+    uint32_t s = 0, e = ix.n;
+    for (uint32_t t = 0; t < kk; t++) {
+      const uint32_t c = (uint32_t)((code >> (bits * (kk - 1u - t))) & ((1u << bits) - 1u)) + 1u;
+      if (c > ix.max_character) { s = 0; e = 0; break; }   // never looked up
+      fmx_lf_map2_pair<FMX_KIND_FM, 1>(ix, c, s, e, g);    // wrapper.rs:109-110
+      if (s == e) break;                                   // wrapper.rs:111-113
+    }
+    if (g == 0) table[code] = make_uint2(s, e);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // count, single 3-bit level (L <= 3: DNA, the BASELINE configs 1/2/3/5).
 // The record counters are absolute (cs[] folded in), so one 128-B line per endpoint IS
 // lf_map2(c, i); no level descriptors, no K[] lookup.  Per step: the two record loads and
@@ -115,9 +157,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
 // skipped when both interval ends fall into the same record (e - s < 256 most of the time).
 // PPG = patterns a group advances concurrently (independent chains -> more loads in flight).
 // ---------------------------------------------------------------------------
-template <int PPG, bool SKIP>
+template <int PPG, bool SKIP, bool KM = false>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
+    const uint2 *__restrict__ kmer, uint32_t kmer_k, uint32_t kmer_bits,
     const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
@@ -151,6 +194,16 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         } else {               // (0, len)   wrapper.rs:41
           s[q] = 0;
           e[q] = n;
+          if (KM && j[q] >= kmer_k) {                  // the first kmer_k steps from the table
+            uint32_t code;
+            if (fmx_kmer_code(pat, pbeg[q] + j[q], kmer_k, kmer_bits, max_character, g, code)) {
+              const uint2 se = kmer[code];
+              s[q] = se.x;
+              e[q] = se.y;
+              j[q] = se.x == se.y ? 0u : j[q] - kmer_k;  // empty already: the reference's break
+              nsteps += kmer_k;
+            }
+          }
         }
         c[q] = j[q] ? pat[pbeg[q] + j[q] - 1] : 0u;   // last symbol: pattern.iter().rev()
         fresh[q] = false;
@@ -302,9 +355,11 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_wave_kernel(
 // collapses the interval, the single step for the LAST symbol decides whether the reference
 // would have stopped after one symbol (then ITS (s, e) is returned) or after two.
 // ---------------------------------------------------------------------------
+template <bool KM>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
     const uint4 *__restrict__ rec1, const uint4 *__restrict__ rec2, uint32_t n,
     uint32_t max_character, uint32_t row0, uint32_t row1, uint32_t *status,
+    const uint2 *__restrict__ kmer, uint32_t kmer_k, uint32_t kmer_bits,
     const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
@@ -328,6 +383,16 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
       } else {
         s = 0;
         e = n;
+        if (KM && j >= kmer_k) {                       // the first kmer_k steps from the table
+          uint32_t code;
+          if (fmx_kmer_code(pat, pbeg + j, kmer_k, kmer_bits, max_character, g, code)) {
+            const uint2 se = kmer[code];
+            s = se.x;
+            e = se.y;
+            j = se.x == se.y ? 0u : j - kmer_k;        // empty already: the reference's break
+            nsteps += kmer_k;
+          }
+        }
       }
       c2 = j ? pat[pbeg + j - 1] : 0u;
       c1 = j > 1 ? pat[pbeg + j - 2] : 0u;
@@ -935,17 +1000,23 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   const FmxMwm &w = idx->dev.bw;
   int variant = fmx_variant();
   const uint8_t *d_pat8 = (const uint8_t *)d_pat;
+  const bool km = idx->dev.kmer != nullptr && variant != 6;   // FMX_VARIANT=6: ignore the k-mer table
   if (idx->dev.pair_rec && idx->sym_bytes == 1 && variant != 0 && variant != 7) {
-    hipLaunchKernelGGL(fmx_count_pair_kernel, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,
-                       idx->dev.pair_rec, idx->dev.n, idx->dev.max_character, idx->dev.pair_row0,
-                       idx->dev.pair_row1, idx->dev.status, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt,
-                       steps);
+#define FMX_PAIR_LAUNCH(KM)                                                                          \
+  hipLaunchKernelGGL(fmx_count_pair_kernel<KM>, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
+                     idx->dev.pair_rec, idx->dev.n, idx->dev.max_character, idx->dev.pair_row0,       \
+                     idx->dev.pair_row1, idx->dev.status, idx->dev.kmer, idx->dev.kmer_k,             \
+                     idx->dev.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+    if (km) FMX_PAIR_LAUNCH(true);
+    else FMX_PAIR_LAUNCH(false);
   } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
              variant != 0) {
-#define FMX_F3_LAUNCH(PPG, SKIP)                                                                   \
-  hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP>), dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), \
-                     dim3(FMX_BLOCK), 0, st, w.lv[0].rec, idx->dev.n, idx->dev.max_character,        \
-                     idx->dev.status, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+#define FMX_F3_LAUNCH(PPG, SKIP, KM)                                                               \
+  hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP, KM>),                                           \
+                     dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), dim3(FMX_BLOCK), 0, st,       \
+                     w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, idx->dev.kmer, \
+                     idx->dev.kmer_k, idx->dev.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e,      \
+                     d_cnt, steps)
     switch (variant) {
       case 8:  // measurement only: lane per pattern
         if (d_s0e0) return FMX_ERR_UNSUPPORTED;
@@ -959,11 +1030,14 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
                            w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, d_pat8, d_off,
                            npat, d_s, d_e, d_cnt, steps);
         break;
-      case 2: FMX_F3_LAUNCH(2, false); break;
-      case 3: FMX_F3_LAUNCH(1, true); break;
-      case 4: FMX_F3_LAUNCH(2, true); break;
-      case 5: FMX_F3_LAUNCH(4, false); break;
-      default: FMX_F3_LAUNCH(1, false); break;
+      case 2: FMX_F3_LAUNCH(2, false, false); break;
+      case 3: FMX_F3_LAUNCH(1, true, false); break;
+      case 4: FMX_F3_LAUNCH(2, true, false); break;
+      case 5: FMX_F3_LAUNCH(4, false, false); break;
+      default:
+        if (km) FMX_F3_LAUNCH(1, false, true);
+        else FMX_F3_LAUNCH(1, false, false);
+        break;
     }
   } else {
     // number of wavelet levels fixed at compile time for the common cases (1, 2), runtime otherwise
@@ -1098,6 +1172,14 @@ int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nr
   if (idx->sym_bytes == 1) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint8_t *)d_out, d_out_len, d_out_next, st);
   if (idx->sym_bytes == 2) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint16_t *)d_out, d_out_len, d_out_next, st);
   return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint32_t *)d_out, d_out_len, d_out_next, st);
+}
+
+int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st) {
+  const uint64_t ncodes = 1ull << (bits * k);
+  hipLaunchKernelGGL(fmx_kmer_build_kernel, dim3(fmx_grid_for_groups(ncodes)), dim3(FMX_BLOCK), 0, st,
+                     idx->dev, d_table, k, bits);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
 }
 
 int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,

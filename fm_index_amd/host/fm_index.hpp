@@ -83,8 +83,9 @@ class Search {  // frontend.rs:70-84
 
 class Index {
  public:
-  Index(const Text &text, uint32_t kind, uint32_t level, int device = 0) {
-    check(fmx_build(text.text().data(), text.text().size(), 1, text.max_character(), kind, level, 0,
+  // `flags`: FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE opt into the small-alphabet accelerators
+  Index(const Text &text, uint32_t kind, uint32_t level, int device = 0, uint32_t flags = 0) {
+    check(fmx_build(text.text().data(), text.text().size(), 1, text.max_character(), kind, level, flags,
                     device, &h_));
   }
   Index(const Index &) = delete;
@@ -116,10 +117,12 @@ class Index {
 };
 
 struct FMIndex : Index {
-  explicit FMIndex(const Text &t, int device = 0) : Index(t, FMX_KIND_FM, FMX_NO_LOCATE, device) {}
+  explicit FMIndex(const Text &t, int device = 0, uint32_t flags = 0)
+      : Index(t, FMX_KIND_FM, FMX_NO_LOCATE, device, flags) {}
 };
 struct FMIndexWithLocate : Index {
-  FMIndexWithLocate(const Text &t, uint32_t level, int device = 0) : Index(t, FMX_KIND_FM, level, device) {}
+  FMIndexWithLocate(const Text &t, uint32_t level, int device = 0, uint32_t flags = 0)
+      : Index(t, FMX_KIND_FM, level, device, flags) {}
 };
 struct RLFMIndex : Index {
   explicit RLFMIndex(const Text &t, int device = 0) : Index(t, FMX_KIND_RLFM, FMX_NO_LOCATE, device) {}

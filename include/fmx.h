@@ -68,6 +68,17 @@ typedef struct fmx_index fmx_index;
  * (s, e) pair left by the early exit of wrapper.rs:111-113 -- are bit-identical to the 1-step
  * path; +1 byte per text symbol of HBM.  Ignored (1-step index only) when not applicable. */
 #define FMX_FLAG_PAIR_INDEX 2u
+/* Opt-in start table for small alphabets (u8 symbols, max_character <= 7, FM kind): for every
+ * k-mer over the symbols 1..max_character the table holds the (s, e) that
+ * SearchWrapper::search (wrapper.rs:103-124, early exit included) returns for it from (0, len),
+ * so a pattern of >= k symbols starts with ONE 8-byte lookup instead of its first k steps
+ * (k = fmx_kmer_k(): 12 for DNA, table = 2^24 entries = 128 MiB; k shrinks for short texts so
+ * that the table never exceeds len/2 bytes).
+ * Results stay bit-identical: if the table entry is already an empty range, it is exactly the
+ * pair the reference's break would have left.  Patterns shorter than k, patterns whose last k
+ * symbols contain 0 or an out-of-range symbol, and refinements from a given (s, e) take the
+ * stepwise path.  Ignored when not applicable. */
+#define FMX_FLAG_KMER_TABLE 4u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
@@ -226,6 +237,7 @@ int fmx_export_sa(const fmx_index *idx, uint32_t *host_out);         /* needs FM
 int fmx_verify_sa(const fmx_index *idx, uint64_t *violations);
 uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r (rlfmi.rs:43) */
 uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol width in HBM / *_dev */
+uint32_t fmx_kmer_k(const fmx_index *idx);   /* k of the FMX_FLAG_KMER_TABLE table, 0 = none */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
 
 #ifdef __cplusplus

@@ -8,7 +8,10 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline ${2:-}"   # optional 2nd arg: extra bench.py flags
+# --no-accel --no-early-exit: only config-2 launches of the headline kernels in the trace;
+# a 2nd argument replaces --no-accel: e.g. "--workload bytes-rlfm --no-accel", or "--workload dna"
+# to profile the opt-in legs (pair index, k-mer table) as well
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-early-exit ${2:---no-accel}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err

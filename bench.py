@@ -290,14 +290,15 @@ def main():
         args.pair_index = args.kmer_table = True
     if args.pair_index and dna:
         legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX"))
-    if args.kmer_table and dna:
+    if args.kmer_table:
         legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE"))
     if args.kmer_table and args.pair_index and dna:
         legs.append(("kmer_table+pair_index", dict(kmer_table=True, pair_index=True),
                      "FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX"))
     for leg_name, leg_kw, leg_note in legs:
         try:
-            pidx = F.FMIndex.from_device_text(text.data_ptr(), n, maxc, device=local, **leg_kw)
+            pidx = (F.RLFMIndex if rlfm else F.FMIndex).from_device_text(text.data_ptr(), n, maxc,
+                                                                          device=local, **leg_kw)
             assert pidx.has_pair_index() == bool(leg_kw.get("pair_index"))
             assert (pidx.kmer_k() > 0) == bool(leg_kw.get("kmer_table"))
             ps = torch.empty(npat, dtype=torch.int64, device=dev)

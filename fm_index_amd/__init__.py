@@ -303,24 +303,24 @@ class RLFMIndex(_Index):
     """RLFMIndex::new(&text) (frontend.rs:223-231)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, device=0, keep_sa=False):
-        super().__init__(text, None, device, keep_sa)
+    def __init__(self, text, device=0, keep_sa=False, kmer_table=False):
+        super().__init__(text, None, device, keep_sa, False, kmer_table)
 
 
 class RLFMIndexWithLocate(_Index):
     """RLFMIndexWithLocate::new(&text, level) (frontend.rs:233-243)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, level, device=0, keep_sa=False):
-        super().__init__(text, level, device, keep_sa)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False):
+        super().__init__(text, level, device, keep_sa, False, kmer_table)
 
 
 class FMIndexMultiPieces(_Index):
     """FMIndexMultiPieces::new(&text) (frontend.rs:245-253): several \\0-separated pieces."""
     _kind = L.KIND_MULTI
 
-    def __init__(self, text, device=0, keep_sa=False):
-        super().__init__(text, None, device, keep_sa)
+    def __init__(self, text, device=0, keep_sa=False, kmer_table=False):
+        super().__init__(text, None, device, keep_sa, False, kmer_table)
 
     def piece_id(self, i):
         return self._scalar(self._lib.fmx_piece_id_batch, i)
@@ -342,8 +342,8 @@ class FMIndexMultiPieces(_Index):
 class FMIndexMultiPiecesWithLocate(FMIndexMultiPieces):
     """FMIndexMultiPiecesWithLocate::new(&text, level) (frontend.rs:255-267)."""
 
-    def __init__(self, text, level, device=0, keep_sa=False):
-        _Index.__init__(self, text, level, device, keep_sa)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False):
+        _Index.__init__(self, text, level, device, keep_sa, False, kmer_table)
 
 
 class Search:

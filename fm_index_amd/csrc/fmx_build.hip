@@ -415,6 +415,14 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   uint64_t *keys_a, *keys_b;
   uint32_t *vals_b, *rank, *head;
   unsigned int *d_ng;
+  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  auto ts0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what, uint64_t h) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[fmx build]   sort: %-10s h=%-10llu %8.1f ms\n", what, (unsigned long long)h,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
+  };
   FMX_HIP(pool.get(&keys_a, n));
   FMX_HIP(pool.get(&keys_b, n));
   FMX_HIP(pool.get(&vals_b, n));
@@ -437,6 +445,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   uint8_t *tmp;
   FMX_HIP(pool.get(&tmp, tmp_bytes));
 
+  mark("alloc", 0);
   hipLaunchKernelGGL(k_init_keys<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
                      d_sa);
   uint64_t *keys_cur = keys_a, *keys_alt = keys_b;
@@ -455,6 +464,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     hipLaunchKernelGGL(k_flag_heads, dim3(nblocks(n)), dim3(BLK), 0, 0, keys_cur, n, head, d_ng);
     unsigned int dup = 0;
     FMX_HIP(hipMemcpy(&dup, d_ng, sizeof dup, hipMemcpyDeviceToHost));
+    mark("round", h);
     if (!dup) break;
     if (h >= n) {  // cannot happen for distinct suffixes; guard against an endless loop
       fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
@@ -749,6 +759,14 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
 template <typename T>
 static int build_impl_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
+  // FMX_BUILD_TRACE=1: elapsed ms after each phase on stderr (each mark synchronises the device)
+  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[fmx build] %-18s %8.1f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   DevPool pool;
   const uint32_t n = (uint32_t)idx->n;
   const uint32_t maxc = (uint32_t)idx->max_character;
@@ -781,6 +799,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     for (uint32_t c = 0; c <= maxc; c++) { idx->h_cs[c] = sum; sum += hist[c]; }
   }
 
+  mark("stats");
   // -- suffix array --
   uint32_t *d_sa;
   FMX_HIP(pool.get(&d_sa, n));
@@ -788,6 +807,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (int rc = suffix_sort<T>(d_text, n, L, d_sa, pool)) return rc;
   }
 
+  mark("suffix sort");
   // -- SA samples (sample.rs:21-44) --
   FmxDev &dv = idx->dev;
   dv.n = n;
@@ -811,6 +831,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     idx->nsamples = nsamp;
   }
 
+  mark("samples");
   // -- BWT (fm_index.rs:44-58) --
   T *d_bwt;
   FMX_HIP(pool.get(&d_bwt, n));
@@ -881,6 +902,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (int rc = build_rlfm<T>(idx, d_bwt, n, L, pool)) return rc;
   }
 
+  mark("rank records");
   // -- opt-in pair index (FMX_FLAG_PAIR_INDEX): sigma <= 4, the terminator is the only zero --
   if ((idx->flags & FMX_FLAG_PAIR_INDEX) && idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= 4 &&
       n >= 4 && hist[0] == 1 && dv.bw.nlevels == 1) {
@@ -912,9 +934,9 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     dv.pair_row1 = sp[1];
   }
 
-  // -- opt-in k-mer start table (FMX_FLAG_KMER_TABLE): one 3-bit level, u8 symbols --
-  if ((idx->flags & FMX_FLAG_KMER_TABLE) && idx->kind == FMX_KIND_FM && sizeof(T) == 1 &&
-      dv.bw.nlevels == 1 && dv.bw.lv[0].fmt == 3 && maxc >= 1) {
+  mark("pair index");
+  // -- opt-in k-mer start table (FMX_FLAG_KMER_TABLE): u8 symbols, any kind --
+  if ((idx->flags & FMX_FLAG_KMER_TABLE) && sizeof(T) == 1 && maxc >= 1 && n >= 2) {
     uint32_t bits = 1;
     while ((1u << bits) < maxc) bits++;             // symbol c is coded c - 1 in 0..maxc-1
     uint32_t kk = 24u / bits;                        // <= 2^24 entries (128 MiB)
@@ -932,6 +954,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     }
   }
 
+  mark("k-mer table");
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
     FMX_HIP(hipMalloc((void **)&kt, (n ? n : 1) * sizeof(T)));

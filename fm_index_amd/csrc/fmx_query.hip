@@ -43,9 +43,51 @@ static inline unsigned fmx_grid_for_groups(uint64_t units) {
 }
 
 // ---------------------------------------------------------------------------
+// k-mer start table (FMX_FLAG_KMER_TABLE).  Entry `code` = the (s, e) SearchWrapper::search
+// leaves for the k-mer, early exit included, so a lookup replaces the first k steps exactly.
+// code: the symbol consumed FIRST (the pattern's last) sits in the top bits, each coded c - 1.
+// ---------------------------------------------------------------------------
+// the group's lanes read the last `kk` (<= 16) symbols of the pattern (two per lane) and combine
+// them; returns false when one of them is 0 or > max_character (then the stepwise path decides)
+__device__ __forceinline__ bool fmx_kmer_code(const uint8_t *__restrict__ pat, uint64_t pend, uint32_t kk,
+                                              uint32_t bits, uint32_t max_character, uint32_t g,
+                                              uint32_t &code) {
+  uint32_t part = 0, bad = 0;
+#pragma unroll
+  for (uint32_t h = 0; h < 2; h++) {
+    const uint32_t t = g + 8u * h;                      // t-th symbol from the back
+    if (t < kk) {
+      const uint32_t cc = pat[pend - 1u - t];
+      bad |= (uint32_t)((cc - 1u) >= max_character);
+      part |= ((cc - 1u) & ((1u << bits) - 1u)) << (bits * (kk - 1u - t));
+    }
+  }
+  code = fmx_group_sum(part);                           // disjoint bit fields: sum == or
+  return fmx_group_sum(bad) == 0u;
+}
+template <int KIND>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_kmer_build_kernel(FmxDev ix, uint2 *__restrict__ table,
+                                                                    uint32_t kk, uint32_t bits) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  const uint64_t ncodes = 1ull << (bits * kk);
+  for (uint64_t code = gid; code < ncodes; code += ngroups) {
+    uint32_t s = 0, e = ix.n;
+    for (uint32_t t = 0; t < kk; t++) {
+      const uint32_t c = (uint32_t)((code >> (bits * (kk - 1u - t))) & ((1u << bits) - 1u)) + 1u;
+      if (c > ix.max_character) { s = 0; e = 0; break; }   // never looked up
+      fmx_lf_map2_pair<KIND, 0>(ix, c, s, e, g);           // wrapper.rs:109-110
+      if (s == e) break;                                   // wrapper.rs:111-113
+    }
+    if (g == 0) table[code] = make_uint2(s, e);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------
-template <int KIND, int NL>
+template <int KIND, int NL, bool KM = false>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
     FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
@@ -73,6 +115,17 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
       } else {               // SearchIndexWrapper::search: (0, len)   (wrapper.rs:41)
         s = 0;
         e = ix.n;
+        if (KM && j >= ix.kmer_k) {                    // the first kmer_k steps from the table (u8 symbols)
+          uint32_t code;
+          if (fmx_kmer_code((const uint8_t *)pat, pbeg + j, ix.kmer_k, ix.kmer_bits, ix.max_character, g,
+                            code)) {
+            const uint2 se = ix.kmer[code];
+            s = se.x;
+            e = se.y;
+            j = se.x == se.y ? 0u : j - ix.kmer_k;     // empty already: the reference's break
+            nsteps += ix.kmer_k;
+          }
+        }
       }
       c = j ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 1) : 0u;  // pattern.iter().rev()  wrapper.rs:108
       fresh = false;
@@ -105,47 +158,6 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
   }
   if (steps_out) {
     if (g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k-mer start table (FMX_FLAG_KMER_TABLE).  Entry `code` = the (s, e) SearchWrapper::search
-// leaves for the k-mer, early exit included, so a lookup replaces the first k steps exactly.
-// code: the symbol consumed FIRST (the pattern's last) sits in the top bits, each coded c - 1.
-// ---------------------------------------------------------------------------
-// the group's lanes read the last `kk` (<= 16) symbols of the pattern (two per lane) and combine
-// them; returns false when one of them is 0 or > max_character (then the stepwise path decides)
-__device__ __forceinline__ bool fmx_kmer_code(const uint8_t *__restrict__ pat, uint64_t pend, uint32_t kk,
-                                              uint32_t bits, uint32_t max_character, uint32_t g,
-                                              uint32_t &code) {
-  uint32_t part = 0, bad = 0;
-#pragma unroll
-  for (uint32_t h = 0; h < 2; h++) {
-    const uint32_t t = g + 8u * h;                      // t-th symbol from the back
-    if (t < kk) {
-      const uint32_t cc = pat[pend - 1u - t];
-      bad |= (uint32_t)((cc - 1u) >= max_character);
-      part |= ((cc - 1u) & ((1u << bits) - 1u)) << (bits * (kk - 1u - t));
-    }
-  }
-  code = fmx_group_sum(part);                           // disjoint bit fields: sum == or
-  return fmx_group_sum(bad) == 0u;
-}
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_kmer_build_kernel(FmxDev ix, uint2 *__restrict__ table,
-                                                                    uint32_t kk, uint32_t bits) {
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  const uint64_t ncodes = 1ull << (bits * kk);
-  for (uint64_t code = gid; code < ncodes; code += ngroups) {
-    uint32_t s = 0, e = ix.n;
-    for (uint32_t t = 0; t < kk; t++) {
-      const uint32_t c = (uint32_t)((code >> (bits * (kk - 1u - t))) & ((1u << bits) - 1u)) + 1u;
-      if (c > ix.max_character) { s = 0; e = 0; break; }   // never looked up
-      fmx_lf_map2_pair<FMX_KIND_FM, 1>(ix, c, s, e, g);    // wrapper.rs:109-110
-      if (s == e) break;                                   // wrapper.rs:111-113
-    }
-    if (g == 0) table[code] = make_uint2(s, e);
   }
 }
 
@@ -1042,8 +1054,14 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   } else {
     // number of wavelet levels fixed at compile time for the common cases (1, 2), runtime otherwise
 #define FMX_COUNT_LAUNCH(KIND, NL)                                                                  \
-  hipLaunchKernelGGL((fmx_count_kernel<KIND, NL>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, d_pat, \
-                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+  do {                                                                                              \
+    if (km && idx->sym_bytes == 1)                                                                  \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true>), dim3(grid), dim3(FMX_BLOCK), 0, st,     \
+                         idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
+    else                                                                                            \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false>), dim3(grid), dim3(FMX_BLOCK), 0, st,    \
+                         idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
+  } while (0)
 #define FMX_COUNT_KIND(KIND)                                                                        \
   do {                                                                                              \
     if (w.nlevels == 1) FMX_COUNT_LAUNCH(KIND, 1);                                                  \
@@ -1176,8 +1194,13 @@ int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nr
 
 int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st) {
   const uint64_t ncodes = 1ull << (bits * k);
-  hipLaunchKernelGGL(fmx_kmer_build_kernel, dim3(fmx_grid_for_groups(ncodes)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, d_table, k, bits);
+  const dim3 grid(fmx_grid_for_groups(ncodes)), block(FMX_BLOCK);
+  if (idx->kind == FMX_KIND_FM)
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_FM>, grid, block, 0, st, idx->dev, d_table, k, bits);
+  else if (idx->kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_MULTI>, grid, block, 0, st, idx->dev, d_table, k, bits);
+  else
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_RLFM>, grid, block, 0, st, idx->dev, d_table, k, bits);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -68,16 +68,16 @@ typedef struct fmx_index fmx_index;
  * (s, e) pair left by the early exit of wrapper.rs:111-113 -- are bit-identical to the 1-step
  * path; +1 byte per text symbol of HBM.  Ignored (1-step index only) when not applicable. */
 #define FMX_FLAG_PAIR_INDEX 2u
-/* Opt-in start table for small alphabets (u8 symbols, max_character <= 7, FM kind): for every
- * k-mer over the symbols 1..max_character the table holds the (s, e) that
- * SearchWrapper::search (wrapper.rs:103-124, early exit included) returns for it from (0, len),
- * so a pattern of >= k symbols starts with ONE 8-byte lookup instead of its first k steps
- * (k = fmx_kmer_k(): 12 for DNA, table = 2^24 entries = 128 MiB; k shrinks for short texts so
- * that the table never exceeds len/2 bytes).
+/* Opt-in k-mer start table (u8 symbols; every index kind): for every k-mer over the symbols
+ * 1..max_character the table holds the (s, e) that SearchWrapper::search (wrapper.rs:103-124,
+ * early exit included) returns for it from (0, len), so a pattern of >= k symbols starts with ONE
+ * 8-byte lookup instead of its first k steps.  k = fmx_kmer_k() = floor(24 / bits per symbol),
+ * reduced for short texts so that the table never exceeds len/2 bytes: 12 for DNA and 3 for
+ * byte alphabets at len = 2^30 (2^24 entries = 128 MiB).
  * Results stay bit-identical: if the table entry is already an empty range, it is exactly the
  * pair the reference's break would have left.  Patterns shorter than k, patterns whose last k
  * symbols contain 0 or an out-of-range symbol, and refinements from a given (s, e) take the
- * stepwise path.  Ignored when not applicable. */
+ * stepwise path.  Ignored when not applicable (wide symbols, texts too short for k >= 2). */
 #define FMX_FLAG_KMER_TABLE 4u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it

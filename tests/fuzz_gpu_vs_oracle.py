@@ -54,6 +54,7 @@ def main():
         t[n - 1] = 0
         level = None if rng.random() < 0.2 else int(rng.integers(0, 6))
         pair = kind == "fm" and not wide and maxc <= 4 and rng.random() < 0.5
+        kmer = kind == "fm" and not wide and rng.random() < 0.5      # ignored by the build when maxc > 7
         t_or = t if dtype == np.uint8 else t.astype(np.uint32)
         try:
             oi = O.OracleIndex(t_or, maxc, level=level, kind=kind)
@@ -61,8 +62,8 @@ def main():
             continue
         text = F.Text.with_max_character(t, maxc)
         if kind == "fm":
-            gi = F.FMIndexWithLocate(text, level, pair_index=pair) if level is not None else \
-                F.FMIndex(text, pair_index=pair)
+            gi = F.FMIndexWithLocate(text, level, pair_index=pair, kmer_table=kmer) if level is not None else \
+                F.FMIndex(text, pair_index=pair, kmer_table=kmer)
         elif kind == "rlfm":
             if n < 2:
                 continue
@@ -92,7 +93,7 @@ def main():
             se = np.stack([np.minimum(a, b2), np.maximum(a, b2)], axis=1).reshape(-1).astype(np.uint64)
         gb = gi.search_many(flat=flat, off=off, s0e0=se)
         os_, oe = oi.count_batch(flat.astype(np.uint32) if dtype != np.uint8 else flat, off, se)
-        assert (gb.s == os_).all() and (gb.e == oe).all(), ("count", it, kind, n, maxc, level, pair, style)
+        assert (gb.s == os_).all() and (gb.e == oe).all(), ("count", it, kind, n, maxc, level, pair, kmer, style)
         if level is not None:
             small = (oe - os_) < 2000
             goff, gpos = gi.locate_many(gb.s[small], gb.e[small])

@@ -84,7 +84,7 @@ def test_kmer_table_other_small_alphabets(maxc, k):
 
 def test_kmer_table_not_applicable_is_ignored():
     t = W.byte_text_np(5000, 4)
-    assert F.FMIndex(F.Text(t), kmer_table=True).kmer_k() == 0           # sigma 255
+    assert F.FMIndex(F.Text(t), kmer_table=True).kmer_k() == 0           # sigma 255: 5000 rows are too few for k = 2
     assert F.RLFMIndex(F.Text.with_max_character(W.dna_text_np(5000, 2), 4)).kmer_k() == 0
 
 
@@ -99,3 +99,31 @@ def test_kmer_table_survives_save_load(tmp_path):
     assert g2.heap_size() == g.heap_size()
     b = g2.search_many(flat=flat, off=off)
     assert (a.s == b.s).all() and (a.e == b.e).all()
+
+
+@pytest.mark.parametrize("kind", ["fm", "rlfm", "multi"])
+@pytest.mark.parametrize("maxc,alphabet,n,k", [(255, 255, 1 << 20, 2), (63, 50, 70000, 2), (20, 20, 300000, 2),
+                                              (15, 12, 70000, 3)])
+def test_kmer_table_generic_kernels(kind, maxc, alphabet, n, k):
+    """byte / protein-sized alphabets go through the generic count kernels (any kind, 2 levels)."""
+    t = ((W.splitmix64_np(maxc + n, 0, n) % np.uint64(alphabet)) + np.uint64(1)).astype(np.uint8)
+    if kind == "multi":
+        t[np.arange(997, n - 5, 4001)] = 0
+    if kind == "rlfm":                      # give the run-length index some runs
+        t = np.repeat(t[: n // 3 + 1], 3)[:n].copy()
+    t[-1] = 0
+    txt = F.Text.with_max_character(t, maxc)
+    cls = {"fm": F.FMIndex, "rlfm": F.RLFMIndex, "multi": F.FMIndexMultiPieces}[kind]
+    plain = cls(txt)
+    g = cls(txt, kmer_table=True)
+    assert g.kmer_k() == k
+    oi = O.OracleIndex(t, maxc, kind=kind)
+    flat, off = W.ragged_patterns_np(3000, 9, alphabet, 5 + maxc)
+    flat2, off2, _ = W.substring_patterns_np(t, 3000, k + 3, 7)
+    flat3, off3, _ = W.substring_patterns_np(t, 2000, k, 8)
+    for fl, of in ((flat, off), (flat2, off2), (flat3, off3)):
+        a = g.search_many(flat=fl, off=of)
+        b = plain.search_many(flat=fl, off=of)
+        os_, oe = oi.count_batch(fl, of)
+        assert (a.s == os_).all() and (a.e == oe).all()
+        assert (b.s == os_).all() and (b.e == oe).all()

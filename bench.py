@@ -300,7 +300,10 @@ def main():
             pidx = (F.RLFMIndex if rlfm else F.FMIndex).from_device_text(text.data_ptr(), n, maxc,
                                                                           device=local, **leg_kw)
             assert pidx.has_pair_index() == bool(leg_kw.get("pair_index"))
-            assert (pidx.kmer_k() > 0) == bool(leg_kw.get("kmer_table"))
+            if leg_kw.get("kmer_table") and pidx.kmer_k() == 0:
+                out[leg_name] = {"skipped": "FMX_FLAG_KMER_TABLE is ignored for this kind / alphabet"}
+                pidx.close()
+                continue
             ps = torch.empty(npat, dtype=torch.int64, device=dev)
             pe = torch.empty(npat, dtype=torch.int64, device=dev)
 

@@ -935,8 +935,11 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
   }
 
   mark("pair index");
-  // -- opt-in k-mer start table (FMX_FLAG_KMER_TABLE): u8 symbols, any kind --
-  if ((idx->flags & FMX_FLAG_KMER_TABLE) && sizeof(T) == 1 && maxc >= 1 && n >= 2) {
+  // -- opt-in k-mer start table (FMX_FLAG_KMER_TABLE): u8 symbols; RLFM always, FM / multi-pieces
+  // when the BWT has one wavelet level (with two levels k is <= 4 and the lookup costs more than
+  // the cache-resident steps it replaces: benchmarks/kmer_table_sweep.py) --
+  if ((idx->flags & FMX_FLAG_KMER_TABLE) && sizeof(T) == 1 && maxc >= 1 && n >= 2 &&
+      (idx->kind == FMX_KIND_RLFM || dv.bw.nlevels == 1)) {
     uint32_t bits = 1;
     while ((1u << bits) < maxc) bits++;             // symbol c is coded c - 1 in 0..maxc-1
     uint32_t kk = 24u / bits;                        // <= 2^24 entries (128 MiB)

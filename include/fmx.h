@@ -68,7 +68,8 @@ typedef struct fmx_index fmx_index;
  * (s, e) pair left by the early exit of wrapper.rs:111-113 -- are bit-identical to the 1-step
  * path; +1 byte per text symbol of HBM.  Ignored (1-step index only) when not applicable. */
 #define FMX_FLAG_PAIR_INDEX 2u
-/* Opt-in k-mer start table (u8 symbols; every index kind): for every k-mer over the symbols
+/* Opt-in k-mer start table (u8 symbols; RLFM, and FM / multi-pieces with max_character <= 15,
+ * i.e. one wavelet level): for every k-mer over the symbols
  * 1..max_character the table holds the (s, e) that SearchWrapper::search (wrapper.rs:103-124,
  * early exit included) returns for it from (0, len), so a pattern of >= k symbols starts with ONE
  * 8-byte lookup instead of its first k steps.  k = fmx_kmer_k() = floor(24 / bits per symbol),
@@ -77,7 +78,8 @@ typedef struct fmx_index fmx_index;
  * Results stay bit-identical: if the table entry is already an empty range, it is exactly the
  * pair the reference's break would have left.  Patterns shorter than k, patterns whose last k
  * symbols contain 0 or an out-of-range symbol, and refinements from a given (s, e) take the
- * stepwise path.  Ignored when not applicable (wide symbols, texts too short for k >= 2). */
+ * stepwise path.  Ignored when not applicable (wide symbols, texts too short for k >= 2, FM over
+ * larger alphabets where the lookup costs more than the steps it replaces). */
 #define FMX_FLAG_KMER_TABLE 4u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it

@@ -42,6 +42,13 @@ __device__ __forceinline__ uint32_t fmx_group_sum(uint32_t v) {
   v += fmx_dpp_half_mirror(v);
   return v;
 }
+// minimum over the 8 lanes of a group
+__device__ __forceinline__ uint32_t fmx_group_min(uint32_t v) {
+  v = min(v, fmx_dpp_xor1(v));
+  v = min(v, fmx_dpp_xor2(v));
+  v = min(v, fmx_dpp_half_mirror(v));
+  return v;
+}
 
 // ---- per-piece helpers -------------------------------------------------------
 // bitmask (over the piece's entries) of entries whose level code == code
@@ -311,6 +318,38 @@ __device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i,
   bit_i = fmx_group_sum(mine * ((word >> (bit & 31u)) & 1u));
   return fmx_group_sum(mine * (pc.x + c));
 }
+// rank1(i) as above, plus `next` = position of the first one at or after i when it lies in the
+// record just loaded (0xFFFFFFFF otherwise).  That position IS select1(rank1(i)) -- the run start
+// the RLFM formulas subtract (rlfmi.rs:132,141) -- so the select (hint word + record search +
+// record: 2-3 dependent loads) is only needed when the run is longer than the rest of the record.
+__device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32_t i, uint32_t g,
+                                                       uint32_t &bit_i, uint32_t &next) {
+  if (i > bv.len) i = bv.len;
+  const uint32_t rec = fmx_div3(i >> 8);            // i / 768
+  const uint32_t within = i - rec * FMX_BITS_PER_REC;
+  const uint32_t p = fmx_div3(within >> 5);         // within / 96
+  const uint32_t bit = within - p * FMX_BITS_PER_PIECE;
+  FMX_CHECK(rec < bv.nrec);
+  const uint4 pc = bv.rec[(size_t)rec * 8u + g];
+  const uint32_t m0 = fmx_lowmask(bit < 32u ? bit : 32u);
+  const uint32_t m1 = bit > 32u ? fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u) : 0u;
+  const uint32_t m2 = bit > 64u ? fmx_lowmask(bit - 64u) : 0u;
+  const uint32_t c = __popc(pc.y & m0) + __popc(pc.z & m1) + __popc(pc.w & m2);
+  const uint32_t word = bit < 32u ? pc.y : (bit < 64u ? pc.z : pc.w);
+  const uint32_t mine = (g == p) ? 1u : 0u;
+  bit_i = fmx_group_sum(mine * ((word >> (bit & 31u)) & 1u));
+  // first one at or after bit `bit` of piece p, or the first one of a later piece
+  uint32_t y = pc.y, z = pc.z, w = pc.w;
+  if (g == p) { y &= ~m0; z &= ~m1; w &= ~m2; }
+  else if (g < p) { y = 0u; z = 0u; w = 0u; }
+  uint32_t cand = 0xFFFFFFFFu;
+  if (y) cand = (uint32_t)__builtin_ctz(y);
+  else if (z) cand = 32u + (uint32_t)__builtin_ctz(z);
+  else if (w) cand = 64u + (uint32_t)__builtin_ctz(w);
+  if (cand != 0xFFFFFFFFu) cand += rec * FMX_BITS_PER_REC + g * FMX_BITS_PER_PIECE;
+  next = fmx_group_min(cand);
+  return fmx_group_sum(mine * (pc.x + c));
+}
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
@@ -374,13 +413,13 @@ __device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0,
 // RLFMIndexBackend::lf_map2 (rlfmi.rs:135-143)
 __device__ __forceinline__ uint32_t fmx_rlfm_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i,
                                                      uint32_t g) {
-  uint32_t bi;
-  uint32_t j = fmx_bits_rank(ix.b, i, g, bi);             // b.rank1(i)
+  uint32_t bi, nx;
+  uint32_t j = fmx_bits_rank_next(ix.b, i, g, bi, nx);    // b.rank1(i)
   uint32_t nr = ix.K[c] + fmx_mwm_rank(ix.bw, c, j, g);   // cs[c] + s.rank(j, c)
   uint32_t l;                                             // get_l(i) = s[b.rank1(i+1) - 1]
   (void)fmx_mwm_lf(ix.bw, j - 1u + bi, g, l);
   uint32_t r = fmx_bits_select(ix.bp, nr, g);             // bp.select1(cs[c] + nr)
-  if (l == c) r = r + i - fmx_bits_select(ix.b, j, g);    // + i - b.select1(j)
+  if (l == c) r = r + i - (nx != 0xFFFFFFFFu ? nx : fmx_bits_select(ix.b, j, g));  // + i - b.select1(j)
   return r;
 }
 // RLFMIndexBackend::get_l + lf_map (rlfmi.rs:122-133)
@@ -391,6 +430,9 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i
   uint32_t j = fmx_bits_rank(ix.b, i, g, bi);
   (void)fmx_mwm_lf<NL>(ix.bw, j - 1u + bi, g, sym);
   uint32_t nr = ix.K[sym] + fmx_mwm_rank<NL>(ix.bw, sym, j, g);
+  // (taking the run start from the B record already loaded, as fmx_rlfm_lf_map2_pair does, was
+  // measured here too: the locate walk got 10 % slower -- its two selects overlap anyway and the
+  // extra lane work sits on every step's dependent chain)
   return fmx_bits_select(ix.bp, nr, g) + i - fmx_bits_select(ix.b, j, g);
 }
 
@@ -404,9 +446,9 @@ template <int NL = 0>
 __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                       uint32_t &e, uint32_t g) {
   const uint32_t kc = ix.K[c];
-  uint32_t bs, be;
-  const uint32_t js = fmx_bits_rank(ix.b, s, g, bs);  // b.rank1(i)        rlfmi.rs:136
-  const uint32_t je = fmx_bits_rank(ix.b, e, g, be);
+  uint32_t bs, be, nxs, nxe;
+  const uint32_t js = fmx_bits_rank_next(ix.b, s, g, bs, nxs);  // b.rank1(i)        rlfmi.rs:136
+  const uint32_t je = fmx_bits_rank_next(ix.b, e, g, be, nxe);
   const uint32_t los = js - 1u + bs, loe = je - 1u + be;  // b.rank1(i+1) - 1   rlfmi.rs:124
   uint32_t pos[4] = {los, los + 1u, loe, loe + 1u};
   uint32_t r[4];
@@ -417,8 +459,9 @@ __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t
   const bool eqe = (r[3] - r[2]) == 1u;
   uint32_t ns, ne;
   fmx_bits_select2(ix.bp, nrs, nre, g, ns, ne);       // bp.select1(cs[c] + nr)
-  if (eqs) ns = ns + s - fmx_bits_select(ix.b, js, g);  // + i - b.select1(j)   rlfmi.rs:141
-  if (eqe) ne = ne + e - fmx_bits_select(ix.b, je, g);
+  // + i - b.select1(j)   rlfmi.rs:141; the run start usually sits in the record already loaded
+  if (eqs) ns = ns + s - (nxs != 0xFFFFFFFFu ? nxs : fmx_bits_select(ix.b, js, g));
+  if (eqe) ne = ne + e - (nxe != 0xFFFFFFFFu ? nxe : fmx_bits_select(ix.b, je, g));
   s = ns;
   e = ne;
 }

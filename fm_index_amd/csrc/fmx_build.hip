@@ -413,7 +413,7 @@ void split_levels(uint32_t L, uint32_t *nlv, uint32_t *bits) {
 template <typename T>
 int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, DevPool &pool) {
   uint64_t *keys_a, *keys_b;
-  uint32_t *vals_b, *rank, *head;
+  uint32_t *vals_b, *rank = nullptr, *head = nullptr;
   unsigned int *d_ng;
   static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
   auto ts0 = std::chrono::steady_clock::now();
@@ -426,9 +426,9 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   FMX_HIP(pool.get(&keys_a, n));
   FMX_HIP(pool.get(&keys_b, n));
   FMX_HIP(pool.get(&vals_b, n));
-  FMX_HIP(pool.get(&rank, n));
-  FMX_HIP(pool.get(&head, n));
   FMX_HIP(pool.get(&d_ng, 1));
+  // `head` and `rank` live in the radix sort's ALTERNATE buffers, which are free between two sorts
+  // (24 instead of 32 bytes of scratch per symbol); assigned after each sort below
   uint32_t k = 64 / sym_bits;
   if (k > 32) k = 32;
   // temp storage: the larger of the sort and scan requirements
@@ -438,8 +438,8 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     hipcub::DoubleBuffer<uint32_t> vb(d_sa, vals_b);
     FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, kb, vb, (size_t)n, 0, 64,
                                                (hipStream_t)0));
-    FMX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, head, head, MaxOp(), (size_t)n,
-                                              (hipStream_t)0));
+    FMX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                              MaxOp(), (size_t)n, (hipStream_t)0));
   }
   size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
   uint8_t *tmp;
@@ -460,6 +460,8 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
                                                (hipStream_t)0));
     keys_cur = kb.Current(); keys_alt = kb.Alternate();
     sa_cur = vb.Current();   sa_alt = vb.Alternate();
+    head = (uint32_t *)keys_alt;
+    rank = sa_alt;
     FMX_HIP(hipMemsetAsync(d_ng, 0, sizeof(unsigned int), 0));
     hipLaunchKernelGGL(k_flag_heads, dim3(nblocks(n)), dim3(BLK), 0, 0, keys_cur, n, head, d_ng);
     unsigned int dup = 0;
@@ -483,7 +485,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, 0));
   FMX_HIP(hipDeviceSynchronize());
   pool.release(keys_a); pool.release(keys_b); pool.release(vals_b);
-  pool.release(rank); pool.release(head); pool.release(tmp); pool.release(d_ng);
+  pool.release(tmp); pool.release(d_ng);
   return FMX_OK;
 }
 

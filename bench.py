@@ -328,7 +328,8 @@ def main():
                              "ms_per_step": pms, "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
                              "build_ms": round(float(lib.fmx_build_ms(pidx.handle())), 1),
                              "traffic": traffic.get(leg_name, {}).get("bytes"),
-                             "note": leg_note + "; (s,e) identical to the plain-index run"}
+                             "note": leg_note + "; (s,e) identical to the plain-index run; rate of rank 0's "
+                                     "shard alone (not aggregated over ranks)"}
             if not args.no_early_exit and "early_exit" in out:
                 # config 2b patterns (uniform random, mostly absent) through the same index
                 rflat2 = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)

@@ -110,8 +110,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
       pbeg = off[k];
       j = (uint32_t)(off[k + 1] - pbeg);
       if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
-        s = (uint32_t)s0e0[2 * k];
-        e = (uint32_t)s0e0[2 * k + 1];
+        const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
+        s = (uint32_t)s64;
+        e = (uint32_t)e64;
+        if (s64 > ix.n || e64 > ix.n) {                // not a range of this index: refuse, do not read
+          if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+          s = 0; e = 0; j = 0;
+        }
       } else {               // SearchIndexWrapper::search: (0, len)   (wrapper.rs:41)
         s = 0;
         e = ix.n;
@@ -201,8 +206,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         pbeg[q] = off[k[q]];
         j[q] = (uint32_t)(off[k[q] + 1] - pbeg[q]);
         if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
-          s[q] = (uint32_t)s0e0[2 * k[q]];
-          e[q] = (uint32_t)s0e0[2 * k[q] + 1];
+          const uint64_t s64 = s0e0[2 * k[q]], e64 = s0e0[2 * k[q] + 1];
+          s[q] = (uint32_t)s64;
+          e[q] = (uint32_t)e64;
+          if (s64 > n || e64 > n) {                    // not a range of this index: refuse, do not read
+            if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+            s[q] = 0; e[q] = 0; j[q] = 0;
+          }
         } else {               // (0, len)   wrapper.rs:41
           s[q] = 0;
           e[q] = n;
@@ -390,8 +400,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
       pbeg = off[k];
       j = (uint32_t)(off[k + 1] - pbeg);
       if (s0e0) {
-        s = (uint32_t)s0e0[2 * k];
-        e = (uint32_t)s0e0[2 * k + 1];
+        const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
+        s = (uint32_t)s64;
+        e = (uint32_t)e64;
+        if (s64 > n || e64 > n) {                      // not a range of this index: refuse, do not read
+          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+          s = 0; e = 0; j = 0;
+        }
       } else {
         s = 0;
         e = n;
@@ -482,7 +497,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
 template <typename T>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
-    const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos) {
+    const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos, uint64_t total,
+    uint32_t n, uint32_t *status) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,6 +510,14 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
       const uint64_t b = e[k];
       o = off[k];
       cnt = b > a ? b - a : 0;
+      // a range that is not one of this index, or offsets that do not leave room for it: refuse
+      // (row 0 is written so that the walk stays inside the index)
+      if (b > n || o > total || cnt > total - o) {
+        atomicOr(status, 1u << FMX_ERR_ARG);
+        a = 0;
+        cnt = o < total ? (cnt < total - o ? cnt : total - o) : 0;
+        if (cnt > n) cnt = n;
+      }
     }
     if (cnt <= 32) {
       for (uint64_t t = 0; t < cnt; t++) out_pos[o + t] = (T)(a + t);
@@ -526,7 +550,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
   if (w0 >= total) return;                          // wave-uniform
   uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
   uint64_t win_base = w0;
-  uint32_t win = rows[win_base + lane < total ? win_base + lane : total - 1];
+  // rows come from fmx_expand_kernel; a slot no range covered (inconsistent offsets, already
+  // reported through the status word) may hold anything, so keep every row inside the index
+  auto load_row = [&](uint64_t x) -> uint32_t {
+    const uint32_t r = rows[x < total ? x : total - 1];
+    return r < ix.n ? r : 0u;
+  };
+  uint32_t win = load_row(win_base + lane);
   uint64_t h = w0 + grp;
   bool active = h < w1;
   uint32_t row = (uint32_t)__shfl((int)win, (int)grp);
@@ -535,7 +565,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
   while (__any(active)) {
     if (next + 8 > win_base + 64 && next < w1) {    // wave-uniform window refill
       win_base = next;
-      win = rows[win_base + lane < total ? win_base + lane : total - 1];
+      win = load_row(win_base + lane);
     }
     bool fin = false;
     if (active) {
@@ -604,7 +634,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
   uint64_t win_base = w0;
   auto load_win = [&](uint64_t base) -> uint32_t {
     uint64_t x = base + lane;
-    return rows[x < total ? x : total - 1];
+    const uint32_t r = rows[x < total ? x : total - 1];
+    return r < n ? r : 0u;                          // see fmx_locate_kernel: never leave the index
   };
   uint32_t win0 = load_win(win_base), win1 = load_win(win_base + 64);
   auto window = [&](uint64_t hh) -> uint32_t {
@@ -1106,7 +1137,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
-                       d_off, npat, rows);
+                       d_off, npat, rows, total, idx->dev.n, idx->dev.status);
   }
   uint64_t nwaves = (total + 7) / 8;
   const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);

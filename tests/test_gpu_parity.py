@@ -274,3 +274,21 @@ def test_empty_text():
         for p in (b"a", b"", b"ab"):
             s = gi.search(p)
             assert s.get_range() == (0, 0) and s.count() == 0
+
+
+def test_ranges_that_are_not_of_this_index_are_refused():
+    """(s, e) handed to the refinement / locate entry points must be rows of this index; anything
+    else is reported (FMX_ERR_ARG) instead of being dereferenced."""
+    t = W.dna_text_np(5000, 2)
+    idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    n = idx.len()
+    flat, off = F.pack_patterns([bytes([1, 2]), bytes([3])])
+    with pytest.raises(F.Error) as ei:
+        idx.search_many(flat=flat, off=off, s0e0=np.array([0, n, 0, n + 7], dtype=np.uint64))
+    assert ei.value.code == F._lib.ERR_ARG
+    with pytest.raises(F.Error) as ei:
+        idx.locate_many(np.array([10, n - 3], dtype=np.uint64), np.array([12, n + 100], dtype=np.uint64))
+    assert ei.value.code == F._lib.ERR_ARG
+    # the handle keeps working
+    b = idx.search_many(flat=flat, off=off)
+    assert b.counts[0] >= 0 and (b.locate()[1] < n).all()

@@ -129,3 +129,39 @@ def test_kmer_table_generic_kernels(kind, maxc, alphabet, n, k):
         os_, oe = oi.count_batch(fl, of)
         assert (a.s == os_).all() and (a.e == oe).all()
         assert (b.s == os_).all() and (b.e == oe).all()
+
+
+@pytest.mark.parametrize("kind", ["rlfm", "multi"])
+def test_kmer_table_other_kinds_save_load_and_zero_symbols(tmp_path, kind):
+    n = 60000
+    t = ((W.splitmix64_np(31, 0, n) % np.uint64(4)) + np.uint64(1)).astype(np.uint8)
+    if kind == "multi":
+        t[np.arange(501, n - 5, 3001)] = 0
+    else:
+        t = np.repeat(t[: n // 4 + 1], 4)[:n].copy()
+    t[-1] = 0
+    txt = F.Text.with_max_character(t, 4)
+    cls = F.RLFMIndexWithLocate if kind == "rlfm" else F.FMIndexMultiPiecesWithLocate
+    g = cls(txt, 2, kmer_table=True)
+    assert g.kmer_k() == 5
+    oi = O.OracleIndex(t, 4, kind=kind, level=2)
+    pats = [bytes([1, 2, 3, 4, 1, 2, 3]), bytes([2, 2, 2, 2, 2, 2]), bytes([4, 3, 0, 1, 2, 3, 4]),
+            bytes([0]), bytes([1, 0]), bytes([3, 3, 3, 3, 3]), bytes([1, 2, 3, 4])]
+    flat, off = F.pack_patterns(pats)
+    flat2, off2, _ = W.substring_patterns_np(t, 2000, 9, 4)
+    flat3, off3 = W.ragged_patterns_np(2000, 12, 4, 6)
+    g.save(tmp_path / "k.fmx")
+    g2 = cls.load(tmp_path / "k.fmx")
+    assert g2.kmer_k() == 5
+    for fl, of in ((flat, off), (flat2, off2), (flat3, off3)):
+        os_, oe = oi.count_batch(fl, of)
+        for h in (g, g2):
+            b = h.search_many(flat=fl, off=of)
+            assert (b.s == os_).all() and (b.e == oe).all()
+    if kind == "multi":   # the start-of-piece / end-of-piece searches go through s0e0 or the row filter
+        plain = cls(txt, 2)
+        for p in (bytes([1, 2, 3, 4, 1]), bytes([2, 2, 2, 2, 2, 2]), bytes(t[502:510])):
+            assert g.search_prefix(p).count() == plain.search_prefix(p).count()
+            assert g.search_suffix(p).count() == plain.search_suffix(p).count()
+            assert g.search_exact(p).count() == plain.search_exact(p).count()
+            assert sorted(g.search_prefix(p).piece_ids()) == sorted(plain.search_prefix(p).piece_ids())

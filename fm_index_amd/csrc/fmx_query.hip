@@ -518,6 +518,16 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
         cnt = o < total ? (cnt < total - o ? cnt : total - o) : 0;
         if (cnt > n) cnt = n;
       }
+      // offsets that leave a gap (before the first range, between two ranges, behind the last):
+      // reported, and the gap is filled with row 0 so that the walk never sees an unwritten slot
+      uint64_t gap_end = k + 1 < npat ? off[k + 1] : total;
+      if (gap_end > total) gap_end = total;
+      const uint64_t used_end = o < total ? o + cnt : total;
+      if (gap_end > used_end || (k == 0 && o != 0)) {
+        atomicOr(status, 1u << FMX_ERR_ARG);
+        for (uint64_t t = used_end; t < gap_end; t++) out_pos[t] = (T)0;
+        if (k == 0) for (uint64_t t = 0; t < (o < total ? o : total); t++) out_pos[t] = (T)0;
+      }
     }
     if (cnt <= 32) {
       for (uint64_t t = 0; t < cnt; t++) out_pos[o + t] = (T)(a + t);
@@ -550,12 +560,9 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
   if (w0 >= total) return;                          // wave-uniform
   uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
   uint64_t win_base = w0;
-  // rows come from fmx_expand_kernel; a slot no range covered (inconsistent offsets, already
-  // reported through the status word) may hold anything, so keep every row inside the index
-  auto load_row = [&](uint64_t x) -> uint32_t {
-    const uint32_t r = rows[x < total ? x : total - 1];
-    return r < ix.n ? r : 0u;
-  };
+  // rows come from fmx_expand_kernel, which writes every slot (gaps left by inconsistent offsets
+  // are filled with row 0 and reported), so every row is inside the index
+  auto load_row = [&](uint64_t x) -> uint32_t { return rows[x < total ? x : total - 1]; };
   uint32_t win = load_row(win_base + lane);
   uint64_t h = w0 + grp;
   bool active = h < w1;
@@ -634,8 +641,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
   uint64_t win_base = w0;
   auto load_win = [&](uint64_t base) -> uint32_t {
     uint64_t x = base + lane;
-    const uint32_t r = rows[x < total ? x : total - 1];
-    return r < n ? r : 0u;                          // see fmx_locate_kernel: never leave the index
+    return rows[x < total ? x : total - 1];         // every slot was written by fmx_expand_kernel
   };
   uint32_t win0 = load_win(win_base), win1 = load_win(win_base + 64);
   auto window = [&](uint64_t hh) -> uint32_t {

@@ -292,3 +292,20 @@ def test_ranges_that_are_not_of_this_index_are_refused():
     # the handle keeps working
     b = idx.search_many(flat=flat, off=off)
     assert b.counts[0] >= 0 and (b.locate()[1] < n).all()
+
+
+def test_locate_offsets_with_gaps_are_reported_not_walked():
+    t = W.dna_text_np(5000, 2)
+    idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    lib = idx._lib
+    s = np.array([10, 100, 200], dtype=np.uint64)
+    e = np.array([12, 103, 201], dtype=np.uint64)
+    off = np.array([4, 9, 20, 30], dtype=np.uint64)          # gaps before, between and behind
+    pos = np.full(30, 2**64 - 1, dtype=np.uint64)
+    rc = lib.fmx_locate_batch(idx.handle(), F._p(s), F._p(e), 3, F._p(off), F._p(pos))
+    assert rc == F._lib.ERR_ARG
+    # the ranges themselves were still located where the offsets put them
+    oi = O.OracleIndex(t, 4, level=2)
+    assert (pos[4:6] == oi.get_sa(np.array([10, 11], dtype=np.uint64))).all()
+    assert (pos[9:12] == oi.get_sa(np.array([100, 101, 102], dtype=np.uint64))).all()
+    assert (pos < 5000).all()                                  # gap slots hold a valid position (row 0's)

@@ -373,6 +373,16 @@ struct Scratch {  // device buffers freed on scope exit
     return e;
   }
 };
+// End of a host-pointer call: wait for its stream(s) and read the sticky status word through the
+// call's own stream and the thread's pinned staging word -- never through the legacy default
+// stream, which would synchronise with every other blocking stream of the process.
+int finish_host_call(const fmx_index *idx, SmallCtx *sx, hipStream_t other = nullptr) {
+  uint32_t *word = (uint32_t *)sx->h;
+  FMX_HIP(hipMemcpyAsync(word, idx->dev.status, sizeof(uint32_t), hipMemcpyDeviceToHost, sx->st));
+  FMX_HIP(hipStreamSynchronize(sx->st));
+  if (other) FMX_HIP(hipStreamSynchronize(other));
+  return *word ? fmx_stream_status(idx) : FMX_OK;   // reading-and-clearing only when something is set
+}
 }  // namespace
 
 int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_off, uint64_t npat,
@@ -462,9 +472,8 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     if (k) FMX_HIP(download(k - 1));
   }
   FMX_HIP(download(nch - 1));
-  FMX_HIP(hipStreamSynchronize(st[0]));
-  FMX_HIP(hipStreamSynchronize(st[1]));
-  return fmx_stream_status(idx);
+  FMX_HIP(hipStreamSynchronize(st[1]));              // st[0] == sx->st is waited for below
+  return finish_host_call(idx, hc.sx);
 }
 
 int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
@@ -489,8 +498,7 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
     return rc;
   }
   FMX_HIP(hipMemcpyAsync(out_pos, d_pos, b_pos, hipMemcpyDeviceToHost, S));
-  FMX_HIP(hipStreamSynchronize(S));
-  return fmx_stream_status(idx);
+  return finish_host_call(idx, hc.sx);
 }
 
 static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const uint64_t *i,
@@ -528,8 +536,7 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
     return rc;
   }
   FMX_HIP(hipMemcpyAsync(out, d_o, bk, hipMemcpyDeviceToHost, S));
-  FMX_HIP(hipStreamSynchronize(S));
-  return fmx_stream_status(idx);
+  return finish_host_call(idx, hc.sx);
 }
 int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 0, nullptr, i, k, out); }
 int fmx_lf_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 1, nullptr, i, k, out); }
@@ -573,8 +580,7 @@ int fmx_extract_batch(const fmx_index *idx, const uint64_t *rows, uint64_t nrows
   if (b_sym) FMX_HIP(hipMemcpyAsync(out_syms, d_sym, b_sym, hipMemcpyDeviceToHost, S));
   if (out_len) FMX_HIP(hipMemcpyAsync(out_len, d_len, b_rows, hipMemcpyDeviceToHost, S));
   if (out_next) FMX_HIP(hipMemcpyAsync(out_next, d_next, b_rows, hipMemcpyDeviceToHost, S));
-  FMX_HIP(hipStreamSynchronize(S));
-  return fmx_stream_status(idx);
+  return finish_host_call(idx, hc.sx);
 }
 
 // one trait method per call

@@ -24,7 +24,7 @@ def main():
     while time.time() < t_end:
         it += 1
         kind = rng.choice(["fm", "fm", "rlfm", "multi"])
-        n = int(rng.choice([2, 3, 5, 17, 64, 255, 256, 257, 700, 1023, 1024, 1025, 3000, 9000]))
+        n = int(rng.choice([2, 3, 5, 17, 64, 255, 256, 257, 700, 1023, 1024, 1025, 3000, 9000, 20000, 66000]))
         wide = kind != "multi" and rng.random() < 0.2
         if wide:
             alpha = int(rng.choice([3, 40, 300, 5000]))
@@ -54,7 +54,7 @@ def main():
         t[n - 1] = 0
         level = None if rng.random() < 0.2 else int(rng.integers(0, 6))
         pair = kind == "fm" and not wide and maxc <= 4 and rng.random() < 0.5
-        kmer = kind == "fm" and not wide and rng.random() < 0.5      # ignored by the build when maxc > 7
+        kmer = not wide and rng.random() < 0.5      # the build ignores it where it would not pay
         t_or = t if dtype == np.uint8 else t.astype(np.uint32)
         try:
             oi = O.OracleIndex(t_or, maxc, level=level, kind=kind)
@@ -67,11 +67,14 @@ def main():
         elif kind == "rlfm":
             if n < 2:
                 continue
-            gi = F.RLFMIndexWithLocate(text, level) if level is not None else F.RLFMIndex(text)
+            gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer) if level is not None else \
+                F.RLFMIndex(text, kmer_table=kmer)
         else:
-            gi = F.FMIndexMultiPiecesWithLocate(text, level) if level is not None else F.FMIndexMultiPieces(text)
+            gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer) if level is not None else \
+                F.FMIndexMultiPieces(text, kmer_table=kmer)
         stats[kind] += 1
         stats["pair"] += int(pair)
+        stats["kmer"] = stats.get("kmer", 0) + int(gi.kmer_k() > 0)
         stats["wide"] += int(wide)
         # patterns: random ragged + substrings (+ occasional zero symbol)
         npat = 200

@@ -74,3 +74,19 @@ def build_readme_example(tmpdir):
 def test_cpp_host_mirror_compiles_and_links(tmp_path):
     exe = build_readme_example(tmp_path)
     assert os.path.exists(exe)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/fmx.h is the boundary a Rust / C / Go binding generator reads: it must compile as
+    strict C99 on its own (no C++-isms, no HIP or torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "fmx.h"\nint main(void) { return fmx_error_message(0) == 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc,
+                           "-fsyntax-only", str(src)])
+    code = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, "fmx.h")).read(), flags=re.S)
+    assert "torch" not in code and "hipStream_t" not in code and "#include <hip" not in code

@@ -240,6 +240,12 @@ def main():
                 "algorithmic_bytes_per_launch": chars_per_step_rank * bytes_per_char,
                 "algorithmic_bytes_per_char": bytes_per_char,
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
+    if roofline["traffic"]:
+        # what the memory system really moved: measured HBM-side bytes / kernel time (frac above is
+        # the contract's algorithmic-bytes figure and exceeds 1 because one 128-B record answers
+        # what the reference reads three 64-B blocks for)
+        roofline["traffic_rate"] = round(roofline["traffic"] / avg_kernel_s / 1e9, 1)
+        roofline["traffic_frac"] = round(roofline["traffic"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)
 
     out = {
         # BASELINE.json's metric, verbatim; `value` is its count half (pattern-chars/s), the locate

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_kmer_build_kernel(FmxDev ix, ui
 // ---------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------
+// (8 waves per SIMD asked for explicitly: the RLFM instantiations need 65-70 VGPRs otherwise and
+// lose a wave of latency hiding to one register)
 template <int KIND, int NL, bool KM = false>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_kernel(
+__global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
     FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {

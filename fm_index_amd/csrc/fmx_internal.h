@@ -53,7 +53,10 @@ struct FmxBits {
   uint32_t ones;
   uint32_t nsel;
 };
-#define FMX_SEL_STEP 512u
+// one hint per 64 ones: on sparse vectors (long runs) the record search behind a hint is a chain of
+// dependent loads; 512 -> 64 cut the repetitive-text count by 13 % and its locate by 16 % for
+// ones/16 bytes of hints
+#define FMX_SEL_STEP 64u
 #define FMX_BITS_PER_REC 768u
 #define FMX_BITS_PER_PIECE 96u
 

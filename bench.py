@@ -40,6 +40,8 @@ def main():
                     help="dna = config 2/3 (headline); bytes-fm / bytes-rlfm = config 4 text "
                          "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex; rep-* = config 4b: "
                          "1 MiB random block repeated with 1 % point mutations (the case RLFM exists for)")
+    ap.add_argument("--mut-per-1024", type=int, default=10,
+                    help="rep-* workloads: point mutations per 1024 symbols (10 = the 1 %% of config 4b)")
     ap.add_argument("--pair-index", action="store_true",
                     help="also build the opt-in 2-step index (FMX_FLAG_PAIR_INDEX) and report its "
                          "count rate in an extra 'pair_index' object (the headline stays 1-step)")
@@ -98,7 +100,7 @@ def main():
     if dna:
         text = W.dna_text_torch(n, 1, dev)
     elif args.workload.startswith("rep"):
-        text = W.repetitive_text_torch(n, 5, dev, base_len=1 << 20)
+        text = W.repetitive_text_torch(n, 5, dev, base_len=1 << 20, mut_per_1024=args.mut_per_1024)
     else:
         text = W.byte_text_torch(n, 4, dev)
     torch.cuda.synchronize()

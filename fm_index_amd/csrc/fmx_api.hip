@@ -723,13 +723,15 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     out[k++] = {(const void **)&d.b.sel, (uint64_t)d.b.nsel * 4};
     out[k++] = {(const void **)&d.bp.rec, (uint64_t)d.bp.nrec * 128};
     out[k++] = {(const void **)&d.bp.sel, (uint64_t)d.bp.nsel * 4};
+    if (d.b.pos) out[k++] = {(const void **)&d.b.pos, (uint64_t)d.b.ones * 4};
+    if (d.bp.pos) out[k++] = {(const void **)&d.bp.pos, (uint64_t)d.bp.ones * 4};
   }
   if (d.pair_rec) out[k++] = {(const void **)&d.pair_rec, ((uint64_t)d.n / 128 + 1) * 128};
   if (d.kmer) out[k++] = {(const void **)&d.kmer, (1ull << (d.kmer_bits * d.kmer_k)) * 8};
   return k;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 2;   // 2: select hints every 64 ones (was 512)
+const uint32_t kFileVersion = 3;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {

@@ -638,6 +638,19 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   return FMX_OK;
 }
 
+// sparse bit vector (ones <= len/32): keep the positions of its ones for one-load selects
+int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
+  bv->pos = nullptr;
+  if (bv->ones == 0 || (uint64_t)bv->ones * 32u > bv->len) return FMX_OK;
+  if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 16) return FMX_OK;   // measurement: no positions
+  uint32_t *p;
+  FMX_HIP(hipMalloc((void **)&p, (size_t)bv->ones * 4));
+  if (int rc = keep(idx, p, (uint64_t)bv->ones * 4)) return rc;
+  FMX_HIP(hipMemcpy(p, d_pos, (size_t)bv->ones * 4, hipMemcpyDeviceToDevice));
+  bv->pos = p;
+  return FMX_OK;
+}
+
 // RLFMIndexBackend::new (rlfmi.rs:30-96) from the L column (d_L is consumed)
 template <typename T>
 int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
@@ -669,6 +682,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   pool.release(tmp);
   // B (rlfmi.rs:46, 58, 61, 85)
   if (int rc = build_bits(idx, &dv.b, flags, n, pool)) return rc;
+  if (int rc = keep_positions(idx, &dv.b, starts)) return rc;        // run starts = the ones of B
   // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
   std::vector<uint64_t> rcs;
   if (int rc = symbol_histogram<T>(heads, r, maxc, rcs, nullptr, pool)) return rc;
@@ -702,6 +716,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   hipLaunchKernelGGL(k_scatter_ones, dim3(nblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
   FMX_HIP(hipDeviceSynchronize());
   if (int rc = build_bits(idx, &dv.bp, flags, n, pool)) return rc;
+  if (int rc = keep_positions(idx, &dv.bp, fpos)) return rc;         // F positions of the runs = the ones of B'
   pool.release(order); pool.release(order2); pool.release(lens); pool.release(fpos);
   pool.release(hk2); pool.release(stmp); pool.release(etmp); pool.release(flags);
   pool.release(starts);

@@ -353,6 +353,7 @@ __device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
+  if (bv.pos) return bv.pos[k];               // sparse vector: the positions are stored
   uint32_t h = k / FMX_SEL_STEP;
   FMX_CHECK(h + 1 < bv.nsel);
   uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
@@ -379,6 +380,12 @@ __device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0,
                                                  uint32_t g, uint32_t &out0, uint32_t &out1) {
   const bool v0 = k0 < bv.ones, v1 = k1 < bv.ones;
   const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
+  if (bv.pos) {                               // sparse vector: the positions are stored
+    const uint32_t a0 = bv.pos[q0], a1 = bv.pos[q1];
+    out0 = v0 ? a0 : bv.len;
+    out1 = v1 ? a1 : bv.len;
+    return;
+  }
   FMX_CHECK(q0 / FMX_SEL_STEP + 1 < bv.nsel && q1 / FMX_SEL_STEP + 1 < bv.nsel);
   uint32_t lo0 = bv.sel[q0 / FMX_SEL_STEP], hi0 = bv.sel[q0 / FMX_SEL_STEP + 1];
   uint32_t lo1 = bv.sel[q1 / FMX_SEL_STEP], hi1 = bv.sel[q1 / FMX_SEL_STEP + 1];

@@ -133,3 +133,38 @@ def test_config4_shape_byte_text_rlfm():
     gb = gi.search_many(flat=flat_r, off=off_r)
     os_, oe = oi.count_batch(flat_r, off_r, nthreads=8)
     assert (gb.s == os_).all() and (gb.e == oe).all()
+
+
+@pytest.mark.parametrize("runlen", [40, 300, 5000])
+def test_rlfm_long_runs_use_stored_positions(tmp_path, runlen):
+    """B / B' with fewer than one 1 per 32 bits keep the positions of their ones (select = one
+    load); every trait method, count, locate and the saved file must still match the oracle."""
+    n = 120000
+    base = ((W.splitmix64_np(runlen, 0, n // runlen + 2) % np.uint64(5)) + np.uint64(1)).astype(np.uint8)
+    t = np.repeat(base, runlen)[:n].copy()
+    t[-1] = 0
+    gi = F.RLFMIndexWithLocate(F.Text.with_max_character(t, 5), 2)
+    oi = O.OracleIndex(t, 5, kind="rlfm", level=2)
+    rows = np.arange(0, n, 7, dtype=np.uint64)
+    assert (gi.get_l(rows) == oi.get_l(rows)).all()
+    assert (gi.lf_map(rows) == oi.lf_map(rows)).all()
+    assert (gi.get_f(rows) == oi.get_f(rows)).all()
+    assert (gi.fl_map(rows) == oi.fl_map(rows)).all()
+    assert (gi.get_sa(rows[:3000]) == oi.get_sa(rows[:3000])).all()
+    cs = (W.splitmix64_np(3, 0, 4000) % np.uint64(6)).astype(np.uint64)
+    ii = (W.splitmix64_np(4, 0, 4000) % np.uint64(n + 1)).astype(np.uint64)
+    assert (gi.lf_map2(cs, ii) == oi.lf_map2(cs, ii)).all()
+    flat, off = W.ragged_patterns_np(1500, 8, 5, 11)
+    flat2, off2, _ = W.substring_patterns_np(t, 1500, runlen // 10 + 3, 12)
+    for fl, of in ((flat, off), (flat2, off2)):
+        b = gi.search_many(flat=fl, off=of)
+        os_, oe = oi.count_batch(fl, of)
+        assert (b.s == os_).all() and (b.e == oe).all()
+    few = gi.search_many(flat=flat2[: 20 * (runlen // 10 + 3)], off=off2[:21])
+    goff, gpos = few.locate()
+    ooff, opos = oi.locate_batch(few.s, few.e)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    gi.save(tmp_path / "r.fmx")
+    g2 = F.RLFMIndexWithLocate.load(tmp_path / "r.fmx")
+    assert g2.heap_size() == gi.heap_size()
+    assert (g2.lf_map(rows) == oi.lf_map(rows)).all() and (g2.fl_map(rows) == oi.fl_map(rows)).all()

@@ -638,10 +638,11 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   return FMX_OK;
 }
 
-// sparse bit vector (ones <= len/32): keep the positions of its ones for one-load selects
+// sparse bit vector (ones <= len/16, i.e. runs of 16+ on average): keep the positions of its ones
+// for one-load selects (<= len/4 bytes, 1.5 x the rank records of the vector)
 int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
   bv->pos = nullptr;
-  if (bv->ones == 0 || (uint64_t)bv->ones * 32u > bv->len) return FMX_OK;
+  if (bv->ones == 0 || (uint64_t)bv->ones * 16u > bv->len) return FMX_OK;
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 16) return FMX_OK;   // measurement: no positions
   uint32_t *p;
   FMX_HIP(hipMalloc((void **)&p, (size_t)bv->ones * 4));

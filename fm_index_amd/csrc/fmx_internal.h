@@ -48,8 +48,8 @@ struct FmxMwm {
 struct FmxBits {
   const uint4 *rec;
   const uint32_t *sel;  // select hints: record index holding the (k*FMX_SEL_STEP)-th one
-  const uint32_t *pos;  // sparse vectors only (ones <= len/32), else NULL: position of every one,
-                        // so that select1 is ONE load (4 bytes per one <= the bit vector's own size)
+  const uint32_t *pos;  // sparse vectors only (ones <= len/16), else NULL: position of every one,
+                        // so that select1 is ONE load (4 bytes per one <= len/4 bytes)
   uint32_t nrec;
   uint32_t len;
   uint32_t ones;

@@ -713,6 +713,11 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   for (uint32_t l = 0; l < d.bw.nlevels; l++) {
     out[k++] = {(const void **)&d.bw.lv[l].rec, (uint64_t)d.bw.lv[l].nrec * 128};
     out[k++] = {(const void **)&d.bw.lv[l].C, 64};
+    if (d.bw.lv[l].sel) {
+      const uint64_t ncode = d.bw.lv[l].fmt == 3 ? 8 : 16;
+      out[k++] = {(const void **)&d.bw.lv[l].sel, ((uint64_t)d.bw.len / FMX_WSEL_STEP + 2 * ncode + 2) * 4};
+      out[k++] = {(const void **)&d.bw.lv[l].selmeta, 48 * 4};
+    }
   }
   out[k++] = {(const void **)&d.K, ((uint64_t)d.max_character + 1) * 4};
   out[k++] = {(const void **)&d.cs, ((uint64_t)d.max_character + 1) * 4};
@@ -731,7 +736,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   return k;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 3;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors
+const uint32_t kFileVersion = 4;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {
@@ -751,7 +756,7 @@ int fmx_save(const fmx_index *idx, const char *path) {
   FmxDev d = idx->dev;
   bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&d, sizeof d, 1, f) == 1 &&
             fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
-  Blob blobs[40];
+  Blob blobs[64];
   int nb = enumerate_blobs(d, idx->nsamples, blobs);
   std::string buf(kChunk, '\0');
   for (int b = 0; ok && b < nb; b++) {
@@ -785,7 +790,7 @@ int fmx_load(const char *path, int device, fmx_index **out) {
     idx->level_requested = h.level_requested;
     idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
     if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
-    Blob blobs[40];
+    Blob blobs[64];
     int nb = enumerate_blobs(idx->dev, idx->nsamples, blobs);
     for (int b = 0; b < nb; b++) *blobs[b].field = nullptr;  // stale pointers of the saving process
     idx->dev.status = nullptr;

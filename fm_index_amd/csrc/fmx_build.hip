@@ -275,6 +275,50 @@ __global__ __launch_bounds__(BLK) void k_mwm_counters(const uint32_t *__restrict
   rec[t] = p;
 }
 
+// ---- select hints of a wavelet level (fl_map: select_u64, fm_index.rs:118 / rlfmi.rs:166) ----
+template <int FMT>
+__device__ __forceinline__ uint32_t lvl_counter(const uint4 *rec, uint32_t r, uint32_t code) {
+  if (FMT == 3) return rec[(size_t)r * 8u + code].x;
+  const uint4 p = rec[(size_t)r * 8u + (code >> 1)];
+  return (code & 1u) ? p.y : p.x;
+}
+// meta[c] = counter of code c at record 0; meta[32 + c] = entries with code c; meta[16 + c] = start
+// of the code's hints (cnt / STEP + 2 entries each)
+template <int FMT>
+__global__ void k_wsel_meta(const uint4 *__restrict__ rec, const uint32_t *__restrict__ scan,
+                            uint32_t nrec, uint32_t total, uint32_t *__restrict__ meta) {
+  constexpr uint32_t NCODE = (FMT == 3) ? 8u : 16u;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t start = 0;
+  for (uint32_t c = 0; c < 16u; c++) {
+    uint32_t cnt = 0, base = 0;
+    if (c < NCODE) {
+      const uint32_t lo = scan[(size_t)c * nrec];
+      const uint32_t hi = c + 1u < NCODE ? scan[(size_t)(c + 1u) * nrec] : total;
+      cnt = hi - lo;
+      base = lvl_counter<FMT>(rec, 0, c);
+    }
+    meta[c] = base;
+    meta[16u + c] = start;
+    meta[32u + c] = cnt;
+    start += cnt / FMX_WSEL_STEP + 2u;
+  }
+}
+template <int FMT>
+__global__ __launch_bounds__(BLK) void k_wsel_hints(const uint4 *__restrict__ rec, uint32_t nrec,
+                                                     const uint32_t *__restrict__ meta,
+                                                     uint32_t *__restrict__ sel) {
+  constexpr uint32_t NCODE = (FMT == 3) ? 8u : 16u;
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  const uint32_t r = (uint32_t)(t / NCODE), c = (uint32_t)(t % NCODE);
+  if (r >= nrec) return;
+  const uint32_t base = meta[c], cnt = meta[32u + c];
+  const uint32_t a = lvl_counter<FMT>(rec, r, c) - base;
+  const uint32_t b = r + 1u < nrec ? lvl_counter<FMT>(rec, r + 1u, c) - base : cnt;
+  uint32_t m = (a + FMX_WSEL_STEP - 1u) / FMX_WSEL_STEP * FMX_WSEL_STEP;
+  for (; m < b; m += FMX_WSEL_STEP) sel[meta[16u + c] + m / FMX_WSEL_STEP] = r;
+}
+
 // ---- RLFM construction (rlfmi.rs:30-96) --------------------------------------------
 // run starts: c0 starts at 0, a run begins wherever c != c0  (rlfmi.rs:41, 56-59)
 template <typename T>
@@ -493,7 +537,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
 // d_seq is consumed (sorted in place between levels).
 template <typename T>
 int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, DevPool &pool,
-              const uint64_t *single_level_add = nullptr, uint32_t nadd = 0) {
+              const uint64_t *single_level_add = nullptr, uint32_t nadd = 0, bool want_select = true) {
   uint32_t nlv, bits[FMX_MAX_LEVELS];
   split_levels(L, &nlv, bits);
   memset(w, 0, sizeof *w);
@@ -550,6 +594,26 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
     FMX_HIP(hipGetLastError());
     lv.rec = rec;
     lv.C = C;
+    if (want_select) {   // hints for select (the forward / fl_map path)
+      const uint32_t nsel = len / FMX_WSEL_STEP + 2u * ncode + 2u;
+      uint32_t *sel, *meta;
+      FMX_HIP(hipMalloc((void **)&sel, (size_t)nsel * 4));
+      if (int rc = keep(idx, sel, (uint64_t)nsel * 4)) return rc;
+      FMX_HIP(hipMalloc((void **)&meta, 48 * 4));
+      if (int rc = keep(idx, meta, 48 * 4)) return rc;
+      hipLaunchKernelGGL(k_fill_u32, dim3(nblocks(nsel)), dim3(BLK), 0, 0, sel, nsel, lv.nrec - 1);
+      const unsigned hgrid = nblocks((uint64_t)lv.nrec * ncode);
+      if (lv.fmt == 3) {
+        hipLaunchKernelGGL(k_wsel_meta<3>, dim3(1), dim3(1), 0, 0, rec, scan, lv.nrec, len, meta);
+        hipLaunchKernelGGL(k_wsel_hints<3>, dim3(hgrid), dim3(BLK), 0, 0, rec, lv.nrec, meta, sel);
+      } else {
+        hipLaunchKernelGGL(k_wsel_meta<4>, dim3(1), dim3(1), 0, 0, rec, scan, lv.nrec, len, meta);
+        hipLaunchKernelGGL(k_wsel_hints<4>, dim3(hgrid), dim3(BLK), 0, 0, rec, lv.nrec, meta, sel);
+      }
+      FMX_HIP(hipGetLastError());
+      lv.sel = sel;
+      lv.selmeta = meta;
+    }
     if (l + 1 < nlv) {
       // stable sort of the whole sequence by this level's code -> order of the next level
       size_t sb = 0;
@@ -946,7 +1010,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     uint32_t sp[2];
     FMX_HIP(hipMemcpy(sp, d_sp, sizeof sp, hipMemcpyDeviceToHost));
     FmxMwm pw;
-    if (int rc = build_mwm<uint8_t>(idx, &pw, d_b2, n, 4, pool, k2, 16)) return rc;
+    if (int rc = build_mwm<uint8_t>(idx, &pw, d_b2, n, 4, pool, k2, 16, false)) return rc;   // never selected
     dv.pair_rec = pw.lv[0].rec;
     dv.pair_row0 = sp[0];
     dv.pair_row1 = sp[1];

@@ -251,6 +251,12 @@ __device__ __forceinline__ uint32_t fmx_level_counter(const FmxLevel &L, uint32_
 __device__ __forceinline__ uint32_t fmx_level_select(const FmxLevel &L, uint32_t code,
                                                      uint32_t target, uint32_t g) {
   uint32_t lo = 0, hi = L.nrec - 1u;
+  if (L.sel) {       // hints: the records of the entries just below and above the target
+    const uint32_t base = L.selmeta[code], start = L.selmeta[16u + code];
+    const uint32_t t = (target - base) / FMX_WSEL_STEP;
+    const uint32_t a = L.sel[start + t], b = L.sel[start + t + 1u];
+    if (a <= b && b < L.nrec) { lo = a; hi = b; }
+  }
   while (lo < hi) {  // last record whose counter <= target
     const uint32_t mid = (lo + hi + 1u) >> 1;
     if (fmx_level_counter(L, mid, code) <= target) lo = mid; else hi = mid - 1u;

@@ -33,7 +33,13 @@ struct FmxLevel {
   uint32_t shift;     // code = (sym >> shift) & mask
   uint32_t mask;
   uint32_t nrec;
+  // select hints (fl_map / iter_chars_forward): for code c, selmeta[c] = its counter at record 0,
+  // selmeta[16 + c] = start of its hints in sel[], selmeta[32 + c] = its number of entries;
+  // sel[start + j] = record holding the code's (j * FMX_WSEL_STEP)-th entry.  NULL = none built.
+  const uint32_t *sel;
+  const uint32_t *selmeta;
 };
+#define FMX_WSEL_STEP 128u
 
 struct FmxMwm {
   FmxLevel lv[FMX_MAX_LEVELS];
@@ -101,7 +107,7 @@ struct fmx_index {
   uint64_t runs;
   double build_ms;
   // owned device allocations
-  void *d_alloc[64];
+  void *d_alloc[96];
   int nalloc;
   uint64_t *h_cs;        // character-based C array (sais.rs:9-32), host copy
   uint8_t *d_text;       // FMX_FLAG_KEEP_SA
@@ -125,7 +131,7 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
 int fmx_build_impl(fmx_index *idx, const void *d_text);
 // registers a device allocation owned by the index (freed by fmx_free, counted in index bytes)
 static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
-  if (idx->nalloc >= 64) return FMX_ERR_ARG;
+  if (idx->nalloc >= 96) return FMX_ERR_ARG;
   idx->d_alloc[idx->nalloc++] = p;
   idx->bytes += bytes;
   return FMX_OK;

@@ -162,3 +162,34 @@ def test_large_host_pointer_batch_is_chunked_consistently():
     # and the handle still works afterwards
     again = idx.search_many(flat=flat, off=off)
     assert (again.counts == big.counts).all()
+
+
+def test_concurrent_builds_and_queries_in_threads():
+    """Builds are not required to run in parallel, but several host threads building and querying
+    their own indexes at the same time must all get the right answers."""
+    texts = [W.dna_text_np(30000 + 1111 * k, 50 + k) for k in range(4)]
+    oracles = [O.OracleIndex(t, 4, level=2) for t in texts]
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                t = texts[k]
+                idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, kmer_table=bool(rep & 1))
+                flat, off, _ = W.substring_patterns_np(t, 500, 9, 7 + rep)
+                b = idx.search_many(flat=flat, off=off)
+                os_, oe = oracles[k].count_batch(flat, off)
+                assert (b.s == os_).all() and (b.e == oe).all()
+                goff, gpos = b.locate()
+                ooff, opos = oracles[k].locate_batch(b.s, b.e)
+                assert (goff == ooff).all() and (gpos == opos).all()
+                idx.close()
+        except Exception as ex:   # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

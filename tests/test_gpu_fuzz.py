@@ -1,5 +1,6 @@
 """Short run of the differential soak test (tests/fuzz_gpu_vs_oracle.py); run that script
-directly with a larger time budget for a real soak (4 minutes / 171 index builds were clean)."""
+directly with a larger time budget for a real soak (about 1 600 random index builds over 25 seeds
+were clean on the final build)."""
 import os
 import subprocess
 import sys

@@ -728,6 +728,8 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     out[k++] = {(const void **)&d.b.sel, (uint64_t)d.b.nsel * 4};
     out[k++] = {(const void **)&d.bp.rec, (uint64_t)d.bp.nrec * 128};
     out[k++] = {(const void **)&d.bp.sel, (uint64_t)d.bp.nsel * 4};
+    if (d.b.dsel) out[k++] = {(const void **)&d.b.dsel, (((uint64_t)d.b.ones + 63) / 64) * 16};
+    if (d.bp.dsel) out[k++] = {(const void **)&d.bp.dsel, (((uint64_t)d.bp.ones + 63) / 64) * 16};
     if (d.b.pos) out[k++] = {(const void **)&d.b.pos, (uint64_t)d.b.ones * 4};
     if (d.bp.pos) out[k++] = {(const void **)&d.bp.pos, (uint64_t)d.bp.ones * 4};
   }
@@ -736,7 +738,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   return k;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 4;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints
+const uint32_t kFileVersion = 5;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {

@@ -702,6 +702,40 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   return FMX_OK;
 }
 
+// dense bit vector (ones >= len/2): select blocks, one per 64 ones (FmxBits::dsel)
+__global__ __launch_bounds__(BLK) void k_dense_select_blocks(const uint8_t *__restrict__ flags,
+                                                              const uint32_t *__restrict__ pos,
+                                                              uint32_t ones, uint32_t len,
+                                                              uint4 *__restrict__ out) {
+  const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  const uint64_t nblk = ((uint64_t)ones + 63u) / 64u;
+  if (j >= nblk) return;
+  const uint32_t first = pos[j * 64u];
+  const uint64_t lastk = j * 64u + 63u < ones ? j * 64u + 63u : (uint64_t)ones - 1u;
+  const uint32_t last = pos[lastk];
+  if (last - first >= 96u) { out[j] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); return; }
+  uint32_t w[3] = {0u, 0u, 0u};
+  for (uint32_t b = 0; b < 96u; b++) {
+    const uint64_t p = (uint64_t)first + b;
+    if (p < len && flags[p]) w[b >> 5] |= 1u << (b & 31u);
+  }
+  out[j] = make_uint4(first, w[0], w[1], w[2]);
+}
+int keep_dense_select(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, const uint32_t *d_pos) {
+  bv->dsel = nullptr;
+  if (bv->ones == 0 || (uint64_t)bv->ones * 2u < bv->len) return FMX_OK;
+  if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 17) return FMX_OK;   // measurement: no blocks
+  const uint64_t nblk = ((uint64_t)bv->ones + 63u) / 64u;
+  uint4 *d;
+  FMX_HIP(hipMalloc((void **)&d, nblk * 16));
+  if (int rc = keep(idx, d, nblk * 16)) return rc;
+  hipLaunchKernelGGL(k_dense_select_blocks, dim3(nblocks(nblk)), dim3(BLK), 0, 0, d_flags, d_pos, bv->ones,
+                     bv->len, d);
+  FMX_HIP(hipGetLastError());
+  bv->dsel = d;
+  return FMX_OK;
+}
+
 // sparse bit vector (ones <= len/16, i.e. runs of 16+ on average): keep the positions of its ones
 // for one-load selects (<= len/4 bytes, 1.5 x the rank records of the vector)
 int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
@@ -748,6 +782,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   // B (rlfmi.rs:46, 58, 61, 85)
   if (int rc = build_bits(idx, &dv.b, flags, n, pool)) return rc;
   if (int rc = keep_positions(idx, &dv.b, starts)) return rc;        // run starts = the ones of B
+  if (int rc = keep_dense_select(idx, &dv.b, flags, starts)) return rc;
   // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
   std::vector<uint64_t> rcs;
   if (int rc = symbol_histogram<T>(heads, r, maxc, rcs, nullptr, pool)) return rc;
@@ -782,6 +817,8 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   FMX_HIP(hipDeviceSynchronize());
   if (int rc = build_bits(idx, &dv.bp, flags, n, pool)) return rc;
   if (int rc = keep_positions(idx, &dv.bp, fpos)) return rc;         // F positions of the runs = the ones of B'
+  if (int rc = keep_dense_select(idx, &dv.bp, flags, fpos)) return rc;
+  FMX_HIP(hipDeviceSynchronize());                                   // flags / fpos are released below
   pool.release(order); pool.release(order2); pool.release(lens); pool.release(fpos);
   pool.release(hk2); pool.release(stmp); pool.release(etmp); pool.release(flags);
   pool.release(starts);

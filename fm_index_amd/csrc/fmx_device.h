@@ -356,10 +356,23 @@ __device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32
   next = fmx_group_min(cand);
   return fmx_group_sum(mine * (pc.x + c));
 }
+// dense-vector select block: position of one number (k & 63) inside the block's 96-bit window
+__device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k) {
+  const uint32_t r = k & 63u, c0 = __popc(blk.y), c1 = __popc(blk.z);
+  uint32_t off;
+  if (r < c0) off = fmx_select32(blk.y, r);
+  else if (r < c0 + c1) off = 32u + fmx_select32(blk.z, r - c0);
+  else off = 64u + fmx_select32(blk.w, r - c0 - c1);
+  return blk.x + off;
+}
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
   if (bv.pos) return bv.pos[k];               // sparse vector: the positions are stored
+  if (bv.dsel) {                              // dense vector: one 16-byte block answers it
+    const uint4 blk = bv.dsel[k >> 6];
+    if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k);
+  }
   uint32_t h = k / FMX_SEL_STEP;
   FMX_CHECK(h + 1 < bv.nsel);
   uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
@@ -391,6 +404,14 @@ __device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0,
     out0 = v0 ? a0 : bv.len;
     out1 = v1 ? a1 : bv.len;
     return;
+  }
+  if (bv.dsel) {                              // dense vector: one 16-byte block per end
+    const uint4 b0 = bv.dsel[q0 >> 6], b1 = bv.dsel[q1 >> 6];
+    if (b0.x != 0xFFFFFFFFu && b1.x != 0xFFFFFFFFu) {
+      out0 = v0 ? fmx_dsel_pos(b0, q0) : bv.len;
+      out1 = v1 ? fmx_dsel_pos(b1, q1) : bv.len;
+      return;
+    }
   }
   FMX_CHECK(q0 / FMX_SEL_STEP + 1 < bv.nsel && q1 / FMX_SEL_STEP + 1 < bv.nsel);
   uint32_t lo0 = bv.sel[q0 / FMX_SEL_STEP], hi0 = bv.sel[q0 / FMX_SEL_STEP + 1];

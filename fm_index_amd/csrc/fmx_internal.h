@@ -54,6 +54,9 @@ struct FmxMwm {
 struct FmxBits {
   const uint4 *rec;
   const uint32_t *sel;  // select hints: record index holding the (k*FMX_SEL_STEP)-th one
+  const uint4 *dsel;    // dense vectors only (ones >= len/2), else NULL: one 16-byte block per 64 ones =
+                        // { position of the block's first one, the 96 bits from there }, so that select1
+                        // is ONE load (x == 0xFFFFFFFF: the 64 ones do not fit, use the records)
   const uint32_t *pos;  // sparse vectors only (ones <= len/16), else NULL: position of every one,
                         // so that select1 is ONE load (4 bytes per one <= len/4 bytes)
   uint32_t nrec;

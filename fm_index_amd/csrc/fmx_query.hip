@@ -27,7 +27,7 @@
 //   6          ignore the k-mer start table even when it was built
 //   7          ignore the pair index even when it was built
 //   8, 9       measurement only: lane-per-pattern / wavefront-per-pattern count kernels
-//   16         (builder) do not store the positions of sparse RLFM bit vectors
+//   16, 17     (builder) do not store the positions of sparse / the select blocks of dense RLFM bit vectors
 static inline int fmx_variant() {
   static const int cached = [] {
     const char *v = getenv("FMX_VARIANT");

@@ -394,37 +394,44 @@ __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t 
   return lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
 }
 
-// two selects on the same vector, probes interleaved (hints, then records)
-__device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0, uint32_t k1,
-                                                 uint32_t g, uint32_t &out0, uint32_t &out1) {
-  const bool v0 = k0 < bv.ones, v1 = k1 < bv.ones;
+// two selects at once, on two vectors of the same index (B and B' always fall into the same
+// density class) or twice on one: every stage -- positions / select blocks / hint words, record
+// searches, records -- is issued for both before either is consumed, so their latencies overlap.
+// SM fixes the structure at compile time (the hot kernels are instantiated per structure, so their
+// loops hold no branch on it): 1 = stored positions, 2 = select blocks, 0 = hints + records,
+// -1 = decide at run time.
+template <int SM = -1>
+__device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k0, const FmxBits &B,
+                                                    uint32_t k1, uint32_t g, uint32_t &out0,
+                                                    uint32_t &out1) {
+  const bool v0 = k0 < A.ones, v1 = k1 < B.ones;
   const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
-  if (bv.pos) {                               // sparse vector: the positions are stored
-    const uint32_t a0 = bv.pos[q0], a1 = bv.pos[q1];
-    out0 = v0 ? a0 : bv.len;
-    out1 = v1 ? a1 : bv.len;
+  if (SM == 1 || (SM < 0 && A.pos && B.pos)) {   // sparse vectors: the positions are stored
+    const uint32_t a0 = A.pos[q0], a1 = B.pos[q1];
+    out0 = v0 ? a0 : A.len;
+    out1 = v1 ? a1 : B.len;
     return;
   }
-  if (bv.dsel) {                              // dense vector: one 16-byte block per end
-    const uint4 b0 = bv.dsel[q0 >> 6], b1 = bv.dsel[q1 >> 6];
+  if (SM == 2 || (SM < 0 && A.dsel && B.dsel)) {   // dense vectors: one 16-byte block per select
+    const uint4 b0 = A.dsel[q0 >> 6], b1 = B.dsel[q1 >> 6];
     if (b0.x != 0xFFFFFFFFu && b1.x != 0xFFFFFFFFu) {
-      out0 = v0 ? fmx_dsel_pos(b0, q0) : bv.len;
-      out1 = v1 ? fmx_dsel_pos(b1, q1) : bv.len;
+      out0 = v0 ? fmx_dsel_pos(b0, q0) : A.len;
+      out1 = v1 ? fmx_dsel_pos(b1, q1) : B.len;
       return;
     }
   }
-  FMX_CHECK(q0 / FMX_SEL_STEP + 1 < bv.nsel && q1 / FMX_SEL_STEP + 1 < bv.nsel);
-  uint32_t lo0 = bv.sel[q0 / FMX_SEL_STEP], hi0 = bv.sel[q0 / FMX_SEL_STEP + 1];
-  uint32_t lo1 = bv.sel[q1 / FMX_SEL_STEP], hi1 = bv.sel[q1 / FMX_SEL_STEP + 1];
-  FMX_CHECK(hi0 < bv.nrec && hi1 < bv.nrec);
+  FMX_CHECK(q0 / FMX_SEL_STEP + 1 < A.nsel && q1 / FMX_SEL_STEP + 1 < B.nsel);
+  uint32_t lo0 = A.sel[q0 / FMX_SEL_STEP], hi0 = A.sel[q0 / FMX_SEL_STEP + 1];
+  uint32_t lo1 = B.sel[q1 / FMX_SEL_STEP], hi1 = B.sel[q1 / FMX_SEL_STEP + 1];
+  FMX_CHECK(hi0 < A.nrec && hi1 < B.nrec);
   while (lo0 < hi0 || lo1 < hi1) {  // group-uniform binary searches over record bases
     const uint32_t m0 = (lo0 + hi0 + 1u) >> 1, m1 = (lo1 + hi1 + 1u) >> 1;
-    const uint32_t x0 = bv.rec[(size_t)m0 * 8u].x, x1 = bv.rec[(size_t)m1 * 8u].x;
+    const uint32_t x0 = A.rec[(size_t)m0 * 8u].x, x1 = B.rec[(size_t)m1 * 8u].x;
     if (lo0 < hi0) { if (x0 <= q0) lo0 = m0; else hi0 = m0 - 1u; }
     if (lo1 < hi1) { if (x1 <= q1) lo1 = m1; else hi1 = m1 - 1u; }
   }
-  const uint4 a = bv.rec[(size_t)lo0 * 8u + g];
-  const uint4 b = bv.rec[(size_t)lo1 * 8u + g];
+  const uint4 a = A.rec[(size_t)lo0 * 8u + g];
+  const uint4 b = B.rec[(size_t)lo1 * 8u + g];
   uint32_t res[2];
 #pragma unroll
   for (int t = 0; t < 2; t++) {
@@ -440,8 +447,13 @@ __device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0,
     pos = fmx_group_sum((g == p) ? pos : 0u);
     res[t] = lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
   }
-  out0 = v0 ? res[0] : bv.len;
-  out1 = v1 ? res[1] : bv.len;
+  out0 = v0 ? res[0] : A.len;
+  out1 = v1 ? res[1] : B.len;
+}
+template <int SM = -1>
+__device__ __forceinline__ void fmx_bits_select2(const FmxBits &bv, uint32_t k0, uint32_t k1,
+                                                 uint32_t g, uint32_t &out0, uint32_t &out1) {
+  fmx_bits_select_two<SM>(bv, k0, bv, k1, g, out0, out1);
 }
 
 // RLFMIndexBackend::lf_map2 (rlfmi.rs:135-143)
@@ -457,7 +469,7 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map2(const FmxDev &ix, uint32_t 
   return r;
 }
 // RLFMIndexBackend::get_l + lf_map (rlfmi.rs:122-133)
-template <int NL = 0>
+template <int NL = 0, int SM = -1>
 __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i, uint32_t g,
                                                     uint32_t &sym) {
   uint32_t bi;
@@ -467,7 +479,9 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i
   // (taking the run start from the B record already loaded, as fmx_rlfm_lf_map2_pair does, was
   // measured here too: the locate walk got 10 % slower -- its two selects overlap anyway and the
   // extra lane work sits on every step's dependent chain)
-  return fmx_bits_select(ix.bp, nr, g) + i - fmx_bits_select(ix.b, j, g);
+  uint32_t f, st;
+  fmx_bits_select_two<SM>(ix.bp, nr, ix.b, j, g, f, st);   // bp.select1(nr), b.select1(j) -- overlapped
+  return f + i - st;
 }
 
 // both interval ends of one backward-search step on the RLFM index, staged so that the
@@ -476,7 +490,7 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lf_map(const FmxDev &ix, uint32_t i
 // (the run holding row i) it is  s.rank(lo+1, c) - s.rank(lo, c) == 1, and b.rank1(i) is lo or
 // lo+1, so one rank chain over the adjacent positions {lo, lo+1} yields nr and the comparison
 // from the same cache lines.
-template <int NL = 0>
+template <int NL = 0, int SM = -1>
 __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                       uint32_t &e, uint32_t g) {
   const uint32_t kc = ix.K[c];
@@ -492,7 +506,7 @@ __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t
   const bool eqs = (r[1] - r[0]) == 1u;               // get_l(i) == c          rlfmi.rs:138
   const bool eqe = (r[3] - r[2]) == 1u;
   uint32_t ns, ne;
-  fmx_bits_select2(ix.bp, nrs, nre, g, ns, ne);       // bp.select1(cs[c] + nr)
+  fmx_bits_select2<SM>(ix.bp, nrs, nre, g, ns, ne);   // bp.select1(cs[c] + nr)
   // + i - b.select1(j)   rlfmi.rs:141; the run start usually sits in the record already loaded
   if (eqs) ns = ns + s - (nxs != 0xFFFFFFFFu ? nxs : fmx_bits_select(ix.b, js, g));
   if (eqe) ne = ne + e - (nxe != 0xFFFFFFFFu ? nxe : fmx_bits_select(ix.b, je, g));
@@ -535,7 +549,7 @@ __device__ __forceinline__ uint32_t fmx_fl_map_any(const FmxDev &ix, uint32_t i,
 __device__ __forceinline__ uint32_t fmx_multi_zero(const FmxDev &ix, uint32_t i, uint32_t rank0) {
   return i < ix.first_row ? rank0 + 1u : (i == ix.first_row ? 0u : rank0);
 }
-template <int KIND, int NL = 0>
+template <int KIND, int NL = 0, int SM = -1>
 __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, uint32_t &s,
                                                  uint32_t &e, uint32_t g) {
   if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
@@ -550,10 +564,10 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
     s = kc + rs;  // fm_index.rs:93-95
     e = kc + re;
   } else {
-    fmx_rlfm_lf_map2_pair<NL>(ix, c, s, e, g);
+    fmx_rlfm_lf_map2_pair<NL, SM>(ix, c, s, e, g);
   }
 }
-template <int KIND, int NL = 0>
+template <int KIND, int NL = 0, int SM = -1>
 __device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
                                                    uint32_t &sym) {
   if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {
@@ -562,6 +576,6 @@ __device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i,
     if (KIND == FMX_KIND_MULTI && sym == 0u) r = fmx_multi_zero(ix, i, r);  // multi_pieces.rs:131-137
     return r;
   } else {
-    return fmx_rlfm_lf_map<NL>(ix, i, g, sym);
+    return fmx_rlfm_lf_map<NL, SM>(ix, i, g, sym);
   }
 }

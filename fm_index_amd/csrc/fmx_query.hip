@@ -90,7 +90,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_kmer_build_kernel(FmxDev ix, ui
 // ---------------------------------------------------------------------------
 // (8 waves per SIMD asked for explicitly: the RLFM instantiations need 65-70 VGPRs otherwise and
 // lose a wave of latency hiding to one register)
-template <int KIND, int NL, bool KM = false>
+template <int KIND, int NL, bool KM = false, int SM = -1>
 __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
     FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
       } else {
         // the next symbol rides along with this step's record loads
         const uint32_t cn = j > 1 ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
-        fmx_lf_map2_pair<KIND, NL>(ix, c, s, e, g);    // wrapper.rs:109-110
+        fmx_lf_map2_pair<KIND, NL, SM>(ix, c, s, e, g);   // wrapper.rs:109-110
         c = cn;
         j--;
         nsteps++;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
 // generic locate walk (any kind / any number of levels): same wave-level dynamic hit assignment
 // and register row window as fmx_locate_f3w_kernel below; one LF step = fmx_lf_map_any (several
 // dependent probes), the sample read is a plain dependent load.
-template <int KIND, int NL>
+template <int KIND, int NL, int SM = -1>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
     FmxDev ix, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
       } else {
         // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
         uint32_t sym;
-        row = fmx_lf_map_any<KIND, NL>(ix, row, g, sym);
+        row = fmx_lf_map_any<KIND, NL, SM>(ix, row, g, sym);
         steps++;
         nsteps++;
       }
@@ -1093,24 +1093,28 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     }
   } else {
     // number of wavelet levels fixed at compile time for the common cases (1, 2), runtime otherwise
-#define FMX_COUNT_LAUNCH(KIND, NL)                                                                  \
+#define FMX_COUNT_LAUNCH(KIND, NL, SM)                                                              \
   do {                                                                                              \
     if (km && idx->sym_bytes == 1)                                                                  \
-      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true>), dim3(grid), dim3(FMX_BLOCK), 0, st,     \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
                          idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
     else                                                                                            \
-      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false>), dim3(grid), dim3(FMX_BLOCK), 0, st,    \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
                          idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
   } while (0)
-#define FMX_COUNT_KIND(KIND)                                                                        \
+#define FMX_COUNT_KIND(KIND, SM)                                                                    \
   do {                                                                                              \
-    if (w.nlevels == 1) FMX_COUNT_LAUNCH(KIND, 1);                                                  \
-    else if (w.nlevels == 2) FMX_COUNT_LAUNCH(KIND, 2);                                             \
-    else FMX_COUNT_LAUNCH(KIND, 0);                                                                 \
+    if (w.nlevels == 1) FMX_COUNT_LAUNCH(KIND, 1, SM);                                              \
+    else if (w.nlevels == 2) FMX_COUNT_LAUNCH(KIND, 2, SM);                                         \
+    else FMX_COUNT_LAUNCH(KIND, 0, SM);                                                             \
   } while (0)
-    if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM);
-    else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI);
-    else FMX_COUNT_KIND(FMX_KIND_RLFM);
+    // RLFM: the select structure of B / B' (positions, select blocks, hints + records) is fixed at
+    // compile time as well, so the search loop holds no branch on it
+    if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
+    else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI, -1);
+    else if (idx->dev.b.pos && idx->dev.bp.pos) FMX_COUNT_KIND(FMX_KIND_RLFM, 1);
+    else if (idx->dev.b.dsel && idx->dev.bp.dsel) FMX_COUNT_KIND(FMX_KIND_RLFM, 2);
+    else FMX_COUNT_KIND(FMX_KIND_RLFM, 0);
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
@@ -1172,18 +1176,20 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                      idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hp, rows, d_pos, steps)
     if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
   } else {
-#define FMX_LOCATE_LAUNCH(KIND, NL)                                                                 \
-  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, total, \
-                     hpw, rows, d_pos, steps)
-#define FMX_LOCATE_KIND(KIND)                                                                       \
+#define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
+  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, \
+                     total, hpw, rows, d_pos, steps)
+#define FMX_LOCATE_KIND(KIND, SM)                                                                   \
   do {                                                                                              \
-    if (w.nlevels == 1) FMX_LOCATE_LAUNCH(KIND, 1);                                                 \
-    else if (w.nlevels == 2) FMX_LOCATE_LAUNCH(KIND, 2);                                            \
-    else FMX_LOCATE_LAUNCH(KIND, 0);                                                                \
+    if (w.nlevels == 1) FMX_LOCATE_LAUNCH(KIND, 1, SM);                                             \
+    else if (w.nlevels == 2) FMX_LOCATE_LAUNCH(KIND, 2, SM);                                        \
+    else FMX_LOCATE_LAUNCH(KIND, 0, SM);                                                            \
   } while (0)
-    if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM);
-    else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI);
-    else FMX_LOCATE_KIND(FMX_KIND_RLFM);
+    if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
+    else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);
+    else if (idx->dev.b.pos && idx->dev.bp.pos) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);
+    else if (idx->dev.b.dsel && idx->dev.bp.dsel) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
+    else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());

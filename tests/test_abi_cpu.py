@@ -71,6 +71,23 @@ def build_readme_example(tmpdir):
     return exe
 
 
+def build_c_example(tmpdir):
+    """gcc (C99) build of tests/c/abi_example.c against libfmx.so: the ABI from plain C."""
+    import subprocess
+    from fm_index_amd import _lib
+    exe = os.path.join(str(tmpdir), "abi_example")
+    subprocess.check_call([
+        "gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "c", "abi_example.c"), "-o", exe,
+        "-L" + os.path.dirname(_lib.LIB_PATH), "-lfmx",
+        "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    return exe
+
+
+def test_plain_c_program_compiles_and_links(tmp_path):
+    assert os.path.exists(build_c_example(tmp_path))
+
+
 def test_cpp_host_mirror_compiles_and_links(tmp_path):
     exe = build_readme_example(tmp_path)
     assert os.path.exists(exe)

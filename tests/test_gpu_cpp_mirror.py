@@ -3,7 +3,7 @@ import subprocess
 
 import pytest
 
-from test_abi_cpu import build_readme_example
+from test_abi_cpu import build_c_example, build_readme_example
 
 pytestmark = pytest.mark.gpu
 
@@ -26,3 +26,10 @@ def test_readme_example_cpp(golden, tmp_path):
     assert lines[6] == "suffix 0 1 2"                       # examples/multi_pieces.rs:80-87
     assert lines[7] == "prefix 0"                           # examples/multi_pieces.rs:70-77
     assert lines[8] == "error invalid text: the given text must end with exactly one zero character"
+
+
+def test_plain_c_example_runs(tmp_path):
+    """tests/c/abi_example.c: build, count, locate and extract through the ABI from a C99 program."""
+    out = subprocess.run([build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok len=12 ")

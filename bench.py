@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on MI355X: pattern-chars/s of batched backward search
-(count) on a 1 GB sigma=4 DNA text (config 2: FMIndex, 1 Mi length-32 patterns that are
-substrings of the text, so all 32 steps execute), plus locate hits/s (config 3) as an
-extra field.  One process per GPU; for N > 1 the patterns are sharded contiguously
-(N x 1 Mi patterns, weak scaling), the index is replicated, and the counts are gathered
-with one RCCL all-gather inside the timed region (config 5).
+"""bench.py -- BASELINE.json's metric on MI355X: pattern-chars/s of batched backward search
+(count) on a 1 GB sigma=4 DNA text (config 2: FMIndex, 2^20 length-32 patterns that are
+substrings of the text, so all 32 steps execute) as `value`, with every other BASELINE config in
+the same line: `locate` (config 3), `locate_3b` (64 K short patterns, wide intervals), `rlfm`
+(config 4: RLFMIndex over a 1 GB sigma=255 byte text, 2^20 length-16 patterns, with its own
+roofline and CPU baseline), `value_incl_d2h` (the same batch through the host-pointer entry point)
+and, with --gpus N, config 5: N x 2^20 patterns sharded over N ranks, index replicated, counts and
+positions gathered over RCCL inside the timed region.
 
-A "step" = one pass of the count kernel over this rank's pattern batch, inputs and
-outputs resident in HBM.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU, before anything touches
+the GPU); under `python -m torch.distributed.run` it is one of the ranks.  A "step" = one pass of
+the count kernel over this rank's pattern batch, inputs and outputs resident in HBM.  Rank 0
+prints ONE JSON line.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes: one 512-bit block per level per endpoint
-BYTES_PER_CHAR_L3 = 2 * 3 * 64      # 384 B per executed backward-search step at L = 3
-HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
+GATHER_CEILING_GLINES = 55.0  # profiles/microbench/gather_r02.txt: dependent random lines the memory
+#                               system sustains (16..128-byte requests alike, 128 MiB..2 GiB tables)
+LINE = 128
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -32,47 +42,445 @@ def main():
     ap.add_argument("--log2n", type=int, default=30, help="text length 2^k incl. terminator")
     ap.add_argument("--npat", type=int, default=1 << 20, help="patterns per GPU")
     ap.add_argument("--plen", type=int, default=32)
-    ap.add_argument("--level", type=int, default=2, help="SA sampling level for the locate leg")
+    ap.add_argument("--level", type=int, default=2, help="SA sampling level for the locate legs")
+    ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm", "rep-fm", "rep-rlfm"],
+                    help="headline workload: dna = config 2/3/5; bytes-rlfm = config 4 as the headline "
+                         "(the default run reports it in the `rlfm` object); bytes-fm = FMIndex on the "
+                         "config-4 text; rep-* = config 4b: 1 MiB random block repeated with point mutations")
+    ap.add_argument("--mut-per-1024", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-locate", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm", "rep-fm", "rep-rlfm"],
-                    help="dna = config 2/3 (headline); bytes-fm / bytes-rlfm = config 4 text "
-                         "(sigma=255, L=8, len-16 patterns) on FMIndex / RLFMIndex; rep-* = config 4b: "
-                         "1 MiB random block repeated with 1 % point mutations (the case RLFM exists for)")
-    ap.add_argument("--mut-per-1024", type=int, default=10,
-                    help="rep-* workloads: point mutations per 1024 symbols (10 = the 1 %% of config 4b)")
-    ap.add_argument("--pair-index", action="store_true",
-                    help="also build the opt-in 2-step index (FMX_FLAG_PAIR_INDEX) and report its "
-                         "count rate in an extra 'pair_index' object (the headline stays 1-step)")
-    ap.add_argument("--kmer-table", action="store_true",
-                    help="also build the opt-in k-mer start table (FMX_FLAG_KMER_TABLE) and report "
-                         "its count rate in 'kmer_table' (and with --pair-index the combination in "
-                         "'kmer_table+pair_index'); the headline stays the plain index")
-    ap.add_argument("--no-accel", action="store_true",
-                    help="skip the extra legs that time the opt-in indexes (pair index, k-mer start table); "
-                         "by default they are built and reported next to the plain-index headline")
-    ap.add_argument("--no-early-exit", action="store_true",
-                    help="skip the config-2b (uniform random patterns) legs, so that a profile of this "
-                         "run holds only config-2 launches of the count kernels")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-accel", action="store_true", help="skip the opt-in index legs (pair index, k-mer table)")
+    ap.add_argument("--no-early-exit", action="store_true", help="skip the config-2b legs")
+    ap.add_argument("--no-rlfm", action="store_true", help="skip the config-4 object of the default run")
+    ap.add_argument("--no-3b", action="store_true", help="skip the config-3b object")
+    ap.add_argument("--no-d2h", action="store_true", help="skip value_incl_d2h")
+    ap.add_argument("--no-census", action="store_true", help="skip the requested / distinct line census")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic live")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl",
-                    help="nccl (= RCCL, the real path) | gloo (single-GPU rehearsal of the N>1 code "
-                         "path: all ranks share cuda:0 and gather through host memory)")
-    args = ap.parse_args()
+                    help="nccl (= RCCL, the real path) | gloo (rehearsal of the N>1 code path: all ranks "
+                         "share cuda:0 and gather through host memory)")
+    ap.add_argument("--dump-counts", default=None, help=argparse.SUPPRESS)   # tests: gathered counts -> .npy
+    ap.add_argument("--pattern-seed", type=int, default=None, help=argparse.SUPPRESS)   # tests: same global set at any N
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------
+# workloads
+# --------------------------------------------------------------------------------------------
+class Workload:
+    """text + index + pattern batch of one BASELINE config, resident in HBM."""
+
+    def __init__(self, name, args, dev, local, rank, world, rlfm=None, with_locate=True, npat=None, plen=None):
+        import torch
+        import fm_index_amd as F
+        from fm_index_amd import workload as W
+        from fm_index_amd import _lib as L
+        self.torch, self.F, self.W = torch, F, W
+        self.lib = L.lib()
+        self.name, self.dev, self.local = name, dev, local
+        self.n = 1 << args.log2n
+        self.dna = name == "dna"
+        self.rlfm = name.endswith("rlfm") if rlfm is None else rlfm
+        self.maxc = 4 if self.dna else 255
+        self.Lbits = 3 if self.dna else 8
+        self.m = plen if plen is not None else (args.plen if self.dna else (16 if args.plen == 32 else args.plen))
+        self.npat = npat if npat is not None else args.npat
+        t0 = time.time()
+        if self.dna:
+            self.text = W.dna_text_torch(self.n, 1, dev)
+        elif name.startswith("rep"):
+            self.text = W.repetitive_text_torch(self.n, 5, dev, base_len=1 << 20, mut_per_1024=args.mut_per_1024)
+        else:
+            self.text = W.byte_text_torch(self.n, 4, dev)
+        torch.cuda.synchronize()
+        self.textgen_s = time.time() - t0
+        self.level = args.level if (with_locate and not args.no_locate) else None
+        if self.rlfm:
+            cls = F.RLFMIndexWithLocate if self.level is not None else F.RLFMIndex
+        else:
+            cls = F.FMIndexWithLocate if self.level is not None else F.FMIndex
+        self.index = cls.from_device_text(self.text.data_ptr(), self.n, self.maxc, level=self.level, device=local)
+        self.h = self.index.handle()
+        self.build_ms = self.lib.fmx_build_ms(self.h)
+        # global pattern set = world * npat substrings of the text; this rank owns a contiguous shard
+        seed = (3 if world == 1 else 7) if self.dna else 6
+        if args.pattern_seed is not None:
+            seed = args.pattern_seed
+        z = W.splitmix64_torch(seed, rank * self.npat, self.npat, dev)
+        self.src_pos = W.umod_torch(z, self.n - 1 - self.m)
+        idx2d = self.src_pos[:, None] + torch.arange(self.m, dtype=torch.int64, device=dev)[None, :]
+        self.pat = self.text[idx2d].reshape(-1).contiguous()
+        del idx2d
+        self.off = (torch.arange(self.npat + 1, dtype=torch.int64, device=dev) * self.m).contiguous()
+        self.d_s = torch.empty(self.npat, dtype=torch.int64, device=dev)
+        self.d_e = torch.empty(self.npat, dtype=torch.int64, device=dev)
+        self.d_c = torch.empty(self.npat, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.current_stream()
+        self.sp = C.c_void_p(self.stream.cuda_stream)
+
+    # SURVEY 8d reference figure: 2 endpoints x L levels x 64 B (FM); 2 x (2L+4) probes x 64 B (RLFM)
+    def ref_bytes_per_char(self):
+        return 2 * (2 * self.Lbits + 4) * 64 if self.rlfm else 2 * self.Lbits * 64
+
+    def count(self, out_cnt=None, lib=None, pat=None):
+        lib = lib or self.lib
+        oc = self.d_c if out_cnt is None else out_cnt
+        p = self.pat if pat is None else pat
+        rc = lib.fmx_count_batch_dev(self.h, C.c_void_p(p.data_ptr()), C.c_void_p(self.off.data_ptr()), self.npat,
+                                     None, C.c_void_p(self.d_s.data_ptr()), C.c_void_p(self.d_e.data_ptr()),
+                                     C.c_void_p(oc.data_ptr()), self.sp)
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+
+    def prepare_locate(self):
+        torch = self.torch
+        self.d_off = torch.empty(self.npat + 1, dtype=torch.int64, device=self.dev)
+        self.lib.fmx_offsets_dev(self.h, C.c_void_p(self.d_s.data_ptr()), C.c_void_p(self.d_e.data_ptr()), self.npat,
+                                 C.c_void_p(self.d_off.data_ptr()), self.sp)
+        self.total_hits = int(self.d_off[-1].item())
+        self.d_pos = torch.empty(max(self.total_hits, 1), dtype=torch.int64, device=self.dev)
+
+    def locate(self, lib=None):
+        lib = lib or self.lib
+        rc = lib.fmx_locate_batch_dev(self.h, C.c_void_p(self.d_s.data_ptr()), C.c_void_p(self.d_e.data_ptr()),
+                                      self.npat, C.c_void_p(self.d_off.data_ptr()), self.total_hits,
+                                      C.c_void_p(self.d_pos.data_ptr()), self.sp)
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+
+    def timed_kernel(self, fn):
+        """one launch with the library's own HIP events around the kernel (launch stream)."""
+        self.lib.fmx_set_timing(self.h, 1)
+        fn()
+        self.torch.cuda.synchronize()
+        ms = self.lib.fmx_last_kernel_ms(self.h)
+        steps = int(self.lib.fmx_last_steps(self.h))
+        self.lib.fmx_set_timing(self.h, 0)
+        return ms, steps
+
+    def describe(self, world):
+        if self.dna:
+            w = "config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d substring patterns per GPU"
+        elif self.name.startswith("rep"):
+            w = "config4b (" + self.name + "): n=2^%d repetitive byte text (L=8), %d x len-%d substring patterns per GPU"
+        else:
+            w = "config4 (" + ("RLFMIndex" if self.rlfm else "FMIndex") + \
+                "): n=2^%d sigma=255 byte text (L=8), %d x len-%d substring patterns per GPU"
+        return w % (self.n.bit_length() - 1, self.npat, self.m)
+
+    def close(self):
+        self.index.close()
+
+
+def event_time_ms(torch, stream, fn, steps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+# --------------------------------------------------------------------------------------------
+# line census (libfmx_census.so: same kernels, every index-line load logged) -- outside timing
+# --------------------------------------------------------------------------------------------
+_CENSUS = {}
+
+
+def census_lib():
+    if "lib" not in _CENSUS:
+        from fm_index_amd import _lib as L
+        path = os.path.join(os.path.dirname(L.LIB_PATH), "libfmx_census.so")
+        lib = None
+        if os.path.exists(path):
+            try:
+                lib = C.CDLL(path)
+                for name, res, argt in L.SYMBOLS:
+                    fn = getattr(lib, name)
+                    fn.restype, fn.argtypes = res, argt
+                lib.fmx_census_begin.restype = C.c_int
+                lib.fmx_census_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+                lib.fmx_census_end.restype = C.c_int
+            except (OSError, AttributeError):
+                lib = None
+        _CENSUS["lib"] = lib
+    return _CENSUS["lib"]
+
+
+def run_census(wl, launch, cap_entries):
+    """lines REQUESTED by one launch and the DISTINCT lines among them (128-byte granules)."""
+    lib = census_lib()
+    if lib is None:
+        return None
+    torch = wl.torch
+    log = torch.empty(cap_entries, dtype=torch.int64, device=wl.dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=wl.dev)
+    torch.cuda.synchronize()
+    if lib.fmx_census_begin(C.c_void_p(log.data_ptr()), cap_entries, C.c_void_p(cnt.data_ptr())) != 0:
+        return None
+    try:
+        launch(lib)
+        torch.cuda.synchronize()
+    finally:
+        lib.fmx_census_end()
+    requested = int(cnt.item())
+    if requested > cap_entries:
+        return {"requested_lines": requested, "distinct_lines": None, "note": "log capacity exceeded"}
+    distinct = int(torch.unique(log[:requested]).numel())
+    del log
+    return {"requested_lines": requested, "distinct_lines": distinct}
+
+
+# --------------------------------------------------------------------------------------------
+# roofline object
+# --------------------------------------------------------------------------------------------
+def csrc_hash():
+    from fm_index_amd import _lib as L
+    return L.csrc_hash()
+
+
+def stored_traffic(workload_key, leg):
+    """HBM-side bytes per launch from profiles/traffic.json -- only when it was measured on THIS
+    source tree (csrc hash), otherwise None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = t.get(workload_key, {})
+    if ent.get("csrc_hash") != csrc_hash():
+        return None
+    return ent.get(leg)
+
+
+def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes, census, traffic):
+    """HBM roofline of one kernel.  `achieved` / `frac` use what the memory system really moved
+    when it was measured (PMC passes), else the lines the kernel REQUESTS (census) -- both are real
+    bytes of this layout and stay below the peak; the SURVEY 8d figure (the reference layout's 64-byte
+    blocks) is kept as `algorithmic_ref_bytes` for information only."""
+    t_s = avg_kernel_ms / 1e3
+    r = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "avg_kernel_ms": round(avg_kernel_ms, 4)}
+    req_bytes = None
+    if census and census.get("requested_lines") is not None:
+        req_bytes = census["requested_lines"] * LINE + stream_bytes
+        r["requested_lines"] = census["requested_lines"]
+        r["requested_bytes"] = req_bytes
+        r["lines_per_s"] = census["requested_lines"] / t_s
+        r["frac_of_gather_ceiling"] = round(census["requested_lines"] / t_s / (GATHER_CEILING_GLINES * 1e9), 4)
+        if census.get("distinct_lines") is not None:
+            r["min_bytes"] = census["distinct_lines"] * LINE + stream_bytes
+    tb = traffic.get("bytes") if traffic else None
+    r["traffic"] = tb
+    if tb:
+        r["traffic_source"] = traffic.get("source")
+        r["achieved"] = round(tb / t_s / 1e9, 1)
+        r["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
+        if r.get("min_bytes"):
+            r["traffic_over_min_bytes"] = round(tb / r["min_bytes"], 3)
+    elif req_bytes:
+        r["achieved"] = round(req_bytes / t_s / 1e9, 1)
+        r["basis"] = "requested lines x 128 B + streamed bytes (census) / kernel time; no PMC traffic for this build"
+    else:
+        r["achieved"] = None
+        r["basis"] = "neither PMC traffic nor a line census is available for this build"
+    r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4) if r["achieved"] else None
+    r["algorithmic_ref_bytes"] = units * ref_bytes_per_unit
+    r["algorithmic_ref_bytes_per_unit"] = ref_bytes_per_unit
+    return r
+
+
+# --------------------------------------------------------------------------------------------
+# live PMC passes: rocprofv3 runs a child of this script; separate --pmc passes, no trace domains
+# --------------------------------------------------------------------------------------------
+PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
+    "dna_count": ["fmx_count_f3_kernel"],
+    "dna_locate": ["fmx_locate_f3w_kernel"],
+    "rlfm_count": ["fmx_count_rlfm_ep_kernel", "fmx_count_kernel"],
+    "rlfm_locate": ["fmx_locate_rlfm_ep_kernel", "fmx_locate_kernel"],
+}
+
+
+def pmc_child(args):
+    """the program rocprofv3 profiles: builds the two indexes and runs each leg's kernel a few times."""
+    import torch
+    local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    reps = 3
+    wl = Workload("dna", args, dev, local, 0, 1)
+    for _ in range(reps):
+        wl.count()
+    if wl.level is not None:
+        wl.prepare_locate()
+        for _ in range(reps):
+            wl.locate()
+    torch.cuda.synchronize()
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
+    if not args.no_rlfm:
+        wr = Workload("bytes-rlfm", args, dev, local, 0, 1)
+        for _ in range(reps):
+            wr.count()
+        if wr.level is not None:
+            wr.prepare_locate()
+            for _ in range(reps):
+                wr.locate()
+        torch.cuda.synchronize()
+        wr.close()
+
+
+def run_pmc_passes(args):
+    """returns {leg: {"bytes", "fetch_kb_raw", "write_kb", "kernel", "source"}} or {} when rocprofv3 is
+    missing / fails.  FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), kernel-trace only."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}, "rocprofv3 not found"
+    out = {}
+    raw = {}
+    work = tempfile.mkdtemp(prefix="fmx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--log2n", str(args.log2n),
+             "--npat", str(args.npat), "--plen", str(args.plen), "--level", str(args.level)]
+    if args.no_rlfm:
+        child.append("--no-rlfm")
+    if args.no_locate:
+        child.append("--no-locate")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=420)
+            if p.returncode != 0:
+                return {}, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode,
+                                                                     p.stderr.decode(errors="replace")[-300:])
+            agg = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        kn = row.get("Kernel_Name", "?")
+                        a = agg.setdefault(kn, [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(row.get("Counter_Value", 0) or 0)
+            raw[counter] = agg
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return {}, "rocprofv3 pass did not finish: %r" % (ex,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+    def per_dispatch(counter, subs):
+        for sub in subs:     # first substring that matches a profiled kernel wins
+            best = None
+            for kn, (nd, tot) in raw.get(counter, {}).items():
+                if sub in kn and (best is None or tot > best[2]):
+                    best = (kn, nd, tot)
+            if best:
+                return best[0], best[2] / best[1]
+        return None, None
+    for leg, subs in PMC_LEGS.items():
+        kn, fetch_kb = per_dispatch("FETCH_SIZE", subs)
+        _, write_kb = per_dispatch("WRITE_SIZE", subs)
+        if kn is None or fetch_kb is None:
+            continue
+        # gfx950: FETCH_SIZE tallies 128-byte requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section;
+        # re-calibrated below on a kernel with a known byte count); WRITE_SIZE reads exactly
+        out[leg] = {"fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb or 0.0, 1),
+                    "bytes": int((2.0 * fetch_kb + (write_kb or 0.0)) * 1024),
+                    "kernel": kn.split("(")[0].replace("void ", ""),
+                    "source": "live rocprofv3 --pmc passes of this run"}
+    # calibration in our own access pattern: k_mwm_pieces<3> reads the n-byte BWT exactly once
+    kn, kb = per_dispatch("FETCH_SIZE", ["k_mwm_pieces<3"])
+    cal = None
+    if kb:
+        cal = {"kernel": "k_mwm_pieces<3>", "fetch_kb_raw": round(kb, 1), "expected_bytes": 1 << args.log2n,
+               "bytes_per_reported_byte": round((1 << args.log2n) / (kb * 1024), 3)}
+    return out, cal
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (port of the reference algorithm) on this box's cores
+# --------------------------------------------------------------------------------------------
+def cpu_baseline(wl, args, kind):
+    import numpy as np
+    from oracle import fm_oracle as O
+    t0 = time.time()
+    bwt = wl.index.export_bwt()
+    cs = wl.index.export_cs()
+    oi = O.OracleIndex.from_bwt(bwt, cs, wl.maxc, native=True, kind=kind)
+    del bwt
+    t_ob = time.time() - t0
+    cores = os.cpu_count() or 1
+    m = wl.m
+    pat_h = wl.pat.cpu().numpy()
+    s_h = wl.d_s.cpu().numpy().view(np.uint64)
+    e_h = wl.d_e.cpu().numpy().view(np.uint64)
+
+    def cpu_run(k, threads):
+        offk = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
+        t = time.perf_counter()
+        so, eo = oi.count_batch(pat_h[:k * m], offk, nthreads=threads)
+        return time.perf_counter() - t, so, eo
+    k0 = 1 << 14
+    t_probe, so, eo = cpu_run(k0, cores)
+    k = int(min(wl.npat, max(k0, k0 * args.cpu_seconds / 4 / max(t_probe, 1e-6))))
+    t_all, so, eo = cpu_run(k, cores)
+    assert (so == s_h[:k]).all() and (eo == e_h[:k]).all(), "GPU != oracle on the CPU sample"
+    times = [t_all]
+    while sum(times) < args.cpu_seconds and len(times) < 25:
+        times.append(cpu_run(k, cores)[0])
+    t_all = sorted(times)[len(times) // 2]
+    k1 = max(1024, k // cores)
+    t_one, _, _ = cpu_run(k1, 1)
+    oi.close()
+    return {"value": k * m / t_all, "unit": "pattern-chars/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the %d patterns (same text, same %s built from the index's exported "
+                      "BWT), median of %d runs of %.2f s on %d threads; GPU (s,e) bit-identical on the sample"
+                      % (k, wl.npat, "RLFM structure" if kind == "rlfm" else "wavelet matrix", len(times), t_all, cores),
+            "single_thread_value": k1 * m / t_one, "oracle_build_s": round(t_ob, 1)}
+
+
+# --------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # one process per GPU, started before anything in THIS process touches the GPU
+        from fm_index_amd import launcher
+        sys.exit(launcher.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.pmc_child:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
+                 "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    if args.pmc_child:
+        pmc_child(args)
+        return
+    run(args, world)
+
+
+def run(args, world):
     import torch
     import numpy as np
     import fm_index_amd as F
     from fm_index_amd import workload as W
-    from fm_index_amd import _lib as L
+    from fm_index_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    gloo = args.dist_backend == "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "gloo":
+        if gloo:
             local = 0
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
@@ -83,98 +491,20 @@ def main():
         dist = None
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    lib = L.lib()
 
-    n = 1 << args.log2n
-    npat, m = args.npat, args.plen
-    dna = args.workload == "dna"
-    if not dna and args.plen == 32:
-        m = 16                                   # config 4: length-16 patterns
-    maxc = 4 if dna else 255
-    Lbits = 3 if dna else 8
-    # 2 endpoints x L levels x 64 B (FM); 2 x (2L+4) probes x 64 B (RLFM)
-    rlfm = args.workload.endswith("rlfm")
-    bytes_per_char = 2 * (2 * Lbits + 4) * 64 if rlfm else 2 * Lbits * 64
-    # ---- synthetic inputs: text seed 1, patterns seed 3 / 7 ----
-    t0 = time.time()
-    if dna:
-        text = W.dna_text_torch(n, 1, dev)
-    elif args.workload.startswith("rep"):
-        text = W.repetitive_text_torch(n, 5, dev, base_len=1 << 20, mut_per_1024=args.mut_per_1024)
-    else:
-        text = W.byte_text_torch(n, 4, dev)
-    torch.cuda.synchronize()
-    t_gen = time.time() - t0
-    level = None if args.no_locate else args.level
     # a throw-away 4 KiB build first: runtime / code-object initialisation is not index construction
     F.FMIndex(F.Text.with_max_character(W.dna_text_np(4096, 9), 4), device=local).close()
-    if rlfm:
-        cls = F.RLFMIndexWithLocate if level is not None else F.RLFMIndex
-    else:
-        cls = F.FMIndexWithLocate if level is not None else F.FMIndex
-    index = cls.from_device_text(text.data_ptr(), n, maxc, level=level, device=local)
-    build_ms = lib.fmx_build_ms(index.handle())
-    # global pattern set = world * npat substrings; this rank owns a contiguous shard
-    seed = (3 if world == 1 else 7) if dna else 6
+    wl = Workload(args.workload, args, dev, local, rank, world)
+    lib, npat, m, n = wl.lib, wl.npat, wl.m, wl.n
     total_pat = npat * world
-    z = W.splitmix64_torch(seed, rank * npat, npat, dev)
-    pos = W.umod_torch(z, n - 1 - m)
-    idx2d = pos[:, None] + torch.arange(m, dtype=torch.int64, device=dev)[None, :]
-    pat = text[idx2d].reshape(-1).contiguous()
-    off = (torch.arange(npat + 1, dtype=torch.int64, device=dev) * m).contiguous()
-    del idx2d
-    d_s = torch.empty(npat, dtype=torch.int64, device=dev)
-    d_e = torch.empty(npat, dtype=torch.int64, device=dev)
-    from fm_index_amd import sharding
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
-    h = index.handle()
+    stream = wl.stream
 
-    # N > 1 (config 5): the per-pattern counts of every rank are all-gathered over RCCL/xGMI.
-    # The gather of step k overlaps the search kernel of step k+1: two result buffers alternate,
-    # the collective is issued async (it runs on RCCL's stream once the kernel that produced its
-    # input has finished) and a buffer is only reused after its gather has completed.  Counts
-    # travel as int32 (n < 2^32): 4 MiB per rank per step instead of 8.
-    pipelined = world > 1 and args.dist_backend == "nccl" and not os.environ.get("FMX_BENCH_SYNC_GATHER")
-    nbuf = 2 if pipelined else 1
-    d_cs = [torch.empty(npat, dtype=torch.int64, device=dev) for _ in range(nbuf)]
-    d_c32 = [torch.empty(npat, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    g_out = [torch.empty(total_pat, dtype=torch.int32, device=dev) for _ in range(nbuf)] if world > 1 else []
-    pending = [None] * nbuf
-    d_c = d_cs[0]
-    step_no = [0]
+    # ---- headline: count (+ gather of every rank's counts for N > 1, config 5) ----
+    pipe = sharding.CountGatherPipeline(npat, world, n, dev, backend="gloo" if gloo else "nccl",
+                                        pipelined=not os.environ.get("FMX_BENCH_SYNC_GATHER"))
 
     def step():
-        b = step_no[0] % nbuf
-        step_no[0] += 1
-        if pending[b] is not None:          # this buffer's previous gather must be done
-            pending[b].wait()
-            pending[b] = None
-        rc = lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat,
-                                     None, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
-                                     C.c_void_p(d_cs[b].data_ptr()), sp)
-        if rc != 0:
-            raise RuntimeError(lib.fmx_last_error().decode())
-        if world > 1:
-            if args.dist_backend == "gloo":     # single-GPU rehearsal of the control flow
-                return sharding.gather_counts(d_cs[b].cpu(), total_pat)
-            d_c32[b].copy_(d_cs[b])
-            if pipelined:
-                try:
-                    pending[b] = dist.all_gather_into_tensor(g_out[b], d_c32[b], async_op=True)
-                except Exception:   # noqa: BLE001 -- fall back to the blocking collective
-                    pending[b] = None
-                    dist.all_gather_into_tensor(g_out[b], d_c32[b])
-            else:
-                dist.all_gather_into_tensor(g_out[b], d_c32[b])
-            return g_out[b]
-        return d_cs[b]
-
-    def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        return pipe.step(lambda out64: wl.count(out_cnt=out64))
 
     def barrier():
         if world > 1:
@@ -183,71 +513,54 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    drain()
+    pipe.drain()
     barrier()
-    # kernel-only time over the timed region: HIP events on the launch stream
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for k in range(args.steps):
+    for _ in range(args.steps):
         step()
-    drain()                      # every gather of the timed steps has completed
+    pipe.drain()                 # every gather of the timed steps has completed
     ev1.record(stream)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64,
-                          device="cpu" if args.dist_backend == "gloo" else dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ev_ms = ev0.elapsed_time(ev1)
-    assert lib.fmx_stream_status(h) == 0
+    assert lib.fmx_stream_status(wl.h) == 0
 
     # ---- validation + step census (outside the timed region) ----
-    lib.fmx_set_timing(h, 1)
-    step_no[0] = 0
+    kernel_ms_single, steps_exec = wl.timed_kernel(lambda: wl.count())
     last = step()
-    drain()
+    pipe.drain()
     torch.cuda.synchronize()
-    if world > 1 and args.dist_backend == "nccl":
+    if world > 1:
         # gathered counts: this rank's shard sits at [rank*npat, (rank+1)*npat) and equals its own
-        assert bool((last[rank * npat:(rank + 1) * npat].to(torch.int64) == d_cs[0]).all())
-    kernel_ms_single = lib.fmx_last_kernel_ms(h)
-    steps_exec = int(lib.fmx_last_steps(h))
-    lib.fmx_set_timing(h, 0)
+        mine = last[rank * npat:(rank + 1) * npat].to(torch.int64).to(dev)
+        assert bool((mine == wl.d_c).all()), "gathered counts differ from this rank's"
+        if args.dump_counts and rank == 0:
+            np.save(args.dump_counts, last.cpu().numpy().astype(np.int64))
+    elif args.dump_counts:
+        np.save(args.dump_counts, wl.d_c.cpu().numpy())
     assert steps_exec == npat * m, (steps_exec, npat * m)   # substrings: every step executes
-    assert bool((d_c >= 1).all()), "a substring of the text must occur at least once"
-    # every pattern's own source position must lie in its SA interval's located set (below)
+    assert bool((wl.d_c >= 1).all()), "a substring of the text must occur at least once"
 
     chars_per_step_rank = npat * m
     value = chars_per_step_rank * world * args.steps / dt
-    # dominant kernel: fmx_count_kernel; avg launch duration from the event bracket of the timed
-    # region at N=1 (launches are back to back on one stream); per-launch event at N>1
-    avg_kernel_s = (ev_ms / 1e3) / args.steps if world == 1 else kernel_ms_single / 1e3
-    achieved = chars_per_step_rank * bytes_per_char / avg_kernel_s / 1e9
-    # HBM-side bytes per launch: PMC counters of the same command, collected in separate
-    # rocprofv3 passes and corrected as profiles/README.md describes (None when not profiled)
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f).get("%s:%d:%d:%d" % (args.workload, npat, m, args.log2n), {})
-    except OSError:
-        pass
-    kname = "fmx_count_f3_kernel<1,false,false>" if dna else \
-        ("fmx_count_kernel<FMX_KIND_RLFM>" if rlfm else "fmx_count_kernel<FMX_KIND_FM>")
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic.get("count", {}).get("bytes"),
-                "algorithmic_bytes_per_launch": chars_per_step_rank * bytes_per_char,
-                "algorithmic_bytes_per_char": bytes_per_char,
-                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
-    if roofline["traffic"]:
-        # what the memory system really moved: measured HBM-side bytes / kernel time (frac above is
-        # the contract's algorithmic-bytes figure and exceeds 1 because one 128-B record answers
-        # what the reference reads three 64-B blocks for)
-        roofline["traffic_rate"] = round(roofline["traffic"] / avg_kernel_s / 1e9, 1)
-        roofline["traffic_frac"] = round(roofline["traffic"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4)
+    # dominant kernel's average launch duration: the event bracket of the timed region at N=1
+    # (launches back to back on one stream), the library's per-launch events at N>1
+    avg_kernel_ms = ev_ms / args.steps if world == 1 else kernel_ms_single
+    stream_bytes = npat * m + (npat + 1) * 8 + 3 * npat * 8      # pattern bytes + offsets + (s, e, count)
+    cen = None
+    if not args.no_census and rank == 0:
+        cen = run_census(wl, lambda cl: wl.count(lib=cl), npat * m * (8 if wl.rlfm else 3) + (1 << 20))
+    key = "%s:%d:%d:%d" % (args.workload, npat, m, args.log2n)
+    kname = {"dna": "fmx_count_f3_kernel<1,false,false>"}.get(
+        args.workload, "fmx_count_rlfm_ep_kernel" if wl.rlfm else "fmx_count_kernel<FMX_KIND_FM>")
+    roofline = make_roofline(kname, avg_kernel_ms, chars_per_step_rank, wl.ref_bytes_per_char(), stream_bytes,
+                             cen, stored_traffic(key, "count"))
 
     out = {
         # BASELINE.json's metric, verbatim; `value` is its count half (pattern-chars/s), the locate
@@ -256,221 +569,362 @@ def main():
         "value": value, "unit": "pattern-chars/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": ("config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d "
-                                "substring patterns per GPU" % (args.log2n, npat, m)) if dna else
-                               ("config4 (%s): n=2^%d sigma=255 byte text (L=8), %d x len-%d substring "
-                                "patterns per GPU" % (args.workload, args.log2n, npat, m)),
-                   "text_len": n, "patterns_per_gpu": npat, "pattern_len": m,
+        "config": {"workload": wl.describe(world), "text_len": n, "patterns_per_gpu": npat, "pattern_len": m,
                    "parallelism": "patterns sharded x%d, index replicated" % world,
-                   "index_bytes": index.heap_size(), "build_ms": round(build_ms, 1),
-                   "textgen_s": round(t_gen, 2)},
+                   "index_bytes": wl.index.heap_size(), "build_ms": round(wl.build_ms, 1),
+                   "textgen_s": round(wl.textgen_s, 2)},
         "roofline": roofline,
     }
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size()
+        out["gather"] = {"backend": "gloo (rehearsal through host memory)" if gloo else "nccl (RCCL)",
+                         "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
+                         "bytes_per_rank_per_step": npat * (4 if pipe.wire == torch.int32 else 8),
+                         "pipelined": pipe.nbuf > 1}
 
+    single = world == 1 and rank == 0
     # ---- config 2b: uniform random patterns -> the early exit of wrapper.rs:111-113 ----
-    if dna and rank == 0 and not args.no_early_exit:
+    rflat = None
+    if wl.dna and single and not args.no_early_exit:
         rflat = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)
-        rs_ = torch.empty(npat, dtype=torch.int64, device=dev)
-        re_ = torch.empty(npat, dtype=torch.int64, device=dev)
-
-        def rstep():
-            rc = lib.fmx_count_batch_dev(h, C.c_void_p(rflat.data_ptr()), C.c_void_p(off.data_ptr()), npat,
-                                         None, C.c_void_p(rs_.data_ptr()), C.c_void_p(re_.data_ptr()), None, sp)
-            assert rc == 0
-        rstep()
+        wl.count(pat=rflat)
         torch.cuda.synchronize()
-        lib.fmx_set_timing(h, 1)
-        rstep()
-        torch.cuda.synchronize()
-        rms = lib.fmx_last_kernel_ms(h)
-        rsteps = int(lib.fmx_last_steps(h))
-        lib.fmx_set_timing(h, 0)
+        rms, rsteps = wl.timed_kernel(lambda: wl.count(pat=rflat))
         out["early_exit"] = {"workload": "config 2b: %d uniform random len-%d patterns" % (npat, m),
                              "executed_steps": rsteps, "offered_chars": npat * m,
                              "mean_steps_per_pattern": round(rsteps / npat, 2),
                              "executed_steps_per_s": rsteps / (rms / 1e3), "kernel_ms": round(rms, 4),
-                             "nonzero_counts": int((re_ > rs_).sum().item())}
-        del rflat, rs_, re_
+                             "nonzero_counts": int((wl.d_e > wl.d_s).sum().item())}
+        wl.count()                                    # restore the config-2 (s, e)
+        torch.cuda.synchronize()
 
     # ---- opt-in accelerators: same patterns, results asserted identical to the plain index ----
+    if single and not args.no_accel:
+        accel_legs(out, wl, args, rflat)
+    del rflat
+
+    # ---- locate (config 3; gathered over the ranks for N > 1) ----
+    if wl.level is not None:
+        locate_leg(out, wl, args, world, rank, dist, gloo, key)
+
+    # ---- config 3b: short patterns, wide intervals ----
+    if single and wl.dna and wl.level is not None and not args.no_3b:
+        try:
+            locate_3b(out, wl, args)
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
+            out["locate_3b"] = {"error": repr(ex)}
+
+    # ---- the same batch through the host-pointer entry point (PCIe both ways) ----
+    if single and not args.no_d2h:
+        try:
+            d2h_leg(out, wl, args)
+        except Exception as ex:  # noqa: BLE001
+            out["value_incl_d2h"] = None
+            out["incl_d2h"] = {"error": repr(ex)}
+
+    # ---- CPU baseline of the headline ----
+    if single and not args.no_cpu_baseline:
+        wl.count()
+        torch.cuda.synchronize()
+        out["cpu_baseline"] = cpu_baseline(wl, args, "rlfm" if wl.rlfm else "fm")
+
+    # ---- config 4 (RLFMIndex, sigma = 255) as its own object ----
+    wr = None
+    if single and wl.dna and not args.no_rlfm:
+        try:
+            wr = rlfm_leg(out, args, dev, local)
+        except Exception as ex:  # noqa: BLE001
+            out["rlfm"] = {"error": repr(ex)}
+        if wr is not None:
+            wr.close()
+            del wr
+
+    # ---- HBM-side traffic measured now: rocprofv3 --pmc passes over a child of this script ----
+    if single and wl.dna and not args.no_pmc:
+        try:
+            pmc, cal = run_pmc_passes(args)
+        except Exception as ex:  # noqa: BLE001
+            pmc, cal = {}, repr(ex)
+        apply_pmc(out, pmc, cal)
+
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def apply_pmc(out, pmc, cal):
+    def redo(roof, ent):
+        if not roof or not ent:
+            return
+        t_s = roof["avg_kernel_ms"] / 1e3
+        roof["traffic"] = ent["bytes"]
+        roof["traffic_source"] = ent["source"]
+        roof["traffic_kernel"] = ent["kernel"]
+        roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent["write_kb"]
+        roof["achieved"] = round(ent["bytes"] / t_s / 1e9, 1)
+        roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+        roof["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
+        if roof.get("min_bytes"):
+            roof["traffic_over_min_bytes"] = round(ent["bytes"] / roof["min_bytes"], 3)
+    if isinstance(cal, str):
+        out["pmc"] = {"status": cal}
+    elif pmc:
+        out["pmc"] = {"status": "ok", "calibration": cal,
+                      "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel-trace only) over "
+                              "`bench.py --pmc-child`; gfx950: FETCH_SIZE x 2"}
+    else:
+        out["pmc"] = {"status": "no counters collected"}
+    redo(out.get("roofline"), pmc.get("dna_count"))
+    redo(out.get("locate", {}).get("roofline"), pmc.get("dna_locate"))
+    redo(out.get("rlfm", {}).get("roofline"), pmc.get("rlfm_count"))
+    redo(out.get("rlfm", {}).get("locate", {}).get("roofline"), pmc.get("rlfm_locate"))
+
+
+def accel_legs(out, wl, args, rflat):
+    torch, F, lib = wl.torch, wl.F, wl.lib
     legs = []
-    if not args.no_accel:
-        args.pair_index = args.kmer_table = True
-    if args.pair_index and dna:
+    if wl.dna:
         legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX"))
-    if args.kmer_table:
-        legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE"))
-    if args.kmer_table and args.pair_index and dna:
+    legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE"))
+    if wl.dna:
         legs.append(("kmer_table+pair_index", dict(kmer_table=True, pair_index=True),
                      "FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX"))
+    npat, m = wl.npat, wl.m
     for leg_name, leg_kw, leg_note in legs:
         try:
-            pidx = (F.RLFMIndex if rlfm else F.FMIndex).from_device_text(text.data_ptr(), n, maxc,
-                                                                          device=local, **leg_kw)
-            assert pidx.has_pair_index() == bool(leg_kw.get("pair_index"))
+            pidx = (F.RLFMIndex if wl.rlfm else F.FMIndex).from_device_text(wl.text.data_ptr(), wl.n, wl.maxc,
+                                                                            device=wl.local, **leg_kw)
             if leg_kw.get("kmer_table") and pidx.kmer_k() == 0:
                 out[leg_name] = {"skipped": "FMX_FLAG_KMER_TABLE is ignored for this kind / alphabet"}
                 pidx.close()
                 continue
-            ps = torch.empty(npat, dtype=torch.int64, device=dev)
-            pe = torch.empty(npat, dtype=torch.int64, device=dev)
+            ps = torch.empty(npat, dtype=torch.int64, device=wl.dev)
+            pe = torch.empty(npat, dtype=torch.int64, device=wl.dev)
 
-            def pstep():
-                rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(pat.data_ptr()),
-                                             C.c_void_p(off.data_ptr()), npat, None,
-                                             C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
+            def pstep(p):
+                rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(p.data_ptr()), C.c_void_p(wl.off.data_ptr()),
+                                             npat, None, C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()),
+                                             None, wl.sp)
                 assert rc == 0
             for _ in range(args.warmup):
-                pstep()
+                pstep(wl.pat)
             torch.cuda.synchronize()
-            p0 = torch.cuda.Event(enable_timing=True)
-            p1 = torch.cuda.Event(enable_timing=True)
-            p0.record(stream)
-            for _ in range(args.steps):
-                pstep()
-            p1.record(stream)
-            torch.cuda.synchronize()
-            pms = p0.elapsed_time(p1) / args.steps
-            assert bool((ps == d_s).all()) and bool((pe == d_e).all()), leg_name + " != plain index"
-            out[leg_name] = {"value": chars_per_step_rank / (pms / 1e3), "unit": "pattern-chars/s",
-                             "ms_per_step": pms, "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
+            pms = event_time_ms(torch, wl.stream, lambda: pstep(wl.pat), args.steps)
+            assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != plain index"
+            out[leg_name] = {"value": npat * m / (pms / 1e3), "unit": "pattern-chars/s", "ms_per_step": pms,
+                             "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
                              "build_ms": round(float(lib.fmx_build_ms(pidx.handle())), 1),
-                             "traffic": traffic.get(leg_name, {}).get("bytes"),
-                             "note": leg_note + "; (s,e) identical to the plain-index run; rate of rank 0's "
-                                     "shard alone (not aggregated over ranks)"}
-            if not args.no_early_exit and "early_exit" in out:
+                             "note": leg_note + "; (s,e) identical to the plain-index run"}
+            if rflat is not None:
                 # config 2b patterns (uniform random, mostly absent) through the same index
-                rflat2 = ((W.splitmix64_torch(5, 0, npat * m, dev) & 3) + 1).to(torch.uint8)
-                lib.fmx_count_batch_dev(h, C.c_void_p(rflat2.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
-                                        C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), None, sp)
-
-                def rstep():
-                    rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(rflat2.data_ptr()),
-                                                 C.c_void_p(off.data_ptr()), npat, None,
-                                                 C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, sp)
-                    assert rc == 0
+                wl.count(pat=rflat)
                 for _ in range(args.warmup):
-                    rstep()
+                    pstep(rflat)
                 torch.cuda.synchronize()
-                p0.record(stream)
-                for _ in range(args.steps):
-                    rstep()
-                p1.record(stream)
-                torch.cuda.synchronize()
-                rms2 = p0.elapsed_time(p1) / args.steps
-                assert bool((ps == d_s).all()) and bool((pe == d_e).all()), leg_name + " != plain index (2b)"
+                rms2 = event_time_ms(torch, wl.stream, lambda: pstep(rflat), args.steps)
+                assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != plain index (2b)"
                 out[leg_name]["early_exit_ms_per_step"] = rms2
                 out[leg_name]["early_exit_offered_chars_per_s"] = npat * m / (rms2 / 1e3)
-                # restore the config-2 (s, e) the locate leg starts from
-                lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
-                                        C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), None, sp)
+                wl.count()                            # restore the config-2 (s, e)
                 torch.cuda.synchronize()
-                del rflat2
             pidx.close()
-        except Exception as ex:  # never lose the headline line to an optional leg
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
             out[leg_name] = {"error": repr(ex)}
 
-    # ---- locate leg (config 3), rank 0 reports ----
-    if level is not None:
-        d_off = torch.empty(npat + 1, dtype=torch.int64, device=dev)
-        lib.fmx_offsets_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
-                            C.c_void_p(d_off.data_ptr()), sp)
-        total_hits = int(d_off[-1].item())
-        d_pos = torch.empty(max(total_hits, 1), dtype=torch.int64, device=dev)
 
-        def locate_step():
-            rc = lib.fmx_locate_batch_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()),
-                                          npat, C.c_void_p(d_off.data_ptr()), total_hits,
-                                          C.c_void_p(d_pos.data_ptr()), sp)
-            if rc != 0:
-                raise RuntimeError(lib.fmx_last_error().decode())
-        locate_step()
-        torch.cuda.synchronize()
-        lsteps = max(3, args.steps // 2)
-        # whole batches back to back (expand + walk kernels, stream-ordered scratch): wall time
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(lsteps):
-            locate_step()
-        torch.cuda.synchronize()
-        ldt = time.perf_counter() - t0
-        # the walk kernel alone, one launch at a time, HIP events on the launch stream
-        lib.fmx_set_timing(h, 1)
-        kms = []
-        for _ in range(lsteps):
-            locate_step()
-            torch.cuda.synchronize()
-            kms.append(lib.fmx_last_kernel_ms(h))
-        lf_steps = int(lib.fmx_last_steps(h))
-        lib.fmx_set_timing(h, 0)
-        # property checks at full size: every located position really holds the pattern, and
-        # each pattern's source position is among its hits
-        hit_pat = torch.repeat_interleave(torch.arange(npat, device=dev), d_c)
-        chk = torch.ones(total_hits, dtype=torch.bool, device=dev)
-        for j in range(m):
-            chk &= text[d_pos[:total_hits] + j] == pat.view(npat, m)[hit_pat, j]
-        assert bool(chk.all()), "located position does not hold the pattern"
-        found_src = torch.zeros(npat, dtype=torch.bool, device=dev)
-        found_src[hit_pat[d_pos[:total_hits] == pos[hit_pat]]] = True
-        assert bool(found_src.all()), "source position missing from locate output"
-        kavg = sum(kms) / len(kms) / 1e3
-        lbytes = lf_steps * Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
-        out["locate"] = {"hits_per_s": total_hits * lsteps / ldt, "hits": total_hits,
-                         "lf_steps": lf_steps, "level": args.level,
-                         "ms_per_batch": ldt / lsteps * 1e3,
-                         "roofline": {"bound": "hbm",
-                                      "kernel": "fmx_locate_f3w_kernel<4>" if dna else
-                                      ("fmx_locate_kernel<FMX_KIND_RLFM>" if rlfm else
-                                       "fmx_locate_kernel<FMX_KIND_FM>"),
-                                      "achieved": round(lbytes / kavg / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(lbytes / kavg / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_kernel_ms": round(kavg * 1e3, 4),
-                                      "traffic": traffic.get("locate", {}).get("bytes")}}
-        del hit_pat, chk, found_src
+def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="locate"):
+    torch, lib = wl.torch, wl.lib
+    from fm_index_amd import sharding
+    dest = out if dest is None else dest
+    wl.count()
+    wl.prepare_locate()
+    total_hits, npat, m = wl.total_hits, wl.npat, wl.m
+    wl.locate()
+    torch.cuda.synchronize()
+    lsteps = max(3, args.steps // 2)
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's cores ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import fm_oracle as O
-        t0 = time.time()
-        bwt = index.export_bwt()
-        cs = index.export_cs()
-        oi = O.OracleIndex.from_bwt(bwt, cs, maxc, native=True)
-        del bwt
-        t_ob = time.time() - t0
-        cores = os.cpu_count() or 1
-        pat_h = pat.cpu().numpy()
-        s_h = d_s.cpu().numpy().view(np.uint64)
-        e_h = d_e.cpu().numpy().view(np.uint64)
-
-        def cpu_run(k, threads):
-            offk = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
-            t = time.perf_counter()
-            so, eo = oi.count_batch(pat_h[:k * m], offk, nthreads=threads)
-            return time.perf_counter() - t, so, eo
-        k0 = 1 << 14
-        t_probe, so, eo = cpu_run(k0, cores)
-        k = int(min(npat, max(k0, k0 * args.cpu_seconds / max(t_probe, 1e-6))))
-        t_all, so, eo = cpu_run(k, cores)
-        assert (so == s_h[:k]).all() and (eo == e_h[:k]).all(), "GPU != oracle on the CPU sample"
-        times = [t_all]
-        while sum(times) < args.cpu_seconds and len(times) < 25:   # ~10-30 s of CPU work in total
-            times.append(cpu_run(k, cores)[0])
-        t_all = sorted(times)[len(times) // 2]
-        k1 = max(1024, k // cores)
-        t_one, _, _ = cpu_run(k1, 1)
-        out["cpu_baseline"] = {"value": k * m / t_all, "unit": "pattern-chars/s", "cores": cores,
-                               "kind": "port",
-                               "sample": "first %d of the %d patterns (same text, same index), "
-                                         "median of %d runs of %.2f s; GPU (s,e) bit-identical on the sample" % (k, npat, len(times), t_all),
-                               "single_thread_value": k1 * m / t_one,
-                               "oracle_build_s": round(t_ob, 1)}
-        oi.close()
-
-    if rank == 0:
-        print(json.dumps(out))
+    def lstep():
+        wl.locate()
+        if world > 1:       # config 5: positions of every rank, in input order, on every rank
+            cnt = (wl.d_e - wl.d_s)
+            lp = wl.d_pos[:total_hits]
+            if gloo:
+                cnt, lp = cnt.cpu(), lp.cpu()
+            return sharding.gather_positions(cnt, lp, npat * world)
+        return None
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(lsteps):
+        g = lstep()
+    torch.cuda.synchronize()
+    ldt = time.perf_counter() - t0
+    all_hits = total_hits
+    if world > 1:
+        tt = torch.tensor([ldt], dtype=torch.float64, device="cpu" if gloo else wl.dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ldt = float(tt.item())
+        goff, gpos = g
+        all_hits = int(goff[-1].item())
+        lo = int(goff[rank * npat].item())
+        assert bool((gpos[lo:lo + total_hits].to(wl.dev) == wl.d_pos[:total_hits]).all()), \
+            "gathered positions differ from this rank's"
+    # the walk kernel alone, one launch at a time, HIP events on the launch stream
+    kms, lf_steps = [], 0
+    for _ in range(lsteps):
+        ms, lf_steps = wl.timed_kernel(wl.locate)
+        kms.append(ms)
+    # property checks at full size: every located position really holds the pattern, and each
+    # pattern's source position is among its hits
+    hit_pat = torch.repeat_interleave(torch.arange(npat, device=wl.dev), wl.d_e - wl.d_s)
+    chk = torch.ones(total_hits, dtype=torch.bool, device=wl.dev)
+    for j in range(m):
+        chk &= wl.text[wl.d_pos[:total_hits] + j] == wl.pat.view(npat, m)[hit_pat, j]
+    assert bool(chk.all()), "located position does not hold the pattern"
+    found_src = torch.zeros(npat, dtype=torch.bool, device=wl.dev)
+    found_src[hit_pat[wl.d_pos[:total_hits] == wl.src_pos[hit_pat]]] = True
+    assert bool(found_src.all()), "source position missing from locate output"
+    del hit_pat, chk, found_src
+    kavg_ms = sum(kms) / len(kms)
+    cen = None
+    if not args.no_census and rank == 0:
+        cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
+    ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
+    kname = "fmx_locate_f3w_kernel<4>" if wl.dna else ("fmx_locate_rlfm_ep_kernel" if wl.rlfm else
+                                                        "fmx_locate_kernel<FMX_KIND_FM>")
+    roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
+                         stored_traffic(key, "locate"))
+    dest[legname] = {"hits_per_s": all_hits * lsteps / ldt, "hits": all_hits, "hits_per_gpu": total_hits,
+                     "lf_steps": lf_steps, "level": wl.level, "ms_per_batch": ldt / lsteps * 1e3,
+                     "includes": "row expansion + walk" + (" + gather of counts and positions over the ranks"
+                                                           if world > 1 else ""),
+                     "roofline": roof}
+
+
+def locate_3b(out, wl, args):
+    """config 3b: 64 K patterns of length 8-12 -> counts of 2^6..2^14, wide [s, e)."""
+    torch, lib, W = wl.torch, wl.lib, wl.W
+    npat = 1 << 16
+    z = W.splitmix64_torch(11, 0, npat, wl.dev)
+    lens = 8 + W.umod_torch(z, 5)
+    off = torch.zeros(npat + 1, dtype=torch.int64, device=wl.dev)
+    off[1:] = torch.cumsum(lens, 0)
+    src = W.umod_torch(W.splitmix64_torch(12, 0, npat, wl.dev), wl.n - 1 - 12)
+    tot = int(off[-1].item())
+    which = torch.repeat_interleave(torch.arange(npat, device=wl.dev), lens)
+    within = torch.arange(tot, device=wl.dev) - off[which]
+    pat = wl.text[src[which] + within].contiguous()
+    s = torch.empty(npat, dtype=torch.int64, device=wl.dev)
+    e = torch.empty(npat, dtype=torch.int64, device=wl.dev)
+    rc = lib.fmx_count_batch_dev(wl.h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                 C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), None, wl.sp)
+    assert rc == 0
+    hoff = torch.empty(npat + 1, dtype=torch.int64, device=wl.dev)
+    lib.fmx_offsets_dev(wl.h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                        C.c_void_p(hoff.data_ptr()), wl.sp)
+    total = int(hoff[-1].item())
+    pos = torch.empty(max(total, 1), dtype=torch.int64, device=wl.dev)
+
+    def lstep():
+        rc = lib.fmx_locate_batch_dev(wl.h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                                      C.c_void_p(hoff.data_ptr()), total, C.c_void_p(pos.data_ptr()), wl.sp)
+        assert rc == 0
+    lstep()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms, lf_steps = wl.timed_kernel(lstep)
+    # every located position holds its pattern's first 8 symbols; positions of a pattern are distinct
+    hp = torch.repeat_interleave(torch.arange(npat, device=wl.dev), e - s)
+    ok = torch.ones(total, dtype=torch.bool, device=wl.dev)
+    for j in range(8):
+        ok &= wl.text[pos[:total] + j] == pat[off[hp] + j]
+    assert bool(ok.all()), "3b: located position does not hold the pattern"
+    cnts = (e - s)
+    out["locate_3b"] = {"workload": "config 3b: %d substring patterns of length 8-12" % npat,
+                        "hits": total, "hits_per_s": total / dt, "ms_per_batch": dt * 1e3,
+                        "walk_kernel_ms": round(kms, 4), "lf_steps": lf_steps,
+                        "count_min": int(cnts.min().item()), "count_median": int(cnts.median().item()),
+                        "count_max": int(cnts.max().item())}
+
+
+def d2h_leg(out, wl, args):
+    """value_incl_d2h: host patterns in, (s, e, count) out in pinned, reused host arrays."""
+    torch, lib = wl.torch, wl.lib
+    import numpy as np
+    npat, m = wl.npat, wl.m
+    hp = torch.empty(npat * m, dtype=torch.uint8, pin_memory=True)
+    hp.copy_(wl.pat)
+    ho = torch.empty(npat + 1, dtype=torch.int64, pin_memory=True)
+    ho.copy_(wl.off)
+    hs = torch.empty(npat, dtype=torch.int64, pin_memory=True)
+    he = torch.empty(npat, dtype=torch.int64, pin_memory=True)
+    hc = torch.empty(npat, dtype=torch.int64, pin_memory=True)
+    torch.cuda.synchronize()
+
+    def call():
+        rc = lib.fmx_count_batch(wl.h, C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), npat, None,
+                                 C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+    for _ in range(3):
+        call()
+    reps = max(5, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    assert bool((hs.to(wl.dev) == wl.d_s).all()) and bool((he.to(wl.dev) == wl.d_e).all())
+    out["value_incl_d2h"] = npat * m / dt
+    out["incl_d2h"] = {"ms_per_call": dt * 1e3, "bytes_in": npat * m + (npat + 1) * 8, "bytes_out": 3 * npat * 8,
+                       "note": "fmx_count_batch (host pointers): upload, count, download, synchronise per call; "
+                               "pinned caller-owned arrays reused across calls; never the headline value"}
+    del hp, ho, hs, he, hc, np
+
+
+def rlfm_leg(out, args, dev, local):
+    """config 4: RLFMIndex (src/rlfmi.rs) over the 1 GB sigma=255 byte text, 2^20 length-16 patterns."""
+    import torch
+    wr = Workload("bytes-rlfm", args, dev, local, 0, 1)
+    npat, m = wr.npat, wr.m
+    for _ in range(args.warmup):
+        wr.count()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms = event_time_ms(torch, wr.stream, wr.count, args.steps)
+    dt = (time.perf_counter() - t0) / args.steps
+    kms, steps_exec = wr.timed_kernel(wr.count)
+    assert steps_exec == npat * m, (steps_exec, npat * m)
+    assert bool((wr.d_c >= 1).all())
+    assert wr.lib.fmx_stream_status(wr.h) == 0
+    cen = None
+    if not args.no_census:
+        cen = run_census(wr, lambda cl: wr.count(lib=cl), npat * m * 10 + (1 << 20))
+    key = "bytes-rlfm:%d:%d:%d" % (npat, m, args.log2n)
+    stream_bytes = npat * m + (npat + 1) * 8 + 3 * npat * 8
+    o = {"value": npat * m / (ms / 1e3), "unit": "pattern-chars/s", "ms_per_step": ms,
+         "wall_ms_per_step": dt * 1e3,
+         "config": {"workload": wr.describe(1), "text_len": wr.n, "patterns": npat, "pattern_len": m,
+                    "index_bytes": wr.index.heap_size(), "runs": int(wr.lib.fmx_num_runs(wr.h)),
+                    "build_ms": round(wr.build_ms, 1), "textgen_s": round(wr.textgen_s, 2)},
+         "roofline": make_roofline("fmx_count_rlfm_ep_kernel", ms, npat * m, wr.ref_bytes_per_char(), stream_bytes,
+                                   cen, stored_traffic(key, "count"))}
+    out["rlfm"] = o
+    if wr.level is not None:
+        locate_leg(out, wr, args, 1, 0, None, False, key, dest=o)
+    if not args.no_cpu_baseline:
+        wr.count()
+        torch.cuda.synchronize()
+        o["cpu_baseline"] = cpu_baseline(wr, args, "rlfm")
+    return wr
 
 
 if __name__ == "__main__":

@@ -92,12 +92,28 @@ SYMBOLS = [
 ]
 
 
+def csrc_hash():
+    """content hash of the HIP sources (the .git directory does not travel to the GPU box):
+    profiles/traffic.json entries are only trusted for the source tree they were measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_library(force=False):
     """Compile fm_index_amd/libfmx.so for gfx950 with hipcc (in-tree)."""
     csrc = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
     subprocess.check_call(["make", "-s", "-j4", "-C", csrc])
+    # the census library (line log for bench.py's byte model; measurement only, never the product path)
+    subprocess.check_call(["make", "-s", "-C", csrc, "census"])
     return LIB_PATH
 
 

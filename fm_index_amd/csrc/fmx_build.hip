@@ -724,7 +724,9 @@ __global__ __launch_bounds__(BLK) void k_dense_select_blocks(const uint8_t *__re
 int keep_dense_select(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, const uint32_t *d_pos) {
   bv->dsel = nullptr;
   if (bv->ones == 0 || (uint64_t)bv->ones * 2u < bv->len) return FMX_OK;
+#ifdef FMX_MEASURE
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 17) return FMX_OK;   // measurement: no blocks
+#endif
   const uint64_t nblk = ((uint64_t)bv->ones + 63u) / 64u;
   uint4 *d;
   FMX_HIP(hipMalloc((void **)&d, nblk * 16));
@@ -741,7 +743,9 @@ int keep_dense_select(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, const
 int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
   bv->pos = nullptr;
   if (bv->ones == 0 || (uint64_t)bv->ones * 16u > bv->len) return FMX_OK;
+#ifdef FMX_MEASURE
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 16) return FMX_OK;   // measurement: no positions
+#endif
   uint32_t *p;
   FMX_HIP(hipMalloc((void **)&p, (size_t)bv->ones * 4));
   if (int rc = keep(idx, p, (uint64_t)bv->ones * 4)) return rc;

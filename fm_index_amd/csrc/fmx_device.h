@@ -19,6 +19,26 @@
 #define FMX_CHECK(cond) do { } while (0)
 #endif
 
+// Census build (make census -> libfmx_census.so, -DFMX_CENSUS; measurement only, never shipped as
+// libfmx.so): every load of an index line appends its 128-byte line address to a log, so that
+// bench.py can count the lines a launch REQUESTS and the DISTINCT lines among them (the byte model
+// of DESIGN.md section 4).  A cooperative 8-lane record load is logged once (lane 0 of the group).
+#ifdef FMX_CENSUS
+struct FmxCensusDev { unsigned long long *log; unsigned long long *count; unsigned long long cap; };
+static __device__ FmxCensusDev fmx_census_dev;
+__device__ __forceinline__ void fmx_touch(const void *p) {
+  if (fmx_census_dev.log) {
+    const unsigned long long i = atomicAdd(fmx_census_dev.count, 1ull);
+    if (i < fmx_census_dev.cap) fmx_census_dev.log[i] = (unsigned long long)(uintptr_t)p >> 7;
+  }
+}
+#define FMX_TOUCH(p) fmx_touch((const void *)(p))
+#define FMX_TOUCH_G0(g, p) do { if ((g) == 0) fmx_touch((const void *)(p)); } while (0)
+#else
+#define FMX_TOUCH(p) do { } while (0)
+#define FMX_TOUCH_G0(g, p) do { } while (0)
+#endif
+
 // pattern / text symbol i of a buffer whose symbols are sb bytes wide (Character, character.rs)
 __device__ __forceinline__ uint32_t fmx_load_sym(const void *p, uint32_t sb, uint64_t i) {
   if (sb == 1) return ((const uint8_t *)p)[i];
@@ -98,6 +118,7 @@ template <int FMT>
 __device__ __forceinline__ uint4 fmx_load_piece(const FmxLevel &L, uint32_t pos, uint32_t g) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
   FMX_CHECK((pos >> SH) < L.nrec);
+  FMX_TOUCH_G0(g, &L.rec[(size_t)(pos >> SH) * 8u]);
   return L.rec[(size_t)(pos >> SH) * 8u + g];
 }
 template <int FMT>
@@ -315,6 +336,7 @@ __device__ __forceinline__ uint32_t fmx_bits_rank(const FmxBits &bv, uint32_t i,
   uint32_t p = fmx_div3(within >> 5);         // within / 96
   uint32_t bit = within - p * FMX_BITS_PER_PIECE;
   FMX_CHECK(rec < bv.nrec);
+  FMX_TOUCH_G0(g, &bv.rec[(size_t)rec * 8u]);
   uint4 pc = bv.rec[(size_t)rec * 8u + g];
   uint32_t c = __popc(pc.y & fmx_lowmask(bit < 32u ? bit : 32u));
   if (bit > 32u) c += __popc(pc.z & fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u));
@@ -336,6 +358,7 @@ __device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32
   const uint32_t p = fmx_div3(within >> 5);         // within / 96
   const uint32_t bit = within - p * FMX_BITS_PER_PIECE;
   FMX_CHECK(rec < bv.nrec);
+  FMX_TOUCH_G0(g, &bv.rec[(size_t)rec * 8u]);
   const uint4 pc = bv.rec[(size_t)rec * 8u + g];
   const uint32_t m0 = fmx_lowmask(bit < 32u ? bit : 32u);
   const uint32_t m1 = bit > 32u ? fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u) : 0u;
@@ -368,20 +391,24 @@ __device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k) {
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
-  if (bv.pos) return bv.pos[k];               // sparse vector: the positions are stored
+  if (bv.pos) { FMX_TOUCH_G0(g, &bv.pos[k]); return bv.pos[k]; }   // sparse vector: the positions are stored
   if (bv.dsel) {                              // dense vector: one 16-byte block answers it
+    FMX_TOUCH_G0(g, &bv.dsel[k >> 6]);
     const uint4 blk = bv.dsel[k >> 6];
     if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k);
   }
   uint32_t h = k / FMX_SEL_STEP;
   FMX_CHECK(h + 1 < bv.nsel);
+  FMX_TOUCH_G0(g, &bv.sel[h]);
   uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
   FMX_CHECK(lo < bv.nrec && hi < bv.nrec);
   while (lo < hi) {  // group-uniform binary search over record bases
     uint32_t mid = (lo + hi + 1u) >> 1;
+    FMX_TOUCH_G0(g, &bv.rec[(size_t)mid * 8u]);
     uint32_t x = bv.rec[(size_t)mid * 8u].x;
     if (x <= k) lo = mid; else hi = mid - 1u;
   }
+  FMX_TOUCH_G0(g, &bv.rec[(size_t)lo * 8u]);
   uint4 pc = bv.rec[(size_t)lo * 8u + g];
   uint32_t p = fmx_group_sum(pc.x <= k ? 1u : 0u) - 1u;  // last piece whose base <= k
   uint32_t rem = k - pc.x;                                // meaningful on lane p only
@@ -407,12 +434,16 @@ __device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k
   const bool v0 = k0 < A.ones, v1 = k1 < B.ones;
   const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
   if (SM == 1 || (SM < 0 && A.pos && B.pos)) {   // sparse vectors: the positions are stored
+    FMX_TOUCH_G0(g, &A.pos[q0]);
+    FMX_TOUCH_G0(g, &B.pos[q1]);
     const uint32_t a0 = A.pos[q0], a1 = B.pos[q1];
     out0 = v0 ? a0 : A.len;
     out1 = v1 ? a1 : B.len;
     return;
   }
   if (SM == 2 || (SM < 0 && A.dsel && B.dsel)) {   // dense vectors: one 16-byte block per select
+    FMX_TOUCH_G0(g, &A.dsel[q0 >> 6]);
+    FMX_TOUCH_G0(g, &B.dsel[q1 >> 6]);
     const uint4 b0 = A.dsel[q0 >> 6], b1 = B.dsel[q1 >> 6];
     if (b0.x != 0xFFFFFFFFu && b1.x != 0xFFFFFFFFu) {
       out0 = v0 ? fmx_dsel_pos(b0, q0) : A.len;
@@ -421,15 +452,21 @@ __device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k
     }
   }
   FMX_CHECK(q0 / FMX_SEL_STEP + 1 < A.nsel && q1 / FMX_SEL_STEP + 1 < B.nsel);
+  FMX_TOUCH_G0(g, &A.sel[q0 / FMX_SEL_STEP]);
+  FMX_TOUCH_G0(g, &B.sel[q1 / FMX_SEL_STEP]);
   uint32_t lo0 = A.sel[q0 / FMX_SEL_STEP], hi0 = A.sel[q0 / FMX_SEL_STEP + 1];
   uint32_t lo1 = B.sel[q1 / FMX_SEL_STEP], hi1 = B.sel[q1 / FMX_SEL_STEP + 1];
   FMX_CHECK(hi0 < A.nrec && hi1 < B.nrec);
   while (lo0 < hi0 || lo1 < hi1) {  // group-uniform binary searches over record bases
     const uint32_t m0 = (lo0 + hi0 + 1u) >> 1, m1 = (lo1 + hi1 + 1u) >> 1;
+    if (lo0 < hi0) FMX_TOUCH_G0(g, &A.rec[(size_t)m0 * 8u]);
+    if (lo1 < hi1) FMX_TOUCH_G0(g, &B.rec[(size_t)m1 * 8u]);
     const uint32_t x0 = A.rec[(size_t)m0 * 8u].x, x1 = B.rec[(size_t)m1 * 8u].x;
     if (lo0 < hi0) { if (x0 <= q0) lo0 = m0; else hi0 = m0 - 1u; }
     if (lo1 < hi1) { if (x1 <= q1) lo1 = m1; else hi1 = m1 - 1u; }
   }
+  FMX_TOUCH_G0(g, &A.rec[(size_t)lo0 * 8u]);
+  FMX_TOUCH_G0(g, &B.rec[(size_t)lo1 * 8u]);
   const uint4 a = A.rec[(size_t)lo0 * 8u + g];
   const uint4 b = B.rec[(size_t)lo1 * 8u + g];
   uint32_t res[2];

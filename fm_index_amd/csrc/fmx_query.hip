@@ -12,22 +12,26 @@
 // up the next unit while its wave-mates keep stepping -- no lane idles on
 // divergence except in the tail.  Integer / popcount work only; HBM-bound.
 #include <cstdlib>
-#include "fmx_device.h"
+#include "fmx_ep.h"
 
 #define FMX_BLOCK 256
 #define FMX_MAX_BLOCKS 2048  // 256 CUs x 8 resident 256-thread blocks
 
-// Kernel variant selector (environment FMX_VARIANT, read once), kept so the measured
-// alternatives of DESIGN.md section 4.1 stay reproducible:
-//   unset / 1  single-level fast paths (count: 1 chain per group, both record loads issued)
-//   0          force the generic kernels (any kind / any number of levels)
-//   2, 5       count with 2 / 4 independent chains per group          (slower: 0.78 / 1.00 ms)
-//   3, 4       count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
-//   (non-temporal loads for the deep steps were also measured: 0.80 ms, removed)
+// Kernel variant selector.  The SHIPPED library (libfmx.so) has one path per index kind: this
+// function is the constant 1 there and no environment variable is read on any launch path.
+// Measurement builds (make measure / make debug, -DFMX_MEASURE) read FMX_VARIANT once, so that the
+// alternatives DESIGN.md section 4.1 quotes stay reproducible:
+//   unset / 1  the shipped paths
+//   0          force the round-1 generic group-per-pattern kernels (any kind / any number of levels)
+//   2, 5       DNA count with 2 / 4 independent chains per group            (slower: 0.78 / 1.00 ms)
+//   3, 4       DNA count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
 //   6          ignore the k-mer start table even when it was built
 //   7          ignore the pair index even when it was built
-//   8, 9       measurement only: lane-per-pattern / wavefront-per-pattern count kernels
+//   8, 9       lane-per-pattern / wavefront-per-pattern DNA count kernels
+//   11, 12, 14 DNA locate with 1 / 2 / 4 walks per group
 //   16, 17     (builder) do not store the positions of sparse / the select blocks of dense RLFM bit vectors
+// and FMX_EP_BLOCKS / FMX_LOC_WAVES (grid sizes of the endpoint-per-lane and locate kernels).
+#ifdef FMX_MEASURE
 static inline int fmx_variant() {
   static const int cached = [] {
     const char *v = getenv("FMX_VARIANT");
@@ -35,6 +39,14 @@ static inline int fmx_variant() {
   }();
   return cached;
 }
+static inline long fmx_env_long(const char *name, long dflt) {
+  const char *v = getenv(name);
+  return v ? atol(v) : dflt;
+}
+#else
+static constexpr int fmx_variant() { return 1; }
+static constexpr long fmx_env_long(const char *, long dflt) { return dflt; }
+#endif
 
 static inline unsigned fmx_grid_for_groups(uint64_t units) {
   uint64_t blocks = (units * FMX_GROUP + FMX_BLOCK - 1) / FMX_BLOCK;
@@ -108,10 +120,13 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
   uint32_t c = 0;            // symbol of the coming step (loaded one step ahead)
   uint32_t nsteps = 0;
 
+  const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
   while (active) {
     if (fresh) {
       pbeg = off[k];
-      j = (uint32_t)(off[k + 1] - pbeg);
+      const uint64_t pend = off[k + 1];
+      j = (uint32_t)(pend - pbeg);
+      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
       if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
         const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
         s = (uint32_t)s64;
@@ -123,10 +138,11 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
       } else {               // SearchIndexWrapper::search: (0, len)   (wrapper.rs:41)
         s = 0;
         e = ix.n;
-        if (KM && j >= ix.kmer_k) {                    // the first kmer_k steps from the table (u8 symbols)
+        if (KM && !badoff && j >= ix.kmer_k) {         // the first kmer_k steps from the table (u8 symbols)
           uint32_t code;
           if (fmx_kmer_code((const uint8_t *)pat, pbeg + j, ix.kmer_k, ix.kmer_bits, ix.max_character, g,
                             code)) {
+            FMX_TOUCH_G0(g, &ix.kmer[code]);
             const uint2 se = ix.kmer[code];
             s = se.x;
             e = se.y;
@@ -134,6 +150,10 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
             nsteps += ix.kmer_k;
           }
         }
+      }
+      if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
+        if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+        s = 0; e = 0; j = 0;
       }
       c = j ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 1) : 0u;  // pattern.iter().rev()  wrapper.rs:108
       fresh = false;
@@ -202,12 +222,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     any |= active[q];
     pbeg[q] = 0; j[q] = 0; s[q] = 0; e[q] = 0; c[q] = 0;
   }
+  const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
   while (any) {
 #pragma unroll
     for (int q = 0; q < PPG; q++) {
       if (active[q] && fresh[q]) {
         pbeg[q] = off[k[q]];
-        j[q] = (uint32_t)(off[k[q] + 1] - pbeg[q]);
+        const uint64_t pend = off[k[q] + 1];
+        j[q] = (uint32_t)(pend - pbeg[q]);
+        const bool badoff = pend < pbeg[q] || pend > ptot || pend - pbeg[q] > 0xFFFFFFFFull;
         if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
           const uint64_t s64 = s0e0[2 * k[q]], e64 = s0e0[2 * k[q] + 1];
           s[q] = (uint32_t)s64;
@@ -219,9 +242,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         } else {               // (0, len)   wrapper.rs:41
           s[q] = 0;
           e[q] = n;
-          if (KM && j[q] >= kmer_k) {                  // the first kmer_k steps from the table
+          if (KM && !badoff && j[q] >= kmer_k) {       // the first kmer_k steps from the table
             uint32_t code;
             if (fmx_kmer_code(pat, pbeg[q] + j[q], kmer_k, kmer_bits, max_character, g, code)) {
+              FMX_TOUCH_G0(g, &kmer[code]);
               const uint2 se = kmer[code];
               s[q] = se.x;
               e[q] = se.y;
@@ -229,6 +253,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
               nsteps += kmer_k;
             }
           }
+        }
+        if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
+          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+          s[q] = 0; e[q] = 0; j[q] = 0;
         }
         c[q] = j[q] ? pat[pbeg[q] + j[q] - 1] : 0u;   // last symbol: pattern.iter().rev()
         fresh[q] = false;
@@ -245,6 +273,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
       if (stepping[q]) {
         uint32_t rs = s[q] >> 8, re = e[q] >> 8;
         FMX_CHECK(rs < nrec && re < nrec);
+        FMX_TOUCH_G0(g, &rec[(size_t)rs * 8u]);
+        if (!SKIP || re != rs) FMX_TOUCH_G0(g, &rec[(size_t)re * 8u]);
         if (SKIP) {
           a[q] = rec[(size_t)rs * 8u + g];
           b[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -294,6 +324,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+#ifdef FMX_MEASURE
 // ---------------------------------------------------------------------------
 // Measurement-only alternatives to the 8-lane-group shape (selected
 // with FMX_VARIANT=8 / 9, never used by default):
@@ -372,6 +403,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_wave_kernel(
   if (steps_out && lane == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+#endif  // FMX_MEASURE
+
 // ---------------------------------------------------------------------------
 // count with the opt-in pair index (FMX_FLAG_PAIR_INDEX): while at least two symbols remain
 // (both in 1..4) one probe of the 2-gram records per interval end advances TWO pattern symbols:
@@ -398,10 +431,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
   uint32_t j = 0, s = 0, e = 0;
   uint32_t c2 = 0, c1 = 0;   // c2 = last unread symbol, c1 = the one before it
   uint32_t nsteps = 0;
+  const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
   while (active) {
     if (fresh) {
       pbeg = off[k];
-      j = (uint32_t)(off[k + 1] - pbeg);
+      const uint64_t pend = off[k + 1];
+      j = (uint32_t)(pend - pbeg);
+      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
       if (s0e0) {
         const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
         s = (uint32_t)s64;
@@ -413,9 +449,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
       } else {
         s = 0;
         e = n;
-        if (KM && j >= kmer_k) {                       // the first kmer_k steps from the table
+        if (KM && !badoff && j >= kmer_k) {            // the first kmer_k steps from the table
           uint32_t code;
           if (fmx_kmer_code(pat, pbeg + j, kmer_k, kmer_bits, max_character, g, code)) {
+            FMX_TOUCH_G0(g, &kmer[code]);
             const uint2 se = kmer[code];
             s = se.x;
             e = se.y;
@@ -423,6 +460,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
             nsteps += kmer_k;
           }
         }
+      }
+      if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
+        if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+        s = 0; e = 0; j = 0;
       }
       c2 = j ? pat[pbeg + j - 1] : 0u;
       c1 = j > 1 ? pat[pbeg + j - 2] : 0u;
@@ -442,6 +483,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
         if (pair) {
           const uint32_t code = (c1 - 1u) * 4u + (c2 - 1u);
           FMX_CHECK((s >> 7) < n / 128u + 1u && (e >> 7) < n / 128u + 1u);
+          FMX_TOUCH_G0(g, &rec2[(size_t)(s >> 7) * 8u]);
+          FMX_TOUCH_G0(g, &rec2[(size_t)(e >> 7) * 8u]);
           const uint4 a = rec2[(size_t)(s >> 7) * 8u + g];
           const uint4 b = rec2[(size_t)(e >> 7) * 8u + g];
           uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(a, s & 127u, code, g));
@@ -454,6 +497,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
           if (ns == ne) {
             // would the reference already have stopped after the last symbol alone?
             FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
+            FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
+            FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
             const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
             const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
             const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));
@@ -463,6 +508,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
           s = ns; e = ne;
         } else {
           FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
+          FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
+          FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
           const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
           const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
           const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));  // wrapper.rs:109
@@ -489,6 +536,101 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
   }
   if (steps_out && g == 0 && nsteps)
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---------------------------------------------------------------------------
+// count on the RLFM index, endpoint per lane (fmx_ep.h): lane 2q carries s and lane 2q+1 carries e
+// of the group's q-th pattern, so a group advances 4 patterns and a wave 32, with 64 probes in
+// flight in each of the four dependent stages of a step (B piece, S level 0, S level 1, B' select).
+// Same state machine as above: a pattern that ends (all symbols consumed, or the `s == e` break of
+// wrapper.rs:111-113) is replaced at once; the loop is wave-uniform because the rank rounds are.
+// SM = 1 (stored positions) or 2 (select blocks); indexes whose B / B' fall into neither class stay
+// on fmx_count_kernel<FMX_KIND_RLFM>.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool fmx_kmer_code_lane(const uint8_t *__restrict__ pat, uint64_t pend, uint32_t kk,
+                                                   uint32_t bits, uint32_t max_character, uint32_t &code) {
+  uint32_t bad = 0;
+  code = 0;
+  for (uint32_t t = 0; t < kk; t++) {                     // t-th symbol from the back
+    const uint32_t cc = pat[pend - 1u - t];
+    bad |= (uint32_t)((cc - 1u) >= max_character);
+    code |= ((cc - 1u) & ((1u << bits) - 1u)) << (bits * (kk - 1u - t));
+  }
+  return bad == 0u;
+}
+template <int NL, int SM, bool KM>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_rlfm_ep_kernel(
+    FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
+  const uint32_t is_e = g & 1u;
+  const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  const uint64_t nslots = ((uint64_t)gridDim.x * blockDim.x) >> 1;
+  const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
+
+  uint64_t k = slot, pbeg = 0;
+  bool active = k < npat, fresh = true;
+  uint32_t j = 0, pos = 0, c = 0, nsteps = 0;
+  while (__any(active)) {
+    if (active && fresh) {
+      pbeg = off[k];
+      const uint64_t pend = off[k + 1];
+      j = (uint32_t)(pend - pbeg);
+      bool bad = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
+        const uint64_t mine = s0e0[2 * k + is_e], other = s0e0[2 * k + (is_e ^ 1u)];
+        pos = (uint32_t)mine;
+        bad |= mine > ix.n || other > ix.n;              // not a range of this index
+      } else {               // SearchIndexWrapper::search: (0, len)   (wrapper.rs:41)
+        pos = is_e ? ix.n : 0u;
+        if (KM && !bad && j >= ix.kmer_k) {              // the first kmer_k steps from the table
+          uint32_t code;
+          if (fmx_kmer_code_lane((const uint8_t *)pat, pbeg + j, ix.kmer_k, ix.kmer_bits, ix.max_character,
+                                 code)) {
+            FMX_TOUCH(&ix.kmer[code]);
+            const uint2 se = ix.kmer[code];
+            pos = is_e ? se.y : se.x;
+            j = se.x == se.y ? 0u : j - ix.kmer_k;       // empty already: the reference's break
+            nsteps += is_e ? 0u : ix.kmer_k;
+          }
+        }
+      }
+      if (bad) {             // refuse, do not read
+        if (is_e) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+        pos = 0; j = 0;
+      }
+      c = j ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 1) : 0u;  // pattern.iter().rev()  wrapper.rs:108
+      fresh = false;
+    }
+    bool stepping = active && j != 0;
+    if (stepping && c > ix.max_character) {              // reference: panic on cs[c]
+      if (is_e) atomicOr(ix.status, 1u << FMX_ERR_SYMBOL_RANGE);
+      pos = 0; j = 0; stepping = false;
+    }
+    // the next symbol rides along with this step's probes
+    const uint32_t cn = (stepping && j > 1) ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
+    const uint32_t np = fmx_rlfm_ep_lf_map2<NL, SM>(ix, stepping ? c : 0u, stepping ? pos : 0u, base, g);  // wrapper.rs:109-110
+    if (stepping) {
+      pos = np;
+      c = cn;
+      j--;
+      nsteps += is_e ^ 1u;
+    }
+    const uint32_t other = fmx_dpp_xor1(pos);            // the pattern's other interval end
+    if (active && (j == 0 || pos == other)) {            // wrapper.rs:111-113
+      if (is_e) {
+        if (out_e) out_e[k] = pos;
+        if (out_cnt) out_cnt[k] = (uint64_t)(pos - other);   // wrapper.rs:132-134
+      } else if (out_s) {
+        out_s[k] = pos;
+      }
+      k += nslots;
+      active = k < npat;
+      fresh = true;
+    }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // ---------------------------------------------------------------------------
@@ -582,6 +724,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
       if ((row & lmask) == 0) {
         // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
         FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
+        FMX_TOUCH_G0(g, &ix.samples[row >> ix.sa_level]);
         uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
         if (v >= ix.n) v -= ix.n;  // steps < n, sa < n
         if (g == 0) out_pos[h] = v;
@@ -611,6 +754,64 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
   }
   if (steps_out && g == 0 && nsteps)
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// locate walk on the RLFM index, one walk per LANE (fmx_ep.h): 64 walks per wave, every LF step =
+// lane-wise B probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects.  A wave
+// owns a contiguous chunk of hits and hands them to its lanes as they finish (ballot + prefix
+// popcount, no atomics).  K[] is staged in LDS when the alphabet is small (it is read with a
+// data-dependent symbol in every step).
+template <int NL, int SM, bool KLDS>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rlfm_ep_kernel(
+    FmxDev ix, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
+  if (KLDS) {
+    for (uint32_t t = threadIdx.x; t <= ix.max_character; t += blockDim.x) kt_lds[t] = ix.K[t];
+    __syncthreads();
+  }
+  const uint32_t *kt = KLDS ? kt_lds : ix.K;
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lmask = (1u << ix.sa_level) - 1u;
+  const uint64_t w0 = wave * hits_per_wave;
+  if (w0 >= total) return;                          // wave-uniform
+  const uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
+  // rows come from fmx_expand_kernel, which writes every slot, so every row is inside the index
+  uint64_t h = w0 + lane;
+  bool active = h < w1;
+  uint32_t row = active ? rows[h] : 0u;
+  uint64_t next = w0 + 64 < w1 ? w0 + 64 : w1;
+  uint32_t steps = 0, nsteps = 0;
+  while (__any(active)) {
+    const bool sampled = active && (row & lmask) == 0u;
+    uint32_t sa = 0;
+    if (sampled) {                                  // sample.rs:46-60 Some(sa)
+      FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
+      FMX_TOUCH(&ix.samples[row >> ix.sa_level]);
+      sa = ix.samples[row >> ix.sa_level];
+    }
+    const bool walking = active && !sampled;
+    if (__any(walking)) {                           // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186
+      uint32_t sym;
+      const uint32_t nrow = fmx_rlfm_ep_lf_map<NL, SM>(ix, kt, walking ? row : 0u, base, g, sym);
+      if (walking) { row = nrow; steps++; nsteps++; }
+    }
+    const unsigned long long fmask = __ballot(sampled);
+    if (fmask) {                                    // wave-uniform
+      if (sampled) {
+        uint64_t v = (uint64_t)sa + steps;          // rlfmi.rs:181: (sa + steps) % len
+        if (v >= ix.n) v -= ix.n;
+        out_pos[h] = v;
+        h = next + (uint64_t)__popcll(fmask & ((1ull << lane) - 1ull));
+        active = h < w1;
+        steps = 0;
+        row = active ? rows[h] : 0u;
+      }
+      next += (uint64_t)__popcll(fmask);
+    }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // locate walk, single 3-bit level (DNA).  A WAVE owns a contiguous chunk of hits and hands them
@@ -690,6 +891,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
         FMX_CHECK(row[q] < n && (row[q] >> 8) < n / 256u + 1u);
         FMX_CHECK(!sampled[q] || (uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
         const uint4 *addr = sampled[q] ? (samp4 + (si >> 2)) : (rec + ((size_t)(row[q] >> 8) * 8u + g));
+        FMX_TOUCH_G0(g, sampled[q] ? addr : addr - g);
         p[q] = *addr;
       }
     }
@@ -1070,6 +1272,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
                      idx->dev.kmer_k, idx->dev.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e,      \
                      d_cnt, steps)
     switch (variant) {
+#ifdef FMX_MEASURE
       case 8:  // measurement only: lane per pattern
         if (d_s0e0) return FMX_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(fmx_count_f3_lane_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
@@ -1086,6 +1289,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
       case 3: FMX_F3_LAUNCH(1, true, false); break;
       case 4: FMX_F3_LAUNCH(2, true, false); break;
       case 5: FMX_F3_LAUNCH(4, false, false); break;
+#endif
       default:
         if (km) FMX_F3_LAUNCH(1, false, true);
         else FMX_F3_LAUNCH(1, false, false);
@@ -1109,11 +1313,38 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     else FMX_COUNT_LAUNCH(KIND, 0, SM);                                                             \
   } while (0)
     // RLFM: the select structure of B / B' (positions, select blocks, hints + records) is fixed at
-    // compile time as well, so the search loop holds no branch on it
-    if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
+    // compile time as well, so the search loop holds no branch on it.  With positions or select
+    // blocks every select is one lane-wise load and the endpoint-per-lane kernel runs (fmx_ep.h);
+    // mixed-density indexes (hints + record search) keep the group-per-pattern kernel.
+    const int sm = idx->kind != FMX_KIND_RLFM ? -1
+                   : (idx->dev.b.pos && idx->dev.bp.pos) ? 1
+                   : (idx->dev.b.dsel && idx->dev.bp.dsel) ? 2 : 0;
+    if (sm > 0 && variant != 0) {
+      // 64 probes in flight per wave and stage: 4 waves per SIMD saturate the memory system
+      const uint64_t ep_cap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", 1024);
+      uint64_t eb = (npat * 2 + FMX_BLOCK - 1) / FMX_BLOCK;
+      if (eb > ep_cap) eb = ep_cap;
+#define FMX_EP_LAUNCH(NL, SM)                                                                        \
+  do {                                                                                               \
+    if (km && idx->sym_bytes == 1)                                                                   \
+      hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, true>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
+                         0, st, idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+    else                                                                                             \
+      hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, false>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
+                         0, st, idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+  } while (0)
+#define FMX_EP_SM(SM)                                                                                \
+  do {                                                                                               \
+    if (w.nlevels == 1) FMX_EP_LAUNCH(1, SM);                                                        \
+    else if (w.nlevels == 2) FMX_EP_LAUNCH(2, SM);                                                   \
+    else FMX_EP_LAUNCH(0, SM);                                                                       \
+  } while (0)
+      if (sm == 1) FMX_EP_SM(1); else FMX_EP_SM(2);
+    }
+    else if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI, -1);
-    else if (idx->dev.b.pos && idx->dev.bp.pos) FMX_COUNT_KIND(FMX_KIND_RLFM, 1);
-    else if (idx->dev.b.dsel && idx->dev.bp.dsel) FMX_COUNT_KIND(FMX_KIND_RLFM, 2);
+    else if (sm == 1) FMX_COUNT_KIND(FMX_KIND_RLFM, 1);
+    else if (sm == 2) FMX_COUNT_KIND(FMX_KIND_RLFM, 2);
     else FMX_COUNT_KIND(FMX_KIND_RLFM, 0);
   }
   fmx_time_end(idx, st);
@@ -1167,7 +1398,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // measured (profiles/README.md): the loop is instruction-issue bound at 8 waves/SIMD, so
     // mid-size batches finish sooner on 4 waves/SIMD with 4 walks per group
     uint64_t cap = total < (4u << 20) ? max_waves / 2 : max_waves;
-    if (const char *e = getenv("FMX_LOC_WAVES")) cap = (uint64_t)atoll(e);
+    cap = (uint64_t)fmx_env_long("FMX_LOC_WAVES", (long)cap);
     if (nw > cap) nw = cap;
     const uint64_t hp = (total + nw - 1) / nw;
     const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
@@ -1185,10 +1416,42 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     else if (w.nlevels == 2) FMX_LOCATE_LAUNCH(KIND, 2, SM);                                        \
     else FMX_LOCATE_LAUNCH(KIND, 0, SM);                                                            \
   } while (0)
-    if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
+    const int sm = idx->kind != FMX_KIND_RLFM ? -1
+                   : (idx->dev.b.pos && idx->dev.bp.pos) ? 1
+                   : (idx->dev.b.dsel && idx->dev.bp.dsel) ? 2 : 0;
+    if (sm > 0 && fmx_variant() != 0) {
+      // one walk per lane: 64 walks per wave
+      // measured (benchmarks/gpu/ep_sweep.sh): 2^20 hits finish soonest on 512 blocks (0.45 ms; 0.47 on
+      // 1024, 0.50 on 2048), 7.9e8 hits on 2048 (84 ms; 91 on 1024, 129 on 512): smaller chunks per wave
+      // balance the walk lengths better once there is enough work for every wave
+      uint64_t nw = (total + 63) / 64;
+      const uint64_t wcap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", total < (4u << 20) ? 512 : 2048) *
+                            (FMX_BLOCK / 64);
+      if (nw > wcap) nw = wcap;
+      const uint64_t hp = (total + nw - 1) / nw;
+      const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+      const bool klds = idx->dev.max_character < 1024u;
+#define FMX_EPL_LAUNCH(NL, SM)                                                                       \
+  do {                                                                                               \
+    if (klds)                                                                                        \
+      hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, true>), dim3(gr), dim3(FMX_BLOCK), 0, st,  \
+                         idx->dev, total, hp, rows, d_pos, steps);                                    \
+    else                                                                                             \
+      hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, false>), dim3(gr), dim3(FMX_BLOCK), 0, st, \
+                         idx->dev, total, hp, rows, d_pos, steps);                                    \
+  } while (0)
+#define FMX_EPL_SM(SM)                                                                               \
+  do {                                                                                               \
+    if (w.nlevels == 1) FMX_EPL_LAUNCH(1, SM);                                                       \
+    else if (w.nlevels == 2) FMX_EPL_LAUNCH(2, SM);                                                  \
+    else FMX_EPL_LAUNCH(0, SM);                                                                      \
+  } while (0)
+      if (sm == 1) FMX_EPL_SM(1); else FMX_EPL_SM(2);
+    }
+    else if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);
-    else if (idx->dev.b.pos && idx->dev.bp.pos) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);
-    else if (idx->dev.b.dsel && idx->dev.bp.dsel) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
+    else if (sm == 1) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);
+    else if (sm == 2) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
     else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);
   }
   fmx_time_end(idx, st);
@@ -1260,3 +1523,25 @@ int fmx_launch_compute_K(const FmxMwm &w, const uint64_t *d_cs, uint32_t *d_K,
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// census build only (make census): line log of the launches that follow fmx_census_begin
+// ---------------------------------------------------------------------------
+#ifdef FMX_CENSUS
+extern "C" int fmx_census_begin(void *d_log, uint64_t cap_entries, void *d_count) {
+  FmxCensusDev h;
+  h.log = (unsigned long long *)d_log;
+  h.count = (unsigned long long *)d_count;
+  h.cap = cap_entries;
+  FMX_HIP(hipMemset(d_count, 0, 8));
+  FMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fmx_census_dev), &h, sizeof h));
+  return FMX_OK;
+}
+extern "C" int fmx_census_end(void) {
+  FmxCensusDev h;
+  h.log = nullptr; h.count = nullptr; h.cap = 0;
+  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fmx_census_dev), &h, sizeof h));
+  return FMX_OK;
+}
+#endif

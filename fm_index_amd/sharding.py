@@ -60,3 +60,66 @@ def gather_positions(local_counts, local_pos, nitems, group=None):
     dist.all_gather_into_tensor(buf, pad, group=group)
     pos = torch.cat([buf[r * mx:r * mx + totals[r]] for r in range(world)])
     return off, pos
+
+
+def wire_dtype(text_len, force=None):
+    """dtype the per-pattern counts travel in: counts are <= len (wrapper.rs:132-134: e - s), so
+    int32 halves the gather while len < 2^31; beyond that they stay int64.  Forcing int32 on a
+    longer text is refused instead of truncating."""
+    if force is not None:
+        if force == torch.int32 and text_len >= (1 << 31):
+            raise ValueError("counts of a text with len >= 2^31 do not fit the int32 wire format")
+        return force
+    return torch.int32 if text_len < (1 << 31) else torch.int64
+
+
+class CountGatherPipeline:
+    """The N > 1 step of bench.py (BASELINE config 5): search this rank's shard, all-gather the
+    per-pattern counts of every rank.
+
+    Two result buffers alternate: the gather of step k is issued asynchronously (on RCCL's stream
+    it starts once the kernel that produced its input has finished) and runs under the search
+    kernel of step k+1; a buffer is reused only after its gather has completed.  `launch(out64)`
+    must enqueue the count of this rank's shard on the current stream, writing int64 counts into
+    `out64` (the ABI's u64 counts).  With backend "gloo" (CPU tests, single-GPU rehearsal) the
+    counts go through host memory.
+    """
+
+    def __init__(self, npat_local, world, text_len, device, backend="nccl", pipelined=True,
+                 group=None, force_wire=None):
+        self.npat, self.world, self.group = npat_local, world, group
+        self.device = torch.device(device)
+        self.host = backend == "gloo"
+        self.wire = wire_dtype(text_len, force_wire)
+        self.nbuf = 2 if (pipelined and world > 1) else 1
+        self.local64 = [torch.empty(npat_local, dtype=torch.int64, device=self.device) for _ in range(self.nbuf)]
+        gdev = torch.device("cpu") if self.host else self.device
+        self.local_w = [torch.empty(npat_local, dtype=self.wire, device=gdev) for _ in range(self.nbuf)]
+        self.gathered = [torch.empty(npat_local * world, dtype=self.wire, device=gdev)
+                         for _ in range(self.nbuf)] if world > 1 else []
+        self.pending = [None] * self.nbuf
+        self.k = 0
+
+    def step(self, launch):
+        """one search + gather; returns the tensor that will hold all ranks' counts in input
+        order (complete after drain(), or after the next step() on the same buffer)."""
+        b = self.k % self.nbuf
+        self.k += 1
+        if self.pending[b] is not None:          # this buffer's previous gather must be done
+            self.pending[b].wait()
+            self.pending[b] = None
+        launch(self.local64[b])
+        if self.world == 1:
+            return self.local64[b]
+        self.local_w[b].copy_(self.local64[b])   # down-cast (and D2H for gloo)
+        work = dist.all_gather_into_tensor(self.gathered[b], self.local_w[b], group=self.group,
+                                           async_op=self.nbuf > 1)
+        if self.nbuf > 1:
+            self.pending[b] = work
+        return self.gathered[b]
+
+    def drain(self):
+        for b in range(self.nbuf):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None

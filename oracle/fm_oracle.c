@@ -581,6 +581,65 @@ int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_c
   *out = f;
   return ORC_OK;
 }
+/* Same construction as orc_rlfm_new (rlfmi.rs:41-96), fed with the L column instead of the text:
+ * the symbol the loop reads for row i, T[SA[i]-1] (T[n-1] = 0 when SA[i] = 0), IS bwt[i]
+ * (fm_index.rs:50-55).  Used by bench.py's cpu_baseline at n = 2^30, where the CPU suffix sort
+ * would take longer than the whole benchmark; `samples` (may be NULL) are the SA samples of `level`. */
+int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                      const uint32_t *samples, int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  orc_rlfm *f = (orc_rlfm *)calloc(1, sizeof(orc_rlfm));
+  uint64_t m = max_character + 1;
+  f->len = n;
+  f->max_character = max_character;
+  uint64_t nw = (n + 63) / 64 + BLK_WORDS;
+  uint64_t *bw = (uint64_t *)calloc(nw, 8), *bpw = (uint64_t *)calloc(nw, 8);
+  uint8_t *heads = (uint8_t *)malloc(n ? n : 1);
+  uint32_t *run_len = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  uint64_t *runs_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t r = 0, c0 = 0;                                       /* rlfmi.rs:41 */
+  for (uint64_t i = 0; i < n; i++) {                            /* rlfmi.rs:48-68 */
+    uint64_t c = bwt[i];
+    if (c0 != c) {
+      heads[r] = (uint8_t)c;
+      run_len[r] = 1;
+      r++;
+      bits_set(bw, i);
+      runs_of[c]++;
+    } else {
+      run_len[r - 1]++;
+    }
+    c0 = c;
+  }
+  f->runs = r;
+  orc_wm_build(&f->s, heads, r, orc_max_bits(max_character));  /* rlfmi.rs:69-70 */
+  f->cs = (uint64_t *)calloc(m, sizeof(uint64_t));
+  uint64_t acc = 0;
+  for (uint64_t c = 0; c < m; c++) { f->cs[c] = acc; acc += runs_of[c]; } /* rlfmi.rs:72-76 */
+  uint64_t *start_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  {
+    uint64_t *chars_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+    for (uint64_t k = 0; k < r; k++) chars_of[heads[k]] += run_len[k];
+    uint64_t a = 0;
+    for (uint64_t c = 0; c < m; c++) { start_of[c] = a; a += chars_of[c]; }
+    free(chars_of);
+  }
+  for (uint64_t k = 0; k < r; k++) {                            /* rlfmi.rs:71-83 */
+    uint64_t c = heads[k];
+    bits_set(bpw, start_of[c]);
+    start_of[c] += run_len[k];
+  }
+  orc_rsvec_build(&f->b, bw, n);                                /* rlfmi.rs:85 */
+  orc_rsvec_build(&f->bp, bpw, n);                              /* rlfmi.rs:86 */
+  if (level >= 0 && samples) {
+    orc_ssa_from_samples(&f->ssa, samples, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  free(start_of); free(runs_of); free(run_len); free(heads);
+  *out = f;
+  return ORC_OK;
+}
 void orc_rlfm_free(orc_rlfm *f) {
   if (!f) return;
   orc_wm_free(&f->s);

@@ -145,6 +145,8 @@ typedef struct orc_rlfm {
 } orc_rlfm;
 int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_character,
                  int level);
+int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                      const uint32_t *samples, int level);
 void orc_rlfm_free(orc_rlfm *f);
 orc_backend orc_rlfm_backend(orc_rlfm *f);
 

@@ -55,6 +55,8 @@ def _bind(lib):
     lib.orc_fm_heap_bytes.restype = C.c_uint64
     lib.orc_fm_heap_bytes.argtypes = [C.c_void_p]
     lib.orc_rlfm_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    lib.orc_rlfm_from_bwt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64,
+                                      C.c_void_p, C.c_int]
     lib.orc_rlfm_free.argtypes = [C.c_void_p]
     lib.orc_rlfm_backend.restype = _Backend
     lib.orc_rlfm_backend.argtypes = [C.c_void_p]
@@ -202,8 +204,11 @@ class OracleIndex:
             b = _u8(b)
             cs = np.ascontiguousarray(cs, dtype=np.uint64)
             sp = _p(np.ascontiguousarray(samples, dtype=np.uint32)) if samples is not None else None
-            rc = self._l.orc_fm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, _p(cs),
-                                         sp, lvl)
+            if kind == "rlfm":   # run-length structure of the same L column (rlfmi.rs:41-96)
+                rc = self._l.orc_rlfm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, sp, lvl)
+            else:
+                rc = self._l.orc_fm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, _p(cs),
+                                             sp, lvl)
         elif _is_wide(text):
             t = _u32(text)
             self._text_keep = t
@@ -224,8 +229,8 @@ class OracleIndex:
         self.has_locate = level is not None
 
     @classmethod
-    def from_bwt(cls, bwt_arr, cs, max_character, samples=None, level=None, native=False):
-        return cls(max_character=max_character, level=level, kind="fm",
+    def from_bwt(cls, bwt_arr, cs, max_character, samples=None, level=None, native=False, kind="fm"):
+        return cls(max_character=max_character, level=level, kind=kind,
                    _lib=lib(native=True) if native else None, _from_bwt=(bwt_arr, cs, samples))
 
     def close(self):

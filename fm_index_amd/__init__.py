@@ -45,15 +45,30 @@ _DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
 
 
 def _sym(x, dtype=None):
-    """symbols as a contiguous array: bytes/str -> u8; arrays keep their unsigned width
-    (Character = u8 / u16 / u32 / u64, character.rs:38-42) unless `dtype` is given."""
+    """symbols as a contiguous array: bytes/str -> u8; unsigned arrays keep their width
+    (Character = u8 / u16 / u32 / u64, character.rs:38-42) unless `dtype` is given.  Anything else
+    (Python lists, signed or object arrays) gets the narrowest unsigned width that holds its
+    maximum; a negative value, or a value that does not fit a forced `dtype`, is refused with
+    ERR_SYMBOL_RANGE instead of wrapping (the reference's typed Character cannot hold it at all)."""
     if isinstance(x, str):
         x = x.encode("latin-1")
     if isinstance(x, (bytes, bytearray, memoryview)):
         x = np.frombuffer(bytes(x), dtype=np.uint8)
     x = np.asarray(x)
+    if x.dtype.kind == "u" and x.dtype.itemsize in _DTYPES:
+        if dtype is None or np.dtype(dtype) == x.dtype:
+            return np.ascontiguousarray(x)
+    elif x.size and x.dtype.kind not in "iub":
+        raise Error(L.ERR_SYMBOL_RANGE, "symbols must be non-negative integers")
+    lo = int(x.min()) if x.size else 0
+    hi = int(x.max()) if x.size else 0
+    if lo < 0:
+        raise Error(L.ERR_SYMBOL_RANGE, "negative symbol %d" % lo)
     if dtype is None:
-        dtype = x.dtype if (x.dtype.kind == "u" and x.dtype.itemsize in _DTYPES) else np.uint8
+        dtype = np.uint8 if hi <= 0xFF else (np.uint16 if hi <= 0xFFFF else
+                                             (np.uint32 if hi <= 0xFFFFFFFF else np.uint64))
+    elif hi > int(np.iinfo(dtype).max):
+        raise Error(L.ERR_SYMBOL_RANGE, "symbol %d does not fit %s" % (hi, np.dtype(dtype).name))
     return np.ascontiguousarray(x, dtype=dtype)
 
 

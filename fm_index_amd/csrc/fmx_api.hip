@@ -48,6 +48,23 @@ static int fail(int code, const char *detail = nullptr) {
   return code;
 }
 
+// every entry point runs on the index's device and puts the caller's current device back on return
+// (a torch program's current device must not change under it)
+namespace {
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  hipError_t set(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev == device) return hipSuccess;
+    changed = true;
+    return hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (changed && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
 // ---------------------------------------------------------------------------
 // construction
 // ---------------------------------------------------------------------------
@@ -57,13 +74,13 @@ static int select_device(int device) {
   if (e != hipSuccess || count == 0)
     return fail(FMX_ERR_HIP, "no HIP device available (libfmx has no CPU fallback)");
   if (device < 0 || device >= count) return fail(FMX_ERR_ARG, "device ordinal out of range");
-  FMX_HIP(hipSetDevice(device));
   return FMX_OK;
 }
 
 void fmx_free(fmx_index *idx) {
   if (!idx) return;
-  (void)hipSetDevice(idx->device);
+  DeviceGuard dg;
+  (void)dg.set(idx->device);
   for (int i = 0; i < idx->nalloc; i++) (void)hipFree(idx->d_alloc[i]);
   if (idx->dev.status) (void)hipFree(idx->dev.status);
   if (idx->d_steps) (void)hipFree(idx->d_steps);
@@ -96,6 +113,8 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "RLFM: n >= 2^31 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
+  DeviceGuard dg;
+  FMX_HIP(dg.set(device));
 
   fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
   idx->device = device;
@@ -205,7 +224,10 @@ static int status_to_code(uint32_t bits) {
 int fmx_stream_status(const fmx_index *idx) {
   if (!idx) return FMX_ERR_ARG;
   uint32_t bits = 0;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   FMX_HIP(hipSetDevice(idx->device));
+  struct Back { int d; ~Back() { if (d >= 0) (void)hipSetDevice(d); } } back{prev == idx->device ? -1 : prev};
   FMX_HIP(hipMemcpy(&bits, idx->dev.status, sizeof bits, hipMemcpyDeviceToHost));
   if (bits) FMX_HIP(hipMemset(idx->dev.status, 0, sizeof bits));
   int code = status_to_code(bits);
@@ -218,7 +240,8 @@ int fmx_stream_status(const fmx_index *idx) {
 // ---------------------------------------------------------------------------
 #define CHECK_IDX(idx)                                   \
   if (!(idx)) return fail(FMX_ERR_ARG, "index is NULL"); \
-  FMX_HIP(hipSetDevice((idx)->device))
+  DeviceGuard _dg;                                       \
+  FMX_HIP(_dg.set((idx)->device))
 
 int fmx_count_batch_dev(const fmx_index *idx, const void *d_pat, const uint64_t *d_pat_off,
                         uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_out_s,
@@ -276,6 +299,7 @@ namespace {
 // small calls, and a grow-only device scratch for batches -- no hipMalloc / hipFree / stream
 // creation per call.  Everything is released when the owning thread exits.
 const size_t kSmallCap = 256u << 10;
+const size_t kSmallUse = kSmallCap - 64;   // the last 64 bytes of both staging buffers hold the call's status word
 const size_t kRetainCap = 1ull << 30;   // larger batch scratch is allocated and freed per call
 struct SmallCtx {
   hipStream_t st = nullptr, st2 = nullptr;
@@ -373,17 +397,33 @@ struct Scratch {  // device buffers freed on scope exit
     return e;
   }
 };
-// End of a host-pointer call: wait for its stream(s) and read the sticky status word through the
-// call's own stream and the thread's pinned staging word -- never through the legacy default
-// stream, which would synchronise with every other blocking stream of the process.
-int finish_host_call(const fmx_index *idx, SmallCtx *sx, hipStream_t other = nullptr) {
-  uint32_t *word = (uint32_t *)sx->h;
-  FMX_HIP(hipMemcpyAsync(word, idx->dev.status, sizeof(uint32_t), hipMemcpyDeviceToHost, sx->st));
+// A host-pointer call owns a status word for its duration (the last 64 bytes of the thread's
+// device staging buffer): its kernels report into it instead of the handle's sticky word, so
+// threads that query one handle concurrently can never see -- or clear -- each other's error.
+thread_local uint32_t *t_call_status = nullptr;
+uint32_t *status_dev(SmallCtx *sx) { return (uint32_t *)(sx->d + kSmallUse); }
+uint32_t *status_host(SmallCtx *sx) { return (uint32_t *)(sx->h + kSmallUse); }
+struct CallStatus {
+  explicit CallStatus(SmallCtx *sx) { t_call_status = status_dev(sx); }
+  ~CallStatus() { t_call_status = nullptr; }
+};
+int status_result(uint32_t bits) {
+  const int code = status_to_code(bits);
+  if (code) fmx_set_error(code, code == FMX_ERR_SYMBOL_RANGE ? "pattern symbol exceeds max_character"
+                                                              : "argument does not belong to this index");
+  return code;
+}
+// End of a host-pointer call: read the call's status word through the call's own stream and the
+// thread's pinned staging word -- never through the legacy default stream, which would
+// synchronise with every other blocking stream of the process -- and wait for the stream(s).
+int finish_host_call(SmallCtx *sx, hipStream_t other = nullptr) {
+  FMX_HIP(hipMemcpyAsync(status_host(sx), status_dev(sx), sizeof(uint32_t), hipMemcpyDeviceToHost, sx->st));
   FMX_HIP(hipStreamSynchronize(sx->st));
   if (other) FMX_HIP(hipStreamSynchronize(other));
-  return *word ? fmx_stream_status(idx) : FMX_OK;   // reading-and-clearing only when something is set
+  return status_result(*status_host(sx));
 }
 }  // namespace
+uint32_t *fmx_call_status(void) { return t_call_status; }
 
 int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_off, uint64_t npat,
                     const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count) {
@@ -391,13 +431,16 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   if (npat == 0) return FMX_OK;
   if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
   uint64_t total = pat_off[npat];
+  if (total && !pat) return fail(FMX_ERR_ARG, "pat is NULL");
   const uint32_t sb = idx->sym_bytes;  // device symbol width
-  if (total * sb + npat * 48 + 128 <= kSmallCap && idx->sym_bytes_abi != 8) {
+  if (total * sb + npat * 48 + 128 <= kSmallUse && idx->sym_bytes_abi != 8) {
     if (SmallCtx *sx = small_ctx(idx->device)) {
       Arena a{sx};
+      CallStatus cs(sx);
+      FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
       const size_t op = a.take(total * sb ? total * sb : 1), oo = a.take((npat + 1) * 8);
       const size_t ose = a.take(s0e0 ? npat * 16 : 0), in_end = a.off;
-      const size_t os = a.take(npat * 8), oe = a.take(npat * 8), oc = a.take(npat * 8), ost = a.take(4);
+      const size_t os = a.take(npat * 8), oe = a.take(npat * 8), oc = a.take(npat * 8), ost = a.off;
       if (total) memcpy(a.host<uint8_t>(op), pat, total * sb);
       memcpy(a.host<uint8_t>(oo), pat_off, (npat + 1) * 8);
       if (s0e0) memcpy(a.host<uint8_t>(ose), s0e0, npat * 16);
@@ -407,12 +450,11 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
                                     a.dev<uint64_t>(oe), a.dev<uint64_t>(oc), sx->st))
         return rc;
       FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), a.dev<uint8_t>(os), (size_t)(ost - os), hipMemcpyDeviceToHost, sx->st));
-      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(ost), idx->dev.status, 4, hipMemcpyDeviceToHost, sx->st));
-      FMX_HIP(hipStreamSynchronize(sx->st));
+      const int rc = finish_host_call(sx);
       if (out_s) memcpy(out_s, a.host<uint8_t>(os), npat * 8);
       if (out_e) memcpy(out_e, a.host<uint8_t>(oe), npat * 8);
       if (out_count) memcpy(out_count, a.host<uint8_t>(oc), npat * 8);
-      return *a.host<uint32_t>(ost) ? fmx_stream_status(idx) : FMX_OK;
+      return rc;
     }
   }
   // batches: pattern bytes go in and (s, e, count) come out in chunks that alternate between the
@@ -435,6 +477,8 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   uint64_t *d_se = s0e0 ? hc.take<uint64_t>(2 * b_out) : nullptr;
   uint64_t *d_s = hc.take<uint64_t>(b_out), *d_e = hc.take<uint64_t>(b_out), *d_c = hc.take<uint64_t>(b_out);
   hipStream_t st[2] = {hc.sx->st, hc.sx->st2};
+  CallStatus cs(hc.sx);
+  FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, st[0]));   // ordered before every chunk by the wait below
   // two halves: every pageable copy has a fixed cost of 50-80 us on this runtime, so more, smaller
   // chunks lose (measured at 2^20 x 32: 1 chunk 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13)
   uint64_t nch = (npat >= (1u << 17) && !idx->timing) ? 2 : 1;
@@ -473,7 +517,7 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   }
   FMX_HIP(download(nch - 1));
   FMX_HIP(hipStreamSynchronize(st[1]));              // st[0] == sx->st is waited for below
-  return finish_host_call(idx, hc.sx);
+  return finish_host_call(hc.sx);
 }
 
 int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
@@ -484,12 +528,15 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
   uint64_t total = out_off[npat];
   if (total == 0) return FMX_OK;
+  if (!out_pos) return fail(FMX_ERR_ARG, "out_pos is NULL");
   HostCall hc;
   const size_t b_in = (size_t)npat * 8, b_pos = (size_t)total * 8;
   FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(b_in) + HostCall::pad(b_in + 8) + HostCall::pad(b_pos)));
   uint64_t *d_s = hc.take<uint64_t>(b_in), *d_e = hc.take<uint64_t>(b_in);
   uint64_t *d_off = hc.take<uint64_t>(b_in + 8), *d_pos = hc.take<uint64_t>(b_pos);
   hipStream_t S = hc.sx->st;
+  CallStatus cs(hc.sx);
+  FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, S));
   FMX_HIP(hipMemcpyAsync(d_s, s, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_e, e, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_off, out_off, b_in + 8, hipMemcpyHostToDevice, S));
@@ -498,7 +545,7 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
     return rc;
   }
   FMX_HIP(hipMemcpyAsync(out_pos, d_pos, b_pos, hipMemcpyDeviceToHost, S));
-  return finish_host_call(idx, hc.sx);
+  return finish_host_call(hc.sx);
 }
 
 static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const uint64_t *i,
@@ -506,11 +553,14 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
   CHECK_IDX(idx);
   if (op == 3 && idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   if (k == 0) return FMX_OK;
-  if (k * 24 + 64 <= kSmallCap) {
+  if (!i || !out) return fail(FMX_ERR_ARG, "NULL argument");
+  if (k * 24 + 64 <= kSmallUse) {
     if (SmallCtx *sx = small_ctx(idx->device)) {
       Arena a{sx};
+      CallStatus cs(sx);
+      FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
       const size_t oi = a.take(k * 8), oc = a.take(c ? k * 8 : 0), in_end = a.off;
-      const size_t oo = a.take(k * 8), os = a.take(4);
+      const size_t oo = a.take(k * 8);
       memcpy(a.host<uint8_t>(oi), i, k * 8);
       if (c) memcpy(a.host<uint8_t>(oc), c, k * 8);
       FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
@@ -518,10 +568,9 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
                                      a.dev<uint64_t>(oo), sx->st))
         return rc;
       FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(oo), a.dev<uint8_t>(oo), k * 8, hipMemcpyDeviceToHost, sx->st));
-      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), idx->dev.status, 4, hipMemcpyDeviceToHost, sx->st));
-      FMX_HIP(hipStreamSynchronize(sx->st));
+      const int rc = finish_host_call(sx);
       memcpy(out, a.host<uint8_t>(oo), k * 8);
-      return *a.host<uint32_t>(os) ? fmx_stream_status(idx) : FMX_OK;
+      return rc;
     }
   }
   HostCall hc;
@@ -529,6 +578,8 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
   FMX_HIP(hc.open(idx->device, 3 * HostCall::pad(bk)));
   uint64_t *d_i = hc.take<uint64_t>(bk), *d_o = hc.take<uint64_t>(bk), *d_c = c ? hc.take<uint64_t>(bk) : nullptr;
   hipStream_t S = hc.sx->st;
+  CallStatus cs(hc.sx);
+  FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, S));
   FMX_HIP(hipMemcpyAsync(d_i, i, bk, hipMemcpyHostToDevice, S));
   if (c) FMX_HIP(hipMemcpyAsync(d_c, c, bk, hipMemcpyHostToDevice, S));
   if (int rc = fmx_launch_scalar(idx, op, d_c, d_i, k, d_o, S)) {
@@ -536,7 +587,7 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
     return rc;
   }
   FMX_HIP(hipMemcpyAsync(out, d_o, bk, hipMemcpyDeviceToHost, S));
-  return finish_host_call(idx, hc.sx);
+  return finish_host_call(hc.sx);
 }
 int fmx_get_l_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 0, nullptr, i, k, out); }
 int fmx_lf_map_batch(const fmx_index *idx, const uint64_t *i, uint64_t k, uint64_t *out) { return scalar_host(idx, 1, nullptr, i, k, out); }
@@ -571,6 +622,8 @@ int fmx_extract_batch(const fmx_index *idx, const uint64_t *rows, uint64_t nrows
   uint64_t *d_next = hc.take<uint64_t>(b_rows);
   uint8_t *d_sym = hc.take<uint8_t>(b_sym);
   hipStream_t S = hc.sx->st;
+  CallStatus cs(hc.sx);
+  FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, S));
   FMX_HIP(hipMemcpyAsync(d_rows, rows, b_rows, hipMemcpyHostToDevice, S));
   if (b_sym) FMX_HIP(hipMemsetAsync(d_sym, 0, b_sym, S));   // slots past a piece end read as 0 on the host side
   if (int rc = fmx_launch_extract(idx, d_rows, nrows, (uint32_t)len, forward, d_sym, d_len, d_next, S)) {
@@ -580,7 +633,7 @@ int fmx_extract_batch(const fmx_index *idx, const uint64_t *rows, uint64_t nrows
   if (b_sym) FMX_HIP(hipMemcpyAsync(out_syms, d_sym, b_sym, hipMemcpyDeviceToHost, S));
   if (out_len) FMX_HIP(hipMemcpyAsync(out_len, d_len, b_rows, hipMemcpyDeviceToHost, S));
   if (out_next) FMX_HIP(hipMemcpyAsync(out_next, d_next, b_rows, hipMemcpyDeviceToHost, S));
-  return finish_host_call(idx, hc.sx);
+  return finish_host_call(hc.sx);
 }
 
 // one trait method per call
@@ -619,6 +672,7 @@ int fmx_match_counts(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
                      int prefix_only, uint64_t *out_count) {
   CHECK_IDX(idx);
   if (npat == 0) return FMX_OK;
+  if (!s || !e || !out_count) return fail(FMX_ERR_ARG, "NULL argument");
   HostCall hc;
   const size_t bk = (size_t)npat * 8;
   FMX_HIP(hc.open(idx->device, 3 * HostCall::pad(bk)));
@@ -637,7 +691,10 @@ int fmx_match_counts(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
 int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
                    int prefix_only, const uint64_t *out_off, uint64_t *out_rows) {
   CHECK_IDX(idx);
-  if (npat == 0 || out_off[npat] == 0) return FMX_OK;
+  if (npat == 0) return FMX_OK;
+  if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
+  if (out_off[npat] == 0) return FMX_OK;
+  if (!out_rows) return fail(FMX_ERR_ARG, "out_rows is NULL");
   uint64_t total = out_off[npat];
   HostCall hc;
   const size_t bk = (size_t)npat * 8, br = (size_t)total * 8;
@@ -737,8 +794,49 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   if (d.kmer) out[k++] = {(const void **)&d.kmer, (1ull << (d.kmer_bits * d.kmer_k)) * 8};
   return k;
 }
+// A file is only trusted as far as its own numbers agree: every field that sizes an array or is
+// used as an array bound is checked against the header and the builder's formulas BEFORE
+// enumerate_blobs / any allocation looks at it, and the blob sizes must add up to the file size.
+const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
+  if (h.kind > FMX_KIND_MULTI || d.kind != h.kind) return "kind";
+  if ((h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) || d.sym_bytes != h.sym_bytes) return "sym_bytes";
+  if (h.sym_bytes_abi != 1 && h.sym_bytes_abi != 2 && h.sym_bytes_abi != 4 && h.sym_bytes_abi != 8) return "sym_bytes_abi";
+  if (h.n >= 0xFFFFFFF0ull || d.n != h.n) return "n";
+  if (h.kind == FMX_KIND_RLFM && h.n >= (1ull << 31)) return "n (RLFM)";
+  if (h.max_character == 0 || h.max_character >= (1ull << 26) || d.max_character != h.max_character) return "max_character";
+  if (h.runs > h.n) return "runs";
+  const FmxMwm &w = d.bw;
+  if (w.nlevels == 0 || w.nlevels > FMX_MAX_LEVELS) return "nlevels";
+  if (w.len != (h.kind == FMX_KIND_RLFM ? h.runs : h.n)) return "wavelet length";
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxLevel &L = w.lv[l];
+    if (L.fmt != 3 && L.fmt != 4) return "level format";
+    if (L.shift >= 32 || (L.fmt == 3 ? (L.mask != 1u && L.mask != 3u && L.mask != 7u) : L.mask != 15u)) return "level shift / mask";
+    if (L.nrec != w.len / (L.fmt == 3 ? 256u : 128u) + 1u) return "level records";
+  }
+  if (d.sa_level != FMX_NO_LOCATE) {
+    if (d.sa_level >= 32 || h.n == 0) return "sa_level";
+    if (h.nsamples != ((h.n - 1) >> d.sa_level) + 1 || d.nsamples != h.nsamples) return "nsamples";
+  } else if (h.nsamples != 0) return "nsamples";
+  if (d.kmer) {
+    if (d.kmer_k == 0 || d.kmer_bits == 0 || d.kmer_bits > 8 || d.kmer_bits * d.kmer_k > 24) return "k-mer table";
+  }
+  if (d.kind == FMX_KIND_MULTI) {
+    if (d.doc_count > h.n || d.first_row > h.n) return "pieces";
+  }
+  if (d.kind == FMX_KIND_RLFM) {
+    const FmxBits *v[2] = {&d.b, &d.bp};
+    for (int t = 0; t < 2; t++) {
+      if (v[t]->len != h.n || v[t]->ones != h.runs) return "bit vector length";
+      if (v[t]->nrec != v[t]->len / FMX_BITS_PER_REC + 1u) return "bit vector records";
+      if (v[t]->nsel != v[t]->ones / FMX_SEL_STEP + 2u) return "select hints";
+    }
+  }
+  if (d.pair_rec && (d.pair_row0 > h.n || d.pair_row1 > h.n)) return "pair index";
+  return nullptr;
+}
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 5;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks
+const uint32_t kFileVersion = 6;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {
@@ -756,10 +854,19 @@ int fmx_save(const fmx_index *idx, const char *path) {
   h.sym_bytes = idx->sym_bytes; h.sym_bytes_abi = idx->sym_bytes_abi; h.kind = idx->kind;
   h.level_requested = idx->level_requested;
   FmxDev d = idx->dev;
-  bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&d, sizeof d, 1, f) == 1 &&
-            fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
   Blob blobs[64];
   int nb = enumerate_blobs(d, idx->nsamples, blobs);
+  // the struct that goes into the file keeps which arrays exist, not where they were: every
+  // pointer field is written as 1 (present) or 0
+  FmxDev dfile = idx->dev;
+  {
+    Blob fb[64];
+    const int nf = enumerate_blobs(dfile, idx->nsamples, fb);
+    for (int b = 0; b < nf; b++) *fb[b].field = (const void *)(uintptr_t)1;
+    dfile.status = nullptr;
+  }
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&dfile, sizeof dfile, 1, f) == 1 &&
+            fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
   std::string buf(kChunk, '\0');
   for (int b = 0; ok && b < nb; b++) {
     const uint8_t *src = (const uint8_t *)*blobs[b].field;
@@ -777,6 +884,8 @@ int fmx_load(const char *path, int device, fmx_index **out) {
   if (!out || !path) return fail(FMX_ERR_ARG, "NULL argument");
   *out = nullptr;
   if (int rc = select_device(device)) return rc;
+  DeviceGuard dg;
+  FMX_HIP(dg.set(device));
   FILE *f = fopen(path, "rb");
   if (!f) return fail(FMX_ERR_ARG, "cannot open index file");
   FileHeader h;
@@ -786,6 +895,13 @@ int fmx_load(const char *path, int device, fmx_index **out) {
     if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "FMXIDX01", 8) != 0 || h.version != kFileVersion ||
         h.dev_struct_bytes != sizeof(FmxDev)) { rc = fail(FMX_ERR_ARG, "not an fmx index file (or another version)"); break; }
     if (fread(&idx->dev, sizeof(FmxDev), 1, f) != 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
+    if (const char *what = validate_loaded(h, idx->dev)) {
+      char msg[128];
+      snprintf(msg, sizeof msg, "corrupt index file: inconsistent %s", what);
+      memset(&idx->dev, 0, sizeof idx->dev);     // nothing of it is a pointer this process owns
+      rc = fail(FMX_ERR_ARG, msg);
+      break;
+    }
     idx->device = device;
     idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = h.nsamples; idx->runs = h.runs;
     idx->sym_bytes = h.sym_bytes; idx->sym_bytes_abi = h.sym_bytes_abi; idx->kind = h.kind;
@@ -794,8 +910,19 @@ int fmx_load(const char *path, int device, fmx_index **out) {
     if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
     Blob blobs[64];
     int nb = enumerate_blobs(idx->dev, idx->nsamples, blobs);
-    for (int b = 0; b < nb; b++) *blobs[b].field = nullptr;  // stale pointers of the saving process
+    uint64_t need = sizeof(FileHeader) + sizeof(FmxDev) + (h.max_character + 1) * 8;
+    for (int b = 0; b < nb; b++) {
+      *blobs[b].field = nullptr;  // presence markers of the file, not addresses
+      need += blobs[b].bytes;
+    }
     idx->dev.status = nullptr;
+    {
+      const long at = ftell(f);
+      fseek(f, 0, SEEK_END);
+      const uint64_t have = (uint64_t)ftell(f);
+      fseek(f, at, SEEK_SET);
+      if (have != need) { rc = fail(FMX_ERR_ARG, "corrupt index file: array sizes do not add up to the file size"); break; }
+    }
     hipError_t e;
     if ((e = hipMalloc((void **)&idx->dev.status, 4)) != hipSuccess || (e = hipMalloc((void **)&idx->d_steps, 8)) != hipSuccess ||
         (e = hipMemset(idx->dev.status, 0, 4)) != hipSuccess || (e = hipMemset(idx->d_steps, 0, 8)) != hipSuccess ||

@@ -114,11 +114,16 @@ __device__ __forceinline__ uint32_t fmx_piece_rank(const uint4 &p, uint32_t off,
   return v;
 }
 
+// `prev` (census only): position whose record the same pattern has just asked for -- a second
+// request for the same line is ONE line of the byte model, so it is not logged again
 template <int FMT>
-__device__ __forceinline__ uint4 fmx_load_piece(const FmxLevel &L, uint32_t pos, uint32_t g) {
+__device__ __forceinline__ uint4 fmx_load_piece(const FmxLevel &L, uint32_t pos, uint32_t g,
+                                                [[maybe_unused]] uint32_t prev = 0xFFFFFFFFu) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
   FMX_CHECK((pos >> SH) < L.nrec);
-  FMX_TOUCH_G0(g, &L.rec[(size_t)(pos >> SH) * 8u]);
+#ifdef FMX_CENSUS
+  if (prev == 0xFFFFFFFFu || (prev >> SH) != (pos >> SH)) FMX_TOUCH_G0(g, &L.rec[(size_t)(pos >> SH) * 8u]);
+#endif
   return L.rec[(size_t)(pos >> SH) * 8u + g];
 }
 template <int FMT>
@@ -171,12 +176,12 @@ __device__ __forceinline__ void fmx_mwm_rank2(const FmxMwm &w, uint32_t c, uint3
     uint32_t code = (c >> L.shift) & L.mask;
     if (L.fmt == 3) {
       uint4 a = fmx_load_piece<3>(L, ps, g);
-      uint4 b = fmx_load_piece<3>(L, pe, g);
+      uint4 b = fmx_load_piece<3>(L, pe, g, ps);
       rs = fmx_group_sum(fmx_piece_rank<3>(a, fmx_off<3>(ps), code, g));
       re = fmx_group_sum(fmx_piece_rank<3>(b, fmx_off<3>(pe), code, g));
     } else {
       uint4 a = fmx_load_piece<4>(L, ps, g);
-      uint4 b = fmx_load_piece<4>(L, pe, g);
+      uint4 b = fmx_load_piece<4>(L, pe, g, ps);
       rs = fmx_group_sum(fmx_piece_rank<4>(a, fmx_off<4>(ps), code, g));
       re = fmx_group_sum(fmx_piece_rank<4>(b, fmx_off<4>(pe), code, g));
     }
@@ -200,13 +205,13 @@ __device__ __forceinline__ void fmx_mwm_rankN(const FmxMwm &w, uint32_t c, uint3
     uint4 p[N];
     if (L.fmt == 3) {
 #pragma unroll
-      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<3>(L, pos[q], g);
+      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<3>(L, pos[q], g, q ? pos[q - 1] : 0xFFFFFFFFu);
 #pragma unroll
       for (int q = 0; q < N; q++)
         r[q] = fmx_group_sum(fmx_piece_rank<3>(p[q], fmx_off<3>(pos[q]), code, g));
     } else {
 #pragma unroll
-      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<4>(L, pos[q], g);
+      for (int q = 0; q < N; q++) p[q] = fmx_load_piece<4>(L, pos[q], g, q ? pos[q - 1] : 0xFFFFFFFFu);
 #pragma unroll
       for (int q = 0; q < N; q++)
         r[q] = fmx_group_sum(fmx_piece_rank<4>(p[q], fmx_off<4>(pos[q]), code, g));

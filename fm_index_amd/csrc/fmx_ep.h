@@ -22,6 +22,26 @@
 
 #define FMX_NONE 0xFFFFFFFFu
 
+// census only: a lane-wise probe is logged unless PAIRED and the lane's partner (the other interval
+// end of the same pattern, lane ^ 1) asks for the same 128-byte line -- that is ONE line of the byte
+// model; the even lane logs it
+#ifdef FMX_CENSUS
+template <bool PAIRED>
+__device__ __forceinline__ void fmx_touch_lane(const void *p, bool want = true) {
+  const unsigned long long line = want ? (unsigned long long)(uintptr_t)p >> 7 : ~0ull;
+  bool log = want;
+  if (PAIRED) {
+    const uint32_t lo = fmx_dpp_xor1((uint32_t)line), hi = fmx_dpp_xor1((uint32_t)(line >> 32));
+    const bool same = lo == (uint32_t)line && hi == (uint32_t)(line >> 32);
+    if (same && (threadIdx.x & 1u)) log = false;
+  }
+  if (log) fmx_touch(p);
+}
+#define FMX_TOUCH_LANE(PAIRED, p, want) fmx_touch_lane<PAIRED>((const void *)(p), (want))
+#else
+#define FMX_TOUCH_LANE(PAIRED, p, want) do { } while (0)
+#endif
+
 // value of lane (base + q) for all lanes of the group
 __device__ __forceinline__ uint32_t fmx_grp_bcast(uint32_t v, uint32_t base, uint32_t q) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + q) << 2), (int)v);
@@ -33,13 +53,14 @@ __device__ __forceinline__ uint32_t fmx_grp_bcast(uint32_t v, uint32_t base, uin
 // Piece p of the vector is bits [96p, 96p+96) -- records are 8 consecutive pieces, so the piece
 // index is simply i / 96.
 struct FmxProbe { uint4 pc; uint32_t pidx, bit; };
+template <bool PAIRED>
 __device__ __forceinline__ FmxProbe fmx_bits_probe_issue(const FmxBits &bv, uint32_t i) {
   FmxProbe pr;
   if (i > bv.len) i = bv.len;
   pr.pidx = fmx_div3(i >> 5);                 // i / 96
   pr.bit = i - pr.pidx * FMX_BITS_PER_PIECE;
   FMX_CHECK(pr.pidx < bv.nrec * 8u);
-  FMX_TOUCH(&bv.rec[pr.pidx]);
+  FMX_TOUCH_LANE(PAIRED, &bv.rec[pr.pidx], true);
   pr.pc = bv.rec[pr.pidx];
   return pr;
 }
@@ -65,20 +86,18 @@ __device__ __forceinline__ uint32_t fmx_bits_probe_rank(const FmxProbe &pr, uint
 // ones do not fit (then the caller goes through fmx_ep_select_slow).  k >= ones gives len
 // (vers-vecs RsVec::select1).
 struct FmxSel { uint4 blk; uint32_t k; bool valid; };
-template <int SM>
+template <int SM, bool PAIRED>
 __device__ __forceinline__ FmxSel fmx_ep_select_issue(const FmxBits &bv, uint32_t k, bool want) {
   FmxSel s;
   s.valid = k < bv.ones;
   s.k = s.valid ? k : 0u;
   s.blk = make_uint4(0u, 0u, 0u, 0u);
-  if (want && bv.ones) {
-    if (SM == 1) {
-      FMX_TOUCH(&bv.pos[s.k]);
-      s.blk.x = bv.pos[s.k];
-    } else {
-      FMX_TOUCH(&bv.dsel[s.k >> 6]);
-      s.blk = bv.dsel[s.k >> 6];
-    }
+  want = want && bv.ones != 0u;
+  if (SM == 1) FMX_TOUCH_LANE(PAIRED, &bv.pos[s.k], want);
+  else FMX_TOUCH_LANE(PAIRED, &bv.dsel[s.k >> 6], want);
+  if (want) {
+    if (SM == 1) s.blk.x = bv.pos[s.k];
+    else s.blk = bv.dsel[s.k >> 6];
   }
   return s;
 }
@@ -135,7 +154,7 @@ __device__ __forceinline__ void fmx_ep_select_slow(const FmxBits &bv, uint32_t k
 // counters: the next level's position, fmx_internal.h) and match = [entry pos itself has the code].
 // ACCESS: the code is READ at entry pos (WaveletMatrix::get) and the rank is of that code.
 // `match` rides in bit 31 of the group sum, so ranks must stay below 2^31 (RLFM: n < 2^31).
-template <int FMT, bool ACCESS>
+template <int FMT, bool ACCESS, bool PAIRED>
 __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint32_t pos, uint32_t &code,
                                              uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
@@ -149,7 +168,9 @@ __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint
     bp[q] = fmx_grp_bcast(pos, base, q);
     bc[q] = ACCESS ? 0u : fmx_grp_bcast(code, base, q);
     const uint4 *r = rec + (size_t)(bp[q] >> SH) * 8u;
-    FMX_TOUCH_G0(g, r);
+#ifdef FMX_CENSUS   // the odd endpoint is the same pattern's other interval end: same record = ONE line
+    if (!(PAIRED && (q & 1u) && (bp[q] >> SH) == (bp[q - 1u] >> SH))) FMX_TOUCH_G0(g, r);
+#endif
     p[q] = r[g];
   }
 #pragma unroll
@@ -173,12 +194,12 @@ __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint
     }
   }
 }
-template <bool ACCESS>
+template <bool ACCESS, bool PAIRED>
 __device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, uint32_t &code, uint32_t base,
                                              uint32_t g, uint32_t &rank, uint32_t &match) {
   FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
-  if (L.fmt == 3) fmx_ep_round<3, ACCESS>(L.rec, pos, code, base, g, rank, match);
-  else fmx_ep_round<4, ACCESS>(L.rec, pos, code, base, g, rank, match);
+  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED>(L.rec, pos, code, base, g, rank, match);
+  else fmx_ep_round<4, ACCESS, PAIRED>(L.rec, pos, code, base, g, rank, match);
 }
 
 // ---- RLFMIndexBackend::lf_map2 for 8 endpoints per group (rlfmi.rs:135-143) -------------------
@@ -192,25 +213,25 @@ template <int NL, int SM>
 __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i, uint32_t base,
                                                         uint32_t g) {
   const uint32_t kc = ix.K[c];
-  const FmxProbe pr = fmx_bits_probe_issue(ix.b, i);
+  const FmxProbe pr = fmx_bits_probe_issue<true>(ix.b, i);
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)            rlfmi.rs:136
   const uint32_t lo = j - 1u + bit;                          // b.rank1(i + 1) - 1    rlfmi.rs:124
   // run start b.select1(j) = first one at or after i: usually in the piece; else one more probe,
   // issued now so that it travels under the rank rounds
-  const FmxSel ss = fmx_ep_select_issue<SM>(ix.b, j, nx == FMX_NONE);
+  const FmxSel ss = fmx_ep_select_issue<SM, true>(ix.b, j, nx == FMX_NONE);
   uint32_t pos = lo, r = 0, m = 1u;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
 #pragma unroll
   for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = ix.bw.lv[l];
     uint32_t code = (c >> L.shift) & L.mask, mt;
-    fmx_ep_level<false>(L, pos, code, base, g, r, mt);
+    fmx_ep_level<false, true>(L, pos, code, base, g, r, mt);
     m &= mt;
     pos = r;                                                 // C_l[code] is folded into the counters
   }
   const uint32_t nr = kc + r + (bit ? 0u : m);               // cs[c] + s.rank(j, c)  rlfmi.rs:137,139
-  const FmxSel sf = fmx_ep_select_issue<SM>(ix.bp, nr, true);
+  const FmxSel sf = fmx_ep_select_issue<SM, true>(ix.bp, nr, true);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);          // bp.select1(cs[c] + nr)
   uint32_t st = nx;
   if (nx == FMX_NONE) st = fmx_ep_select_finish<SM>(ix.b, ss);
@@ -227,11 +248,11 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32
 template <int NL, int SM>
 __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const uint32_t *kt, uint32_t i,
                                                        uint32_t base, uint32_t g, uint32_t &sym) {
-  const FmxProbe pr = fmx_bits_probe_issue(ix.b, i);
+  const FmxProbe pr = fmx_bits_probe_issue<false>(ix.b, i);
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)
   const uint32_t lo = j - 1u + bit;
-  const FmxSel ss = fmx_ep_select_issue<SM>(ix.b, j, nx == FMX_NONE);
+  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, j, nx == FMX_NONE);
   uint32_t pos = lo, r = 0;
   sym = 0;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
@@ -239,12 +260,12 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
   for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = ix.bw.lv[l];
     uint32_t code = 0, mt;
-    fmx_ep_level<true>(L, pos, code, base, g, r, mt);
+    fmx_ep_level<true, false>(L, pos, code, base, g, r, mt);
     sym |= code << L.shift;
     pos = r;
   }
   const uint32_t nr = kt[sym] + r + (bit ? 0u : 1u);         // cs[c] + s.rank(j, c)   rlfmi.rs:129-130
-  const FmxSel sf = fmx_ep_select_issue<SM>(ix.bp, nr, true);
+  const FmxSel sf = fmx_ep_select_issue<SM, false>(ix.bp, nr, true);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);
   uint32_t st = nx;
   if (nx == FMX_NONE) st = fmx_ep_select_finish<SM>(ix.b, ss);

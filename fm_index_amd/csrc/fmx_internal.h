@@ -132,6 +132,16 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// The FmxDev a launcher hands to its kernels: idx->dev, with `status` replaced by the calling
+// thread's own status word while a host-pointer call is in progress (so that two threads querying
+// one handle never read each other's error); the *_dev entry points report into the handle's
+// sticky word, read with fmx_stream_status.
+uint32_t *fmx_call_status(void);
+static inline FmxDev fmx_launch_dev(const fmx_index *idx) {
+  FmxDev d = idx->dev;
+  if (uint32_t *st = fmx_call_status()) d.status = st;
+  return d;
+}
 // registers a device allocation owned by the index (freed by fmx_free, counted in index bytes)
 static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
   if (idx->nalloc >= 96) return FMX_ERR_ARG;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         uint32_t rs = s[q] >> 8, re = e[q] >> 8;
         FMX_CHECK(rs < nrec && re < nrec);
         FMX_TOUCH_G0(g, &rec[(size_t)rs * 8u]);
-        if (!SKIP || re != rs) FMX_TOUCH_G0(g, &rec[(size_t)re * 8u]);
+        if (re != rs) FMX_TOUCH_G0(g, &rec[(size_t)re * 8u]);   // both ends in one record: ONE line
         if (SKIP) {
           a[q] = rec[(size_t)rs * 8u + g];
           b[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
           const uint32_t code = (c1 - 1u) * 4u + (c2 - 1u);
           FMX_CHECK((s >> 7) < n / 128u + 1u && (e >> 7) < n / 128u + 1u);
           FMX_TOUCH_G0(g, &rec2[(size_t)(s >> 7) * 8u]);
-          FMX_TOUCH_G0(g, &rec2[(size_t)(e >> 7) * 8u]);
+          if ((e >> 7) != (s >> 7)) FMX_TOUCH_G0(g, &rec2[(size_t)(e >> 7) * 8u]);
           const uint4 a = rec2[(size_t)(s >> 7) * 8u + g];
           const uint4 b = rec2[(size_t)(e >> 7) * 8u + g];
           uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(a, s & 127u, code, g));
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
             // would the reference already have stopped after the last symbol alone?
             FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
             FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
-            FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
+            if ((e >> 8) != (s >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
             const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
             const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
             const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
         } else {
           FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
           FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
-          FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
+          if ((e >> 8) != (s >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
           const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
           const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
           const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));  // wrapper.rs:109
@@ -1147,13 +1147,14 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, void
   }
 }
 int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (idx->n == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM || idx->kind == FMX_KIND_MULTI)
     hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(idx->n)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
+                       dim3(FMX_BLOCK), 0, st, dv, d_out);
   else
     hipLaunchKernelGGL(fmx_export_l_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(idx->n)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, d_out);
+                       dim3(FMX_BLOCK), 0, st, dv, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -1198,18 +1199,20 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_match_rows_kernel(
 }
 int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                             uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_counts_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, d_s, d_e, npat, prefix_only, d_cnt);
+                     dv, d_s, d_e, npat, prefix_only, d_cnt);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 int fmx_launch_match_rows(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                           uint64_t npat, int prefix_only, const uint64_t *d_off, uint64_t *d_rows,
                           hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_rows_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
-                     idx->dev, d_s, d_e, d_off, npat, prefix_only, d_rows);
+                     dv, d_s, d_e, d_off, npat, prefix_only, d_rows);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -1247,20 +1250,21 @@ static void fmx_time_end(const fmx_index *idx, hipStream_t st) {
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
                      uint64_t *d_cnt, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   unsigned grid = fmx_grid_for_groups(npat);
   fmx_time_begin(idx, st);
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
-  const FmxMwm &w = idx->dev.bw;
+  const FmxMwm &w = dv.bw;
   int variant = fmx_variant();
   const uint8_t *d_pat8 = (const uint8_t *)d_pat;
-  const bool km = idx->dev.kmer != nullptr && variant != 6;   // FMX_VARIANT=6: ignore the k-mer table
-  if (idx->dev.pair_rec && idx->sym_bytes == 1 && variant != 0 && variant != 7) {
+  const bool km = dv.kmer != nullptr && variant != 6;   // FMX_VARIANT=6: ignore the k-mer table
+  if (dv.pair_rec && idx->sym_bytes == 1 && variant != 0 && variant != 7) {
 #define FMX_PAIR_LAUNCH(KM)                                                                          \
   hipLaunchKernelGGL(fmx_count_pair_kernel<KM>, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
-                     idx->dev.pair_rec, idx->dev.n, idx->dev.max_character, idx->dev.pair_row0,       \
-                     idx->dev.pair_row1, idx->dev.status, idx->dev.kmer, idx->dev.kmer_k,             \
-                     idx->dev.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+                     dv.pair_rec, dv.n, dv.max_character, dv.pair_row0,       \
+                     dv.pair_row1, dv.status, dv.kmer, dv.kmer_k,             \
+                     dv.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
     if (km) FMX_PAIR_LAUNCH(true);
     else FMX_PAIR_LAUNCH(false);
   } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
@@ -1268,21 +1272,21 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
 #define FMX_F3_LAUNCH(PPG, SKIP, KM)                                                               \
   hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP, KM>),                                           \
                      dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), dim3(FMX_BLOCK), 0, st,       \
-                     w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, idx->dev.kmer, \
-                     idx->dev.kmer_k, idx->dev.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e,      \
+                     w.lv[0].rec, dv.n, dv.max_character, dv.status, dv.kmer, \
+                     dv.kmer_k, dv.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e,      \
                      d_cnt, steps)
     switch (variant) {
 #ifdef FMX_MEASURE
       case 8:  // measurement only: lane per pattern
         if (d_s0e0) return FMX_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(fmx_count_f3_lane_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
-                           w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, d_pat8, d_off,
+                           w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8, d_off,
                            npat, d_s, d_e, d_cnt, steps);
         break;
       case 9:  // measurement only: wavefront per pattern
         if (d_s0e0) return FMX_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(fmx_count_f3_wave_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
-                           w.lv[0].rec, idx->dev.n, idx->dev.max_character, idx->dev.status, d_pat8, d_off,
+                           w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8, d_off,
                            npat, d_s, d_e, d_cnt, steps);
         break;
       case 2: FMX_F3_LAUNCH(2, false, false); break;
@@ -1301,10 +1305,10 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   do {                                                                                              \
     if (km && idx->sym_bytes == 1)                                                                  \
       hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
-                         idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
+                         dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
     else                                                                                            \
       hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
-                         idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
+                         dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
   } while (0)
 #define FMX_COUNT_KIND(KIND, SM)                                                                    \
   do {                                                                                              \
@@ -1317,8 +1321,8 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     // blocks every select is one lane-wise load and the endpoint-per-lane kernel runs (fmx_ep.h);
     // mixed-density indexes (hints + record search) keep the group-per-pattern kernel.
     const int sm = idx->kind != FMX_KIND_RLFM ? -1
-                   : (idx->dev.b.pos && idx->dev.bp.pos) ? 1
-                   : (idx->dev.b.dsel && idx->dev.bp.dsel) ? 2 : 0;
+                   : (dv.b.pos && dv.bp.pos) ? 1
+                   : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
     if (sm > 0 && variant != 0) {
       // 64 probes in flight per wave and stage: 4 waves per SIMD saturate the memory system
       const uint64_t ep_cap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", 1024);
@@ -1328,10 +1332,10 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   do {                                                                                               \
     if (km && idx->sym_bytes == 1)                                                                   \
       hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, true>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
     else                                                                                             \
       hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, false>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, idx->dev, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
   } while (0)
 #define FMX_EP_SM(SM)                                                                                \
   do {                                                                                               \
@@ -1371,8 +1375,9 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
                       hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0 || total == 0) return FMX_OK;
-  const FmxMwm &w = idx->dev.bw;
+  const FmxMwm &w = dv.bw;
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   // rows in their own read-only buffer: the walk's loads never alias its stores
   uint32_t *rows = nullptr;
@@ -1381,7 +1386,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
-                       d_off, npat, rows, total, idx->dev.n, idx->dev.status);
+                       d_off, npat, rows, total, dv.n, dv.status);
   }
   uint64_t nwaves = (total + 7) / 8;
   const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
@@ -1404,11 +1409,11 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
 #define FMX_LOC_LAUNCH(Q)                                                                          \
   hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
-                     idx->dev.samples, idx->dev.n, idx->dev.sa_level, total, hp, rows, d_pos, steps)
+                     dv.samples, dv.n, dv.sa_level, total, hp, rows, d_pos, steps)
     if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
   } else {
 #define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
-  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, idx->dev, \
+  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, dv, \
                      total, hpw, rows, d_pos, steps)
 #define FMX_LOCATE_KIND(KIND, SM)                                                                   \
   do {                                                                                              \
@@ -1417,8 +1422,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     else FMX_LOCATE_LAUNCH(KIND, 0, SM);                                                            \
   } while (0)
     const int sm = idx->kind != FMX_KIND_RLFM ? -1
-                   : (idx->dev.b.pos && idx->dev.bp.pos) ? 1
-                   : (idx->dev.b.dsel && idx->dev.bp.dsel) ? 2 : 0;
+                   : (dv.b.pos && dv.bp.pos) ? 1
+                   : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
     if (sm > 0 && fmx_variant() != 0) {
       // one walk per lane: 64 walks per wave
       // measured (benchmarks/gpu/ep_sweep.sh): 2^20 hits finish soonest on 512 blocks (0.45 ms; 0.47 on
@@ -1430,15 +1435,15 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       if (nw > wcap) nw = wcap;
       const uint64_t hp = (total + nw - 1) / nw;
       const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
-      const bool klds = idx->dev.max_character < 1024u;
+      const bool klds = dv.max_character < 1024u;
 #define FMX_EPL_LAUNCH(NL, SM)                                                                       \
   do {                                                                                               \
     if (klds)                                                                                        \
       hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, true>), dim3(gr), dim3(FMX_BLOCK), 0, st,  \
-                         idx->dev, total, hp, rows, d_pos, steps);                                    \
+                         dv, total, hp, rows, d_pos, steps);                                    \
     else                                                                                             \
       hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, false>), dim3(gr), dim3(FMX_BLOCK), 0, st, \
-                         idx->dev, total, hp, rows, d_pos, steps);                                    \
+                         dv, total, hp, rows, d_pos, steps);                                    \
   } while (0)
 #define FMX_EPL_SM(SM)                                                                               \
   do {                                                                                               \
@@ -1462,16 +1467,17 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
 
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   if (k == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM)
     hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_FM>, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK),
-                       0, st, idx->dev, op, d_c, d_i, k, d_out);
+                       0, st, dv, op, d_c, d_i, k, d_out);
   else if (idx->kind == FMX_KIND_MULTI)
     hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_MULTI>, dim3(fmx_grid_for_groups(k)), dim3(FMX_BLOCK),
-                       0, st, idx->dev, op, d_c, d_i, k, d_out);
+                       0, st, dv, op, d_c, d_i, k, d_out);
   else
     hipLaunchKernelGGL(fmx_scalar_kernel<FMX_KIND_RLFM>, dim3(fmx_grid_for_groups(k)),
-                       dim3(FMX_BLOCK), 0, st, idx->dev, op, d_c, d_i, k, d_out);
+                       dim3(FMX_BLOCK), 0, st, dv, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -1479,15 +1485,16 @@ int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const u
 template <typename T>
 static int fmx_launch_extract_t(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
                                 int forward, T *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   const dim3 grid(fmx_grid_for_groups(nrows)), block(FMX_BLOCK);
   if (idx->kind == FMX_KIND_FM)
-    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_FM, T>), grid, block, 0, st, idx->dev, d_rows, nrows, len,
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_FM, T>), grid, block, 0, st, dv, d_rows, nrows, len,
                        forward, d_out, d_out_len, d_out_next);
   else if (idx->kind == FMX_KIND_MULTI)
-    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_MULTI, T>), grid, block, 0, st, idx->dev, d_rows, nrows,
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_MULTI, T>), grid, block, 0, st, dv, d_rows, nrows,
                        len, forward, d_out, d_out_len, d_out_next);
   else
-    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_RLFM, T>), grid, block, 0, st, idx->dev, d_rows, nrows,
+    hipLaunchKernelGGL((fmx_extract_kernel<FMX_KIND_RLFM, T>), grid, block, 0, st, dv, d_rows, nrows,
                        len, forward, d_out, d_out_len, d_out_next);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1502,14 +1509,15 @@ int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nr
 }
 
 int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st) {
+  const FmxDev dv = fmx_launch_dev(idx);
   const uint64_t ncodes = 1ull << (bits * k);
   const dim3 grid(fmx_grid_for_groups(ncodes)), block(FMX_BLOCK);
   if (idx->kind == FMX_KIND_FM)
-    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_FM>, grid, block, 0, st, idx->dev, d_table, k, bits);
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_FM>, grid, block, 0, st, dv, d_table, k, bits);
   else if (idx->kind == FMX_KIND_MULTI)
-    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_MULTI>, grid, block, 0, st, idx->dev, d_table, k, bits);
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_MULTI>, grid, block, 0, st, dv, d_table, k, bits);
   else
-    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_RLFM>, grid, block, 0, st, idx->dev, d_table, k, bits);
+    hipLaunchKernelGGL(fmx_kmer_build_kernel<FMX_KIND_RLFM>, grid, block, 0, st, dv, d_table, k, bits);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -258,6 +258,15 @@ def stored_traffic(workload_key, leg):
     return ent.get(leg)
 
 
+def set_miss_lines(r, traffic_bytes, stream_bytes):
+    """lines that left the L2 per second (traffic minus the streamed inputs / outputs, in 128-byte
+    lines) against the rate of dependent random lines the memory system sustains"""
+    t_s = r["avg_kernel_ms"] / 1e3
+    r["stream_bytes"] = stream_bytes
+    r["miss_lines_per_s"] = max(traffic_bytes - stream_bytes, 0) / LINE / t_s
+    r["frac_of_gather_ceiling"] = round(r["miss_lines_per_s"] / (GATHER_CEILING_GLINES * 1e9), 4)
+
+
 def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes, census, traffic):
     """HBM roofline of one kernel.  `achieved` / `frac` use what the memory system really moved
     when it was measured (PMC passes), else the lines the kernel REQUESTS (census) -- both are real
@@ -265,14 +274,13 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
     blocks) is kept as `algorithmic_ref_bytes` for information only."""
     t_s = avg_kernel_ms / 1e3
     r = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "avg_kernel_ms": round(avg_kernel_ms, 4)}
+         "avg_kernel_ms": round(avg_kernel_ms, 4), "stream_bytes": stream_bytes}
     req_bytes = None
     if census and census.get("requested_lines") is not None:
         req_bytes = census["requested_lines"] * LINE + stream_bytes
         r["requested_lines"] = census["requested_lines"]
         r["requested_bytes"] = req_bytes
-        r["lines_per_s"] = census["requested_lines"] / t_s
-        r["frac_of_gather_ceiling"] = round(census["requested_lines"] / t_s / (GATHER_CEILING_GLINES * 1e9), 4)
+        r["requested_lines_per_s"] = census["requested_lines"] / t_s     # L2 hits included
         if census.get("distinct_lines") is not None:
             r["min_bytes"] = census["distinct_lines"] * LINE + stream_bytes
     tb = traffic.get("bytes") if traffic else None
@@ -280,6 +288,7 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
     if tb:
         r["traffic_source"] = traffic.get("source")
         r["achieved"] = round(tb / t_s / 1e9, 1)
+        set_miss_lines(r, tb, stream_bytes)
         r["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
         if r.get("min_bytes"):
             r["traffic_over_min_bytes"] = round(tb / r["min_bytes"], 3)
@@ -666,6 +675,7 @@ def apply_pmc(out, pmc, cal):
         roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent["write_kb"]
         roof["achieved"] = round(ent["bytes"] / t_s / 1e9, 1)
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+        set_miss_lines(roof, ent["bytes"], roof.get("stream_bytes", 0))
         roof["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
         if roof.get("min_bytes"):
             roof["traffic_over_min_bytes"] = round(ent["bytes"] / roof["min_bytes"], 3)

@@ -11,7 +11,9 @@
 //   SA samples             suffix_array/sample.rs:21-44
 //   rank structure         vers-vecs WaveletMatrix::from_slice -> 128-B multi-ary
 //                          wavelet-matrix records (fmx_internal.h)
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <iterator>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 #include <chrono>
 #include "fmx_device.h"
@@ -120,6 +122,12 @@ struct MaxOp {
     return a > b ? a : b;
   }
 };
+// exclusive prefix sum on the default stream, accumulated in the OUTPUT's value type
+template <typename In, typename Out>
+static hipError_t exclusive_sum(void *tmp, size_t &bytes, In in, Out out, size_t n) {
+  using V = typename std::iterator_traits<Out>::value_type;
+  return rocprim::exclusive_scan(tmp, bytes, in, out, V(0), n, rocprim::plus<V>(), (hipStream_t)0);
+}
 __global__ __launch_bounds__(BLK) void k_scatter_rank(const uint32_t *__restrict__ sa,
                                                        const uint32_t *__restrict__ head,
                                                        uint32_t n, uint32_t *__restrict__ rank) {
@@ -478,12 +486,11 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   // temp storage: the larger of the sort and scan requirements
   size_t tmp_sort = 0, tmp_scan = 0;
   {
-    hipcub::DoubleBuffer<uint64_t> kb(keys_a, keys_b);
-    hipcub::DoubleBuffer<uint32_t> vb(d_sa, vals_b);
-    FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, kb, vb, (size_t)n, 0, 64,
-                                               (hipStream_t)0));
-    FMX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                              MaxOp(), (size_t)n, (hipStream_t)0));
+    rocprim::double_buffer<uint64_t> kb(keys_a, keys_b);
+    rocprim::double_buffer<uint32_t> vb(d_sa, vals_b);
+    FMX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort, kb, vb, (size_t)n, 0u, 64u, (hipStream_t)0));
+    FMX_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n,
+                                    MaxOp(), (hipStream_t)0));
   }
   size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
   uint8_t *tmp;
@@ -497,13 +504,12 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   int end_bit = (int)(k * sym_bits);
   uint64_t h = k;
   for (;;) {
-    hipcub::DoubleBuffer<uint64_t> kb(keys_cur, keys_alt);
-    hipcub::DoubleBuffer<uint32_t> vb(sa_cur, sa_alt);
+    rocprim::double_buffer<uint64_t> kb(keys_cur, keys_alt);
+    rocprim::double_buffer<uint32_t> vb(sa_cur, sa_alt);
     size_t tb = tmp_bytes;
-    FMX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, kb, vb, (size_t)n, 0, end_bit,
-                                               (hipStream_t)0));
-    keys_cur = kb.Current(); keys_alt = kb.Alternate();
-    sa_cur = vb.Current();   sa_alt = vb.Alternate();
+    FMX_HIP(rocprim::radix_sort_pairs(tmp, tb, kb, vb, (size_t)n, 0u, (unsigned)end_bit, (hipStream_t)0));
+    keys_cur = kb.current(); keys_alt = kb.alternate();
+    sa_cur = vb.current();   sa_alt = vb.alternate();
     head = (uint32_t *)keys_alt;
     rank = sa_alt;
     FMX_HIP(hipMemsetAsync(d_ng, 0, sizeof(unsigned int), 0));
@@ -517,8 +523,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
       return FMX_ERR_HIP;
     }
     tb = tmp_bytes;
-    FMX_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, head, MaxOp(), (size_t)n,
-                                              (hipStream_t)0));
+    FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp(), (hipStream_t)0));
     hipLaunchKernelGGL(k_scatter_rank, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, head, n, rank);
     hipLaunchKernelGGL(k_double_keys, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, rank, n, h,
                        keys_cur);
@@ -573,10 +578,10 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
       hipLaunchKernelGGL((k_mwm_pieces<4, T>), dim3(grid), dim3(BLK), 0, 0, cur, len, lv.shift, lv.mask,
                          lv.nrec, rec, hist);
     size_t tb = 0;
-    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, scan, nh, (hipStream_t)0));
+    FMX_HIP(exclusive_sum(nullptr, tb, hist, scan, nh));
     uint8_t *tmp;
     FMX_HIP(pool.get(&tmp, tb));
-    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, scan, nh, (hipStream_t)0));
+    FMX_HIP(exclusive_sum(tmp, tb, hist, scan, nh));
     int fold_c = (l + 1 < nlv) ? 1 : 0;
     uint32_t *d_add = nullptr;
     if (nlv == 1 && single_level_add) {  // cs[] folded into the only level's counters
@@ -617,12 +622,12 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
     if (l + 1 < nlv) {
       // stable sort of the whole sequence by this level's code -> order of the next level
       size_t sb = 0;
-      FMX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, sb, cur, alt, (size_t)len, (int)lv.shift,
-                                                (int)(lv.shift + bits[l]), (hipStream_t)0));
+      FMX_HIP(rocprim::radix_sort_keys(nullptr, sb, cur, alt, (size_t)len, lv.shift, lv.shift + bits[l],
+                                       (hipStream_t)0));
       uint8_t *stmp;
       FMX_HIP(pool.get(&stmp, sb));
-      FMX_HIP(hipcub::DeviceRadixSort::SortKeys(stmp, sb, cur, alt, (size_t)len, (int)lv.shift,
-                                                (int)(lv.shift + bits[l]), (hipStream_t)0));
+      FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)len, lv.shift, lv.shift + bits[l],
+                                       (hipStream_t)0));
       FMX_HIP(hipDeviceSynchronize());
       pool.release(stmp);
       T *x = cur; cur = alt; alt = x;
@@ -679,11 +684,10 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   hipLaunchKernelGGL(k_bits_pieces, dim3(nblocks(npieces)), dim3(BLK), 0, 0, d_flags, n, npieces, rec,
                      cnt);
   size_t tb = 0;
-  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, base, (size_t)npieces + 1,
-                                           (hipStream_t)0));
+  FMX_HIP(exclusive_sum(nullptr, tb, cnt, base, (size_t)npieces + 1));
   uint8_t *tmp;
   FMX_HIP(pool.get(&tmp, tb));
-  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, base, (size_t)npieces + 1, (hipStream_t)0));
+  FMX_HIP(exclusive_sum(tmp, tb, cnt, base, (size_t)npieces + 1));
   hipLaunchKernelGGL(k_bits_counters, dim3(nblocks(npieces)), dim3(BLK), 0, 0, base, npieces, rec);
   uint32_t ones = 0;
   FMX_HIP(hipMemcpy(&ones, base + npieces, 4, hipMemcpyDeviceToHost));
@@ -769,16 +773,16 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   hipLaunchKernelGGL(k_run_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_L, n, flags);
   // S = run heads (rlfmi.rs:57), starts = first row of every run
   size_t t1 = 0, t2 = 0;
-  hipcub::CountingInputIterator<uint32_t> rows(0);
-  FMX_HIP(hipcub::DeviceSelect::Flagged(nullptr, t1, d_L, flags, heads, d_num, (int)n, (hipStream_t)0));
-  FMX_HIP(hipcub::DeviceSelect::Flagged(nullptr, t2, rows, flags, starts, d_num, (int)n, (hipStream_t)0));
+  rocprim::counting_iterator<uint32_t> rows(0);
+  FMX_HIP(rocprim::select(nullptr, t1, d_L, flags, heads, d_num, (size_t)n, (hipStream_t)0));
+  FMX_HIP(rocprim::select(nullptr, t2, rows, flags, starts, d_num, (size_t)n, (hipStream_t)0));
   size_t tb = t1 > t2 ? t1 : t2;
   uint8_t *tmp;
   FMX_HIP(pool.get(&tmp, tb));
   size_t tt = tb;
-  FMX_HIP(hipcub::DeviceSelect::Flagged(tmp, tt, d_L, flags, heads, d_num, (int)n, (hipStream_t)0));
+  FMX_HIP(rocprim::select(tmp, tt, d_L, flags, heads, d_num, (size_t)n, (hipStream_t)0));
   tt = tb;
-  FMX_HIP(hipcub::DeviceSelect::Flagged(tmp, tt, rows, flags, starts, d_num, (int)n, (hipStream_t)0));
+  FMX_HIP(rocprim::select(tmp, tt, rows, flags, starts, d_num, (size_t)n, (hipStream_t)0));
   uint32_t r = 0;
   FMX_HIP(hipMemcpy(&r, d_num, 4, hipMemcpyDeviceToHost));
   idx->runs = r;
@@ -804,18 +808,18 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   FMX_HIP(pool.get(&hk2, r));
   hipLaunchKernelGGL(k_iota, dim3(nblocks(r)), dim3(BLK), 0, 0, order, r);
   size_t sb = 0;
-  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0, (int)L,
-                                             (hipStream_t)0));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0u, (unsigned)L,
+                                    (hipStream_t)0));
   uint8_t *stmp;
   FMX_HIP(pool.get(&stmp, sb));
-  FMX_HIP(hipcub::DeviceRadixSort::SortPairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0, (int)L,
-                                             (hipStream_t)0));
+  FMX_HIP(rocprim::radix_sort_pairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0u, (unsigned)L,
+                                    (hipStream_t)0));
   hipLaunchKernelGGL(k_sorted_run_lens, dim3(nblocks(r)), dim3(BLK), 0, 0, starts, order2, r, n, lens);
   size_t eb = 0;
-  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, eb, lens, fpos, (size_t)r, (hipStream_t)0));
+  FMX_HIP(exclusive_sum(nullptr, eb, lens, fpos, (size_t)r));
   uint8_t *etmp;
   FMX_HIP(pool.get(&etmp, eb));
-  FMX_HIP(hipcub::DeviceScan::ExclusiveSum(etmp, eb, lens, fpos, (size_t)r, (hipStream_t)0));
+  FMX_HIP(exclusive_sum(etmp, eb, lens, fpos, (size_t)r));
   FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
   hipLaunchKernelGGL(k_scatter_ones, dim3(nblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
   FMX_HIP(hipDeviceSynchronize());
@@ -976,13 +980,13 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_bwt, n, zl);
     hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, zt);
     size_t tb = 0;
-    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, zl, zlr, (size_t)n, (hipStream_t)0));
+    FMX_HIP(exclusive_sum(nullptr, tb, zl, zlr, (size_t)n));
     uint8_t *tmp;
     FMX_HIP(pool.get(&tmp, tb));
     size_t t1 = tb;
-    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, t1, zl, zlr, (size_t)n, (hipStream_t)0));
+    FMX_HIP(exclusive_sum(tmp, t1, zl, zlr, (size_t)n));
     t1 = tb;
-    FMX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, t1, zt, ztr, (size_t)n, (hipStream_t)0));
+    FMX_HIP(exclusive_sum(tmp, t1, zt, ztr, (size_t)n));
     hipLaunchKernelGGL(k_doc, dim3(nblocks(n)), dim3(BLK), 0, 0, d_sa, zl, zlr, ztr, n, pieces, d_doc,
                        d_first);
     uint32_t first = 0;

@@ -258,13 +258,21 @@ def stored_traffic(workload_key, leg):
     return ent.get(leg)
 
 
-def set_miss_lines(r, traffic_bytes, stream_bytes):
-    """lines that left the L2 per second (traffic minus the streamed inputs / outputs, in 128-byte
-    lines) against the rate of dependent random lines the memory system sustains"""
+def set_miss_lines(r, traffic_bytes, stream_bytes, fetch_kb_raw=None):
+    """requests that left the L2 per second against the rate of dependent random requests the memory
+    system sustains.  FETCH_SIZE tallies 64 B per fabric request whatever its size (calibrated:
+    profiles/microbench/gather_fetch_calibration_r02.txt -- 16-, 32-, 64- and 128-byte random requests
+    all report 64 B), so requests = raw FETCH_SIZE / 64 B; without the raw counter, (traffic -
+    streamed bytes) / 128 B."""
     t_s = r["avg_kernel_ms"] / 1e3
     r["stream_bytes"] = stream_bytes
-    r["miss_lines_per_s"] = max(traffic_bytes - stream_bytes, 0) / LINE / t_s
-    r["frac_of_gather_ceiling"] = round(r["miss_lines_per_s"] / (GATHER_CEILING_GLINES * 1e9), 4)
+    if fetch_kb_raw:
+        req = max(fetch_kb_raw * 1024.0 - stream_bytes / 2.0, 0.0) / 64.0     # streamed lines are 128-B requests too
+    else:
+        req = max(traffic_bytes - stream_bytes, 0) / LINE
+    r["fabric_requests"] = int(req)
+    r["fabric_requests_per_s"] = req / t_s
+    r["frac_of_gather_ceiling"] = round(req / t_s / (GATHER_CEILING_GLINES * 1e9), 4)
 
 
 def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes, census, traffic):
@@ -288,16 +296,16 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
     if tb:
         r["traffic_source"] = traffic.get("source")
         r["achieved"] = round(tb / t_s / 1e9, 1)
-        set_miss_lines(r, tb, stream_bytes)
+        set_miss_lines(r, tb, stream_bytes, traffic.get("fetch_kb_raw"))
         r["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
         if r.get("min_bytes"):
             r["traffic_over_min_bytes"] = round(tb / r["min_bytes"], 3)
-    elif req_bytes:
-        r["achieved"] = round(req_bytes / t_s / 1e9, 1)
-        r["basis"] = "requested lines x 128 B + streamed bytes (census) / kernel time; no PMC traffic for this build"
     else:
+        # the census counts L2 hits too, so requested bytes are not HBM-side traffic: no number is
+        # better than one that can exceed the peak
         r["achieved"] = None
-        r["basis"] = "neither PMC traffic nor a line census is available for this build"
+        r["basis"] = "no PMC traffic for this build (rocprofv3 unavailable and no profiles/traffic.json entry " \
+                     "measured on these sources)"
     r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4) if r["achieved"] else None
     r["algorithmic_ref_bytes"] = units * ref_bytes_per_unit
     r["algorithmic_ref_bytes_per_unit"] = ref_bytes_per_unit
@@ -311,7 +319,7 @@ PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counte
     "dna_count": ["fmx_count_f3_kernel"],
     "dna_locate": ["fmx_locate_f3w_kernel"],
     "rlfm_count": ["fmx_count_rlfm_ep_kernel", "fmx_count_kernel"],
-    "rlfm_locate": ["fmx_locate_rlfm_ep_kernel", "fmx_locate_kernel"],
+    "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
 }
 
 
@@ -675,7 +683,7 @@ def apply_pmc(out, pmc, cal):
         roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent["write_kb"]
         roof["achieved"] = round(ent["bytes"] / t_s / 1e9, 1)
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-        set_miss_lines(roof, ent["bytes"], roof.get("stream_bytes", 0))
+        set_miss_lines(roof, ent["bytes"], roof.get("stream_bytes", 0), ent["fetch_kb_raw"])
         roof["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
         if roof.get("min_bytes"):
             roof["traffic_over_min_bytes"] = round(ent["bytes"] / roof["min_bytes"], 3)
@@ -804,7 +812,7 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     if not args.no_census and rank == 0:
         cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
     ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
-    kname = "fmx_locate_f3w_kernel<4>" if wl.dna else ("fmx_locate_rlfm_ep_kernel" if wl.rlfm else
+    kname = "fmx_locate_f3w_kernel<4>" if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else
                                                         "fmx_locate_kernel<FMX_KIND_FM>")
     roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
                          stored_traffic(key, "locate"))

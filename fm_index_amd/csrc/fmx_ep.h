@@ -54,13 +54,14 @@ __device__ __forceinline__ uint32_t fmx_grp_bcast(uint32_t v, uint32_t base, uin
 // index is simply i / 96.
 struct FmxProbe { uint4 pc; uint32_t pidx, bit; };
 template <bool PAIRED>
-__device__ __forceinline__ FmxProbe fmx_bits_probe_issue(const FmxBits &bv, uint32_t i) {
+__device__ __forceinline__ FmxProbe fmx_bits_probe_issue(const FmxBits &bv, uint32_t i,
+                                                         [[maybe_unused]] bool live = true) {
   FmxProbe pr;
   if (i > bv.len) i = bv.len;
   pr.pidx = fmx_div3(i >> 5);                 // i / 96
   pr.bit = i - pr.pidx * FMX_BITS_PER_PIECE;
   FMX_CHECK(pr.pidx < bv.nrec * 8u);
-  FMX_TOUCH_LANE(PAIRED, &bv.rec[pr.pidx], true);
+  FMX_TOUCH_LANE(PAIRED, &bv.rec[pr.pidx], live);
   pr.pc = bv.rec[pr.pidx];
   return pr;
 }
@@ -87,14 +88,15 @@ __device__ __forceinline__ uint32_t fmx_bits_probe_rank(const FmxProbe &pr, uint
 // (vers-vecs RsVec::select1).
 struct FmxSel { uint4 blk; uint32_t k; bool valid; };
 template <int SM, bool PAIRED>
-__device__ __forceinline__ FmxSel fmx_ep_select_issue(const FmxBits &bv, uint32_t k, bool want) {
+__device__ __forceinline__ FmxSel fmx_ep_select_issue(const FmxBits &bv, uint32_t k, bool want,
+                                                      [[maybe_unused]] bool live = true) {
   FmxSel s;
   s.valid = k < bv.ones;
   s.k = s.valid ? k : 0u;
   s.blk = make_uint4(0u, 0u, 0u, 0u);
   want = want && bv.ones != 0u;
-  if (SM == 1) FMX_TOUCH_LANE(PAIRED, &bv.pos[s.k], want);
-  else FMX_TOUCH_LANE(PAIRED, &bv.dsel[s.k >> 6], want);
+  if (SM == 1) FMX_TOUCH_LANE(PAIRED, &bv.pos[s.k], want && live);
+  else FMX_TOUCH_LANE(PAIRED, &bv.dsel[s.k >> 6], want && live);
   if (want) {
     if (SM == 1) s.blk.x = bv.pos[s.k];
     else s.blk = bv.dsel[s.k >> 6];
@@ -156,25 +158,34 @@ __device__ __forceinline__ void fmx_ep_select_slow(const FmxBits &bv, uint32_t k
 // `match` rides in bit 31 of the group sum, so ranks must stay below 2^31 (RLFM: n < 2^31).
 template <int FMT, bool ACCESS, bool PAIRED>
 __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint32_t pos, uint32_t &code,
-                                             uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
+                                             bool live, uint32_t base, uint32_t g, uint32_t &rank,
+                                             uint32_t &match) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
   constexpr uint32_t OM = (FMT == 3) ? 255u : 127u;
   constexpr uint32_t PER = (FMT == 3) ? 32u : 16u;
   constexpr int PSH = (FMT == 3) ? 5 : 4;
   uint32_t bp[8], bc[8];
   uint4 p[8];
+  // endpoint q is skipped when it is dead in EVERY group of the wave (wave-uniform): in the tail of a
+  // locate batch a wave holds a few long walks and a round then costs their instructions only
+  const unsigned long long lv = __ballot(live);
 #pragma unroll
   for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
     bp[q] = fmx_grp_bcast(pos, base, q);
     bc[q] = ACCESS ? 0u : fmx_grp_bcast(code, base, q);
     const uint4 *r = rec + (size_t)(bp[q] >> SH) * 8u;
-#ifdef FMX_CENSUS   // the odd endpoint is the same pattern's other interval end: same record = ONE line
-    if (!(PAIRED && (q & 1u) && (bp[q] >> SH) == (bp[q - 1u] >> SH))) FMX_TOUCH_G0(g, r);
+#ifdef FMX_CENSUS   // dead endpoints (record 0, cached) are not the algorithm's lines; the odd endpoint is
+                    // the same pattern's other interval end: same record = ONE line
+    if (fmx_grp_bcast(live ? 1u : 0u, base, q) &&
+        !(PAIRED && (q & 1u) && (bp[q] >> SH) == (bp[q - 1u] >> SH)))
+      FMX_TOUCH_G0(g, r);
 #endif
     p[q] = r[g];
   }
 #pragma unroll
   for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
     const uint32_t off = bp[q] & OM;
     const bool mine = g == (off >> PSH);
     uint32_t cd = bc[q];
@@ -188,18 +199,18 @@ __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint
     if (!ACCESS) v |= mine ? (((mt >> (off & (PER - 1u))) & 1u) << 31) : 0u;
     const uint32_t sum = fmx_group_sum(v);
     if (g == q) {
-      rank = sum & 0x7FFFFFFFu;
-      match = sum >> 31;
+      rank = ACCESS ? sum : (sum & 0x7FFFFFFFu);   // ACCESS carries no match bit: ranks may use all 32 bits
+      match = ACCESS ? 1u : (sum >> 31);
       if (ACCESS) code = cd;
     }
   }
 }
 template <bool ACCESS, bool PAIRED>
-__device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, uint32_t &code, uint32_t base,
-                                             uint32_t g, uint32_t &rank, uint32_t &match) {
+__device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, uint32_t &code, bool live,
+                                             uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
   FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
-  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED>(L.rec, pos, code, base, g, rank, match);
-  else fmx_ep_round<4, ACCESS, PAIRED>(L.rec, pos, code, base, g, rank, match);
+  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED>(L.rec, pos, code, live, base, g, rank, match);
+  else fmx_ep_round<4, ACCESS, PAIRED>(L.rec, pos, code, live, base, g, rank, match);
 }
 
 // ---- RLFMIndexBackend::lf_map2 for 8 endpoints per group (rlfmi.rs:135-143) -------------------
@@ -208,30 +219,31 @@ __device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, ui
 //             s.rank(lo, c) and m = [s[lo] == c]; s.rank(lo+1, c) = s.rank(lo, c) + m, so
 //             nr = s.rank(j, c) with j in {lo, lo+1}, and get_l(i) == c is m  (rlfmi.rs:137-138).
 // Lane-wise:  bp.select1(cs[c] + nr); + i - b.select1(j) when m                  (rlfmi.rs:139-141)
-// Dead lanes pass i = 0, c = 0 and ignore the result.
+// Dead lanes pass i = 0, c = 0, live = false and ignore the result (`live` only keeps their cached
+// dummy probes out of the census).
 template <int NL, int SM>
-__device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i, uint32_t base,
-                                                        uint32_t g) {
+__device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i, bool live,
+                                                        uint32_t base, uint32_t g) {
   const uint32_t kc = ix.K[c];
-  const FmxProbe pr = fmx_bits_probe_issue<true>(ix.b, i);
+  const FmxProbe pr = fmx_bits_probe_issue<true>(ix.b, i, live);
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)            rlfmi.rs:136
   const uint32_t lo = j - 1u + bit;                          // b.rank1(i + 1) - 1    rlfmi.rs:124
   // run start b.select1(j) = first one at or after i: usually in the piece; else one more probe,
   // issued now so that it travels under the rank rounds
-  const FmxSel ss = fmx_ep_select_issue<SM, true>(ix.b, j, nx == FMX_NONE);
+  const FmxSel ss = fmx_ep_select_issue<SM, true>(ix.b, j, nx == FMX_NONE, live);
   uint32_t pos = lo, r = 0, m = 1u;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
 #pragma unroll
   for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = ix.bw.lv[l];
     uint32_t code = (c >> L.shift) & L.mask, mt;
-    fmx_ep_level<false, true>(L, pos, code, base, g, r, mt);
+    fmx_ep_level<false, true>(L, pos, code, live, base, g, r, mt);
     m &= mt;
     pos = r;                                                 // C_l[code] is folded into the counters
   }
   const uint32_t nr = kc + r + (bit ? 0u : m);               // cs[c] + s.rank(j, c)  rlfmi.rs:137,139
-  const FmxSel sf = fmx_ep_select_issue<SM, true>(ix.bp, nr, true);
+  const FmxSel sf = fmx_ep_select_issue<SM, true>(ix.bp, nr, true, live);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);          // bp.select1(cs[c] + nr)
   uint32_t st = nx;
   if (nx == FMX_NONE) st = fmx_ep_select_finish<SM>(ix.b, ss);
@@ -246,13 +258,13 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32
 // One access+rank chain at lo = b.rank1(i+1) - 1 yields c = s[lo] and s.rank(lo, c); since s[lo] = c,
 // s.rank(j, c) = s.rank(lo, c) + (j - lo).  K[] comes from LDS (`kt`, staged by the kernel).
 template <int NL, int SM>
-__device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const uint32_t *kt, uint32_t i,
+__device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const uint32_t *kt, uint32_t i, bool live,
                                                        uint32_t base, uint32_t g, uint32_t &sym) {
-  const FmxProbe pr = fmx_bits_probe_issue<false>(ix.b, i);
+  const FmxProbe pr = fmx_bits_probe_issue<false>(ix.b, i, live);
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)
   const uint32_t lo = j - 1u + bit;
-  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, j, nx == FMX_NONE);
+  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, j, nx == FMX_NONE, live);
   uint32_t pos = lo, r = 0;
   sym = 0;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
@@ -260,12 +272,12 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
   for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = ix.bw.lv[l];
     uint32_t code = 0, mt;
-    fmx_ep_level<true, false>(L, pos, code, base, g, r, mt);
+    fmx_ep_level<true, false>(L, pos, code, live, base, g, r, mt);
     sym |= code << L.shift;
     pos = r;
   }
   const uint32_t nr = kt[sym] + r + (bit ? 0u : 1u);         // cs[c] + s.rank(j, c)   rlfmi.rs:129-130
-  const FmxSel sf = fmx_ep_select_issue<SM, false>(ix.bp, nr, true);
+  const FmxSel sf = fmx_ep_select_issue<SM, false>(ix.bp, nr, true, live);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);
   uint32_t st = nx;
   if (nx == FMX_NONE) st = fmx_ep_select_finish<SM>(ix.b, ss);
@@ -274,4 +286,23 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
     fmx_ep_select_slow(ix.b, j, st == FMX_NONE, base, g, st);
   }
   return f + i - st;                                         // rlfmi.rs:132
+}
+
+// ---- FMIndexBackend::get_l + lf_map for 8 walks per group (fm_index.rs:82-91) -------------------
+// access + rank along the same positions, one round per wavelet level
+template <int NL>
+__device__ __forceinline__ uint32_t fmx_fm_ep_lf_map(const FmxDev &ix, const uint32_t *kt, uint32_t i, bool live,
+                                                     uint32_t base, uint32_t g, uint32_t &sym) {
+  uint32_t pos = i, r = 0;
+  sym = 0;
+  const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
+    const FmxLevel &L = ix.bw.lv[l];
+    uint32_t code = 0, mt;
+    fmx_ep_level<true, false>(L, pos, code, live, base, g, r, mt);
+    sym |= code << L.shift;
+    pos = r;                                                 // C_l[code] is folded into the counters
+  }
+  return kt[sym] + r;                                        // fm_index.rs:86-91
 }

@@ -189,6 +189,28 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
   }
 }
 
+// count on the index of an EMPTY text (sais.rs:121-123 accepts n = 0): every interval is (0, 0) --
+// the start pair (0, len), any refinement pair, and what a step maps them to.  One lane per
+// pattern; offsets, given ranges and symbols are still checked like everywhere else.
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_empty_kernel(
+    uint32_t max_character, uint32_t sym_bytes, uint32_t *status, const void *__restrict__ pat,
+    const uint64_t *__restrict__ off, uint64_t npat, const uint64_t *__restrict__ s0e0,
+    uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt) {
+  const uint64_t ptot = npat ? off[npat] : 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < npat; k += stride) {
+    const uint64_t a = off[k], b = off[k + 1];
+    if (b < a || b > ptot || (s0e0 && (s0e0[2 * k] | s0e0[2 * k + 1]) != 0)) {
+      atomicOr(status, 1u << FMX_ERR_ARG);
+    } else if (b > a && fmx_load_sym(pat, sym_bytes, b - 1) > max_character) {   // the first step's cs[c]
+      atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
+    }
+    if (out_s) out_s[k] = 0;
+    if (out_e) out_e[k] = 0;
+    if (out_cnt) out_cnt[k] = 0;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // count, single 3-bit level (L <= 3: DNA, the BASELINE configs 1/2/3/5).
 // The record counters are absolute (cs[] folded in), so one 128-B line per endpoint IS
@@ -610,7 +632,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_rlfm_ep_kernel(
     }
     // the next symbol rides along with this step's probes
     const uint32_t cn = (stepping && j > 1) ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
-    const uint32_t np = fmx_rlfm_ep_lf_map2<NL, SM>(ix, stepping ? c : 0u, stepping ? pos : 0u, base, g);  // wrapper.rs:109-110
+    const uint32_t np = fmx_rlfm_ep_lf_map2<NL, SM>(ix, stepping ? c : 0u, stepping ? pos : 0u, stepping, base, g);  // wrapper.rs:109-110
     if (stepping) {
       pos = np;
       c = cn;
@@ -756,129 +778,127 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// locate walk on the RLFM index, one walk per LANE (fmx_ep.h): 64 walks per wave, every LF step =
-// lane-wise B probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects.  A wave
-// owns a contiguous chunk of hits and hands them to its lanes as they finish (ballot + prefix
-// popcount, no atomics).  K[] is staged in LDS when the alphabet is small (it is read with a
-// data-dependent symbol in every step).
-template <int NL, int SM, bool KLDS>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rlfm_ep_kernel(
-    FmxDev ix, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
-    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
-  if (KLDS) {
-    for (uint32_t t = threadIdx.x; t <= ix.max_character; t += blockDim.x) kt_lds[t] = ix.K[t];
-    __syncthreads();
+// ---------------------------------------------------------------------------
+// work queue of the locate kernels.  With a private chunk of hits per wave, a wave ran as long as its
+// unluckiest slot (walk lengths are geometric: 56 % efficiency at 2^20 hits).  A global ticket
+// counter fixes the balance but not the clock: device-scope atomics on one address are served one
+// after the other at the memory side, and 2^14 tickets cost more than they saved (measured: DNA
+// locate 0.153 -> 0.25 ms).  So the queue is per WORKGROUP, in LDS: a 1024-thread block owns a
+// contiguous slice of the hits (large enough for the law of large numbers to balance the blocks:
+// 4096 hits -> +-1.4 % of work) and its 16 waves draw 64-row chunks from an LDS counter as they
+// run dry.  A wave keeps two chunks resident (their 64 rows each in one register per lane).
+// ---------------------------------------------------------------------------
+#define FMX_LCHUNK 64u
+#define FMX_NOCHUNK 0xFFFFFFFFu
+#define FMX_LOC_BLOCK 1024
+struct FmxHitQueue {
+  const uint32_t *rows;   // rows of this block's slice
+  uint64_t lo;            // first hit of the slice (index into out_pos)
+  uint32_t nhits;         // hits in the slice
+  uint32_t lane;
+  uint32_t c0, c1;        // resident chunks of the slice (FMX_NOCHUNK once it is exhausted), wave-uniform
+  uint32_t win0, win1;    // rows of the resident chunks, one per lane
+  uint32_t used;          // hits already handed out of c0|c1
+  __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
+    const uint32_t x = c * FMX_LCHUNK + lane;
+    return (c != FMX_NOCHUNK && x < nhits) ? rows[x] : 0u;   // every slot was written by fmx_expand_kernel
   }
-  const uint32_t *kt = KLDS ? kt_lds : ix.K;
-  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lmask = (1u << ix.sa_level) - 1u;
-  const uint64_t w0 = wave * hits_per_wave;
-  if (w0 >= total) return;                          // wave-uniform
-  const uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
-  // rows come from fmx_expand_kernel, which writes every slot, so every row is inside the index
-  uint64_t h = w0 + lane;
-  bool active = h < w1;
-  uint32_t row = active ? rows[h] : 0u;
-  uint64_t next = w0 + 64 < w1 ? w0 + 64 : w1;
-  uint32_t steps = 0, nsteps = 0;
-  while (__any(active)) {
-    const bool sampled = active && (row & lmask) == 0u;
-    uint32_t sa = 0;
-    if (sampled) {                                  // sample.rs:46-60 Some(sa)
-      FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
-      FMX_TOUCH(&ix.samples[row >> ix.sa_level]);
-      sa = ix.samples[row >> ix.sa_level];
-    }
-    const bool walking = active && !sampled;
-    if (__any(walking)) {                           // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186
-      uint32_t sym;
-      const uint32_t nrow = fmx_rlfm_ep_lf_map<NL, SM>(ix, kt, walking ? row : 0u, base, g, sym);
-      if (walking) { row = nrow; steps++; nsteps++; }
-    }
-    const unsigned long long fmask = __ballot(sampled);
-    if (fmask) {                                    // wave-uniform
-      if (sampled) {
-        uint64_t v = (uint64_t)sa + steps;          // rlfmi.rs:181: (sa + steps) % len
-        if (v >= ix.n) v -= ix.n;
-        out_pos[h] = v;
-        h = next + (uint64_t)__popcll(fmask & ((1ull << lane) - 1ull));
-        active = h < w1;
-        steps = 0;
-        row = active ? rows[h] : 0u;
-      }
-      next += (uint64_t)__popcll(fmask);
+  __device__ __forceinline__ uint32_t valid(uint32_t c) const {
+    return (c != FMX_NOCHUNK && c * FMX_LCHUNK < nhits) ? c : FMX_NOCHUNK;
+  }
+  __device__ __forceinline__ uint32_t draw(unsigned int &counter, uint32_t k) const {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&counter, k);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  }
+  __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t ln,
+                                       unsigned int &counter) {
+    rows = r; lo = first; nhits = count; lane = ln;
+    const uint32_t t = draw(counter, 2u);
+    c0 = valid(t);
+    c1 = valid(t + 1u);
+    win0 = load_win(c0);
+    win1 = load_win(c1);
+    used = 0;
+  }
+  // the hit with index `used + rank`: returns false when the slice has run dry
+  __device__ __forceinline__ bool take(uint32_t rank, uint64_t &h, uint32_t &row) const {
+    const uint32_t idx = used + rank;
+    const uint32_t c = idx < FMX_LCHUNK ? c0 : c1;
+    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(idx & 63u));
+    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(idx & 63u));
+    const uint32_t x = c * FMX_LCHUNK + (idx & 63u);
+    h = lo + x;
+    row = idx < FMX_LCHUNK ? v0 : v1;
+    return idx < 2u * FMX_LCHUNK && c != FMX_NOCHUNK && x < nhits;
+  }
+  // `count` hits were handed out (wave-uniform, count <= 64)
+  __device__ __forceinline__ void advance(uint32_t count, unsigned int &counter) {
+    used += count;
+    if (used >= FMX_LCHUNK) {                        // wave-uniform: slide
+      used -= FMX_LCHUNK;
+      c0 = c1;
+      win0 = win1;
+      c1 = c1 != FMX_NOCHUNK ? valid(draw(counter, 1u)) : FMX_NOCHUNK;
+      win1 = load_win(c1);
     }
   }
-  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
+};
 
-// locate walk, single 3-bit level (DNA).  A WAVE owns a contiguous chunk of hits and hands them
-// to its 8 groups dynamically (ballot + prefix popcount, no atomics), so the wave runs
-// sum(work)/8 iterations instead of max over its groups of their statically assigned work.  The
-// rows of the next 64 hits sit in a register window (one coalesced load per 56 hits); a finishing
-// group takes its next row from the window with a ds_bpermute -- no dependent memory access to
-// start a walk.  Every iteration a group issues exactly ONE 16-B load per lane whose address
-// depends on its state -- a record piece while walking (fm_index.rs:134-137) or the aligned
-// chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking and
-// finishing groups of one wave overlap their latencies instead of serialising two branches.
+// locate walk, single 3-bit level (DNA).  The wave's 8 groups take hits from the queue above as they
+// finish (ballot + prefix popcount), so the wave runs sum(work) / (8 Q) iterations, not max over its
+// groups; a finishing group takes its next row from the register window with a ds_bpermute -- no
+// dependent memory access to start a walk.  Every iteration a group issues exactly ONE 16-B load per
+// lane whose address depends on its state -- a record piece while walking (fm_index.rs:134-137) or
+// the aligned chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking
+// and finishing groups of one wave overlap their latencies instead of serialising two branches.
 template <int Q>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
-    uint32_t sa_level, uint64_t total, uint64_t hits_per_wave, const uint32_t *__restrict__ rows,
+    uint32_t sa_level, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  // Q independent walks per group: Q record loads in flight per lane, and the wave needs
-  // sum(work) / (8 Q) iterations for the bulk of its chunk (the longest single walk of the batch
-  // still bounds the kernel from below).
+  __shared__ unsigned int lds_q;
+  if (threadIdx.x == 0) lds_q = 0;
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  // Q independent walks per group: Q record loads in flight per lane (the longest single walk of
+  // the batch still bounds the kernel from below).
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane & (FMX_GROUP - 1);
   const uint32_t grp = lane >> 3;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t lmask = (1u << sa_level) - 1u;
   const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
-  uint64_t w0 = wave * hits_per_wave;
-  if (w0 >= total) return;                          // wave-uniform
-  uint64_t w1 = w0 + hits_per_wave < total ? w0 + hits_per_wave : total;
-
-  // register window over the next 128 rows of this wave's chunk
-  uint64_t win_base = w0;
-  auto load_win = [&](uint64_t base) -> uint32_t {
-    uint64_t x = base + lane;
-    return rows[x < total ? x : total - 1];         // every slot was written by fmx_expand_kernel
-  };
-  uint32_t win0 = load_win(win_base), win1 = load_win(win_base + 64);
-  auto window = [&](uint64_t hh) -> uint32_t {
-    const uint32_t rel = (uint32_t)(hh - win_base);
-    uint32_t v = (uint32_t)__shfl((int)win0, (int)(rel & 63u));
-    if (__any(rel >= 64u)) {
-      const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(rel & 63u));
-      v = rel >= 64u ? v1 : v;
-    }
-    return v;
-  };
+  FmxHitQueue hq;
+  hq.init(rows + blo, blo, bn, lane, lds_q);
 
   uint64_t h[Q], pend_h[Q], pend_v[Q];
   uint32_t row[Q], steps[Q];
   bool active[Q], pending[Q];
-  uint64_t next = w0;
   uint32_t nsteps = 0;
 #pragma unroll
   for (int q = 0; q < Q; q++) {
-    h[q] = next + grp;
-    active[q] = h[q] < w1;
-    row[q] = window(active[q] ? h[q] : win_base);
-    next = next + 8 < w1 ? next + 8 : w1;
+    active[q] = hq.take(grp, h[q], row[q]);
+    hq.advance(8u, lds_q);
+    if (!active[q]) row[q] = 0u;
     steps[q] = 0;
     pending[q] = false;
     pend_h[q] = 0;
     pend_v[q] = 0;
   }
   for (;;) {
+    // slots that are dead in EVERY group of the wave are skipped altogether (wave-uniform): towards
+    // the end of a batch a wave holds one or two long walks, and an iteration then costs one
+    // slot's instructions instead of Q slots' -- the tail runs at memory latency, not at issue rate
+    bool live[Q];
     bool any = false;
 #pragma unroll
-    for (int q = 0; q < Q; q++) any |= active[q] || pending[q];
-    if (!__any(any)) break;
+    for (int q = 0; q < Q; q++) {
+      live[q] = __any(active[q]) != 0;
+      any |= live[q] || __any(pending[q]) != 0;
+    }
+    if (!any) break;
     // issue every load of this round
     uint4 p[Q];
     bool sampled[Q];
@@ -886,7 +906,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
     for (int q = 0; q < Q; q++) {
       sampled[q] = (row[q] & lmask) == 0;
       p[q] = make_uint4(0u, 0u, 0u, 0u);
-      if (active[q]) {
+      if (live[q] && active[q]) {
         const uint32_t si = row[q] >> sa_level;
         FMX_CHECK(row[q] < n && (row[q] >> 8) < n / 256u + 1u);
         FMX_CHECK(!sampled[q] || (uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
@@ -903,6 +923,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
     }
 #pragma unroll
     for (int q = 0; q < Q; q++) {
+      if (!live[q]) continue;                                     // wave-uniform
       bool fin = false;
       if (active[q]) {
         if (sampled[q]) {
@@ -925,27 +946,89 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_f3w_kernel(
       }
       const unsigned long long fmask = __ballot(fin && g == 0);  // one bit per finishing group
       if (fmask) {                                                // wave-uniform
-        if (next >= win_base + 64) {                              // slide the row window
-          win_base += 64;
-          win0 = win1;
-          win1 = load_win(win_base + 64);
-        }
         const uint32_t leader = lane & ~7u;
         const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
-        const uint64_t h_new = next + my_rank;
-        const uint32_t r_new = window(h_new < w1 ? h_new : win_base);
+        uint64_t h_new;
+        uint32_t r_new;
+        const bool ok = hq.take(my_rank, h_new, r_new);
         if (fin) {
           h[q] = h_new;
-          active[q] = h_new < w1;
-          row[q] = r_new;
+          active[q] = ok;
+          row[q] = ok ? r_new : 0u;
           steps[q] = 0;
         }
-        next += (uint64_t)__popcll(fmask);
+        hq.advance((uint32_t)__popcll(fmask), lds_q);
       }
     }
   }
   if (steps_out && g == 0 && nsteps)
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
+// probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects; FM over several wavelet
+// levels: one access+rank round per level (eight records in flight per lane).  Lanes take
+// their hits from the global queue (FmxHitQueue) as they finish.  K[] is staged in LDS when the
+// alphabet is small (it is read with a data-dependent symbol in every step).
+template <int KIND, int NL, int SM, bool KLDS>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
+    FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
+  __shared__ unsigned int lds_q;
+  if (threadIdx.x == 0) lds_q = 0;
+  if (KLDS) {
+    for (uint32_t t = threadIdx.x; t <= ix.max_character; t += blockDim.x) kt_lds[t] = ix.K[t];
+  }
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t *kt = KLDS ? kt_lds : ix.K;
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
+  const uint32_t lmask = (1u << ix.sa_level) - 1u;
+  FmxHitQueue hq;
+  hq.init(rows + blo, blo, bn, lane, lds_q);
+  uint64_t h;
+  uint32_t row;
+  bool active = hq.take(lane, h, row);
+  hq.advance(64u, lds_q);
+  if (!active) row = 0u;
+  uint32_t steps = 0, nsteps = 0;
+  while (__any(active)) {
+    const bool sampled = active && (row & lmask) == 0u;
+    uint32_t sa = 0;
+    if (sampled) {                                  // sample.rs:46-60 Some(sa)
+      FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
+      FMX_TOUCH(&ix.samples[row >> ix.sa_level]);
+      sa = ix.samples[row >> ix.sa_level];
+    }
+    const bool walking = active && !sampled;
+    if (__any(walking)) {                           // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186
+      uint32_t sym;
+      const uint32_t nrow = KIND == FMX_KIND_RLFM
+                                ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
+                                : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
+      if (walking) { row = nrow; steps++; nsteps++; }
+    }
+    const unsigned long long fmask = __ballot(sampled);
+    if (fmask) {                                    // wave-uniform
+      uint64_t h_new;
+      uint32_t r_new;
+      const bool ok = hq.take((uint32_t)__popcll(fmask & ((1ull << lane) - 1ull)), h_new, r_new);
+      if (sampled) {
+        uint64_t v = (uint64_t)sa + steps;          // rlfmi.rs:181: (sa + steps) % len
+        if (v >= ix.n) v -= ix.n;
+        out_pos[h] = v;
+        h = h_new;
+        active = ok;
+        steps = 0;
+        row = ok ? r_new : 0u;
+      }
+      hq.advance((uint32_t)__popcll(fmask), lds_q);
+    }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // counts -> exclusive offsets (single block scan is enough off the hot path? no:
@@ -1253,6 +1336,13 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   unsigned grid = fmx_grid_for_groups(npat);
+  if (idx->n == 0) {                                 // no record of any structure may be probed
+    hipLaunchKernelGGL(fmx_count_empty_kernel, dim3(fmx_grid_for_groups((npat + 7) / 8)), dim3(FMX_BLOCK), 0,
+                       st, dv.max_character, idx->sym_bytes, dv.status, d_pat, d_off, npat, d_s0e0, d_s, d_e,
+                       d_cnt);
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
   fmx_time_begin(idx, st);
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   const FmxMwm &w = dv.bw;
@@ -1382,6 +1472,16 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   // rows in their own read-only buffer: the walk's loads never alias its stores
   uint32_t *rows = nullptr;
   FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
+  // 1024-thread blocks that each own a slice of the hits (FmxHitQueue): `nb` blocks wanted -> slice
+  // length (a multiple of the 64-row chunk, below 2^31) and the blocks that are really needed
+  auto slice = [total](uint64_t nb, uint32_t &hpb, unsigned &grid) {
+    const uint64_t min_nb = (total >> 31) + 1;
+    if (nb < min_nb) nb = min_nb;
+    uint64_t per = (total + nb - 1) / nb;
+    per = (per + FMX_LCHUNK - 1) / FMX_LCHUNK * FMX_LCHUNK;
+    hpb = (uint32_t)per;
+    grid = (unsigned)((total + per - 1) / per);
+  };
   {
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
@@ -1399,17 +1499,15 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // walks per group: 4 when the batch is large enough to keep every group busy with them
     const int v = fmx_variant();
     const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (total >= (1u << 16) ? 4 : 1);
-    uint64_t nw = (total + 8 * q - 1) / (8 * q);
-    // measured (profiles/README.md): the loop is instruction-issue bound at 8 waves/SIMD, so
-    // mid-size batches finish sooner on 4 waves/SIMD with 4 walks per group
-    uint64_t cap = total < (4u << 20) ? max_waves / 2 : max_waves;
-    cap = (uint64_t)fmx_env_long("FMX_LOC_WAVES", (long)cap);
-    if (nw > cap) nw = cap;
-    const uint64_t hp = (total + nw - 1) / nw;
-    const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+    // one 1024-thread block per CU = 4 waves per SIMD (69 VGPRs at Q = 4 admit no second one): the walk
+    // is bound by the loaded latency of its longest chain, and more walks in flight lengthen that
+    // latency without adding throughput (benchmarks/gpu/locate_queue_sweep.sh)
+    uint32_t hpb;
+    unsigned gr;
+    slice((uint64_t)fmx_env_long("FMX_LOC_BLOCKS", 256), hpb, gr);
 #define FMX_LOC_LAUNCH(Q)                                                                          \
-  hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
-                     dv.samples, dv.n, dv.sa_level, total, hp, rows, d_pos, steps)
+  hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, w.lv[0].rec,  \
+                     dv.samples, dv.n, dv.sa_level, total, hpb, rows, d_pos, steps)
     if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
   } else {
 #define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
@@ -1424,34 +1522,35 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     const int sm = idx->kind != FMX_KIND_RLFM ? -1
                    : (dv.b.pos && dv.bp.pos) ? 1
                    : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
-    if (sm > 0 && fmx_variant() != 0) {
-      // one walk per lane: 64 walks per wave
-      // measured (benchmarks/gpu/ep_sweep.sh): 2^20 hits finish soonest on 512 blocks (0.45 ms; 0.47 on
-      // 1024, 0.50 on 2048), 7.9e8 hits on 2048 (84 ms; 91 on 1024, 129 on 512): smaller chunks per wave
-      // balance the walk lengths better once there is enough work for every wave
-      uint64_t nw = (total + 63) / 64;
-      const uint64_t wcap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", total < (4u << 20) ? 512 : 2048) *
-                            (FMX_BLOCK / 64);
-      if (nw > wcap) nw = wcap;
-      const uint64_t hp = (total + nw - 1) / nw;
-      const unsigned gr = (unsigned)((nw + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+    const bool fm_ep = idx->kind == FMX_KIND_FM && w.nlevels >= 2;
+    if ((sm > 0 || fm_ep) && fmx_variant() != 0) {
+      // one walk per lane: 64 walks per wave.  2^20 hits finish soonest on one 1024-thread block per CU
+      // (0.435 ms; 0.52 on 128 blocks); large batches want every wave the registers admit (94 VGPRs ->
+      // 5 per SIMD): two 640-thread blocks per CU (config 4b, 7.9e8 hits: 84 ms against 100 ms)
+      const bool big = total >= (4u << 20);
+      const unsigned ep_threads = big ? 640u : (unsigned)FMX_LOC_BLOCK;
+      uint32_t hpb;
+      unsigned gr;
+      slice((uint64_t)fmx_env_long("FMX_EP_LOC_BLOCKS", big ? 512 : 256), hpb, gr);
       const bool klds = dv.max_character < 1024u;
-#define FMX_EPL_LAUNCH(NL, SM)                                                                       \
+#define FMX_EPL_LAUNCH(KIND, NL, SM)                                                                 \
   do {                                                                                               \
     if (klds)                                                                                        \
-      hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, true>), dim3(gr), dim3(FMX_BLOCK), 0, st,  \
-                         dv, total, hp, rows, d_pos, steps);                                    \
+      hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, true>), dim3(gr), dim3(ep_threads), 0,    \
+                         st, dv, total, hpb, rows, d_pos, steps);                                     \
     else                                                                                             \
-      hipLaunchKernelGGL((fmx_locate_rlfm_ep_kernel<NL, SM, false>), dim3(gr), dim3(FMX_BLOCK), 0, st, \
-                         dv, total, hp, rows, d_pos, steps);                                    \
+      hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, false>), dim3(gr), dim3(ep_threads), 0,   \
+                         st, dv, total, hpb, rows, d_pos, steps);                                     \
   } while (0)
-#define FMX_EPL_SM(SM)                                                                               \
+#define FMX_EPL_SM(KIND, SM)                                                                         \
   do {                                                                                               \
-    if (w.nlevels == 1) FMX_EPL_LAUNCH(1, SM);                                                       \
-    else if (w.nlevels == 2) FMX_EPL_LAUNCH(2, SM);                                                  \
-    else FMX_EPL_LAUNCH(0, SM);                                                                      \
+    if (w.nlevels == 1) FMX_EPL_LAUNCH(KIND, 1, SM);                                                 \
+    else if (w.nlevels == 2) FMX_EPL_LAUNCH(KIND, 2, SM);                                            \
+    else FMX_EPL_LAUNCH(KIND, 0, SM);                                                                \
   } while (0)
-      if (sm == 1) FMX_EPL_SM(1); else FMX_EPL_SM(2);
+      if (fm_ep) FMX_EPL_SM(FMX_KIND_FM, 0);
+      else if (sm == 1) FMX_EPL_SM(FMX_KIND_RLFM, 1);
+      else FMX_EPL_SM(FMX_KIND_RLFM, 2);
     }
     else if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);

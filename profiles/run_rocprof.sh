@@ -1,20 +1,21 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the
-# repo root):   bash profiles/run_rocprof.sh <tag>
-# Pass 1: --kernel-trace --stats (per-kernel durations).  Pass 2/3: --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in their own runs (TCC slots: MI355X_MICROARCH.md "rocprofv3 PMC slots").
-TAG=${1:-r01}
+# repo root):   bash profiles/run_rocprof.sh <tag> ["extra bench flags"]
+# Pass 1: --kernel-trace --stats of the bench command (per-kernel durations; bench.py's own HIP-event
+#         figures of the same run land in bench_trace.json and must agree).
+# Pass 2/3: --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own runs over `bench.py --pmc-child` (the
+#         same passes bench.py runs live for roofline.traffic) -- TCC slots: MI355X_MICROARCH.md
+#         "rocprofv3 PMC slots"; counters are never combined with trace domains.
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# --no-accel --no-early-exit: only config-2 launches of the headline kernels in the trace;
-# a 2nd argument replaces --no-accel: e.g. "--workload bytes-rlfm --no-accel", or "--workload dna"
-# to profile the opt-in legs (pair index, k-mer table) as well
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-early-exit ${2:---no-accel}"
+# --no-accel --no-early-exit: only config-2/3/4 launches of the headline kernels in the trace
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-early-exit --no-d2h ${2:---no-accel}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_write.out 2> $OUT/pmc_write.err
 # keep only the small summaries (the full traces can be large)
 cd $OUT
 find . -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats.csv \;
@@ -25,7 +26,7 @@ for tag in ("pmc_fetch", "pmc_write"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(tag + "/**/*counter_collection*.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            k = (row.get("Kernel_Name", "?")[:60], row.get("Counter_Name", "?"))
+            k = (row.get("Kernel_Name", "?").split("(")[0][:90], row.get("Counter_Name", "?"))
             agg[k][0] += 1
             agg[k][1] += float(row.get("Counter_Value", 0) or 0)
     out[tag] = {"%s|%s" % k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)}

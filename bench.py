@@ -318,7 +318,7 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
 PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
     "dna_count": ["fmx_count_f3_kernel"],
     "dna_locate": ["fmx_locate_f3w_kernel"],
-    "rlfm_count": ["fmx_count_rlfm_ep_kernel", "fmx_count_kernel"],
+    "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
     "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
 }
 
@@ -575,7 +575,7 @@ def run(args, world):
         cen = run_census(wl, lambda cl: wl.count(lib=cl), npat * m * (8 if wl.rlfm else 3) + (1 << 20))
     key = "%s:%d:%d:%d" % (args.workload, npat, m, args.log2n)
     kname = {"dna": "fmx_count_f3_kernel<1,false,false>"}.get(
-        args.workload, "fmx_count_rlfm_ep_kernel" if wl.rlfm else "fmx_count_kernel<FMX_KIND_FM>")
+        args.workload, "fmx_count_ep_kernel" if wl.rlfm else "fmx_count_kernel<FMX_KIND_FM>")
     roofline = make_roofline(kname, avg_kernel_ms, chars_per_step_rank, wl.ref_bytes_per_char(), stream_bytes,
                              cen, stored_traffic(key, "count"))
 
@@ -933,7 +933,7 @@ def rlfm_leg(out, args, dev, local):
          "config": {"workload": wr.describe(1), "text_len": wr.n, "patterns": npat, "pattern_len": m,
                     "index_bytes": wr.index.heap_size(), "runs": int(wr.lib.fmx_num_runs(wr.h)),
                     "build_ms": round(wr.build_ms, 1), "textgen_s": round(wr.textgen_s, 2)},
-         "roofline": make_roofline("fmx_count_rlfm_ep_kernel", ms, npat * m, wr.ref_bytes_per_char(), stream_bytes,
+         "roofline": make_roofline("fmx_count_ep_kernel", ms, npat * m, wr.ref_bytes_per_char(), stream_bytes,
                                    cen, stored_traffic(key, "count"))}
     out["rlfm"] = o
     if wr.level is not None:

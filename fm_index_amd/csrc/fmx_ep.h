@@ -156,7 +156,7 @@ __device__ __forceinline__ void fmx_ep_select_slow(const FmxBits &bv, uint32_t k
 // counters: the next level's position, fmx_internal.h) and match = [entry pos itself has the code].
 // ACCESS: the code is READ at entry pos (WaveletMatrix::get) and the rank is of that code.
 // `match` rides in bit 31 of the group sum, so ranks must stay below 2^31 (RLFM: n < 2^31).
-template <int FMT, bool ACCESS, bool PAIRED>
+template <int FMT, bool ACCESS, bool PAIRED, bool NOMATCH = false>
 __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint32_t pos, uint32_t &code,
                                              bool live, uint32_t base, uint32_t g, uint32_t &rank,
                                              uint32_t &match) {
@@ -196,21 +196,21 @@ __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint
     uint32_t v = __popc(mt & (uint32_t)((1ull << nb) - 1ull));
     if (FMT == 3) v += (g == cd) ? p[q].x : 0u;
     else v += (g == (cd >> 1)) ? ((cd & 1u) ? p[q].y : p[q].x) : 0u;
-    if (!ACCESS) v |= mine ? (((mt >> (off & (PER - 1u))) & 1u) << 31) : 0u;
+    if (!ACCESS && !NOMATCH) v |= mine ? (((mt >> (off & (PER - 1u))) & 1u) << 31) : 0u;
     const uint32_t sum = fmx_group_sum(v);
     if (g == q) {
-      rank = ACCESS ? sum : (sum & 0x7FFFFFFFu);   // ACCESS carries no match bit: ranks may use all 32 bits
-      match = ACCESS ? 1u : (sum >> 31);
+      rank = (ACCESS || NOMATCH) ? sum : (sum & 0x7FFFFFFFu);   // no match bit: ranks may use all 32 bits
+      match = (ACCESS || NOMATCH) ? 1u : (sum >> 31);
       if (ACCESS) code = cd;
     }
   }
 }
-template <bool ACCESS, bool PAIRED>
+template <bool ACCESS, bool PAIRED, bool NOMATCH = false>
 __device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, uint32_t &code, bool live,
                                              uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
   FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
-  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED>(L.rec, pos, code, live, base, g, rank, match);
-  else fmx_ep_round<4, ACCESS, PAIRED>(L.rec, pos, code, live, base, g, rank, match);
+  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match);
+  else fmx_ep_round<4, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match);
 }
 
 // ---- RLFMIndexBackend::lf_map2 for 8 endpoints per group (rlfmi.rs:135-143) -------------------
@@ -305,4 +305,22 @@ __device__ __forceinline__ uint32_t fmx_fm_ep_lf_map(const FmxDev &ix, const uin
     pos = r;                                                 // C_l[code] is folded into the counters
   }
   return kt[sym] + r;                                        // fm_index.rs:86-91
+}
+
+// ---- FMIndexBackend::lf_map2 for 8 endpoints per group (fm_index.rs:93-95) ---------------------
+// one rank round per wavelet level; the two ends of a pattern sit in adjacent lanes
+template <int NL>
+__device__ __forceinline__ uint32_t fmx_fm_ep_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i, bool live,
+                                                      uint32_t base, uint32_t g) {
+  const uint32_t kc = ix.K[c];
+  uint32_t pos = i, r = 0;
+  const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
+#pragma unroll
+  for (uint32_t l = 0; l < nl; l++) {
+    const FmxLevel &L = ix.bw.lv[l];
+    uint32_t code = (c >> L.shift) & L.mask, mt;
+    fmx_ep_level<false, true, true>(L, pos, code, live, base, g, r, mt);
+    pos = r;                                                 // C_l[code] is folded into the counters
+  }
+  return kc + r;
 }

@@ -561,9 +561,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// count on the RLFM index, endpoint per lane (fmx_ep.h): lane 2q carries s and lane 2q+1 carries e
-// of the group's q-th pattern, so a group advances 4 patterns and a wave 32, with 64 probes in
-// flight in each of the four dependent stages of a step (B piece, S level 0, S level 1, B' select).
+// count, endpoint per lane (fmx_ep.h): lane 2q carries s and lane 2q+1 carries e of the group's q-th
+// pattern, so a group advances 4 patterns and a wave 32, with 64 probes in flight in every dependent
+// stage of a step (RLFM: B piece, S level 0, S level 1, B' select; FM over several wavelet levels:
+// one record per level).
 // Same state machine as above: a pattern that ends (all symbols consumed, or the `s == e` break of
 // wrapper.rs:111-113) is replaced at once; the loop is wave-uniform because the rank rounds are.
 // SM = 1 (stored positions) or 2 (select blocks); indexes whose B / B' fall into neither class stay
@@ -580,8 +581,8 @@ __device__ __forceinline__ bool fmx_kmer_code_lane(const uint8_t *__restrict__ p
   }
   return bad == 0u;
 }
-template <int NL, int SM, bool KM>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_rlfm_ep_kernel(
+template <int KIND, int NL, int SM, bool KM>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_ep_kernel(
     FmxDev ix, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
@@ -632,7 +633,9 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_rlfm_ep_kernel(
     }
     // the next symbol rides along with this step's probes
     const uint32_t cn = (stepping && j > 1) ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 2) : 0u;
-    const uint32_t np = fmx_rlfm_ep_lf_map2<NL, SM>(ix, stepping ? c : 0u, stepping ? pos : 0u, stepping, base, g);  // wrapper.rs:109-110
+    const uint32_t np = KIND == FMX_KIND_RLFM
+                            ? fmx_rlfm_ep_lf_map2<NL, (SM > 0 ? SM : 1)>(ix, stepping ? c : 0u, stepping ? pos : 0u, stepping, base, g)
+                            : fmx_fm_ep_lf_map2<NL>(ix, stepping ? c : 0u, stepping ? pos : 0u, stepping, base, g);  // wrapper.rs:109-110
     if (stepping) {
       pos = np;
       c = cn;
@@ -1358,7 +1361,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     if (km) FMX_PAIR_LAUNCH(true);
     else FMX_PAIR_LAUNCH(false);
   } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
-             variant != 0) {
+             variant != 0 && variant != 20) {
 #define FMX_F3_LAUNCH(PPG, SKIP, KM)                                                               \
   hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP, KM>),                                           \
                      dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), dim3(FMX_BLOCK), 0, st,       \
@@ -1413,27 +1416,40 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     const int sm = idx->kind != FMX_KIND_RLFM ? -1
                    : (dv.b.pos && dv.bp.pos) ? 1
                    : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
-    if (sm > 0 && variant != 0) {
+    // FM indexes keep the group-per-pattern kernels: their steps are one light record probe per level
+    // and those kernels already run at the request ceiling; the endpoint-per-lane shape measured
+    // slower there (DNA 1.11 vs 0.67 ms, sigma = 255 two levels 0.97 vs 0.74 ms:
+    // benchmarks/gpu/ep_fm_count.sh, FMX_VARIANT=20 in measurement builds)
+#ifdef FMX_MEASURE
+    const bool fm_ep = idx->kind == FMX_KIND_FM && variant == 20;
+#else
+    constexpr bool fm_ep = false;
+#endif
+    if ((sm > 0 || fm_ep) && variant != 0) {
       // 64 probes in flight per wave and stage: 4 waves per SIMD saturate the memory system
       const uint64_t ep_cap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", 1024);
       uint64_t eb = (npat * 2 + FMX_BLOCK - 1) / FMX_BLOCK;
       if (eb > ep_cap) eb = ep_cap;
-#define FMX_EP_LAUNCH(NL, SM)                                                                        \
+#define FMX_EP_LAUNCH(KIND, NL, SM)                                                                  \
   do {                                                                                               \
     if (km && idx->sym_bytes == 1)                                                                   \
-      hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, true>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, true>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
+                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
     else                                                                                             \
-      hipLaunchKernelGGL((fmx_count_rlfm_ep_kernel<NL, SM, false>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);        \
+      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, false>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
+                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
   } while (0)
-#define FMX_EP_SM(SM)                                                                                \
+#define FMX_EP_SM(KIND, SM)                                                                          \
   do {                                                                                               \
-    if (w.nlevels == 1) FMX_EP_LAUNCH(1, SM);                                                        \
-    else if (w.nlevels == 2) FMX_EP_LAUNCH(2, SM);                                                   \
-    else FMX_EP_LAUNCH(0, SM);                                                                       \
+    if (w.nlevels == 1) FMX_EP_LAUNCH(KIND, 1, SM);                                                  \
+    else if (w.nlevels == 2) FMX_EP_LAUNCH(KIND, 2, SM);                                             \
+    else FMX_EP_LAUNCH(KIND, 0, SM);                                                                 \
   } while (0)
-      if (sm == 1) FMX_EP_SM(1); else FMX_EP_SM(2);
+#ifdef FMX_MEASURE
+      if (fm_ep) FMX_EP_SM(FMX_KIND_FM, 0); else
+#endif
+      if (sm == 1) FMX_EP_SM(FMX_KIND_RLFM, 1);
+      else FMX_EP_SM(FMX_KIND_RLFM, 2);
     }
     else if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI, -1);

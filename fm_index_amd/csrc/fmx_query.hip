@@ -126,19 +126,24 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = (uint32_t)(pend - pbeg);
+      // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
       const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      if (badoff) {
+        if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+        j = 0;
+      }
       if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
         const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
         s = (uint32_t)s64;
         e = (uint32_t)e64;
-        if (s64 > ix.n || e64 > ix.n) {                // not a range of this index: refuse, do not read
+        if (s64 > ix.n || e64 > ix.n || badoff) {      // not a range of this index: refuse, do not read
           if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
           s = 0; e = 0; j = 0;
         }
       } else {               // SearchIndexWrapper::search: (0, len)   (wrapper.rs:41)
         s = 0;
-        e = ix.n;
-        if (KM && !badoff && j >= ix.kmer_k) {         // the first kmer_k steps from the table (u8 symbols)
+        e = badoff ? 0u : ix.n;
+        if (KM && j >= ix.kmer_k) {                    // the first kmer_k steps from the table (u8 symbols)
           uint32_t code;
           if (fmx_kmer_code((const uint8_t *)pat, pbeg + j, ix.kmer_k, ix.kmer_bits, ix.max_character, g,
                             code)) {
@@ -150,10 +155,6 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
             nsteps += ix.kmer_k;
           }
         }
-      }
-      if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
-        if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
-        s = 0; e = 0; j = 0;
       }
       c = j ? fmx_load_sym(pat, ix.sym_bytes, pbeg + j - 1) : 0u;  // pattern.iter().rev()  wrapper.rs:108
       fresh = false;
@@ -252,19 +253,25 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         pbeg[q] = off[k[q]];
         const uint64_t pend = off[k[q] + 1];
         j[q] = (uint32_t)(pend - pbeg[q]);
+        // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on;
+        // kept AHEAD of the table lookup: a trailing fix-up of (s, e, j) cost the pair kernel 30 %)
         const bool badoff = pend < pbeg[q] || pend > ptot || pend - pbeg[q] > 0xFFFFFFFFull;
+        if (badoff) {
+          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+          j[q] = 0;
+        }
         if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
           const uint64_t s64 = s0e0[2 * k[q]], e64 = s0e0[2 * k[q] + 1];
           s[q] = (uint32_t)s64;
           e[q] = (uint32_t)e64;
-          if (s64 > n || e64 > n) {                    // not a range of this index: refuse, do not read
+          if (s64 > n || e64 > n || badoff) {          // not a range of this index: refuse, do not read
             if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
             s[q] = 0; e[q] = 0; j[q] = 0;
           }
         } else {               // (0, len)   wrapper.rs:41
           s[q] = 0;
-          e[q] = n;
-          if (KM && !badoff && j[q] >= kmer_k) {       // the first kmer_k steps from the table
+          e[q] = badoff ? 0u : n;
+          if (KM && j[q] >= kmer_k) {                  // the first kmer_k steps from the table
             uint32_t code;
             if (fmx_kmer_code(pat, pbeg[q] + j[q], kmer_k, kmer_bits, max_character, g, code)) {
               FMX_TOUCH_G0(g, &kmer[code]);
@@ -275,10 +282,6 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
               nsteps += kmer_k;
             }
           }
-        }
-        if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
-          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
-          s[q] = 0; e[q] = 0; j[q] = 0;
         }
         c[q] = j[q] ? pat[pbeg[q] + j[q] - 1] : 0u;   // last symbol: pattern.iter().rev()
         fresh[q] = false;
@@ -459,19 +462,24 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = (uint32_t)(pend - pbeg);
+      // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
       const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      if (badoff) {
+        if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+        j = 0;
+      }
       if (s0e0) {
         const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
         s = (uint32_t)s64;
         e = (uint32_t)e64;
-        if (s64 > n || e64 > n) {                      // not a range of this index: refuse, do not read
+        if (s64 > n || e64 > n || badoff) {            // not a range of this index: refuse, do not read
           if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
           s = 0; e = 0; j = 0;
         }
       } else {
         s = 0;
-        e = n;
-        if (KM && !badoff && j >= kmer_k) {            // the first kmer_k steps from the table
+        e = badoff ? 0u : n;
+        if (KM && j >= kmer_k) {                       // the first kmer_k steps from the table
           uint32_t code;
           if (fmx_kmer_code(pat, pbeg + j, kmer_k, kmer_bits, max_character, g, code)) {
             FMX_TOUCH_G0(g, &kmer[code]);
@@ -482,10 +490,6 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
             nsteps += kmer_k;
           }
         }
-      }
-      if (badoff) {          // offsets that go backwards or leave the pattern buffer: refuse, do not read
-        if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
-        s = 0; e = 0; j = 0;
       }
       c2 = j ? pat[pbeg + j - 1] : 0u;
       c1 = j > 1 ? pat[pbeg + j - 2] : 0u;

@@ -901,11 +901,30 @@ def d2h_leg(out, wl, args):
         call()
     dt = (time.perf_counter() - t0) / reps
     assert bool((hs.to(wl.dev) == wl.d_s).all()) and bool((he.to(wl.dev) == wl.d_e).all())
+    # the same call on ordinary (pageable) numpy arrays, also reused across calls
+    pp, po = hp.numpy().copy(), ho.numpy().copy()
+    ps, pe, pc = (np.zeros(npat, dtype=np.int64) for _ in range(3))
+
+    def call_pageable():
+        rc = lib.fmx_count_batch(wl.h, pp.ctypes.data_as(C.c_void_p), po.ctypes.data_as(C.c_void_p), npat, None,
+                                 ps.ctypes.data_as(C.c_void_p), pe.ctypes.data_as(C.c_void_p),
+                                 pc.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+    for _ in range(3):
+        call_pageable()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call_pageable()
+    dtp = (time.perf_counter() - t0) / reps
+    assert (ps == hs.numpy()).all() and (pe == he.numpy()).all()
     out["value_incl_d2h"] = npat * m / dt
     out["incl_d2h"] = {"ms_per_call": dt * 1e3, "bytes_in": npat * m + (npat + 1) * 8, "bytes_out": 3 * npat * 8,
+                       "pageable_ms_per_call": dtp * 1e3, "pageable_value": npat * m / dtp,
                        "note": "fmx_count_batch (host pointers): upload, count, download, synchronise per call; "
-                               "pinned caller-owned arrays reused across calls; never the headline value"}
-    del hp, ho, hs, he, hc, np
+                               "caller-owned arrays reused across calls -- pinned (value_incl_d2h) and pageable; "
+                               "never the headline value"}
+    del hp, ho, hs, he, hc
 
 
 def rlfm_leg(out, args, dev, local):

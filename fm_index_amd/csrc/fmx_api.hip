@@ -479,8 +479,10 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   hipStream_t st[2] = {hc.sx->st, hc.sx->st2};
   CallStatus cs(hc.sx);
   FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, st[0]));   // ordered before every chunk by the wait below
-  // two halves: every pageable copy has a fixed cost of 50-80 us on this runtime, so more, smaller
-  // chunks lose (measured at 2^20 x 32: 1 chunk 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13)
+  // two halves: every host copy has a fixed cost of 50-80 us on this runtime, so more, smaller chunks
+  // lose (pageable arrays at 2^20 x 32: 1 chunk 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13;
+  // page-locked arrays: 2 chunks 2.0 ms, 8 chunks 3.7 ms -- their DMA copies are slower than the
+  // runtime's staged copies of pageable memory, so pinning buys nothing here)
   uint64_t nch = (npat >= (1u << 17) && !idx->timing) ? 2 : 1;
   // all offsets first (every chunk's kernel reads its own slice plus one entry)
   FMX_HIP(hipMemcpyAsync(d_off, pat_off, b_off, hipMemcpyHostToDevice, st[0]));

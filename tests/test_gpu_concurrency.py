@@ -193,3 +193,40 @@ def test_concurrent_builds_and_queries_in_threads():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_pinned_host_batch_agrees_with_pageable():
+    """Page-locked caller arrays go through the same two-chunk pipeline as pageable ones (their copies
+    are real DMA): ragged patterns incl. empty ones and refinement must give what the pageable path
+    gives, and a bad interior offset is still refused."""
+    import ctypes as C
+    import torch
+    t = W.dna_text_np(300000, 23)
+    idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    npat = (1 << 17) + 4321
+    flat, off = W.ragged_patterns_np(npat, 9, 4, 37)
+    want = idx.search_many(flat=flat, off=off)                       # pageable numpy arrays
+    hp = torch.from_numpy(flat.copy()).pin_memory()
+    ho = torch.from_numpy(off.astype(np.int64)).pin_memory()
+    hs, he, hc = (torch.zeros(npat, dtype=torch.int64).pin_memory() for _ in range(3))
+    lib = idx._lib
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), npat, None,
+                             C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+    assert rc == 0
+    assert (hs.numpy().view(np.uint64) == want.s).all() and (he.numpy().view(np.uint64) == want.e).all()
+    assert (hc.numpy().view(np.uint64) == want.counts).all()
+    # refinement from pinned (s, e) pairs, counts only
+    se = torch.from_numpy(np.stack([want.s, want.e], axis=1).reshape(-1).astype(np.int64)).pin_memory()
+    one = torch.full((npat,), 3, dtype=torch.uint8).pin_memory()
+    off1 = torch.arange(npat + 1, dtype=torch.int64).pin_memory()
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(one.data_ptr()), C.c_void_p(off1.data_ptr()), npat,
+                             C.c_void_p(se.data_ptr()), None, None, C.c_void_p(hc.data_ptr()))
+    assert rc == 0
+    ref = idx.search_many(flat=one.numpy(), off=off1.numpy().astype(np.uint64),
+                          s0e0=se.numpy().view(np.uint64))
+    assert (hc.numpy().view(np.uint64) == ref.counts).all()
+    # a bad interior offset in pinned memory is still refused
+    ho[npat // 3] = int(off[-1]) + 99
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), npat, None,
+                             C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+    assert rc == F._lib.ERR_ARG

@@ -481,10 +481,19 @@ def main():
     if args.pmc_child:
         pmc_child(args)
         return
-    run(args, world)
+    # HBM-side traffic of this build, measured now: rocprofv3 --pmc passes over a child of this
+    # script.  Started BEFORE this process touches the GPU (no torch import yet): the children are
+    # then spawned from a process that holds no device state.
+    pmc = None
+    if world == 1 and args.workload == "dna" and not args.no_pmc:
+        try:
+            pmc = run_pmc_passes(args)
+        except Exception as ex:  # noqa: BLE001 -- never lose the line to the counter passes
+            pmc = ({}, repr(ex))
+    run(args, world, pmc)
 
 
-def run(args, world):
+def run(args, world, pmc=None):
     import torch
     import numpy as np
     import fm_index_amd as F
@@ -656,13 +665,9 @@ def run(args, world):
             wr.close()
             del wr
 
-    # ---- HBM-side traffic measured now: rocprofv3 --pmc passes over a child of this script ----
-    if single and wl.dna and not args.no_pmc:
-        try:
-            pmc, cal = run_pmc_passes(args)
-        except Exception as ex:  # noqa: BLE001
-            pmc, cal = {}, repr(ex)
-        apply_pmc(out, pmc, cal)
+    # ---- HBM-side traffic measured by the counter passes at the start of this run ----
+    if pmc is not None and rank == 0:
+        apply_pmc(out, pmc[0], pmc[1])
 
     if rank == 0:
         print(json.dumps(out))

@@ -875,6 +875,11 @@ def locate_3b(out, wl, args):
     out["locate_3b"] = {"workload": "config 3b: %d substring patterns of length 8-12" % npat,
                         "hits": total, "hits_per_s": total / dt, "ms_per_batch": dt * 1e3,
                         "walk_kernel_ms": round(kms, 4), "lf_steps": lf_steps,
+                        # one record line per LF step + one sample chunk per hit (what the census counts
+                        # for config 3: requested_lines == lf_steps + hits); wide intervals, so few L2 hits
+                        "requests": lf_steps + total,
+                        "requests_per_s": (lf_steps + total) / (kms / 1e3),
+                        "frac_of_gather_ceiling": round((lf_steps + total) / (kms / 1e3) / (GATHER_CEILING_GLINES * 1e9), 4),
                         "count_min": int(cnts.min().item()), "count_median": int(cnts.median().item()),
                         "count_max": int(cnts.max().item())}
 

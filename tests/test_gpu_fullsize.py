@@ -1,8 +1,9 @@
 """BASELINE.json full sizes (n = 2^30) through size-independent properties:
 suffix-array sortedness + permutation checked on the device, count >= 1 for substrings, every
 located position holds its pattern, the source position is among the hits, executed steps, and
-bit-identity with the CPU oracle (fed the exported BWT) on a pattern sample.  Config 4 (RLFM
-over a sigma=255 text) additionally asserts RLFM (s,e) == FM (s,e)."""
+bit-identity with the CPU oracle (fed the exported BWT) on a pattern sample -- the FM path for
+config 2 / 3, the RLFM path (its own S / B / B' and the rlfmi.rs formulas) for config 4, which
+additionally asserts RLFM (s,e) == FM (s,e)."""
 import ctypes as C
 
 import numpy as np
@@ -129,6 +130,23 @@ def test_config4_rlfm_byte_text_1gb():
     found = torch.zeros(k, dtype=torch.bool, device=dev)
     found[hit_pat[d_pos == pos[hit_pat]]] = True
     assert bool(found.all())
+    # the oracle's RLFM path (rlfmi.rs formulas over its own S / B / B' built from the exported L column)
+    # at FULL size: (s, e) of a pattern sample, lf_map2 / lf_map / get_l at random rows, locate order
+    from oracle import fm_oracle as O
+    oi = O.OracleIndex.from_bwt(rl.export_bwt(), rl.export_cs(), 255, samples=rl.export_sa_samples(),
+                                level=3, kind="rlfm")
+    ks = 1 << 14
+    so, eo = oi.count_batch(pat[:ks * m].cpu().numpy(), np.arange(ks + 1, dtype=np.uint64) * np.uint64(m),
+                            nthreads=16)
+    assert (so == s[:ks].cpu().numpy().view(np.uint64)).all()
+    assert (eo == e[:ks].cpu().numpy().view(np.uint64)).all()
+    rows = (W.splitmix64_np(77, 0, 4096) % np.uint64(N)).astype(np.uint64)
+    syms = (W.splitmix64_np(78, 0, 4096) % np.uint64(256)).astype(np.uint64)
+    assert (rl.lf_map2(syms, rows) == oi.lf_map2(syms, rows)).all()
+    assert (rl.lf_map(rows) == oi.lf_map(rows)).all() and (rl.get_l(rows) == oi.get_l(rows)).all()
+    ooff, opos = oi.locate_batch(so[:2048], eo[:2048], nthreads=16)
+    assert (opos == d_pos[:int(ooff[-1])].cpu().numpy().view(np.uint64)).all()
+    oi.close()
     rl.close()
     fm = F.FMIndex.from_device_text(text.data_ptr(), N, 255)
     s2, e2, c2 = _count_dev(fm, pat, off, npat)

@@ -787,8 +787,8 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     out[k++] = {(const void **)&d.b.sel, (uint64_t)d.b.nsel * 4};
     out[k++] = {(const void **)&d.bp.rec, (uint64_t)d.bp.nrec * 128};
     out[k++] = {(const void **)&d.bp.sel, (uint64_t)d.bp.nsel * 4};
-    if (d.b.dsel) out[k++] = {(const void **)&d.b.dsel, (((uint64_t)d.b.ones + 63) / 64) * 16};
-    if (d.bp.dsel) out[k++] = {(const void **)&d.bp.dsel, (((uint64_t)d.bp.ones + 63) / 64) * 16};
+    if (d.b.dsel) out[k++] = {(const void **)&d.b.dsel, (((uint64_t)d.b.ones + (1ull << d.b.dsel_shift) - 1) >> d.b.dsel_shift) * 16};
+    if (d.bp.dsel) out[k++] = {(const void **)&d.bp.dsel, (((uint64_t)d.bp.ones + (1ull << d.bp.dsel_shift) - 1) >> d.bp.dsel_shift) * 16};
     if (d.b.pos) out[k++] = {(const void **)&d.b.pos, (uint64_t)d.b.ones * 4};
     if (d.bp.pos) out[k++] = {(const void **)&d.bp.pos, (uint64_t)d.bp.ones * 4};
   }
@@ -832,13 +832,14 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
       if (v[t]->len != h.n || v[t]->ones != h.runs) return "bit vector length";
       if (v[t]->nrec != v[t]->len / FMX_BITS_PER_REC + 1u) return "bit vector records";
       if (v[t]->nsel != v[t]->ones / FMX_SEL_STEP + 2u) return "select hints";
+      if (v[t]->dsel && (v[t]->dsel_shift < 3 || v[t]->dsel_shift > 6)) return "select blocks";
     }
   }
   if (d.pair_rec && (d.pair_row0 > h.n || d.pair_row1 > h.n)) return "pair index";
   return nullptr;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 6;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load
+const uint32_t kFileVersion = 7;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {

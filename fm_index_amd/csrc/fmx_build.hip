@@ -706,16 +706,18 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   return FMX_OK;
 }
 
-// dense bit vector (ones >= len/2): select blocks, one per 64 ones (FmxBits::dsel)
-__global__ __launch_bounds__(BLK) void k_dense_select_blocks(const uint8_t *__restrict__ flags,
-                                                              const uint32_t *__restrict__ pos,
-                                                              uint32_t ones, uint32_t len,
-                                                              uint4 *__restrict__ out) {
+// select blocks (FmxBits::dsel): one 16-byte block per 2^shift ones = { position of the first of them,
+// the 96 bits from there }
+__global__ __launch_bounds__(BLK) void k_select_blocks(const uint8_t *__restrict__ flags,
+                                                        const uint32_t *__restrict__ pos,
+                                                        uint32_t ones, uint32_t len, uint32_t shift,
+                                                        uint4 *__restrict__ out) {
   const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  const uint64_t nblk = ((uint64_t)ones + 63u) / 64u;
+  const uint64_t per = 1ull << shift;
+  const uint64_t nblk = ((uint64_t)ones + per - 1u) >> shift;
   if (j >= nblk) return;
-  const uint32_t first = pos[j * 64u];
-  const uint64_t lastk = j * 64u + 63u < ones ? j * 64u + 63u : (uint64_t)ones - 1u;
+  const uint32_t first = pos[j << shift];
+  const uint64_t lastk = (j << shift) + per - 1u < ones ? (j << shift) + per - 1u : (uint64_t)ones - 1u;
   const uint32_t last = pos[lastk];
   if (last - first >= 96u) { out[j] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); return; }
   uint32_t w[3] = {0u, 0u, 0u};
@@ -725,28 +727,42 @@ __global__ __launch_bounds__(BLK) void k_dense_select_blocks(const uint8_t *__re
   }
   out[j] = make_uint4(first, w[0], w[1], w[2]);
 }
+// Every vector gets a one-load select: select blocks while a block's ones almost always fit its
+// 96-bit window (ones per block chosen by density: span of the block ~ ones / density <= ~74 bits),
+// the positions of the ones themselves below that.  Thresholds in 1/256ths of a one per bit.
+static uint32_t select_block_shift(const FmxBits *bv) {
+  const uint64_t d256 = bv->len ? (uint64_t)bv->ones * 256u / bv->len : 0;
+  if (d256 >= 222) return 6;   // >= 0.87: 64 ones per block
+  if (d256 >= 112) return 5;   // >= 0.44: 32
+  if (d256 >= 56) return 4;    // >= 0.22: 16
+  if (d256 >= 28) return 3;    // >= 0.11: 8
+  return 0;                    // sparser: stored positions
+}
 int keep_dense_select(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, const uint32_t *d_pos) {
   bv->dsel = nullptr;
-  if (bv->ones == 0 || (uint64_t)bv->ones * 2u < bv->len) return FMX_OK;
+  bv->dsel_shift = 0;
+  const uint32_t shift = select_block_shift(bv);
+  if (bv->ones == 0 || shift == 0) return FMX_OK;
 #ifdef FMX_MEASURE
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 17) return FMX_OK;   // measurement: no blocks
 #endif
-  const uint64_t nblk = ((uint64_t)bv->ones + 63u) / 64u;
+  const uint64_t nblk = ((uint64_t)bv->ones + (1ull << shift) - 1u) >> shift;
   uint4 *d;
   FMX_HIP(hipMalloc((void **)&d, nblk * 16));
   if (int rc = keep(idx, d, nblk * 16)) return rc;
-  hipLaunchKernelGGL(k_dense_select_blocks, dim3(nblocks(nblk)), dim3(BLK), 0, 0, d_flags, d_pos, bv->ones,
-                     bv->len, d);
+  hipLaunchKernelGGL(k_select_blocks, dim3(nblocks(nblk)), dim3(BLK), 0, 0, d_flags, d_pos, bv->ones,
+                     bv->len, shift, d);
   FMX_HIP(hipGetLastError());
   bv->dsel = d;
+  bv->dsel_shift = shift;
   return FMX_OK;
 }
 
-// sparse bit vector (ones <= len/16, i.e. runs of 16+ on average): keep the positions of its ones
-// for one-load selects (<= len/4 bytes, 1.5 x the rank records of the vector)
+// sparse bit vector (< 0.11 ones per bit, i.e. runs of 9+ on average): keep the positions of its ones
+// for one-load selects (4 bytes per one: < 0.44 bytes per bit of the vector)
 int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
   bv->pos = nullptr;
-  if (bv->ones == 0 || (uint64_t)bv->ones * 16u > bv->len) return FMX_OK;
+  if (bv->ones == 0 || select_block_shift(bv) != 0) return FMX_OK;
 #ifdef FMX_MEASURE
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 16) return FMX_OK;   // measurement: no positions
 #endif

@@ -385,8 +385,8 @@ __device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32
   return fmx_group_sum(mine * (pc.x + c));
 }
 // dense-vector select block: position of one number (k & 63) inside the block's 96-bit window
-__device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k) {
-  const uint32_t r = k & 63u, c0 = __popc(blk.y), c1 = __popc(blk.z);
+__device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k, uint32_t shift) {
+  const uint32_t r = k & ((1u << shift) - 1u), c0 = __popc(blk.y), c1 = __popc(blk.z);
   uint32_t off;
   if (r < c0) off = fmx_select32(blk.y, r);
   else if (r < c0 + c1) off = 32u + fmx_select32(blk.z, r - c0);
@@ -398,9 +398,9 @@ __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t 
   if (k >= bv.ones) return bv.len;
   if (bv.pos) { FMX_TOUCH_G0(g, &bv.pos[k]); return bv.pos[k]; }   // sparse vector: the positions are stored
   if (bv.dsel) {                              // dense vector: one 16-byte block answers it
-    FMX_TOUCH_G0(g, &bv.dsel[k >> 6]);
-    const uint4 blk = bv.dsel[k >> 6];
-    if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k);
+    FMX_TOUCH_G0(g, &bv.dsel[k >> bv.dsel_shift]);
+    const uint4 blk = bv.dsel[k >> bv.dsel_shift];
+    if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k, bv.dsel_shift);
   }
   uint32_t h = k / FMX_SEL_STEP;
   FMX_CHECK(h + 1 < bv.nsel);
@@ -447,12 +447,12 @@ __device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k
     return;
   }
   if (SM == 2 || (SM < 0 && A.dsel && B.dsel)) {   // dense vectors: one 16-byte block per select
-    FMX_TOUCH_G0(g, &A.dsel[q0 >> 6]);
-    FMX_TOUCH_G0(g, &B.dsel[q1 >> 6]);
-    const uint4 b0 = A.dsel[q0 >> 6], b1 = B.dsel[q1 >> 6];
+    FMX_TOUCH_G0(g, &A.dsel[q0 >> A.dsel_shift]);
+    FMX_TOUCH_G0(g, &B.dsel[q1 >> B.dsel_shift]);
+    const uint4 b0 = A.dsel[q0 >> A.dsel_shift], b1 = B.dsel[q1 >> B.dsel_shift];
     if (b0.x != 0xFFFFFFFFu && b1.x != 0xFFFFFFFFu) {
-      out0 = v0 ? fmx_dsel_pos(b0, q0) : A.len;
-      out1 = v1 ? fmx_dsel_pos(b1, q1) : B.len;
+      out0 = v0 ? fmx_dsel_pos(b0, q0, A.dsel_shift) : A.len;
+      out1 = v1 ? fmx_dsel_pos(b1, q1, B.dsel_shift) : B.len;
       return;
     }
   }

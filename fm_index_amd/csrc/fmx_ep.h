@@ -96,10 +96,10 @@ __device__ __forceinline__ FmxSel fmx_ep_select_issue(const FmxBits &bv, uint32_
   s.blk = make_uint4(0u, 0u, 0u, 0u);
   want = want && bv.ones != 0u;
   if (SM == 1) FMX_TOUCH_LANE(PAIRED, &bv.pos[s.k], want && live);
-  else FMX_TOUCH_LANE(PAIRED, &bv.dsel[s.k >> 6], want && live);
+  else FMX_TOUCH_LANE(PAIRED, &bv.dsel[s.k >> bv.dsel_shift], want && live);
   if (want) {
     if (SM == 1) s.blk.x = bv.pos[s.k];
-    else s.blk = bv.dsel[s.k >> 6];
+    else s.blk = bv.dsel[s.k >> bv.dsel_shift];
   }
   return s;
 }
@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t fmx_ep_select_finish(const FmxBits &bv, cons
   if (!s.valid) return bv.len;
   if (SM == 1) return s.blk.x;
   if (s.blk.x == FMX_NONE) return FMX_NONE;
-  return fmx_dsel_pos(s.blk, s.k);
+  return fmx_dsel_pos(s.blk, s.k, bv.dsel_shift);
 }
 // the rare select a block cannot answer: the group serves its lanes one after the other with the
 // cooperative record search (wave-uniform loop; groups without a request run it on a dummy)

@@ -54,15 +54,19 @@ struct FmxMwm {
 struct FmxBits {
   const uint4 *rec;
   const uint32_t *sel;  // select hints: record index holding the (k*FMX_SEL_STEP)-th one
-  const uint4 *dsel;    // dense vectors only (ones >= len/2), else NULL: one 16-byte block per 64 ones =
-                        // { position of the block's first one, the 96 bits from there }, so that select1
-                        // is ONE load (x == 0xFFFFFFFF: the 64 ones do not fit, use the records)
-  const uint32_t *pos;  // sparse vectors only (ones <= len/16), else NULL: position of every one,
-                        // so that select1 is ONE load (4 bytes per one <= len/4 bytes)
+  const uint4 *dsel;    // vectors with >= 0.11 ones per bit, else NULL: one 16-byte SELECT BLOCK per
+                        // 2^dsel_shift ones = { position of the block's first one, the 96 bits from there },
+                        // so that select1 is ONE load (x == 0xFFFFFFFF: the block's ones do not fit the 96
+                        // bits, use the records).  Ones per block by density, so that a block almost always
+                        // fits: >= 0.87 -> 64, >= 0.44 -> 32, >= 0.22 -> 16, >= 0.11 -> 8
+  const uint32_t *pos;  // sparser vectors only (< 0.11 ones per bit, i.e. runs of 9+ on average), else NULL:
+                        // position of every one, so that select1 is ONE load (4 bytes per one)
   uint32_t nrec;
   uint32_t len;
   uint32_t ones;
   uint32_t nsel;
+  uint32_t dsel_shift;  // log2(ones per select block): 6, 5, 4 or 3 (0 when dsel is NULL)
+  uint32_t pad;
 };
 // one hint per 64 ones: on sparse vectors (long runs) the record search behind a hint is a chain of
 // dependent loads; 512 -> 64 cut the repetitive-text count by 13 % and its locate by 16 % for

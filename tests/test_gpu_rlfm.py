@@ -168,3 +168,35 @@ def test_rlfm_long_runs_use_stored_positions(tmp_path, runlen):
     g2 = F.RLFMIndexWithLocate.load(tmp_path / "r.fmx")
     assert g2.heap_size() == gi.heap_size()
     assert (g2.lf_map(rows) == oi.lf_map(rows)).all() and (g2.fl_map(rows) == oi.fl_map(rows)).all()
+
+
+@pytest.mark.parametrize("gen", ["sigma2", "sigma4", "sigma255", "rep400", "rep150", "rep100", "rep60", "rep25", "rep5"])
+def test_every_run_density_gets_a_one_load_select(gen):
+    """B / B' with any density of ones: select blocks of 64 / 32 / 16 / 8 ones or stored positions
+    (fmx_internal.h).  Count, locate and the trait calls must equal the oracle in every band, and
+    every band runs the endpoint-per-lane kernels."""
+    n = 1 << 17
+    if gen.startswith("sigma"):
+        sig = int(gen[5:])
+        t = (W.splitmix64_np(91, 0, n) % np.uint64(sig)).astype(np.uint8) + 1
+        t[-1] = 0
+    else:
+        t = W.repetitive_text_np(n, 5, base_len=1 << 9, mut_per_1024=int(gen[3:]))
+    gi = F.RLFMIndexWithLocate(F.Text(t), 2)
+    oi = O.OracleIndex(t, 255, level=2, kind="rlfm")
+    runs = int(gi._lib.fmx_num_runs(gi.handle()))
+    flat, off, _ = W.substring_patterns_np(t, 3000, 6, 13)
+    rflat, roff = W.ragged_patterns_np(500, 7, int(t.max()), 17)
+    for f, o in ((flat, off), (rflat, roff)):
+        gb = gi.search_many(flat=f, off=o)
+        os_, oe = oi.count_batch(f, o)
+        assert (gb.s == os_).all() and (gb.e == oe).all(), (gen, runs / n)
+        goff, gpos = gb.locate()
+        ooff, opos = oi.locate_batch(os_, oe)
+        assert (goff == ooff).all() and (gpos == opos).all(), (gen, runs / n)
+    rows = (W.splitmix64_np(19, 0, 2000) % np.uint64(n + 1)).astype(np.uint64)
+    syms = (W.splitmix64_np(21, 0, 2000) % np.uint64(int(t.max()) + 1)).astype(np.uint64)
+    assert (gi.lf_map2(syms, rows) == oi.lf_map2(syms, rows)).all()
+    r2 = rows[rows < n]
+    assert (gi.lf_map(r2) == oi.lf_map(r2)).all() and (gi.get_sa(r2) == oi.get_sa(r2)).all()
+    assert (gi.fl_map(r2) == oi.fl_map(r2)).all()

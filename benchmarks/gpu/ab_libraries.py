@@ -1,3 +1,6 @@
+"""A/B of several builds of libfmx on the same index and box: python benchmarks/gpu/ab_libraries.py "" _measure ...
+(tags name fm_index_amd/libfmx<tag>.so; the first one builds the indexes).  Used for the pair+table kernel
+regression hunt of round 2 (profiles/r02/sweeps.md)."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch

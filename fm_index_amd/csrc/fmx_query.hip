@@ -1457,9 +1457,11 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     }
     else if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI, -1);
+#ifdef FMX_MEASURE   // round-1 group-per-pattern RLFM kernels, per select structure (FMX_VARIANT=0)
     else if (sm == 1) FMX_COUNT_KIND(FMX_KIND_RLFM, 1);
     else if (sm == 2) FMX_COUNT_KIND(FMX_KIND_RLFM, 2);
-    else FMX_COUNT_KIND(FMX_KIND_RLFM, 0);
+#endif
+    else FMX_COUNT_KIND(FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
@@ -1574,9 +1576,11 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     }
     else if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);
+#ifdef FMX_MEASURE   // round-1 group-per-walk RLFM kernels, per select structure (FMX_VARIANT=0)
     else if (sm == 1) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);
     else if (sm == 2) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
-    else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);
+#endif
+    else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());

@@ -49,15 +49,20 @@ def gather_positions(local_counts, local_pos, nitems, group=None):
     counts = gather_counts(local_counts, nitems, group)
     off = torch.zeros(nitems + 1, dtype=torch.int64, device=counts.device)
     off[1:] = torch.cumsum(counts, 0)
-    totals = []
-    for r in range(world):
-        lo, hi = shard_range(nitems, r, world)
-        totals.append(int(off[hi] - off[lo]))
+    # hits of every rank's shard with ONE device-to-host synchronisation
+    cuts = torch.tensor([shard_range(nitems, r, world)[0] for r in range(world)] + [nitems],
+                        dtype=torch.int64, device=counts.device)
+    totals = (off[cuts[1:]] - off[cuts[:-1]]).tolist()
     mx = max(max(totals), 1)
-    pad = torch.zeros(mx, dtype=local_pos.dtype, device=local_pos.device)
-    pad[:local_pos.numel()] = local_pos
+    if local_pos.numel() == mx:
+        pad = local_pos.contiguous()
+    else:
+        pad = torch.zeros(mx, dtype=local_pos.dtype, device=local_pos.device)
+        pad[:local_pos.numel()] = local_pos
     buf = torch.empty(mx * world, dtype=local_pos.dtype, device=local_pos.device)
     dist.all_gather_into_tensor(buf, pad, group=group)
+    if all(t == mx for t in totals):
+        return off, buf
     pos = torch.cat([buf[r * mx:r * mx + totals[r]] for r in range(world)])
     return off, pos
 

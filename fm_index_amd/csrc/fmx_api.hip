@@ -109,8 +109,6 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
   if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
-  if (kind == FMX_KIND_RLFM && n >= (1ull << 31))
-    return fail(FMX_ERR_UNSUPPORTED, "RLFM: n >= 2^31 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
   DeviceGuard dg;
@@ -804,7 +802,6 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
   if ((h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) || d.sym_bytes != h.sym_bytes) return "sym_bytes";
   if (h.sym_bytes_abi != 1 && h.sym_bytes_abi != 2 && h.sym_bytes_abi != 4 && h.sym_bytes_abi != 8) return "sym_bytes_abi";
   if (h.n >= 0xFFFFFFF0ull || d.n != h.n) return "n";
-  if (h.kind == FMX_KIND_RLFM && h.n >= (1ull << 31)) return "n (RLFM)";
   if (h.max_character == 0 || h.max_character >= (1ull << 26) || d.max_character != h.max_character) return "max_character";
   if (h.runs > h.n) return "runs";
   const FmxMwm &w = d.bw;

@@ -155,11 +155,12 @@ __device__ __forceinline__ void fmx_ep_select_slow(const FmxBits &bv, uint32_t k
 // lane's own endpoint: rank = counter[code] + #{entries before pos with that code} (absolute
 // counters: the next level's position, fmx_internal.h) and match = [entry pos itself has the code].
 // ACCESS: the code is READ at entry pos (WaveletMatrix::get) and the rank is of that code.
-// `match` rides in bit 31 of the group sum, so ranks must stay below 2^31 (RLFM: n < 2^31).
+// `match` rides in bit 31 of the group sum while the index has fewer than 2^31 rows; beyond that
+// (`wide`) it is broadcast from the one lane that owns it.
 template <int FMT, bool ACCESS, bool PAIRED, bool NOMATCH = false>
 __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint32_t pos, uint32_t &code,
                                              bool live, uint32_t base, uint32_t g, uint32_t &rank,
-                                             uint32_t &match) {
+                                             uint32_t &match, bool wide = false) {
   constexpr int SH = (FMT == 3) ? 8 : 7;
   constexpr uint32_t OM = (FMT == 3) ? 255u : 127u;
   constexpr uint32_t PER = (FMT == 3) ? 32u : 16u;
@@ -196,21 +197,29 @@ __device__ __forceinline__ void fmx_ep_round(const uint4 *__restrict__ rec, uint
     uint32_t v = __popc(mt & (uint32_t)((1ull << nb) - 1ull));
     if (FMT == 3) v += (g == cd) ? p[q].x : 0u;
     else v += (g == (cd >> 1)) ? ((cd & 1u) ? p[q].y : p[q].x) : 0u;
-    if (!ACCESS && !NOMATCH) v |= mine ? (((mt >> (off & (PER - 1u))) & 1u) << 31) : 0u;
+    // the match bit of the entry at `pos` lives in ONE lane (`mine`): on indexes below 2^31 rows it
+    // rides in bit 31 of the group sum, beyond that (`wide`, wave-uniform) it is broadcast from that lane
+    const uint32_t mb = (mt >> (off & (PER - 1u))) & 1u;
+    uint32_t msum = 1u;
+    if (!ACCESS && !NOMATCH) {
+      if (wide) msum = fmx_grp_bcast(mb, base, off >> PSH);
+      else v |= mine ? (mb << 31) : 0u;
+    }
     const uint32_t sum = fmx_group_sum(v);
     if (g == q) {
-      rank = (ACCESS || NOMATCH) ? sum : (sum & 0x7FFFFFFFu);   // no match bit: ranks may use all 32 bits
-      match = (ACCESS || NOMATCH) ? 1u : (sum >> 31);
+      rank = (ACCESS || NOMATCH || wide) ? sum : (sum & 0x7FFFFFFFu);
+      match = (ACCESS || NOMATCH) ? 1u : (wide ? msum : (sum >> 31));
       if (ACCESS) code = cd;
     }
   }
 }
 template <bool ACCESS, bool PAIRED, bool NOMATCH = false>
 __device__ __forceinline__ void fmx_ep_level(const FmxLevel &L, uint32_t pos, uint32_t &code, bool live,
-                                             uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
+                                             uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match,
+                                             bool wide = false) {
   FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
-  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match);
-  else fmx_ep_round<4, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match);
+  if (L.fmt == 3) fmx_ep_round<3, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match, wide);
+  else fmx_ep_round<4, ACCESS, PAIRED, NOMATCH>(L.rec, pos, code, live, base, g, rank, match, wide);
 }
 
 // ---- RLFMIndexBackend::lf_map2 for 8 endpoints per group (rlfmi.rs:135-143) -------------------
@@ -225,6 +234,7 @@ template <int NL, int SM>
 __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32_t c, uint32_t i, bool live,
                                                         uint32_t base, uint32_t g) {
   const uint32_t kc = ix.K[c];
+  const bool wide = ix.n >= (1u << 31);                      // wave-uniform
   const FmxProbe pr = fmx_bits_probe_issue<true>(ix.b, i, live);
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)            rlfmi.rs:136
@@ -238,7 +248,7 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32
   for (uint32_t l = 0; l < nl; l++) {
     const FmxLevel &L = ix.bw.lv[l];
     uint32_t code = (c >> L.shift) & L.mask, mt;
-    fmx_ep_level<false, true>(L, pos, code, live, base, g, r, mt);
+    fmx_ep_level<false, true>(L, pos, code, live, base, g, r, mt, wide);
     m &= mt;
     pos = r;                                                 // C_l[code] is folded into the counters
   }

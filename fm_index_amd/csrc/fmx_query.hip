@@ -592,8 +592,13 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_ep_kernel(
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
   const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
   const uint32_t is_e = g & 1u;
-  const uint64_t slot = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-  const uint64_t nslots = ((uint64_t)gridDim.x * blockDim.x) >> 1;
+  // pattern slots are dealt to the GROUPS first (slot = pair * ngroups + group): a batch smaller than
+  // the grid then has one live lane pair per group, the rank rounds skip the dead endpoints
+  // (fmx_ep_round) and a step costs one record per level instead of eight -- small batches are
+  // latency-bound, and this is what keeps them at the group-per-pattern kernels' latency
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+  const uint64_t slot = (uint64_t)(g >> 1) * ngroups + (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+  const uint64_t nslots = ngroups * 4u;
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
 
   uint64_t k = slot, pbeg = 0;
@@ -996,9 +1001,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
   FmxHitQueue hq;
   hq.init(rows + blo, blo, bn, lane, lds_q);
+  // the first 8 hits of a chunk go to lane 0 of the wave's 8 groups, the next 8 to lane 1, ...: a wave
+  // that gets few hits (small batches) has few live endpoint positions and its rank rounds skip the rest
   uint64_t h;
   uint32_t row;
-  bool active = hq.take(lane, h, row);
+  bool active = hq.take((g << 3) | (lane >> 3), h, row);
   hq.advance(64u, lds_q);
   if (!active) row = 0u;
   uint32_t steps = 0, nsteps = 0;
@@ -1432,7 +1439,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     if ((sm > 0 || fm_ep) && variant != 0) {
       // 64 probes in flight per wave and stage: 4 waves per SIMD saturate the memory system
       const uint64_t ep_cap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", 1024);
-      uint64_t eb = (npat * 2 + FMX_BLOCK - 1) / FMX_BLOCK;
+      uint64_t eb = (npat + FMX_BLOCK / 8 - 1) / (FMX_BLOCK / 8);   // one pattern per group while the grid lasts
       if (eb > ep_cap) eb = ep_cap;
 #define FMX_EP_LAUNCH(KIND, NL, SM)                                                                  \
   do {                                                                                               \
@@ -1500,7 +1507,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     const uint64_t min_nb = (total >> 31) + 1;
     if (nb < min_nb) nb = min_nb;
     uint64_t per = (total + nb - 1) / nb;
-    per = (per + FMX_LCHUNK - 1) / FMX_LCHUNK * FMX_LCHUNK;
+    if (per >= FMX_LCHUNK) per = (per + FMX_LCHUNK - 1) / FMX_LCHUNK * FMX_LCHUNK;
+    else per = (per + 7) / 8 * 8;       // small batches: a few hits for many blocks beat many for few
     hpb = (uint32_t)per;
     grid = (unsigned)((total + per - 1) / per);
   };
@@ -1544,8 +1552,15 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     const int sm = idx->kind != FMX_KIND_RLFM ? -1
                    : (dv.b.pos && dv.bp.pos) ? 1
                    : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
-    const bool fm_ep = idx->kind == FMX_KIND_FM && w.nlevels >= 2;
-    if ((sm > 0 || fm_ep) && fmx_variant() != 0) {
+    // FM over several levels: the endpoint-per-lane walk pays once the batch is throughput-bound
+    // (7.9e8 hits: 7.4e9 hits/s against 5.9e9); up to 2^20 hits the group-per-walk kernel has the shorter
+    // step (benchmarks/gpu/small_shapes.py: 175 vs 187 us at n = 2^16, 247 vs 297 us at n = 2^27)
+    const bool fm_ep = idx->kind == FMX_KIND_FM && w.nlevels >= 2 && total >= (4u << 20);
+    // RLFM: one walk per lane wins once there are enough hits to keep its 64-wide rounds busy: 2^20 hits
+    // 0.22-0.38 ms against 0.44-0.67 ms, but 2^16 hits 0.10-0.16 against 0.09-0.12 ms and fewer about
+    // equal (benchmarks/gpu/small_shapes.py) -- below 2^18 hits the group-per-walk kernel runs
+    const bool rl_ep = sm > 0 && total >= (1u << 18);
+    if ((rl_ep || fm_ep) && fmx_variant() != 0) {
       // one walk per lane: 64 walks per wave.  2^20 hits finish soonest on one 1024-thread block per CU
       // (0.435 ms; 0.52 on 128 blocks); large batches want every wave the registers admit (94 VGPRs ->
       // 5 per SIMD): two 640-thread blocks per CU (config 4b, 7.9e8 hits: 84 ms against 100 ms)
@@ -1576,10 +1591,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     }
     else if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
     else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);
-#ifdef FMX_MEASURE   // round-1 group-per-walk RLFM kernels, per select structure (FMX_VARIANT=0)
-    else if (sm == 1) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);
+    else if (sm == 1) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);   // group per walk, per select structure
     else if (sm == 2) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
-#endif
     else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
   }
   fmx_time_end(idx, st);

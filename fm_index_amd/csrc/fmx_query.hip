@@ -807,48 +807,54 @@ struct FmxHitQueue {
   const uint32_t *rows;   // rows of this block's slice
   uint64_t lo;            // first hit of the slice (index into out_pos)
   uint32_t nhits;         // hits in the slice
+  uint32_t chunk;         // rows per ticket: 64, or 8..56 when the batch has fewer than 64 hits per wave
+                          // (every slot of every wave then starts a walk at once -- mid-size batches are
+                          // latency-bound, and two walks in a row per slot are twice the chain)
   uint32_t lane;
   uint32_t c0, c1;        // resident chunks of the slice (FMX_NOCHUNK once it is exhausted), wave-uniform
-  uint32_t win0, win1;    // rows of the resident chunks, one per lane
+  uint32_t win0, win1;    // rows of the resident chunks, one per lane (lanes >= chunk unused)
   uint32_t used;          // hits already handed out of c0|c1
   __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
-    const uint32_t x = c * FMX_LCHUNK + lane;
-    return (c != FMX_NOCHUNK && x < nhits) ? rows[x] : 0u;   // every slot was written by fmx_expand_kernel
+    const uint32_t x = c * chunk + lane;
+    return (c != FMX_NOCHUNK && lane < chunk && x < nhits) ? rows[x] : 0u;   // every slot was written by fmx_expand_kernel
   }
   __device__ __forceinline__ uint32_t valid(uint32_t c) const {
-    return (c != FMX_NOCHUNK && c * FMX_LCHUNK < nhits) ? c : FMX_NOCHUNK;
+    return (c != FMX_NOCHUNK && c * chunk < nhits) ? c : FMX_NOCHUNK;
   }
   __device__ __forceinline__ uint32_t draw(unsigned int &counter, uint32_t k) const {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&counter, k);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   }
-  __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t ln,
-                                       unsigned int &counter) {
-    rows = r; lo = first; nhits = count; lane = ln;
-    const uint32_t t = draw(counter, 2u);
-    c0 = valid(t);
-    c1 = valid(t + 1u);
+  __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t rows_per_ticket,
+                                       uint32_t ln, unsigned int &counter) {
+    rows = r; lo = first; nhits = count; chunk = rows_per_ticket; lane = ln;
+    // every wave of the block draws its FIRST ticket before any draws a second one (called by all
+    // threads of the block at kernel start): with fewer tickets than 2 x waves, no wave goes without
+    c0 = valid(draw(counter, 1u));
     win0 = load_win(c0);
+    __syncthreads();
+    c1 = valid(draw(counter, 1u));
     win1 = load_win(c1);
     used = 0;
   }
-  // the hit with index `used + rank`: returns false when the slice has run dry
+  // the hit with index `used + rank` (< 2 * chunk): returns false when the slice has run dry
   __device__ __forceinline__ bool take(uint32_t rank, uint64_t &h, uint32_t &row) const {
     const uint32_t idx = used + rank;
-    const uint32_t c = idx < FMX_LCHUNK ? c0 : c1;
-    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(idx & 63u));
-    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(idx & 63u));
-    const uint32_t x = c * FMX_LCHUNK + (idx & 63u);
+    const bool first = idx < chunk;
+    const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
+    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
+    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
+    const uint32_t x = c * chunk + within;
     h = lo + x;
-    row = idx < FMX_LCHUNK ? v0 : v1;
-    return idx < 2u * FMX_LCHUNK && c != FMX_NOCHUNK && x < nhits;
+    row = first ? v0 : v1;
+    return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
   }
-  // `count` hits were handed out (wave-uniform, count <= 64)
+  // `count` hits were handed out (wave-uniform, count <= chunk)
   __device__ __forceinline__ void advance(uint32_t count, unsigned int &counter) {
     used += count;
-    if (used >= FMX_LCHUNK) {                        // wave-uniform: slide
-      used -= FMX_LCHUNK;
+    if (used >= chunk) {                             // wave-uniform: slide
+      used -= chunk;
       c0 = c1;
       win0 = win1;
       c1 = c1 != FMX_NOCHUNK ? valid(draw(counter, 1u)) : FMX_NOCHUNK;
@@ -867,8 +873,8 @@ struct FmxHitQueue {
 template <int Q>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
-    uint32_t sa_level, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
-    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+    uint32_t sa_level, uint64_t total, uint32_t hits_per_block, uint32_t chunk,
+    const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ unsigned int lds_q;
   if (threadIdx.x == 0) lds_q = 0;
   __syncthreads();
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
   const uint32_t lmask = (1u << sa_level) - 1u;
   const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
   FmxHitQueue hq;
-  hq.init(rows + blo, blo, bn, lane, lds_q);
+  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
 
   uint64_t h[Q], pend_h[Q], pend_v[Q];
   uint32_t row[Q], steps[Q];
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
   const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
   FmxHitQueue hq;
-  hq.init(rows + blo, blo, bn, lane, lds_q);
+  hq.init(rows + blo, blo, bn, FMX_LCHUNK, lane, lds_q);
   // the first 8 hits of a chunk go to lane 0 of the wave's 8 groups, the next 8 to lane 1, ...: a wave
   // that gets few hits (small batches) has few live endpoint positions and its rank rounds skip the rest
   uint64_t h;
@@ -1503,12 +1509,11 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
   // 1024-thread blocks that each own a slice of the hits (FmxHitQueue): `nb` blocks wanted -> slice
   // length (a multiple of the 64-row chunk, below 2^31) and the blocks that are really needed
-  auto slice = [total](uint64_t nb, uint32_t &hpb, unsigned &grid) {
+  auto slice = [total](uint64_t nb, uint32_t chunk, uint32_t &hpb, unsigned &grid) {
     const uint64_t min_nb = (total >> 31) + 1;
     if (nb < min_nb) nb = min_nb;
     uint64_t per = (total + nb - 1) / nb;
-    if (per >= FMX_LCHUNK) per = (per + FMX_LCHUNK - 1) / FMX_LCHUNK * FMX_LCHUNK;
-    else per = (per + 7) / 8 * 8;       // small batches: a few hits for many blocks beat many for few
+    per = (per + chunk - 1) / chunk * chunk;
     hpb = (uint32_t)per;
     grid = (unsigned)((total + per - 1) / per);
   };
@@ -1534,10 +1539,18 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // latency without adding throughput (benchmarks/gpu/locate_queue_sweep.sh)
     uint32_t hpb;
     unsigned gr;
-    slice((uint64_t)fmx_env_long("FMX_LOC_BLOCKS", 256), hpb, gr);
+    const uint64_t nb = (uint64_t)fmx_env_long("FMX_LOC_BLOCKS", 256);
+    // rows per ticket: 64 once every wave gets that many; below, one hit per slot of every wave
+    // (mid-size batches are latency-bound: 1.3e5 hits 54 us against 84 us with 64-row tickets)
+    const uint64_t per_wave = (total + nb * (FMX_LOC_BLOCK / 64) - 1) / (nb * (FMX_LOC_BLOCK / 64));
+    uint32_t chunk = (uint32_t)((per_wave + 7) / 8 * 8);
+    if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
+    if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;      // the first round hands out 8 q hits at once
+    if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
+    slice(nb, chunk, hpb, gr);
 #define FMX_LOC_LAUNCH(Q)                                                                          \
   hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, w.lv[0].rec,  \
-                     dv.samples, dv.n, dv.sa_level, total, hpb, rows, d_pos, steps)
+                     dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps)
     if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
   } else {
 #define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
@@ -1568,7 +1581,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       const unsigned ep_threads = big ? 640u : (unsigned)FMX_LOC_BLOCK;
       uint32_t hpb;
       unsigned gr;
-      slice((uint64_t)fmx_env_long("FMX_EP_LOC_BLOCKS", big ? 512 : 256), hpb, gr);
+      slice((uint64_t)fmx_env_long("FMX_EP_LOC_BLOCKS", big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       const bool klds = dv.max_character < 1024u;
 #define FMX_EPL_LAUNCH(KIND, NL, SM)                                                                 \
   do {                                                                                               \

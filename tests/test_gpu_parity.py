@@ -309,3 +309,23 @@ def test_locate_offsets_with_gaps_are_reported_not_walked():
     assert (pos[4:6] == oi.get_sa(np.array([10, 11], dtype=np.uint64))).all()
     assert (pos[9:12] == oi.get_sa(np.array([100, 101, 102], dtype=np.uint64))).all()
     assert (pos < 5000).all()                                  # gap slots hold a valid position (row 0's)
+
+
+def test_multi_level_fm_locate_large_batch():
+    """FM over two wavelet levels: batches of >= 2^22 hits take the walk-per-lane kernel
+    (fmx_locate_ep_kernel<FM>), smaller ones the group-per-walk kernel; same ordered positions as the
+    oracle either way."""
+    n = 1 << 16
+    t = W.byte_text_np(n, 4)
+    gi = F.FMIndexWithLocate(F.Text(t), 2)
+    oi = O.OracleIndex(t, 255, level=2)
+    for npat in (300, 20000):                      # ~7.7e4 and ~5.1e6 hits
+        flat, off, _ = W.substring_patterns_np(t, npat, 1, 31)
+        gb = gi.search_many(flat=flat, off=off)
+        os_, oe = oi.count_batch(flat, off)
+        assert (gb.s == os_).all() and (gb.e == oe).all()
+        total = int((oe - os_).sum())
+        assert (total >= (1 << 22)) == (npat == 20000), total
+        goff, gpos = gb.locate()
+        ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
+        assert (goff == ooff).all() and (gpos == opos).all(), npat

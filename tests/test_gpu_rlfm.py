@@ -200,3 +200,30 @@ def test_every_run_density_gets_a_one_load_select(gen):
     r2 = rows[rows < n]
     assert (gi.lf_map(r2) == oi.lf_map(r2)).all() and (gi.get_sa(r2) == oi.get_sa(r2)).all()
     assert (gi.fl_map(r2) == oi.fl_map(r2)).all()
+
+
+@pytest.mark.parametrize("gen", ["sigma4", "sigma255", "rep60", "rep5"])
+def test_large_hit_batches_take_the_walk_per_lane_kernel(gen):
+    """locate batches of >= 2^18 hits run fmx_locate_ep_kernel (one walk per lane, LDS hit queue);
+    smaller ones the group-per-walk kernel.  Both must give the oracle's ordered positions -- here a
+    batch of 3-6 x 10^5 hits, for select blocks of several sizes and for stored positions."""
+    n = 1 << 17
+    if gen.startswith("sigma"):
+        sig = int(gen[5:])
+        t = (W.splitmix64_np(93, 0, n) % np.uint64(sig)).astype(np.uint8) + 1
+        t[-1] = 0
+        m = 2 if sig == 4 else 1
+    else:
+        t = W.repetitive_text_np(n, 5, base_len=1 << 9, mut_per_1024=int(gen[3:]))
+        m = 6
+    gi = F.RLFMIndexWithLocate(F.Text(t), 2)
+    oi = O.OracleIndex(t, 255, level=2, kind="rlfm")
+    flat, off, _ = W.substring_patterns_np(t, 4096 if gen != "sigma4" else 64, m, 29)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    total = int((oe - os_).sum())
+    assert total >= (1 << 18), (gen, total)
+    goff, gpos = gb.locate()
+    ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
+    assert (goff == ooff).all() and (gpos == opos).all(), gen

@@ -733,10 +733,21 @@ int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {
   memcpy(host_out, idx->h_cs, (idx->max_character + 1) * sizeof(uint64_t));
   return FMX_OK;
 }
+// SOSampledSuffixArray's payload (sample.rs:33-37): SA[k << level] for k = 0 .. ((n-1) >> level).  With
+// text-order sampling the stored samples are other rows', so the values are computed: get_sa of
+// those rows (same numbers, whatever is sampled inside).
 int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
-  FMX_HIP(hipMemcpy(host_out, idx->dev.samples, idx->nsamples * 4, hipMemcpyDeviceToHost));
+  if (!idx->dev.phase) {
+    FMX_HIP(hipMemcpy(host_out, idx->dev.samples, idx->nsamples * 4, hipMemcpyDeviceToHost));
+    return FMX_OK;
+  }
+  const uint64_t k = idx->nsamples, step = 1ull << idx->dev.sa_level;
+  std::vector<uint64_t> rows((size_t)k), vals((size_t)k);
+  for (uint64_t j = 0; j < k; j++) rows[j] = j * step;
+  if (int rc = fmx_get_sa_batch(idx, rows.data(), k, vals.data())) return rc;
+  for (uint64_t j = 0; j < k; j++) host_out[j] = (uint32_t)vals[j];
   return FMX_OK;
 }
 int fmx_export_sa(const fmx_index *idx, uint32_t *host_out) {
@@ -780,6 +791,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
   out[k++] = {(const void **)&d.cs, ((uint64_t)d.max_character + 1) * 4};
   if (d.kind == FMX_KIND_MULTI) out[k++] = {(const void **)&d.doc, (uint64_t)d.doc_count * 4};
   if (d.sa_level != FMX_NO_LOCATE) out[k++] = {(const void **)&d.samples, (nsamples + 4) * 4};
+  if (d.phase) out[k++] = {(const void **)&d.phase, ((uint64_t)d.n / (3u * (32u / d.sa_level)) + 1) * 16};
   if (d.kind == FMX_KIND_RLFM) {
     out[k++] = {(const void **)&d.b.rec, (uint64_t)d.b.nrec * 128};
     out[k++] = {(const void **)&d.b.sel, (uint64_t)d.b.nsel * 4};
@@ -817,6 +829,7 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
     if (d.sa_level >= 32 || h.n == 0) return "sa_level";
     if (h.nsamples != ((h.n - 1) >> d.sa_level) + 1 || d.nsamples != h.nsamples) return "nsamples";
   } else if (h.nsamples != 0) return "nsamples";
+  if (d.phase && (d.sa_level == FMX_NO_LOCATE || d.sa_level < 1 || d.sa_level > FMX_PHASE_MAX_LEVEL)) return "text-order sampling";
   if (d.kmer) {
     if (d.kmer_k == 0 || d.kmer_bits == 0 || d.kmer_bits > 8 || d.kmer_bits * d.kmer_k > 24) return "k-mer table";
   }
@@ -836,7 +849,7 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
   return nullptr;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 7;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density
+const uint32_t kFileVersion = 8;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {

@@ -174,6 +174,34 @@ __global__ __launch_bounds__(BLK) void k_samples(const uint32_t *__restrict__ sa
   if (j < nsamp) out[j] = sa[j << level];  // sample.rs:35-37
 }
 
+// text-order sampling (FmxDev::phase): one thread packs the phases SA[row] mod 2^level of one piece
+// (floor(32 / level) per word, three words) and counts its phase-0 rows; rows past the end get phase 1
+__global__ __launch_bounds__(BLK) void k_phase_pieces(const uint32_t *__restrict__ sa, uint32_t n,
+                                                       uint32_t level, uint32_t npieces,
+                                                       uint4 *__restrict__ out, uint32_t *__restrict__ zeros) {
+  const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j >= npieces) return;
+  const uint32_t fpw = 32u / level, rpp = 3u * fpw, mask = (1u << level) - 1u;
+  uint32_t w[3] = {0u, 0u, 0u}, z = 0;
+  for (uint32_t t = 0; t < rpp; t++) {
+    const uint64_t row = j * rpp + t;
+    const uint32_t ph = row < n ? (sa[row] & mask) : 1u;
+    z += ph == 0u;
+    w[t / fpw] |= ph << ((t % fpw) * level);
+  }
+  out[j] = make_uint4(0u, w[0], w[1], w[2]);
+  zeros[j] = z;
+}
+__global__ __launch_bounds__(BLK) void k_phase_counts(const uint32_t *__restrict__ base, uint32_t npieces,
+                                                       uint4 *__restrict__ out) {
+  const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j < npieces) out[j].x = base[j];
+}
+struct PhaseZero {   // flag of rocprim::select: rows whose suffix-array value is a multiple of 2^level
+  uint32_t mask;
+  __host__ __device__ bool operator()(uint32_t v) const { return (v & mask) == 0u; }
+};
+
 // 2-gram BWT for the opt-in pair index: code = (T[p-2]-1)*4 + (T[p-1]-1), p = SA[i] >= 2.
 // The two rows with p < 2 have no 2-gram: they are stored as code 0 and reported in
 // special[] so the query subtracts them from rank_0.
@@ -967,7 +995,55 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     FMX_HIP(hipMalloc((void **)&d_samp, (nsamp + 4) * sizeof(uint32_t)));
     FMX_HIP(hipMemset(d_samp, 0, (nsamp + 4) * sizeof(uint32_t)));
     if (int rc = keep(idx, d_samp, nsamp * 4)) return rc;
-    hipLaunchKernelGGL(k_samples, dim3(nblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    dv.phase = nullptr;
+    // text-order sampling where one LF step costs several dependent requests (RLFM; FM / multi-pieces
+    // over two or more wavelet levels): a walk is then SA[row] mod 2^level steps -- half the mean of
+    // row-order sampling and no geometric tail -- at the price of two phase-piece reads.  One-level
+    // indexes (DNA) keep row-order sampling: their LF step is ONE request, so the two extra reads cost
+    // more than the saved steps (2^20 hits 0.255 ms against 0.158 ms, profiles/r02/sweeps.md).
+    bool text_order = level >= 1 && level <= FMX_PHASE_MAX_LEVEL && (idx->kind == FMX_KIND_RLFM || L > 4);
+#ifdef FMX_MEASURE
+    if (const char *v = getenv("FMX_VARIANT")) {
+      if (atoi(v) == 18) text_order = false;                                          // sampled rows everywhere
+      if (atoi(v) == 19) text_order = level >= 1 && level <= FMX_PHASE_MAX_LEVEL;     // text order everywhere
+    }
+#endif
+    if (text_order) {
+      // sample the rows whose SA value is a multiple of 2^level (same number of samples), in row order,
+      // and keep every row's phase SA[row] mod 2^level with a rank over the phase-0 rows (fmx_internal.h)
+      const uint32_t rpp = 3u * (32u / level);
+      const uint32_t npieces = n / rpp + 1u;
+      uint4 *d_phase;
+      uint32_t *zeros, *zbase, *d_cnt;
+      FMX_HIP(hipMalloc((void **)&d_phase, (size_t)npieces * 16));
+      if (int rc = keep(idx, d_phase, (uint64_t)npieces * 16)) return rc;
+      FMX_HIP(pool.get(&zeros, (size_t)npieces + 1));
+      FMX_HIP(pool.get(&zbase, (size_t)npieces + 1));
+      FMX_HIP(pool.get(&d_cnt, 1));
+      hipLaunchKernelGGL(k_phase_pieces, dim3(nblocks(npieces)), dim3(BLK), 0, 0, d_sa, n, level, npieces,
+                         d_phase, zeros);
+      size_t tb = 0, sb = 0;
+      FMX_HIP(exclusive_sum(nullptr, tb, zeros, zbase, (size_t)npieces));
+      auto flags = rocprim::make_transform_iterator(d_sa, PhaseZero{(1u << level) - 1u});
+      FMX_HIP(rocprim::select(nullptr, sb, d_sa, flags, d_samp, d_cnt, (size_t)n, (hipStream_t)0));
+      uint8_t *tmp;
+      FMX_HIP(pool.get(&tmp, tb > sb ? tb : sb));
+      size_t t1 = tb;
+      FMX_HIP(exclusive_sum(tmp, t1, zeros, zbase, (size_t)npieces));
+      hipLaunchKernelGGL(k_phase_counts, dim3(nblocks(npieces)), dim3(BLK), 0, 0, zbase, npieces, d_phase);
+      t1 = sb;
+      FMX_HIP(rocprim::select(tmp, t1, d_sa, flags, d_samp, d_cnt, (size_t)n, (hipStream_t)0));
+      uint32_t got = 0;
+      FMX_HIP(hipMemcpy(&got, d_cnt, 4, hipMemcpyDeviceToHost));
+      if (got != nsamp) {
+        fmx_set_error(FMX_ERR_HIP, "text-order sampling: unexpected number of samples");
+        return FMX_ERR_HIP;
+      }
+      pool.release(tmp); pool.release(d_cnt); pool.release(zbase); pool.release(zeros);
+      dv.phase = d_phase;
+    } else {
+      hipLaunchKernelGGL(k_samples, dim3(nblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    }
     dv.samples = d_samp;
     dv.nsamples = (uint32_t)nsamp;
     dv.sa_level = level;

@@ -556,6 +556,42 @@ __device__ __forceinline__ void fmx_rlfm_lf_map2_pair(const FmxDev &ix, uint32_t
   e = ne;
 }
 
+// ---- text-order sampling (FmxDev::phase) ------------------------------------------------------
+__device__ __forceinline__ uint32_t fmx_div15(uint32_t x) {
+  return (uint32_t(((uint64_t)x * 0x88888889ull) >> 35));
+}
+// piece holding `row` and the row's index inside it; rows per piece = 3 * floor(32 / level)
+__device__ __forceinline__ uint32_t fmx_phase_piece(uint32_t row, uint32_t level, uint32_t &t) {
+  uint32_t p;
+  if (level == 1) { p = fmx_div3(row >> 5); t = row - p * 96u; }
+  else if (level == 2) { p = fmx_div3(row >> 4); t = row - p * 48u; }
+  else if (level == 3) { p = fmx_div15(row >> 1); t = row - p * 30u; }
+  else { p = fmx_div3(row >> 3); t = row - p * 24u; }
+  return p;
+}
+// fields of one word whose phase is 0, as a mask over the fields' lowest bits
+__device__ __forceinline__ uint32_t fmx_phase_zero_fields(uint32_t w, uint32_t level) {
+  if (level == 1) return ~w;
+  if (level == 2) return ~(w | (w >> 1)) & 0x55555555u;
+  if (level == 3) return ~(w | (w >> 1) | (w >> 2)) & 0x09249249u;
+  return ~(w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x11111111u;
+}
+// phase of the piece's t-th row, and the number of phase-0 rows before it in the whole index
+__device__ __forceinline__ uint32_t fmx_phase_decode(const uint4 pc, uint32_t t, uint32_t level, uint32_t &rank0) {
+  // the three words are read into registers BEFORE the data-dependent choice: a choice between
+  // members of a by-reference uint4 becomes a dynamically indexed private array (scratch memory)
+  const uint32_t py = pc.y, pz = pc.z, pw = pc.w;
+  const uint32_t fpw = level == 1 ? 32u : (level == 2 ? 16u : (level == 3 ? 10u : 8u));
+  const uint32_t wi = level == 3 ? (uint32_t)(t >= 10u) + (uint32_t)(t >= 20u)
+                                 : (level == 1 ? t >> 5 : (level == 2 ? t >> 4 : t >> 3));
+  const uint32_t k = t - wi * fpw;
+  const uint32_t w = wi == 0 ? py : (wi == 1 ? pz : pw);
+  const uint32_t z0 = fmx_phase_zero_fields(py, level), z1 = fmx_phase_zero_fields(pz, level);
+  const uint32_t zc = fmx_phase_zero_fields(w, level);
+  rank0 = pc.x + (wi > 0 ? __popc(z0) : 0u) + (wi > 1 ? __popc(z1) : 0u) + __popc(zc & fmx_lowmask(k * level));
+  return (w >> (k * level)) & ((1u << level) - 1u);
+}
+
 // greatest c with cs[c] <= v  (get_f's binary search, fm_index.rs:97-112)
 __device__ __forceinline__ uint32_t fmx_cs_upper(const uint32_t *cs, uint32_t max_character,
                                                  uint32_t v) {

@@ -97,7 +97,17 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   const uint2 *kmer;    // FMX_FLAG_KMER_TABLE: (s, e) of searching each k-mer from (0, n)
   uint32_t kmer_k;      // symbols per entry (0 = no table)
   uint32_t kmer_bits;   // bits per symbol in the table index (symbol c is coded c - 1)
+  // Text-order sampling (levels 1..4; NULL = the rows i with i mod 2^level == 0 are the sampled ones,
+  // as in sample.rs).  get_sa(i) is SA[i] whatever is sampled, so the structure is ours to choose:
+  // sampling the rows whose SA VALUE is a multiple of 2^level makes every walk exactly
+  // SA[i] mod 2^level steps long -- (2^level - 1) / 2 on average and never more than 2^level - 1,
+  // against 2^level - 1 on average and a geometric tail (48 steps in 2^20 hits) for sampled rows.
+  //   phase[] = 16-byte pieces { phase-0 rows before this piece (absolute), 3 words of level-bit
+  //             phases SA[row] mod 2^level, floor(32 / level) per word } -> 96, 48, 30, 24 rows per piece;
+  //   samples[] then holds SA[row] of the phase-0 rows in row order (same ((n-1) >> level) + 1 entries).
+  const uint4 *phase;
 };
+#define FMX_PHASE_MAX_LEVEL 4u
 
 struct fmx_index {
   FmxDev dev;

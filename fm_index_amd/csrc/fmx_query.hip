@@ -723,6 +723,32 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
   }
 }
 
+// get_sa(row) with text-order sampling (FmxDev::phase), for an 8-lane group that holds one row: the
+// row's phase says how many LF steps lead to a sampled row (never more than 2^level - 1), and the
+// rank over the phase-0 rows at that row is the index of its sample.  No wrap can occur: the walk
+// goes from text position SA[row] down to SA[row] - phase >= 0.
+template <int KIND, int NL, int SM>
+__device__ __forceinline__ uint64_t fmx_get_sa_text(const FmxDev &ix, uint32_t row, uint32_t g,
+                                                    uint32_t &nsteps) {
+  uint32_t t, rank0;
+  uint32_t p = fmx_phase_piece(row, ix.sa_level, t);
+  FMX_TOUCH_G0(g, &ix.phase[p]);
+  const uint32_t phi = fmx_phase_decode(ix.phase[p], t, ix.sa_level, rank0);
+  for (uint32_t k = 0; k < phi; k++) {               // i = lf_map(i); steps += 1     fm_index.rs:134-137
+    uint32_t sym;
+    row = fmx_lf_map_any<KIND, NL, SM>(ix, row, g, sym);
+  }
+  nsteps += phi;
+  if (phi) {
+    p = fmx_phase_piece(row, ix.sa_level, t);
+    FMX_TOUCH_G0(g, &ix.phase[p]);
+    (void)fmx_phase_decode(ix.phase[p], t, ix.sa_level, rank0);
+  }
+  FMX_CHECK(rank0 < ix.nsamples);
+  FMX_TOUCH_G0(g, &ix.samples[rank0]);
+  return (uint64_t)ix.samples[rank0] + phi;          // fm_index.rs:131-133 (sa + steps)
+}
+
 // generic locate walk (any kind / any number of levels): same wave-level dynamic hit assignment
 // and register row window as fmx_locate_f3w_kernel below; one LF step = fmx_lf_map_any (several
 // dependent probes), the sample read is a plain dependent load.
@@ -754,7 +780,11 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
       win = load_row(win_base + lane);
     }
     bool fin = false;
-    if (active) {
+    if (active && ix.phase) {                       // text-order sampling: the whole (short) walk at once
+      const uint64_t v = fmx_get_sa_text<KIND, NL, SM>(ix, row, g, nsteps);
+      if (g == 0) out_pos[h] = v;
+      fin = true;
+    } else if (active) {
       if ((row & lmask) == 0) {
         // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
         FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
@@ -870,10 +900,13 @@ struct FmxHitQueue {
 // lane whose address depends on its state -- a record piece while walking (fm_index.rs:134-137) or
 // the aligned chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking
 // and finishing groups of one wave overlap their latencies instead of serialising two branches.
-template <int Q>
+// TEXT: text-order sampling (FmxDev::phase).  A walk is then four kinds of iteration, each ONE 16-byte
+// load per lane like before: read the row's phase piece -> `phase` LF steps (no test in between) ->
+// read the final row's phase piece for its rank among the sampled rows -> read the sample.
+template <int Q, bool TEXT>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
-    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n,
-    uint32_t sa_level, uint64_t total, uint32_t hits_per_block, uint32_t chunk,
+    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, const uint4 *__restrict__ phase,
+    uint32_t n, uint32_t sa_level, uint64_t total, uint32_t hits_per_block, uint32_t chunk,
     const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ unsigned int lds_q;
   if (threadIdx.x == 0) lds_q = 0;
@@ -893,6 +926,9 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
 
   uint64_t h[Q], pend_h[Q], pend_v[Q];
   uint32_t row[Q], steps[Q];
+  // TEXT: stage of the walk (0 phase of the start row, 1 LF steps, 2 rank at the final row, 3 sample),
+  // LF steps still to do, index of the sample
+  [[maybe_unused]] uint32_t st[Q], rem[Q], sidx[Q];
   bool active[Q], pending[Q];
   uint32_t nsteps = 0;
 #pragma unroll
@@ -901,6 +937,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
     hq.advance(8u, lds_q);
     if (!active[q]) row[q] = 0u;
     steps[q] = 0;
+    st[q] = 0; rem[q] = 0; sidx[q] = 0;
     pending[q] = false;
     pend_h[q] = 0;
     pend_v[q] = 0;
@@ -920,16 +957,19 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
     // issue every load of this round
     uint4 p[Q];
     bool sampled[Q];
+    [[maybe_unused]] uint32_t pt[Q];               // TEXT: the row's index inside its phase piece
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-      sampled[q] = (row[q] & lmask) == 0;
+      sampled[q] = TEXT ? st[q] == 3u : (row[q] & lmask) == 0;
       p[q] = make_uint4(0u, 0u, 0u, 0u);
+      pt[q] = 0;
       if (live[q] && active[q]) {
-        const uint32_t si = row[q] >> sa_level;
+        const uint32_t si = TEXT ? sidx[q] : row[q] >> sa_level;
         FMX_CHECK(row[q] < n && (row[q] >> 8) < n / 256u + 1u);
         FMX_CHECK(!sampled[q] || (uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
         const uint4 *addr = sampled[q] ? (samp4 + (si >> 2)) : (rec + ((size_t)(row[q] >> 8) * 8u + g));
-        FMX_TOUCH_G0(g, sampled[q] ? addr : addr - g);
+        if (TEXT && (st[q] == 0u || st[q] == 2u)) addr = phase + fmx_phase_piece(row[q], sa_level, pt[q]);
+        FMX_TOUCH_G0(g, (!TEXT || st[q] == 1u) && !sampled[q] ? addr - g : addr);
         p[q] = *addr;
       }
     }
@@ -945,14 +985,21 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
       bool fin = false;
       if (active[q]) {
         if (sampled[q]) {
-          const uint32_t w = (row[q] >> sa_level) & 3u;
-          const uint32_t sa = w == 0 ? p[q].x : (w == 1 ? p[q].y : (w == 2 ? p[q].z : p[q].w));
+          const uint32_t w = (TEXT ? sidx[q] : row[q] >> sa_level) & 3u;
+          const uint32_t p0 = p[q].x, p1 = p[q].y, p2 = p[q].z, p3 = p[q].w;
+          const uint32_t sa = w == 0 ? p0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
           uint64_t v = (uint64_t)sa + steps[q];     // fm_index.rs:131-133: (sa + steps) % len
           if (v >= n) v -= n;
           pend_v[q] = v;
           pend_h[q] = h[q];
           pending[q] = true;
           fin = true;
+        } else if (TEXT && st[q] != 1u) {           // phase piece: of the start row (0) or the final row (2)
+          uint32_t rank0;
+          const uint32_t phi = fmx_phase_decode(p[q], pt[q], sa_level, rank0);
+          sidx[q] = rank0;
+          rem[q] = phi;
+          st[q] = (st[q] == 2u || phi == 0u) ? 3u : 1u;
         } else {
           const uint32_t off = row[q] & 255u;
           const uint32_t sym =
@@ -960,6 +1007,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
           row[q] = fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));  // lf_map (absolute counters)
           steps[q]++;
           nsteps++;
+          if (TEXT && --rem[q] == 0u) st[q] = 2u;
         }
       }
       const unsigned long long fmask = __ballot(fin && g == 0);  // one bit per finishing group
@@ -974,6 +1022,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
           active[q] = ok;
           row[q] = ok ? r_new : 0u;
           steps[q] = 0;
+          st[q] = 0;
         }
         hq.advance((uint32_t)__popcll(fmask), lds_q);
       }
@@ -1015,21 +1064,44 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
   hq.advance(64u, lds_q);
   if (!active) row = 0u;
   uint32_t steps = 0, nsteps = 0;
+  // text-order sampling (FmxDev::phase; wave-uniform): stage of the lane's walk -- 0 phase piece of the
+  // start row, 1 LF steps (`rem` of them, no test in between), 2 phase piece of the final row for its
+  // rank among the sampled rows, 3 the sample -- every stage one lane-wise 16-byte probe or one LF step
+  const bool text = ix.phase != nullptr;
+  uint32_t st = 0, rem = 0, sidx = 0;
   while (__any(active)) {
-    const bool sampled = active && (row & lmask) == 0u;
-    uint32_t sa = 0;
-    if (sampled) {                                  // sample.rs:46-60 Some(sa)
-      FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
-      FMX_TOUCH(&ix.samples[row >> ix.sa_level]);
-      sa = ix.samples[row >> ix.sa_level];
+    const bool probing = text && active && (st == 0u || st == 2u);
+    const bool sampled = active && (text ? st == 3u : (row & lmask) == 0u);
+    uint32_t sa = 0, pt = 0;
+    uint4 pc = make_uint4(0u, 0u, 0u, 0u);
+    if (probing) {
+      const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
+      FMX_TOUCH(&ix.phase[pi]);
+      pc = ix.phase[pi];
     }
-    const bool walking = active && !sampled;
+    if (sampled) {                                  // sample.rs:46-60 Some(sa)
+      const uint32_t si = text ? sidx : row >> ix.sa_level;
+      FMX_CHECK(si < ix.nsamples);
+      FMX_TOUCH(&ix.samples[si]);
+      sa = ix.samples[si];
+    }
+    const bool walking = active && !sampled && !probing;
     if (__any(walking)) {                           // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186
       uint32_t sym;
       const uint32_t nrow = KIND == FMX_KIND_RLFM
                                 ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
                                 : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
-      if (walking) { row = nrow; steps++; nsteps++; }
+      if (walking) {
+        row = nrow; steps++; nsteps++;
+        if (text && --rem == 0u) st = 2u;
+      }
+    }
+    if (probing) {
+      uint32_t rank0;
+      const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
+      sidx = rank0;
+      rem = phi;
+      st = (st == 2u || phi == 0u) ? 3u : 1u;
     }
     const unsigned long long fmask = __ballot(sampled);
     if (fmask) {                                    // wave-uniform
@@ -1043,6 +1115,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
         h = h_new;
         active = ok;
         steps = 0;
+        st = 0;
         row = ok ? r_new : 0u;
       }
       hq.advance((uint32_t)__popcll(fmask), lds_q);
@@ -1178,6 +1251,9 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
       uint32_t sym;
       uint32_t r = fmx_fl_map_any<KIND>(ix, (uint32_t)i64, g, sym);
       res = op == 4 ? (uint64_t)sym : (r == 0xFFFFFFFFu && KIND == FMX_KIND_MULTI ? ~0ull : (uint64_t)r);
+    } else if (ix.phase) {  // get_sa, text-order sampling
+      uint32_t ns = 0;
+      res = fmx_get_sa_text<KIND, 0, -1>(ix, (uint32_t)i64, g, ns);
     } else {  // get_sa (fm_index.rs:127-140)
       uint32_t row = (uint32_t)i64, steps = 0;
       const uint32_t lmask = (1u << ix.sa_level) - 1u;
@@ -1548,10 +1624,15 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;      // the first round hands out 8 q hits at once
     if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
     slice(nb, chunk, hpb, gr);
-#define FMX_LOC_LAUNCH(Q)                                                                          \
-  hipLaunchKernelGGL(fmx_locate_f3w_kernel<Q>, dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, w.lv[0].rec,  \
-                     dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps)
-    if (q == 4) FMX_LOC_LAUNCH(4); else if (q == 2) FMX_LOC_LAUNCH(2); else FMX_LOC_LAUNCH(1);
+#define FMX_LOC_LAUNCH(Q, TEXT)                                                                    \
+  hipLaunchKernelGGL((fmx_locate_f3w_kernel<Q, TEXT>), dim3(gr), dim3(FMX_LOC_BLOCK), 0, st,        \
+                     w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
+                     d_pos, steps)
+    if (dv.phase) {
+      if (q == 4) FMX_LOC_LAUNCH(4, true); else if (q == 2) FMX_LOC_LAUNCH(2, true); else FMX_LOC_LAUNCH(1, true);
+    } else {
+      if (q == 4) FMX_LOC_LAUNCH(4, false); else if (q == 2) FMX_LOC_LAUNCH(2, false); else FMX_LOC_LAUNCH(1, false);
+    }
   } else {
 #define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
   hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, dv, \

@@ -114,6 +114,9 @@ def build_library(force=False):
     subprocess.check_call(["make", "-s", "-j4", "-C", csrc])
     # the census library (line log for bench.py's byte model; measurement only, never the product path)
     subprocess.check_call(["make", "-s", "-C", csrc, "census"])
+    # the measurement library (FMX_VARIANT switches for A/B runs and for tests that force a code path the
+    # shipped dispatch would not pick; never the product path)
+    subprocess.check_call(["make", "-s", "-C", csrc, "measure"])
     return LIB_PATH
 
 

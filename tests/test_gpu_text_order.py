@@ -4,6 +4,8 @@ multiple of 2^level.  Same answers as the reference's row-order sampling (suffix
 on every row, the samples the reference would hold are still exported, and a walk is SA[row] mod
 2^level LF steps -- never more than 2^level - 1."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -90,3 +92,16 @@ def test_save_load_keeps_text_order(kind, tmp_path):
     p1, s1 = _locate_steps(li, np.array([0], np.uint64), np.array([n], np.uint64))
     assert (np.asarray(p0) == np.asarray(p1)).all() and s0 == s1 and s0 <= 7 * n
     assert li.heap_size() == gi.heap_size()
+
+
+def test_text_order_forced_on_one_level_indexes():
+    """The measurement build with FMX_VARIANT=19 samples in text order on one-level indexes as well: the
+    text-order branches of the DNA walk kernel stay correct although the shipped builder never picks them."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "fm_index_amd", "libfmx_measure.so")
+    assert os.path.exists(lib), "libfmx_measure.so is built by __graft_entry__.build()"
+    env = dict(os.environ, FMX_LIB=lib, FMX_VARIANT="19", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "text_order_forced.py")], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().startswith("OK 12")

@@ -1606,7 +1606,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
   fmx_time_begin(idx, st);
   if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 &&
-      fmx_variant() != 0) {
+      fmx_variant() != 0 && fmx_variant() != 21) {
     // walks per group: 4 when the batch is large enough to keep every group busy with them
     const int v = fmx_variant();
     const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (total >= (1u << 16) ? 4 : 1);
@@ -1649,7 +1649,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // FM over several levels: the endpoint-per-lane walk pays once the batch is throughput-bound
     // (7.9e8 hits: 7.4e9 hits/s against 5.9e9); up to 2^20 hits the group-per-walk kernel has the shorter
     // step (benchmarks/gpu/small_shapes.py: 175 vs 187 us at n = 2^16, 247 vs 297 us at n = 2^27)
-    const bool fm_ep = idx->kind == FMX_KIND_FM && w.nlevels >= 2 && total >= (4u << 20);
+    const bool fm_ep = idx->kind == FMX_KIND_FM && ((w.nlevels >= 2 && total >= (4u << 20)) || fmx_variant() == 21);
     // RLFM: one walk per lane wins once there are enough hits to keep its 64-wide rounds busy: 2^20 hits
     // 0.22-0.38 ms against 0.44-0.67 ms, but 2^16 hits 0.10-0.16 against 0.09-0.12 ms and fewer about
     // equal (benchmarks/gpu/small_shapes.py) -- below 2^18 hits the group-per-walk kernel runs

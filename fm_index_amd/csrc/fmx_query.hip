@@ -893,6 +893,7 @@ struct FmxHitQueue {
   }
 };
 
+#ifdef FMX_MEASURE   // the round-1/2 form of the DNA walk, kept for A/B runs (FMX_VARIANT=22)
 // locate walk, single 3-bit level (DNA).  The wave's 8 groups take hits from the queue above as they
 // finish (ballot + prefix popcount), so the wave runs sum(work) / (8 Q) iterations, not max over its
 // groups; a finishing group takes its next row from the register window with a ds_bpermute -- no
@@ -1030,6 +1031,150 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
   }
   if (steps_out && g == 0 && nsteps)
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+#endif  // FMX_MEASURE
+
+// value of lane (4 * (lane / 4) + q) for the four lanes of a quad (DPP quad_perm [q,q,q,q])
+template <int QQ>
+__device__ __forceinline__ uint32_t fmx_quad_bcast_c(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, QQ * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t fmx_quad_bcast(uint32_t v, int q) {
+  return q == 0 ? fmx_quad_bcast_c<0>(v) : q == 1 ? fmx_quad_bcast_c<1>(v) : q == 2 ? fmx_quad_bcast_c<2>(v)
+                                                                                    : fmx_quad_bcast_c<3>(v);
+}
+
+// locate walk, single 3-bit level (DNA), walk state DISTRIBUTED over the lanes of a group.  A group of 8
+// lanes still serves Q walks at a time with one 128-byte record per LF step (fm_index.rs:134-137), but the
+// state of walk q (row, steps, hit index, stage) lives in lane q of each quad of the group instead of being
+// repeated in all 8 lanes: the sampled test, the sample read (sample.rs:46-60), the position
+// (fm_index.rs:131-133), the hand-over of the next hit and the deferred store are executed ONCE per
+// iteration for all Q walks -- lane-wise -- and only the record load + decode run per walk, with the row
+// broadcast inside the quad (DPP quad_perm).  fmx_locate_f3w_kernel repeats that bookkeeping per walk in
+// every lane and is bound by vector-instruction issue (100 instructions per record load,
+// profiles/r02/sweeps.md); this form issues about half.
+// TEXT: text-order sampling (FmxDev::phase) -- the phase pieces are lane-wise 16-byte probes like the sample.
+template <int Q, bool TEXT>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3q_kernel(
+    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, const uint4 *__restrict__ phase,
+    uint32_t n, uint32_t sa_level, uint64_t total, uint32_t hits_per_block, uint32_t chunk,
+    const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  static_assert(Q == 1 || Q == 2 || Q == 4, "walks per group");
+  __shared__ unsigned int lds_q;
+  if (threadIdx.x == 0) lds_q = 0;
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint32_t slot = g & (uint32_t)(Q - 1);        // the walk whose state this lane keeps (8 / Q replicas)
+  const bool owner = g < (uint32_t)Q;                 // the replica that counts, stores and is counted
+  const uint32_t olane = (lane & ~7u) | slot;         // its lane
+  // lanes holding walk 0 of their group: one bit per replica
+  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : Q == 2 ? 0x5555555555555555ull
+                                                                                : 0xFFFFFFFFFFFFFFFFull;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row (n < 2^32 - 16)
+  const uint32_t lmask = (1u << sa_level) - 1u;
+  FmxHitQueue hq;
+  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
+  // the first 8 hits go to walk 0 of the wave's 8 groups, the next 8 to walk 1, ...: a wave that gets few
+  // hits has few live walk slots and skips the others' loads and decodes
+  uint64_t h;
+  uint32_t row;
+  bool active = hq.take((slot << 3) | grp, h, row);
+  hq.advance(8u * (uint32_t)Q, lds_q);
+  if (!active) row = 0u;
+  uint32_t steps = 0, nsteps = 0;
+  // TEXT: stage of the walk (0 phase piece of the start row, 1 LF steps, 2 phase piece of the final row
+  // for its rank among the sampled rows, 3 the sample), LF steps still to do, index of the sample
+  [[maybe_unused]] uint32_t st = 0, rem = 0, sidx = 0;
+  bool pending = false;
+  uint64_t pend_h = 0, pend_v = 0;
+  for (;;) {
+    if (!__any(active || pending)) break;
+    const bool probing = TEXT && active && (st == 0u || st == 2u);
+    const bool sampled = active && (TEXT ? st == 3u : (row & lmask) == 0u);
+    const bool walking = active && !sampled && !probing;
+    // lane-wise probes of this round: the sample of a sampled row, the phase piece of a start / final row
+    uint32_t sa = 0;
+    [[maybe_unused]] uint32_t pt = 0;
+    [[maybe_unused]] uint4 pc = make_uint4(0u, 0u, 0u, 0u);
+    if (TEXT && probing) {
+      const uint32_t pi = fmx_phase_piece(row, sa_level, pt);
+      if (owner) FMX_TOUCH(&phase[pi]);
+      pc = phase[pi];
+    }
+    if (sampled) {                                    // sample.rs:46-60 Some(sa)
+      const uint32_t si = TEXT ? sidx : row >> sa_level;
+      FMX_CHECK((uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
+      if (owner) FMX_TOUCH(&samples[si]);
+      sa = samples[si];
+    }
+    // one record per walking walk: the row goes from the lane that keeps it to its quad
+    const uint32_t rowx = walking ? row : NONE;
+    const unsigned long long wm = __ballot(walking);
+    uint4 p[Q];
+    uint32_t rq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      rq[q] = NONE;
+      if (!(wm & (SLOT0 << q))) continue;             // walk q idle in every group of the wave
+      rq[q] = Q == 1 ? rowx : fmx_quad_bcast(rowx, q);
+      if (rq[q] != NONE) {                            // group-uniform
+        FMX_CHECK(rq[q] < n && (rq[q] >> 8) < n / 256u + 1u);
+        const uint4 *addr = rec + ((size_t)(rq[q] >> 8) * 8u + g);
+        FMX_TOUCH_G0(g, addr - g);
+        p[q] = *addr;
+      }
+    }
+    // the position finished in the previous round is stored behind these loads
+    if (pending && owner) out_pos[pend_h] = pend_v;
+    pending = false;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (!(wm & (SLOT0 << q))) continue;
+      if (rq[q] != NONE) {                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+        const uint32_t off = rq[q] & 255u;
+        const uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
+        const uint32_t nr = fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));   // absolute counters
+        if (slot == (uint32_t)q) {
+          row = nr;
+          steps++;
+          if (TEXT && --rem == 0u) st = 2u;
+        }
+      }
+    }
+    if (TEXT && probing) {                            // phase piece: of the start row (0) or the final row (2)
+      uint32_t rank0;
+      const uint32_t phi = fmx_phase_decode(pc, pt, sa_level, rank0);
+      sidx = rank0;
+      rem = phi;
+      st = (st == 2u || phi == 0u) ? 3u : 1u;
+    }
+    const unsigned long long fm = __ballot(sampled && owner);   // one bit per finishing walk
+    if (fm) {                                         // wave-uniform
+      uint64_t h_new;
+      uint32_t r_new;
+      const bool ok = hq.take((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), h_new, r_new);
+      if (sampled) {
+        uint64_t v = (uint64_t)sa + steps;            // fm_index.rs:131-133: (sa + steps) % len
+        if (v >= n) v -= n;
+        pend_v = v;
+        pend_h = h;
+        pending = true;
+        nsteps += steps;
+        h = h_new;
+        active = ok;
+        row = ok ? r_new : 0u;
+        steps = 0;
+        st = 0;
+      }
+      hq.advance((uint32_t)__popcll(fm), lds_q);
+    }
+  }
+  if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
@@ -1610,15 +1755,16 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // walks per group: 4 when the batch is large enough to keep every group busy with them
     const int v = fmx_variant();
     const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (total >= (1u << 16) ? 4 : 1);
-    // one 1024-thread block per CU = 4 waves per SIMD (69 VGPRs at Q = 4 admit no second one): the walk
-    // is bound by the loaded latency of its longest chain, and more walks in flight lengthen that
-    // latency without adding throughput (benchmarks/gpu/locate_queue_sweep.sh)
     uint32_t hpb;
     unsigned gr;
-    const uint64_t nb = (uint64_t)fmx_env_long("FMX_LOC_BLOCKS", 256);
+    const unsigned lthreads = (unsigned)fmx_env_long("FMX_LOC_THREADS", FMX_LOC_BLOCK);
+    // 1024-thread blocks (one LDS hit queue per 16 waves); 50 VGPRs at Q = 4, so two of them fit a CU.
+    // Batches of millions of hits want both (config 3b: 14.7 ms on 512 blocks, 18.7 on 256); a 2^20-hit
+    // batch is bound by the chain of its longest walks and as fast on one (benchmarks/gpu/f3q_grid_sweep.sh)
+    const uint64_t nb = (uint64_t)fmx_env_long("FMX_LOC_BLOCKS", total >= (4u << 20) && v != 22 ? 512 : 256);
     // rows per ticket: 64 once every wave gets that many; below, one hit per slot of every wave
     // (mid-size batches are latency-bound: 1.3e5 hits 54 us against 84 us with 64-row tickets)
-    const uint64_t per_wave = (total + nb * (FMX_LOC_BLOCK / 64) - 1) / (nb * (FMX_LOC_BLOCK / 64));
+    const uint64_t per_wave = (total + nb * (lthreads / 64) - 1) / (nb * (lthreads / 64));
     uint32_t chunk = (uint32_t)((per_wave + 7) / 8 * 8);
     if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
     if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;      // the first round hands out 8 q hits at once
@@ -1628,11 +1774,24 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   hipLaunchKernelGGL((fmx_locate_f3w_kernel<Q, TEXT>), dim3(gr), dim3(FMX_LOC_BLOCK), 0, st,        \
                      w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
                      d_pos, steps)
-    if (dv.phase) {
+#define FMX_LOCQ_LAUNCH(Q, TEXT)                                                                   \
+  hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(lthreads), 0, st,             \
+                     w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
+                     d_pos, steps)
+    if (v != 22) {          // walk state distributed over the lanes of a group
+      if (dv.phase) {
+        if (q == 4) FMX_LOCQ_LAUNCH(4, true); else if (q == 2) FMX_LOCQ_LAUNCH(2, true); else FMX_LOCQ_LAUNCH(1, true);
+      } else {
+        if (q == 4) FMX_LOCQ_LAUNCH(4, false); else if (q == 2) FMX_LOCQ_LAUNCH(2, false); else FMX_LOCQ_LAUNCH(1, false);
+      }
+    }
+#ifdef FMX_MEASURE
+    else if (dv.phase) {    // FMX_VARIANT=22: walk state repeated in all 8 lanes
       if (q == 4) FMX_LOC_LAUNCH(4, true); else if (q == 2) FMX_LOC_LAUNCH(2, true); else FMX_LOC_LAUNCH(1, true);
     } else {
       if (q == 4) FMX_LOC_LAUNCH(4, false); else if (q == 2) FMX_LOC_LAUNCH(2, false); else FMX_LOC_LAUNCH(1, false);
     }
+#endif
   } else {
 #define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
   hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, dv, \

@@ -1,6 +1,6 @@
 """Run with FMX_LIB=<libfmx_measure.so> FMX_VARIANT=19: text-order sampling forced on ONE-level indexes too
 (the shipped builder keeps row-order there), so the text-order branch of the one-level DNA walk kernel
-(fmx_locate_f3w_kernel<Q, true>) and of the generic walk at one level are checked against the oracle.
+(fmx_locate_f3q_kernel<Q, true>) and of the generic walk at one level are checked against the oracle.
 Prints "OK <cases>" on success."""
 import sys
 

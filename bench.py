@@ -317,7 +317,7 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
 # --------------------------------------------------------------------------------------------
 PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
     "dna_count": ["fmx_count_f3_kernel"],
-    "dna_locate": ["fmx_locate_f3q_kernel"],
+    "dna_locate": ["fmx_locate_f3p_kernel"],
     "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
     "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
 }
@@ -817,7 +817,7 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     if not args.no_census and rank == 0:
         cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
     ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
-    kname = "fmx_locate_f3q_kernel<4,false>" if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else
+    kname = "fmx_locate_f3p_kernel<4>" if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else
                                                         "fmx_locate_kernel<FMX_KIND_FM>")
     roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
                          stored_traffic(key, "locate"))

@@ -74,24 +74,26 @@ __device__ __forceinline__ uint32_t fmx_group_min(uint32_t v) {
 // bitmask (over the piece's entries) of entries whose level code == code
 template <int FMT>
 __device__ __forceinline__ uint32_t fmx_piece_match(const uint4 &p, uint32_t code) {
+  // bit k of the code, sign-extended (v_bfe_i32): all ones where the plane must hold a 1
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0u, 1u);
+  const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1u, 1u);
+  const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2u, 1u);
   if (FMT == 3) {
-    uint32_t a = p.y ^ ((code & 1u) - 1u);
-    uint32_t b = p.z ^ (((code >> 1) & 1u) - 1u);
-    uint32_t c = p.w ^ (((code >> 2) & 1u) - 1u);
-    return a & b & c;
+    return ~((p.y ^ m0) | (p.z ^ m1) | (p.w ^ m2));
   } else {
-    uint32_t a = p.z ^ ((code & 1u) - 1u);
-    uint32_t b = (p.z ^ (((code >> 1) & 1u) - 1u)) >> 16;
-    uint32_t c = p.w ^ (((code >> 2) & 1u) - 1u);
-    uint32_t d = (p.w ^ (((code >> 3) & 1u) - 1u)) >> 16;
-    return a & b & c & d & 0xFFFFu;
+    const uint32_t m3 = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3u, 1u);
+    const uint32_t lo = (p.z ^ m0) | (p.w ^ m2);         // planes 0 and 2 in the low halves
+    const uint32_t hi = (p.z ^ m1) | (p.w ^ m3);         // planes 1 and 3 in the high halves
+    return ~(lo | (hi >> 16)) & 0xFFFFu;
   }
 }
 // code stored at entry `bit` of this piece
 template <int FMT>
 __device__ __forceinline__ uint32_t fmx_piece_code(const uint4 &p, uint32_t bit) {
-  if (FMT == 3) {
-    return ((p.y >> bit) & 1u) | (((p.z >> bit) & 1u) << 1) | (((p.w >> bit) & 1u) << 2);
+  if (FMT == 3) {   // three v_bfe_u32 + two v_lshl_or_b32
+    const uint32_t b0 = __builtin_amdgcn_ubfe(p.y, bit, 1u), b1 = __builtin_amdgcn_ubfe(p.z, bit, 1u),
+                   b2 = __builtin_amdgcn_ubfe(p.w, bit, 1u);
+    return (b2 << 2) | ((b1 << 1) | b0);
   } else {
     return ((p.z >> bit) & 1u) | (((p.z >> (16 + bit)) & 1u) << 1) | (((p.w >> bit) & 1u) << 2) |
            (((p.w >> (16 + bit)) & 1u) << 3);

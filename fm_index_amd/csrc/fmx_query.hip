@@ -1177,6 +1177,109 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3q_kernel(
   if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+// The same walk for row-order sampling, with the hand-over moved to the TOP of the round: a walk that
+// stands on a sampled row gives its slot to the next hit at once and its sample (sample.rs:46-60) is read
+// in the same round as the new walk's first record, so a hit costs `steps` rounds of its slot instead of
+// steps + 1 (3.25 against 4 at level 2: the fresh hit that is itself sampled -- one in 2^level -- idles a round).
+template <int Q>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
+    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n, uint32_t sa_level,
+    uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  static_assert(Q == 1 || Q == 2 || Q == 4, "walks per group");
+  __shared__ unsigned int lds_q;
+  if (threadIdx.x == 0) lds_q = 0;
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint32_t slot = g & (uint32_t)(Q - 1);        // the walk whose state this lane keeps (8 / Q replicas)
+  const bool owner = g < (uint32_t)Q;                 // the replica that counts, stores and is counted
+  const uint32_t olane = (lane & ~7u) | slot;         // its lane
+  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : Q == 2 ? 0x5555555555555555ull
+                                                                                : 0xFFFFFFFFFFFFFFFFull;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample (n < 2^32 - 16)
+  const uint32_t lmask = (1u << sa_level) - 1u;
+  FmxHitQueue hq;
+  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
+  uint64_t h;
+  uint32_t row;
+  bool active = hq.take((slot << 3) | grp, h, row);   // first 8 hits -> walk 0 of the 8 groups, ...
+  hq.advance(8u * (uint32_t)Q, lds_q);
+  if (!active) row = 0u;
+  uint32_t steps = 0, nsteps = 0;
+  for (;;) {
+    if (!__any(active)) break;                        // nothing is left over: a finished walk is completed below
+    // walks standing on a sampled row: the slot goes to the next hit, the walk is completed in this round
+    const bool done = active && (row & lmask) == 0u;
+    const unsigned long long fm = __ballot(done && owner);     // one bit per finishing walk
+    uint32_t fin_si = NONE, fin_steps = 0;
+    uint64_t fin_h = 0;
+    if (fm) {                                         // wave-uniform
+      uint64_t h_new;
+      uint32_t r_new;
+      const bool ok = hq.take((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), h_new, r_new);
+      if (done) {
+        fin_si = row >> sa_level;
+        fin_steps = steps;
+        fin_h = h;
+        nsteps += steps;
+        h = h_new;
+        active = ok;
+        row = ok ? r_new : 0u;
+        steps = 0;
+      }
+      hq.advance((uint32_t)__popcll(fm), lds_q);
+    }
+    uint32_t sa = 0;
+    if (fin_si != NONE) {                             // sample.rs:46-60 Some(sa)
+      FMX_CHECK((uint64_t)fin_si <= (((uint64_t)n - 1) >> sa_level));
+      if (owner) FMX_TOUCH(&samples[fin_si]);
+      sa = samples[fin_si];
+    }
+    // one record per walking walk: the row goes from the lane that keeps it to its quad
+    const bool walking = active && (row & lmask) != 0u;
+    const uint32_t rowx = walking ? row : NONE;
+    const unsigned long long wm = __ballot(walking);
+    uint4 p[Q];
+    uint32_t rq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      rq[q] = NONE;
+      if (!(wm & (SLOT0 << q))) continue;             // walk q idle in every group of the wave
+      rq[q] = Q == 1 ? rowx : fmx_quad_bcast(rowx, q);
+      if (rq[q] != NONE) {                            // group-uniform
+        FMX_CHECK(rq[q] < n && (rq[q] >> 8) < n / 256u + 1u);
+        const uint4 *addr = rec + ((size_t)(rq[q] >> 8) * 8u + g);
+        FMX_TOUCH_G0(g, addr - g);
+        p[q] = *addr;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (!(wm & (SLOT0 << q))) continue;
+      if (rq[q] != NONE) {                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+        const uint32_t off = rq[q] & 255u;
+        const uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
+        const uint32_t nr = fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));   // absolute counters
+        if (slot == (uint32_t)q) {
+          row = nr;
+          steps++;
+        }
+      }
+    }
+    if (fin_si != NONE && owner) {
+      uint64_t v = (uint64_t)sa + fin_steps;          // fm_index.rs:131-133: (sa + steps) % len
+      if (v >= n) v -= n;
+      out_pos[fin_h] = v;
+    }
+  }
+  if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
 // probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects; FM over several wavelet
 // levels: one access+rank round per level (eight records in flight per lane).  Lanes take
@@ -1211,50 +1314,46 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
   uint32_t steps = 0, nsteps = 0;
   // text-order sampling (FmxDev::phase; wave-uniform): stage of the lane's walk -- 0 phase piece of the
   // start row, 1 LF steps (`rem` of them, no test in between), 2 phase piece of the final row for its
-  // rank among the sampled rows, 3 the sample -- every stage one lane-wise 16-byte probe or one LF step
+  // rank among the sampled rows, 3 the sample.
+  // One round = the lane-wise probes of the lanes that need them, chained (phase piece -> sample ->
+  // position -> next hit), THEN one LF step of every walking lane: a hit costs `steps` rounds (+ 1 in
+  // text order) of its lane instead of one round per stage, and no LF step runs with idle probing lanes.
   const bool text = ix.phase != nullptr;
   uint32_t st = 0, rem = 0, sidx = 0;
   while (__any(active)) {
-    const bool probing = text && active && (st == 0u || st == 2u);
-    const bool sampled = active && (text ? st == 3u : (row & lmask) == 0u);
-    uint32_t sa = 0, pt = 0;
-    uint4 pc = make_uint4(0u, 0u, 0u, 0u);
-    if (probing) {
-      const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
-      FMX_TOUCH(&ix.phase[pi]);
-      pc = ix.phase[pi];
-    }
-    if (sampled) {                                  // sample.rs:46-60 Some(sa)
-      const uint32_t si = text ? sidx : row >> ix.sa_level;
-      FMX_CHECK(si < ix.nsamples);
-      FMX_TOUCH(&ix.samples[si]);
-      sa = ix.samples[si];
-    }
-    const bool walking = active && !sampled && !probing;
-    if (__any(walking)) {                           // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186
-      uint32_t sym;
-      const uint32_t nrow = KIND == FMX_KIND_RLFM
-                                ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
-                                : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
-      if (walking) {
-        row = nrow; steps++; nsteps++;
-        if (text && --rem == 0u) st = 2u;
+    if (text) {
+      const bool probing = active && (st == 0u || st == 2u);
+      if (__any(probing)) {                           // wave-uniform
+        uint32_t pt = 0;
+        uint4 pc = make_uint4(0u, 0u, 0u, 0u);
+        if (probing) {
+          const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
+          FMX_TOUCH(&ix.phase[pi]);
+          pc = ix.phase[pi];
+          uint32_t rank0;
+          const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
+          sidx = rank0;
+          rem = phi;
+          st = (st == 2u || phi == 0u) ? 3u : 1u;
+        }
       }
     }
-    if (probing) {
-      uint32_t rank0;
-      const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
-      sidx = rank0;
-      rem = phi;
-      st = (st == 2u || phi == 0u) ? 3u : 1u;
-    }
+    // walks standing on their sampled row: sample -> position; their lanes take the next hits
+    const bool sampled = active && (text ? st == 3u : (row & lmask) == 0u);
     const unsigned long long fmask = __ballot(sampled);
-    if (fmask) {                                    // wave-uniform
+    if (fmask) {                                      // wave-uniform
+      uint32_t sa = 0;
+      if (sampled) {                                  // sample.rs:46-60 Some(sa)
+        const uint32_t si = text ? sidx : row >> ix.sa_level;
+        FMX_CHECK(si < ix.nsamples);
+        FMX_TOUCH(&ix.samples[si]);
+        sa = ix.samples[si];
+      }
       uint64_t h_new;
       uint32_t r_new;
       const bool ok = hq.take((uint32_t)__popcll(fmask & ((1ull << lane) - 1ull)), h_new, r_new);
       if (sampled) {
-        uint64_t v = (uint64_t)sa + steps;          // rlfmi.rs:181: (sa + steps) % len
+        uint64_t v = (uint64_t)sa + steps;            // rlfmi.rs:181: (sa + steps) % len
         if (v >= ix.n) v -= ix.n;
         out_pos[h] = v;
         h = h_new;
@@ -1264,6 +1363,19 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
         row = ok ? r_new : 0u;
       }
       hq.advance((uint32_t)__popcll(fmask), lds_q);
+    }
+    // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186 -- a hit taken above walks in this same round
+    // (row order) or after its phase piece in the next (text order)
+    const bool walking = active && (text ? st == 1u : (row & lmask) != 0u);
+    if (__any(walking)) {
+      uint32_t sym;
+      const uint32_t nrow = KIND == FMX_KIND_RLFM
+                                ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
+                                : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
+      if (walking) {
+        row = nrow; steps++; nsteps++;
+        if (text && --rem == 0u) st = 2u;
+      }
     }
   }
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
@@ -1778,11 +1890,20 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(lthreads), 0, st,             \
                      w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
                      d_pos, steps)
+#define FMX_LOCP_LAUNCH(Q)                                                                         \
+  hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q>), dim3(gr), dim3(lthreads), 0, st, w.lv[0].rec,       \
+                     dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps)
     if (v != 22) {          // walk state distributed over the lanes of a group
       if (dv.phase) {
         if (q == 4) FMX_LOCQ_LAUNCH(4, true); else if (q == 2) FMX_LOCQ_LAUNCH(2, true); else FMX_LOCQ_LAUNCH(1, true);
-      } else {
+      }
+#ifdef FMX_MEASURE
+      else if (v == 23) {   // hand-over at the end of the round
         if (q == 4) FMX_LOCQ_LAUNCH(4, false); else if (q == 2) FMX_LOCQ_LAUNCH(2, false); else FMX_LOCQ_LAUNCH(1, false);
+      }
+#endif
+      else {
+        if (q == 4) FMX_LOCP_LAUNCH(4); else if (q == 2) FMX_LOCP_LAUNCH(2); else FMX_LOCP_LAUNCH(1);
       }
     }
 #ifdef FMX_MEASURE

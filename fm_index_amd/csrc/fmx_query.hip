@@ -1929,11 +1929,12 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // FM over several levels: the endpoint-per-lane walk pays once the batch is throughput-bound
     // (7.9e8 hits: 7.4e9 hits/s against 5.9e9); up to 2^20 hits the group-per-walk kernel has the shorter
     // step (benchmarks/gpu/small_shapes.py: 175 vs 187 us at n = 2^16, 247 vs 297 us at n = 2^27)
-    const bool fm_ep = idx->kind == FMX_KIND_FM && ((w.nlevels >= 2 && total >= (4u << 20)) || fmx_variant() == 21);
+    const bool fm_ep = idx->kind == FMX_KIND_FM &&
+                       ((w.nlevels >= 2 && total >= (uint64_t)fmx_env_long("FMX_FM_EP_MIN", 4l << 20)) || fmx_variant() == 21);
     // RLFM: one walk per lane wins once there are enough hits to keep its 64-wide rounds busy: 2^20 hits
     // 0.22-0.38 ms against 0.44-0.67 ms, but 2^16 hits 0.10-0.16 against 0.09-0.12 ms and fewer about
     // equal (benchmarks/gpu/small_shapes.py) -- below 2^18 hits the group-per-walk kernel runs
-    const bool rl_ep = sm > 0 && total >= (1u << 18);
+    const bool rl_ep = sm > 0 && total >= (uint64_t)fmx_env_long("FMX_RL_EP_MIN", 1l << 18);
     if ((rl_ep || fm_ep) && fmx_variant() != 0) {
       // one walk per lane: 64 walks per wave.  2^20 hits finish soonest on one 1024-thread block per CU
       // (0.435 ms; 0.52 on 128 blocks); large batches want every wave the registers admit (94 VGPRs ->

@@ -880,6 +880,18 @@ struct FmxHitQueue {
     row = first ? v0 : v1;
     return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
   }
+  // the same with the hit as an index into the slice (out_pos index = lo + x): 32-bit state for the kernels
+  // that keep one walk per lane
+  __device__ __forceinline__ bool take32(uint32_t rank, uint32_t &x, uint32_t &row) const {
+    const uint32_t idx = used + rank;
+    const bool first = idx < chunk;
+    const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
+    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
+    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
+    x = c * chunk + within;
+    row = first ? v0 : v1;
+    return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
+  }
   // `count` hits were handed out (wave-uniform, count <= chunk)
   __device__ __forceinline__ void advance(uint32_t count, unsigned int &counter) {
     used += count;
@@ -1044,6 +1056,26 @@ __device__ __forceinline__ uint32_t fmx_quad_bcast(uint32_t v, int q) {
                                                                                     : fmx_quad_bcast_c<3>(v);
 }
 
+// value of lane (8 * (lane / 8) + q) for the eight lanes of a group: broadcast inside the quad that holds
+// lane q, then mirrored into the group's other quad (row_half_mirror, written to that quad's banks only)
+template <int QQ>
+__device__ __forceinline__ uint32_t fmx_oct_bcast_c(uint32_t v) {
+  const int t = __builtin_amdgcn_update_dpp(0, (int)v, (QQ & 3) * 0x55, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, QQ < 4 ? 0xA : 0x5, false);
+}
+__device__ __forceinline__ uint32_t fmx_oct_bcast(uint32_t v, int q) {
+  switch (q) {
+    case 0: return fmx_oct_bcast_c<0>(v);
+    case 1: return fmx_oct_bcast_c<1>(v);
+    case 2: return fmx_oct_bcast_c<2>(v);
+    case 3: return fmx_oct_bcast_c<3>(v);
+    case 4: return fmx_oct_bcast_c<4>(v);
+    case 5: return fmx_oct_bcast_c<5>(v);
+    case 6: return fmx_oct_bcast_c<6>(v);
+    default: return fmx_oct_bcast_c<7>(v);
+  }
+}
+
 // locate walk, single 3-bit level (DNA), walk state DISTRIBUTED over the lanes of a group.  A group of 8
 // lanes still serves Q walks at a time with one 128-byte record per LF step (fm_index.rs:134-137), but the
 // state of walk q (row, steps, hit index, stage) lives in lane q of each quad of the group instead of being
@@ -1186,7 +1218,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n, uint32_t sa_level,
     uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  static_assert(Q == 1 || Q == 2 || Q == 4, "walks per group");
+  static_assert(Q == 1 || Q == 2 || Q == 4 || Q == 8, "walks per group");
   __shared__ unsigned int lds_q;
   if (threadIdx.x == 0) lds_q = 0;
   __syncthreads();
@@ -1199,15 +1231,17 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
   const uint32_t slot = g & (uint32_t)(Q - 1);        // the walk whose state this lane keeps (8 / Q replicas)
   const bool owner = g < (uint32_t)Q;                 // the replica that counts, stores and is counted
   const uint32_t olane = (lane & ~7u) | slot;         // its lane
-  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : Q == 2 ? 0x5555555555555555ull
-                                                                                : 0xFFFFFFFFFFFFFFFFull;
+  constexpr unsigned long long SLOT0 = Q == 8   ? 0x0101010101010101ull
+                                       : Q == 4 ? 0x1111111111111111ull
+                                       : Q == 2 ? 0x5555555555555555ull
+                                                : 0xFFFFFFFFFFFFFFFFull;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample (n < 2^32 - 16)
   const uint32_t lmask = (1u << sa_level) - 1u;
   FmxHitQueue hq;
   hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
-  uint64_t h;
-  uint32_t row;
-  bool active = hq.take((slot << 3) | grp, h, row);   // first 8 hits -> walk 0 of the 8 groups, ...
+  uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
+  uint32_t hx, row;                                   // hit (index into the slice) and current row of the walk
+  bool active = hq.take32((slot << 3) | grp, hx, row);   // first 8 hits -> walk 0 of the 8 groups, ...
   hq.advance(8u * (uint32_t)Q, lds_q);
   if (!active) row = 0u;
   uint32_t steps = 0, nsteps = 0;
@@ -1216,18 +1250,16 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     // walks standing on a sampled row: the slot goes to the next hit, the walk is completed in this round
     const bool done = active && (row & lmask) == 0u;
     const unsigned long long fm = __ballot(done && owner);     // one bit per finishing walk
-    uint32_t fin_si = NONE, fin_steps = 0;
-    uint64_t fin_h = 0;
+    uint32_t fin_si = NONE, fin_steps = 0, fin_x = 0;
     if (fm) {                                         // wave-uniform
-      uint64_t h_new;
-      uint32_t r_new;
-      const bool ok = hq.take((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), h_new, r_new);
+      uint32_t x_new, r_new;
+      const bool ok = hq.take32((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), x_new, r_new);
       if (done) {
         fin_si = row >> sa_level;
         fin_steps = steps;
-        fin_h = h;
+        fin_x = hx;
         nsteps += steps;
-        h = h_new;
+        hx = x_new;
         active = ok;
         row = ok ? r_new : 0u;
         steps = 0;
@@ -1240,7 +1272,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
       if (owner) FMX_TOUCH(&samples[fin_si]);
       sa = samples[fin_si];
     }
-    // one record per walking walk: the row goes from the lane that keeps it to its quad
+    // one record per walking walk: the row goes from the lane that keeps it to the group
     const bool walking = active && (row & lmask) != 0u;
     const uint32_t rowx = walking ? row : NONE;
     const unsigned long long wm = __ballot(walking);
@@ -1250,7 +1282,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     for (int q = 0; q < Q; q++) {
       rq[q] = NONE;
       if (!(wm & (SLOT0 << q))) continue;             // walk q idle in every group of the wave
-      rq[q] = Q == 1 ? rowx : fmx_quad_bcast(rowx, q);
+      rq[q] = Q == 1 ? rowx : Q == 8 ? fmx_oct_bcast(rowx, q) : fmx_quad_bcast(rowx, q);
       if (rq[q] != NONE) {                            // group-uniform
         FMX_CHECK(rq[q] < n && (rq[q] >> 8) < n / 256u + 1u);
         const uint4 *addr = rec + ((size_t)(rq[q] >> 8) * 8u + g);
@@ -1272,9 +1304,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
       }
     }
     if (fin_si != NONE && owner) {
-      uint64_t v = (uint64_t)sa + fin_steps;          // fm_index.rs:131-133: (sa + steps) % len
-      if (v >= n) v -= n;
-      out_pos[fin_h] = v;
+      // fm_index.rs:131-133: (sa + steps) % len, in 32 bits: sa < n, steps < n, so the sum is below 2n and
+      // one subtraction of n (modulo 2^32) is exact whether or not the addition wrapped
+      uint32_t v = sa + fin_steps;
+      if (v < sa || v >= n) v -= n;
+      out[fin_x] = (uint64_t)v;
     }
   }
   if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
@@ -1866,7 +1900,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       fmx_variant() != 0 && fmx_variant() != 21) {
     // walks per group: 4 when the batch is large enough to keep every group busy with them
     const int v = fmx_variant();
-    const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (total >= (1u << 16) ? 4 : 1);
+    const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (v == 15) ? 8 : (total >= (1u << 16) ? 4 : 1);
     uint32_t hpb;
     unsigned gr;
     const unsigned lthreads = (unsigned)fmx_env_long("FMX_LOC_THREADS", FMX_LOC_BLOCK);
@@ -1903,6 +1937,9 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       }
 #endif
       else {
+#ifdef FMX_MEASURE   // 8 walks per group (FMX_VARIANT=15): 16 % fewer instructions per walk, 71 VGPRs, no faster
+        if (q == 8) FMX_LOCP_LAUNCH(8); else
+#endif
         if (q == 4) FMX_LOCP_LAUNCH(4); else if (q == 2) FMX_LOCP_LAUNCH(2); else FMX_LOCP_LAUNCH(1);
       }
     }

@@ -70,6 +70,36 @@ __device__ __forceinline__ uint32_t fmx_group_min(uint32_t v) {
   return v;
 }
 
+// value of lane (4 * (lane / 4) + q) for the four lanes of a quad (DPP quad_perm [q,q,q,q])
+template <int QQ>
+__device__ __forceinline__ uint32_t fmx_quad_bcast_c(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, QQ * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t fmx_quad_bcast(uint32_t v, int q) {
+  return q == 0 ? fmx_quad_bcast_c<0>(v) : q == 1 ? fmx_quad_bcast_c<1>(v) : q == 2 ? fmx_quad_bcast_c<2>(v)
+                                                                                    : fmx_quad_bcast_c<3>(v);
+}
+
+// value of lane (8 * (lane / 8) + q) for the eight lanes of a group: broadcast inside the quad that holds
+// lane q, then mirrored into the group's other quad (row_half_mirror, written to that quad's banks only)
+template <int QQ>
+__device__ __forceinline__ uint32_t fmx_oct_bcast_c(uint32_t v) {
+  const int t = __builtin_amdgcn_update_dpp(0, (int)v, (QQ & 3) * 0x55, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, QQ < 4 ? 0xA : 0x5, false);
+}
+__device__ __forceinline__ uint32_t fmx_oct_bcast(uint32_t v, int q) {
+  switch (q) {
+    case 0: return fmx_oct_bcast_c<0>(v);
+    case 1: return fmx_oct_bcast_c<1>(v);
+    case 2: return fmx_oct_bcast_c<2>(v);
+    case 3: return fmx_oct_bcast_c<3>(v);
+    case 4: return fmx_oct_bcast_c<4>(v);
+    case 5: return fmx_oct_bcast_c<5>(v);
+    case 6: return fmx_oct_bcast_c<6>(v);
+    default: return fmx_oct_bcast_c<7>(v);
+  }
+}
+
 // ---- per-piece helpers -------------------------------------------------------
 // bitmask (over the piece's entries) of entries whose level code == code
 template <int FMT>

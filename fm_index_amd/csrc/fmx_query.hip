@@ -349,6 +349,128 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+// ---------------------------------------------------------------------------
+// The same count with the PATTERN STATE DISTRIBUTED over the lanes of a group (the form the DNA walk
+// kernel takes, fmx_locate_f3p_kernel): a group of 8 lanes still reads one 128-byte record per interval
+// end, but it advances Q patterns at a time and lane q of each quad keeps pattern q -- its offsets, the
+// symbols still to consume, (s, e) -- so fetching the next symbol, the early exit (wrapper.rs:111-113),
+// the outputs and the start of the next pattern run once per round for all Q, lane-wise, and only the
+// two record loads + the two rank decodes run per pattern (s, e, c broadcast inside the quad).
+// No k-mer table here (that lookup is cooperative over the group): fmx_count_f3_kernel serves it.
+// ---------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ uint32_t fmx_slot_bcast(uint32_t v, int q) {
+  return Q == 1 ? v : fmx_quad_bcast(v, q);
+}
+template <int Q>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3d_kernel(
+    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
+    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  static_assert(Q == 2 || Q == 4, "patterns per group");
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  [[maybe_unused]] const uint32_t nrec = n / 256u + 1u;
+  const uint32_t slot = g & (uint32_t)(Q - 1);        // the pattern whose state this lane keeps (8 / Q replicas)
+  const bool owner = g < (uint32_t)Q;                 // the replica that stores and counts
+  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // not a position (n < 2^32 - 16)
+  const uint64_t ptot = npat ? off[npat] : 0;         // symbols the caller declares behind `pat`
+
+  uint64_t k = gid * (uint64_t)Q + slot;              // a group's Q patterns are neighbours: their offsets,
+  const uint64_t kstride = ngroups * (uint64_t)Q;     // symbols and outputs share cache lines
+  bool active = k < npat, fresh = true;
+  uint64_t pbeg = 0;
+  uint32_t j = 0, s = 0, e = 0, c = 0, nsteps = 0;
+  while (__any(active)) {
+    if (active && fresh) {
+      pbeg = off[k];
+      const uint64_t pend = off[k + 1];
+      j = (uint32_t)(pend - pbeg);
+      // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
+      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      if (badoff) j = 0;
+      bool bad = badoff;
+      if (s0e0) {              // Search::search on an existing Search (wrapper.rs:105-106)
+        const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
+        s = (uint32_t)s64;
+        e = (uint32_t)e64;
+        if (s64 > n || e64 > n || badoff) {            // not a range of this index: refuse, do not read
+          bad = true;
+          s = 0; e = 0; j = 0;
+        }
+      } else {                 // (0, len)   wrapper.rs:41
+        s = 0;
+        e = badoff ? 0u : n;
+      }
+      if (bad && owner) atomicOr(status, 1u << FMX_ERR_ARG);
+      c = j ? pat[pbeg + j - 1] : 0u;                  // last symbol: pattern.iter().rev()
+      fresh = false;
+    }
+    const bool stepping = active && j != 0 && c <= max_character;
+    // the next symbol rides along with this round's record loads
+    uint32_t cn = 0;
+    if (stepping && j > 1) cn = pat[pbeg + j - 2];
+    const uint32_t sx = stepping ? s : NONE;
+    const unsigned long long wm = __ballot(stepping);
+    uint4 a[Q], b[Q];
+    uint32_t sq[Q], eq[Q], cq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      sq[q] = NONE; eq[q] = 0; cq[q] = 0;
+      if (!(wm & (SLOT0 << q))) continue;              // pattern q idle in every group of the wave
+      sq[q] = fmx_slot_bcast<Q>(sx, q);
+      eq[q] = fmx_slot_bcast<Q>(e, q);
+      cq[q] = fmx_slot_bcast<Q>(c, q);
+      if (sq[q] != NONE) {                             // group-uniform
+        const uint32_t rs = sq[q] >> 8, re = eq[q] >> 8;
+        FMX_CHECK(rs < nrec && re < nrec);
+        FMX_TOUCH_G0(g, &rec[(size_t)rs * 8u]);
+        if (re != rs) FMX_TOUCH_G0(g, &rec[(size_t)re * 8u]);   // both ends in one record: ONE line
+        a[q] = rec[(size_t)rs * 8u + g];
+        b[q] = rec[(size_t)re * 8u + g];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (!(wm & (SLOT0 << q))) continue;
+      if (sq[q] != NONE) {
+        const uint32_t ns = fmx_group_sum(fmx_piece_rank<3>(a[q], sq[q] & 255u, cq[q], g));  // wrapper.rs:109
+        const uint32_t ne = fmx_group_sum(fmx_piece_rank<3>(b[q], eq[q] & 255u, cq[q], g));  // wrapper.rs:110
+        if (slot == (uint32_t)q) { s = ns; e = ne; }
+      }
+    }
+    if (active) {
+      bool done = j == 0;
+      if (!done) {
+        if (!stepping) {                               // reference: panic on cs[c]
+          if (owner) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
+          s = 0; e = 0; done = true;
+        } else {
+          c = cn;
+          j--;
+          nsteps++;
+          if (s == e || j == 0) done = true;           // wrapper.rs:111-113
+        }
+      }
+      if (done) {
+        if (owner) {
+          if (out_s) out_s[k] = s;
+          if (out_e) out_e[k] = e;
+          if (out_cnt) out_cnt[k] = (uint64_t)(e - s);  // wrapper.rs:132-134
+        }
+        k += kstride;
+        active = k < npat;
+        fresh = true;
+      }
+    }
+  }
+  if (steps_out && owner && nsteps)
+    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 #ifdef FMX_MEASURE
 // ---------------------------------------------------------------------------
 // Measurement-only alternatives to the 8-lane-group shape (selected
@@ -1046,36 +1168,6 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
 }
 #endif  // FMX_MEASURE
 
-// value of lane (4 * (lane / 4) + q) for the four lanes of a quad (DPP quad_perm [q,q,q,q])
-template <int QQ>
-__device__ __forceinline__ uint32_t fmx_quad_bcast_c(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, QQ * 0x55, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t fmx_quad_bcast(uint32_t v, int q) {
-  return q == 0 ? fmx_quad_bcast_c<0>(v) : q == 1 ? fmx_quad_bcast_c<1>(v) : q == 2 ? fmx_quad_bcast_c<2>(v)
-                                                                                    : fmx_quad_bcast_c<3>(v);
-}
-
-// value of lane (8 * (lane / 8) + q) for the eight lanes of a group: broadcast inside the quad that holds
-// lane q, then mirrored into the group's other quad (row_half_mirror, written to that quad's banks only)
-template <int QQ>
-__device__ __forceinline__ uint32_t fmx_oct_bcast_c(uint32_t v) {
-  const int t = __builtin_amdgcn_update_dpp(0, (int)v, (QQ & 3) * 0x55, 0xF, 0xF, true);
-  return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, QQ < 4 ? 0xA : 0x5, false);
-}
-__device__ __forceinline__ uint32_t fmx_oct_bcast(uint32_t v, int q) {
-  switch (q) {
-    case 0: return fmx_oct_bcast_c<0>(v);
-    case 1: return fmx_oct_bcast_c<1>(v);
-    case 2: return fmx_oct_bcast_c<2>(v);
-    case 3: return fmx_oct_bcast_c<3>(v);
-    case 4: return fmx_oct_bcast_c<4>(v);
-    case 5: return fmx_oct_bcast_c<5>(v);
-    case 6: return fmx_oct_bcast_c<6>(v);
-    default: return fmx_oct_bcast_c<7>(v);
-  }
-}
-
 // locate walk, single 3-bit level (DNA), walk state DISTRIBUTED over the lanes of a group.  A group of 8
 // lanes still serves Q walks at a time with one 128-byte record per LF step (fm_index.rs:134-137), but the
 // state of walk q (row, steps, hit index, stage) lives in lane q of each quad of the group instead of being
@@ -1770,6 +1862,14 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
       case 3: FMX_F3_LAUNCH(1, true, false); break;
       case 4: FMX_F3_LAUNCH(2, true, false); break;
       case 5: FMX_F3_LAUNCH(4, false, false); break;
+#endif
+#define FMX_F3D_LAUNCH(Q)                                                                          \
+  hipLaunchKernelGGL((fmx_count_f3d_kernel<Q>), dim3(fmx_grid_for_groups((npat + Q - 1) / Q)),        \
+                     dim3(FMX_BLOCK), 0, st, w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8,  \
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
+#ifdef FMX_MEASURE
+      case 24: FMX_F3D_LAUNCH(4); break;
+      case 25: FMX_F3D_LAUNCH(2); break;
 #endif
       default:
         if (km) FMX_F3_LAUNCH(1, false, true);

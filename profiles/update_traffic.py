@@ -29,6 +29,9 @@ def main():
                      "when `csrc_hash` equals the hash of the current fm_index_amd/csrc sources "
                      "(fm_index_amd/_lib.py::csrc_hash); regenerate with profiles/update_traffic.py.",
          key: {"csrc_hash": h, "count": ent(d["roofline"], src), "locate": ent(d["locate"]["roofline"], src)}}
+    r3b = (d.get("locate_3b") or {}).get("roofline")
+    if r3b and r3b.get("traffic") and r3b.get("fetch_kb_raw"):
+        t[key]["locate_3b"] = ent(r3b, src)
     if "rlfm" in d and "roofline" in d["rlfm"]:
         rc = d["rlfm"]["config"]
         rkey = "bytes-rlfm:%d:%d:%d" % (rc["patterns"], rc["pattern_len"], rc["text_len"].bit_length() - 1)

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r02
 timeout 2700 python -m pytest tests -m gpu -q > gpurun_out/r02/pytest_gpu.txt 2>&1
 tail -6 gpurun_out/r02/pytest_gpu.txt
 # the same kernels with every record / sample / piece index range-checked (libfmx_debug.so: -DFMX_DEBUG_BOUNDS)
-FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_multi_pieces.py tests/test_naive_fixtures.py -m gpu -q > gpurun_out/r02/pytest_gpu_debuglib.txt 2>&1
+FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_large_batches.py tests/test_naive_fixtures.py -m gpu -q > gpurun_out/r02/pytest_gpu_debuglib.txt 2>&1
 tail -3 gpurun_out/r02/pytest_gpu_debuglib.txt
 ( time timeout 900 python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err ) 2> gpurun_out/r02/bench_default.time
 tail -2 gpurun_out/r02/bench_default.err; grep real gpurun_out/r02/bench_default.time

@@ -1005,8 +1005,13 @@ struct FmxHitQueue {
   // the same with the hit as an index into the slice (out_pos index = lo + x): 32-bit state for the kernels
   // that keep one walk per lane
   __device__ __forceinline__ bool take32(uint32_t rank, uint32_t &x, uint32_t &row) const {
+    bool first;
+    return take32(rank, x, row, first);
+  }
+  // `first`: the hit comes from the older resident chunk c0 (else from c1)
+  __device__ __forceinline__ bool take32(uint32_t rank, uint32_t &x, uint32_t &row, bool &first) const {
     const uint32_t idx = used + rank;
-    const bool first = idx < chunk;
+    first = idx < chunk;
     const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
     const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
     const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
@@ -1015,7 +1020,8 @@ struct FmxHitQueue {
     return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
   }
   // `count` hits were handed out (wave-uniform, count <= chunk)
-  __device__ __forceinline__ void advance(uint32_t count, unsigned int &counter) {
+  // returns true when the window slid: c1 became c0 and a new c1 was drawn (wave-uniform)
+  __device__ __forceinline__ bool advance(uint32_t count, unsigned int &counter) {
     used += count;
     if (used >= chunk) {                             // wave-uniform: slide
       used -= chunk;
@@ -1023,7 +1029,9 @@ struct FmxHitQueue {
       win0 = win1;
       c1 = c1 != FMX_NOCHUNK ? valid(draw(counter, 1u)) : FMX_NOCHUNK;
       win1 = load_win(c1);
+      return true;
     }
+    return false;
   }
 };
 
@@ -1305,13 +1313,23 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3q_kernel(
 // stands on a sampled row gives its slot to the next hit at once and its sample (sample.rs:46-60) is read
 // in the same round as the new walk's first record, so a hit costs `steps` rounds of its slot instead of
 // steps + 1 (3.25 against 4 at level 2: the fresh hit that is itself sampled -- one in 2^level -- idles a round).
-template <int Q>
+// WC: the positions go through a write-combining ring in LDS.  A wave's hits come in tickets of 64
+// consecutive hit indices = 512 contiguous bytes of out_pos, but walks finish in any order, and an 8-byte
+// store on its own is one 32-byte sector and one request at the memory side (config 3b: 2.9e8 of them, 40 %
+// of the kernel's requests).  Each wave keeps its last FMX_WC_SLOTS tickets as 64 x u32 in LDS; a finished
+// walk whose ticket is still there drops its position into it, and when the slot is recycled for a new
+// ticket the wave stores what has arrived with ONE contiguous 64 x 8-byte store.  Walks that outlive
+// their ticket's residency (~4 tickets = ~26 rounds) store directly as before.  Needs 64-hit tickets.
+#define FMX_WC_SLOTS 4
+template <int Q, bool WC>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, uint32_t n, uint32_t sa_level,
     uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   static_assert(Q == 1 || Q == 2 || Q == 4 || Q == 8, "walks per group");
   __shared__ unsigned int lds_q;
+  __shared__ uint32_t wc_ring[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS * 64 : 1];
+  __shared__ uint32_t wc_tag[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS : 1];
   if (threadIdx.x == 0) lds_q = 0;
   __syncthreads();
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
@@ -1327,14 +1345,34 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
                                        : Q == 4 ? 0x1111111111111111ull
                                        : Q == 2 ? 0x5555555555555555ull
                                                 : 0xFFFFFFFFFFFFFFFFull;
-  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample (n < 2^32 - 16)
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample / no position (n < 2^32 - 16)
   const uint32_t lmask = (1u << sa_level) - 1u;
   FmxHitQueue hq;
   hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
+  // write-combining ring of this wave: slot r holds ticket ring_tag[r]; entry i of it = position of hit
+  // 64 * ticket + i (NONE until its walk has finished).  Only this wave touches its ring.
+  // (volatile: lanes read what other lanes of the wave wrote -- every access must be a real LDS operation,
+  // in program order; the LDS serves one wave's operations in order)
+  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64);
+  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS;
+  [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;   // ring slots of the resident tickets c0 / c1; tickets drawn
+  if (WC) {
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) ring[r * 64u + lane] = NONE;
+    if (lane < FMX_WC_SLOTS) ring_tag[lane] = lane == 0 ? hq.c0 : (lane == 1 ? hq.c1 : FMX_NOCHUNK);
+  }
   uint32_t hx, row;                                   // hit (index into the slice) and current row of the walk
-  bool active = hq.take32((slot << 3) | grp, hx, row);   // first 8 hits -> walk 0 of the 8 groups, ...
-  hq.advance(8u * (uint32_t)Q, lds_q);
+  [[maybe_unused]] uint32_t myslot = 0;               // WC: ring slot of the ticket the hit came from
+  bool active = hq.take32((slot << 3) | grp, hx, row);   // first 8 hits -> walk 0 of the 8 groups, ... (all of c0)
+  {
+    const bool slid = hq.advance(8u * (uint32_t)Q, lds_q);
+    if (WC && slid) {                                 // Q = 8 hands out a whole ticket at once
+      const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+      if (lane == 0) ring_tag[ns] = hq.c1;            // slot ns is still empty (all NONE)
+      rseq++; rs0 = rs1; rs1 = ns;
+    }
+  }
   if (!active) row = 0u;
   uint32_t steps = 0, nsteps = 0;
   for (;;) {
@@ -1343,20 +1381,35 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     const bool done = active && (row & lmask) == 0u;
     const unsigned long long fm = __ballot(done && owner);     // one bit per finishing walk
     uint32_t fin_si = NONE, fin_steps = 0, fin_x = 0;
+    [[maybe_unused]] uint32_t fin_slot = 0;
     if (fm) {                                         // wave-uniform
       uint32_t x_new, r_new;
-      const bool ok = hq.take32((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), x_new, r_new);
+      bool first;
+      const bool ok = hq.take32((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), x_new, r_new, first);
       if (done) {
         fin_si = row >> sa_level;
         fin_steps = steps;
         fin_x = hx;
+        fin_slot = myslot;
         nsteps += steps;
         hx = x_new;
+        myslot = first ? rs0 : rs1;
         active = ok;
         row = ok ? r_new : 0u;
         steps = 0;
       }
-      hq.advance((uint32_t)__popcll(fm), lds_q);
+      const bool slid = hq.advance((uint32_t)__popcll(fm), lds_q);
+      if (WC && slid) {
+        // a new ticket was drawn: it gets the ring slot of the oldest one, whose arrived positions leave
+        // now in one contiguous store (hit index = 64 * ticket + lane)
+        const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+        const uint32_t old_tag = ring_tag[ns];
+        const uint32_t v = ring[ns * 64u + lane];
+        if (old_tag != FMX_NOCHUNK && v != NONE) out[old_tag * 64u + lane] = (uint64_t)v;
+        ring[ns * 64u + lane] = NONE;
+        if (lane == 0) ring_tag[ns] = hq.c1;
+        rseq++; rs0 = rs1; rs1 = ns;
+      }
     }
     uint32_t sa = 0;
     if (fin_si != NONE) {                             // sample.rs:46-60 Some(sa)
@@ -1400,7 +1453,16 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
       // one subtraction of n (modulo 2^32) is exact whether or not the addition wrapped
       uint32_t v = sa + fin_steps;
       if (v < sa || v >= n) v -= n;
-      out[fin_x] = (uint64_t)v;
+      if (WC && ring_tag[fin_slot] == (fin_x >> 6)) ring[fin_slot * 64u + (fin_x & 63u)] = v;   // its ticket is resident
+      else out[fin_x] = (uint64_t)v;
+    }
+  }
+  if (WC) {                                           // what is still in the ring
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) {
+      const uint32_t tag = ring_tag[r];
+      const uint32_t v = ring[r * 64u + lane];
+      if (tag != FMX_NOCHUNK && v != NONE) out[tag * 64u + lane] = (uint64_t)v;
     }
   }
   if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
@@ -2024,9 +2086,17 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(lthreads), 0, st,             \
                      w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
                      d_pos, steps)
+    // positions through the write-combining ring when the tickets are whole 64-hit chunks
+    const bool wc = chunk == FMX_LCHUNK && v != 26;   // FMX_VARIANT=26 (measurement build): direct stores
 #define FMX_LOCP_LAUNCH(Q)                                                                         \
-  hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q>), dim3(gr), dim3(lthreads), 0, st, w.lv[0].rec,       \
-                     dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps)
+  do {                                                                                             \
+    if (wc)                                                                                        \
+      hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, true>), dim3(gr), dim3(lthreads), 0, st,         \
+                         w.lv[0].rec, dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps); \
+    else                                                                                           \
+      hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, false>), dim3(gr), dim3(lthreads), 0, st,        \
+                         w.lv[0].rec, dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps); \
+  } while (0)
     if (v != 22) {          // walk state distributed over the lanes of a group
       if (dv.phase) {
         if (q == 4) FMX_LOCQ_LAUNCH(4, true); else if (q == 2) FMX_LOCQ_LAUNCH(2, true); else FMX_LOCQ_LAUNCH(1, true);

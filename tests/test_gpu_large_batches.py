@@ -51,3 +51,20 @@ def test_rlfm_locate_millions_of_hits():
     goff, gpos = gb.locate()
     ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
     assert (goff == ooff).all() and (gpos == opos).all()
+
+
+@pytest.mark.parametrize("extra", [0, 37, 4099])
+def test_dna_locate_just_above_the_write_combining_threshold(extra):
+    """From 64 hits per wave on (>= 2^18 hits or so) the DNA walk kernel hands out whole 64-hit tickets and
+    sends the positions through its LDS write-combining ring; a batch right at that size, with a ragged
+    last ticket, must give the same ordered positions (every row of the index, then `extra` more rows)."""
+    n = 1 << 18
+    t = (W.splitmix64_np(71, 0, n) % np.uint64(4)).astype(np.uint8) + 1
+    t[-1] = 0
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    oi = O.OracleIndex(t, 4, level=2)
+    s = np.array([0, 1000], dtype=np.uint64)
+    e = np.array([n, 1000 + extra], dtype=np.uint64)
+    goff, gpos = gi.locate_many(s, e)
+    want = oi.get_sa(np.concatenate([np.arange(n), np.arange(1000, 1000 + extra)]))
+    assert int(goff[-1]) == n + extra and (gpos == want.astype(np.uint64)).all()

@@ -6,11 +6,13 @@
 //                          FMIndexBackend::get_sa      (fm_index.rs:127-140)
 //                          SOSampledSuffixArray::get   (sample.rs:46-60)
 //
-// Shape: persistent 8-lane groups.  A group owns one pattern (count) or one hit
-// (locate) at a time and runs a small state machine, so a group that finishes
-// early (the `s == e` break of wrapper.rs:111-113, or a short locate walk) picks
-// up the next unit while its wave-mates keep stepping -- no lane idles on
-// divergence except in the tail.  Integer / popcount work only; HBM-bound.
+// Shape: persistent 8-lane groups, one 128-byte record per group per request.  A count group owns one
+// pattern at a time and runs a small state machine, so a group that finishes early (the `s == e` break
+// of wrapper.rs:111-113) picks up the next pattern while its wave-mates keep stepping.  The DNA walk
+// kernel (fmx_locate_f3p_kernel) serves 4 walks per group with the state of each walk kept in ONE lane
+// of every quad, so its bookkeeping runs once per round for all of them; the run-length index and
+// large multi-level batches use one interval endpoint / one walk per lane (fmx_ep.h).
+// Integer / popcount / DPP work only; bound by HBM requests (count) and by the walk chain (locate).
 #include <cstdlib>
 #include "fmx_ep.h"
 
@@ -28,9 +30,14 @@
 //   6          ignore the k-mer start table even when it was built
 //   7          ignore the pair index even when it was built
 //   8, 9       lane-per-pattern / wavefront-per-pattern DNA count kernels
-//   11, 12, 14 DNA locate with 1 / 2 / 4 walks per group
+//   11, 12, 14, 15  DNA locate with 1 / 2 / 4 / 8 walks per group
 //   16, 17     (builder) do not store the positions of sparse / the select blocks of dense RLFM bit vectors
-// and FMX_EP_BLOCKS / FMX_LOC_WAVES (grid sizes of the endpoint-per-lane and locate kernels).
+//   18, 19     (builder) row-order / text-order suffix-array sampling for every index kind
+//   20         endpoint-per-lane count on FM indexes;  21  one-walk-per-lane locate on the one-level index
+//   22         DNA walk kernel of rounds 1-2 (state repeated in all 8 lanes);  23  hand-over at the end of the round
+//   24, 25     distributed-state DNA count kernel with 4 / 2 patterns per group;  26  positions stored directly
+// and the grid knobs FMX_EP_BLOCKS, FMX_LOC_BLOCKS, FMX_LOC_THREADS, FMX_EP_LOC_BLOCKS, FMX_RL_EP_MIN, FMX_FM_EP_MIN
+// (benchmarks/gpu/README.md).
 #ifdef FMX_MEASURE
 static inline int fmx_variant() {
   static const int cached = [] {

@@ -325,6 +325,56 @@ PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counte
 }
 
 
+def pmc_aggregate(rows, counter):
+    """{kernel: [launches, total]} of one counter from rocprofv3 counter_collection rows.  Launches of the DNA
+    walk kernel are keyed by grid as well (it runs two shapes under one name: config 3 with 2^20 hits, config 3b
+    with 2.9e8 hits on twice the blocks), and only a kernel's HEAVY launches count: a kernel may also run once
+    on a small side batch (the count that prepares config 3b), which must not dilute the per-launch mean."""
+    agg = {}
+    for row in rows:
+        if row.get("Counter_Name") != counter:
+            continue
+        kn = row.get("Kernel_Name", "?")
+        if WALK_KERNEL in kn:
+            kn = "%s @grid %s" % (kn, row.get("Grid_Size", "?"))
+        agg.setdefault(kn, []).append(float(row.get("Counter_Value", 0) or 0))
+    out = {}
+    for kn, vals in agg.items():
+        heavy = [v for v in vals if v >= 0.9 * max(vals)]
+        out[kn] = [len(heavy), sum(heavy)]
+    return out
+
+
+def pmc_grid_of(kn):
+    try:
+        return int(kn.rsplit("@grid ", 1)[1])
+    except (IndexError, ValueError):
+        return 0
+
+
+def pmc_per_dispatch(agg, subs, which="largest"):
+    """(kernel name, counter value per launch) of the leg whose kernel matches the first of `subs` present.
+    which: "largest" = the instantiation that moved the most; "grid_min" / "grid_max" = the walk kernel's
+    launches on its smallest / largest grid ("grid_max" only when two shapes were launched)."""
+    for sub in subs:
+        cands = [(kn, nd, tot) for kn, (nd, tot) in agg.items() if sub in kn]
+        if not cands:
+            continue
+        if which == "largest":
+            best = max(cands, key=lambda c: c[2])
+        else:
+            grids = sorted({pmc_grid_of(c[0]) for c in cands})
+            if which == "grid_max" and len(grids) < 2:
+                return None, None
+            g = grids[0] if which == "grid_min" else grids[-1]
+            best = max((c for c in cands if pmc_grid_of(c[0]) == g), key=lambda c: c[2])
+        return best[0], best[2] / best[1]
+    return None, None
+
+
+PMC_WHICH = {"dna_locate": "grid_min", "dna_locate_3b": "grid_max"}
+
+
 def pmc_child(args):
     """the program rocprofv3 profiles: builds the two indexes and runs each leg's kernel a few times."""
     import torch
@@ -389,52 +439,20 @@ def run_pmc_passes(args):
             if p.returncode != 0:
                 return {}, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode,
                                                                      p.stderr.decode(errors="replace")[-300:])
-            agg = {}
+            rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
                 with open(f, newline="") as fh:
-                    for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") != counter:
-                            continue
-                        # the DNA walk kernel runs two shapes under one name (config 3: 2^20 hits, config 3b:
-                        # 2.9e8 hits on twice the blocks): its launches are told apart by their grid
-                        kn = row.get("Kernel_Name", "?")
-                        if WALK_KERNEL in kn:
-                            kn = "%s @grid %s" % (kn, row.get("Grid_Size", "?"))
-                        agg.setdefault(kn, []).append(float(row.get("Counter_Value", 0) or 0))
-            # per kernel: (launches, total) of its HEAVY launches -- a kernel may also run once on a small
-            # side batch (the count that prepares config 3b), which must not dilute the per-launch mean
-            raw[counter] = {}
-            for kn, vals in agg.items():
-                heavy = [v for v in vals if v >= 0.9 * max(vals)]
-                raw[counter][kn] = [len(heavy), sum(heavy)]
+                    rows.extend(csv.DictReader(fh))
+            raw[counter] = pmc_aggregate(rows, counter)
     except (subprocess.TimeoutExpired, OSError) as ex:
         return {}, "rocprofv3 pass did not finish: %r" % (ex,)
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
-    def grid_of(kn):
-        try:
-            return int(kn.rsplit("@grid ", 1)[1])
-        except (IndexError, ValueError):
-            return 0
-
     def per_dispatch(counter, subs, which="largest"):
-        for sub in subs:     # first substring that matches a profiled kernel wins
-            cands = [(kn, nd, tot) for kn, (nd, tot) in raw.get(counter, {}).items() if sub in kn]
-            if not cands:
-                continue
-            if which == "largest":                      # the instantiation that moved the most bytes
-                best = max(cands, key=lambda c: c[2])
-            else:                                       # walk kernel: smallest / largest grid of its launches
-                grids = sorted({grid_of(c[0]) for c in cands})
-                if which == "grid_max" and len(grids) < 2:
-                    return None, None                   # only one shape was launched
-                g = grids[0] if which == "grid_min" else grids[-1]
-                best = max((c for c in cands if grid_of(c[0]) == g), key=lambda c: c[2])
-            return best[0], best[2] / best[1]
-        return None, None
+        return pmc_per_dispatch(raw.get(counter, {}), subs, which)
     for leg, subs in PMC_LEGS.items():
-        which = {"dna_locate": "grid_min", "dna_locate_3b": "grid_max"}.get(leg, "largest")
+        which = PMC_WHICH.get(leg, "largest")
         kn, fetch_kb = per_dispatch("FETCH_SIZE", subs, which)
         _, write_kb = per_dispatch("WRITE_SIZE", subs, which)
         if kn is None or fetch_kb is None:

@@ -63,6 +63,13 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real path) | gloo (rehearsal of the N>1 code path: all ranks "
                          "share cuda:0 and gather through host memory)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still open the process group (a 1-rank RCCL communicator on this GPU) and "
+                         "drive the N>1 step -- pipelined all-gather of the counts, counts-then-positions gather of "
+                         "locate -- through it; the line is the config-5 line at one rank")
+    ap.add_argument("--no-rccl-check", action="store_true",
+                    help="default N=1 run: skip the `rccl_1rank` object (the config-5 step through a 1-rank RCCL "
+                         "communicator, after the headline measurement)")
     ap.add_argument("--dump-counts", default=None, help=argparse.SUPPRESS)   # tests: gathered counts -> .npy
     ap.add_argument("--pattern-seed", type=int, default=None, help=argparse.SUPPRESS)   # tests: same global set at any N
     return ap.parse_args(argv)
@@ -532,7 +539,7 @@ def main():
     # script.  Started BEFORE this process touches the GPU (no torch import yet): the children are
     # then spawned from a process that holds no device state.
     pmc = None
-    if world == 1 and args.workload == "dna" and not args.no_pmc:
+    if world == 1 and args.workload == "dna" and not args.no_pmc and not args.force_dist:
         try:
             pmc = run_pmc_passes(args)
         except Exception as ex:  # noqa: BLE001 -- never lose the line to the counter passes
@@ -550,16 +557,11 @@ def run(args, world, pmc=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     gloo = args.dist_backend == "gloo"
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_dist = world > 1 or args.force_dist      # the N>1 step, also on a 1-rank communicator when forced
+    if use_dist:
+        dist = open_process_group(torch, local, rank, world, gloo)
         if gloo:
             local = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(local)
@@ -574,13 +576,14 @@ def run(args, world, pmc=None):
 
     # ---- headline: count (+ gather of every rank's counts for N > 1, config 5) ----
     pipe = sharding.CountGatherPipeline(npat, world, n, dev, backend="gloo" if gloo else "nccl",
-                                        pipelined=not os.environ.get("FMX_BENCH_SYNC_GATHER"))
+                                        pipelined=not os.environ.get("FMX_BENCH_SYNC_GATHER"),
+                                        force_collective=use_dist)
 
     def step():
         return pipe.step(lambda out64: wl.count(out_cnt=out64))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -597,7 +600,8 @@ def run(args, world, pmc=None):
     ev1.record(stream)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    dt_rank = dt
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -609,7 +613,7 @@ def run(args, world, pmc=None):
     last = step()
     pipe.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         # gathered counts: this rank's shard sits at [rank*npat, (rank+1)*npat) and equals its own
         mine = last[rank * npat:(rank + 1) * npat].to(torch.int64).to(dev)
         assert bool((mine == wl.d_c).all()), "gathered counts differ from this rank's"
@@ -624,7 +628,7 @@ def run(args, world, pmc=None):
     value = chars_per_step_rank * world * args.steps / dt
     # dominant kernel's average launch duration: the event bracket of the timed region at N=1
     # (launches back to back on one stream), the library's per-launch events at N>1
-    avg_kernel_ms = ev_ms / args.steps if world == 1 else kernel_ms_single
+    avg_kernel_ms = ev_ms / args.steps if not use_dist else kernel_ms_single
     stream_bytes = npat * m + (npat + 1) * 8 + 3 * npat * 8      # pattern bytes + offsets + (s, e, count)
     cen = None
     if not args.no_census and rank == 0:
@@ -648,14 +652,11 @@ def run(args, world, pmc=None):
                    "textgen_s": round(wl.textgen_s, 2)},
         "roofline": roofline,
     }
-    if world > 1:
-        out["rccl_ranks"] = dist.get_world_size()
-        out["gather"] = {"backend": "gloo (rehearsal through host memory)" if gloo else "nccl (RCCL)",
-                         "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
-                         "bytes_per_rank_per_step": npat * (4 if pipe.wire == torch.int32 else 8),
-                         "pipelined": pipe.nbuf > 1}
+    if use_dist:
+        dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, gloo, dt_rank, ev_ms,
+                    kernel_ms_single, step)
 
-    single = world == 1 and rank == 0
+    single = world == 1 and rank == 0 and not use_dist
     # ---- config 2b: uniform random patterns -> the early exit of wrapper.rs:111-113 ----
     rflat = None
     if wl.dna and single and not args.no_early_exit:
@@ -679,6 +680,13 @@ def run(args, world, pmc=None):
     # ---- locate (config 3; gathered over the ranks for N > 1) ----
     if wl.level is not None:
         locate_leg(out, wl, args, world, rank, dist, gloo, key)
+
+    # ---- the config-5 step through a 1-rank RCCL communicator on this GPU (default N=1 run) ----
+    if single and not args.no_rccl_check:
+        try:
+            rccl_1rank_leg(out, wl, args, dev, local)
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
+            out["rccl_1rank"] = {"error": repr(ex)}
 
     # ---- config 3b: short patterns, wide intervals ----
     if single and wl.dna and wl.level is not None and not args.no_3b:
@@ -719,8 +727,142 @@ def run(args, world, pmc=None):
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def open_process_group(torch, local, rank, world, gloo):
+    """one process per GPU: backend "nccl" IS RCCL on ROCm (communicator bound to this rank's device);
+    "gloo" is the rehearsal in which all ranks share cuda:0 and gather through host memory"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:            # --force-dist at N=1, started without a launcher
+        from fm_index_amd import launcher
+        os.environ["MASTER_PORT"] = str(launcher.free_port())
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
+    if gloo:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return dist
+
+
+def rccl_version_string(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def timed_sync_gather(torch, dist, pipe, gloo, reps=5):
+    """one count gather on its own (not overlapped), ms: HIP events on the launch stream around the
+    synchronous collective (nccl) / wall clock (gloo through host memory)"""
+    src, dst = pipe.local_w[0], pipe.gathered[0]
+    dist.all_gather_into_tensor(dst, src)
+    torch.cuda.synchronize()
+    if gloo:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(dst, src)
+        return (time.perf_counter() - t0) / reps * 1e3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(dst, src)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, gloo, dt_rank, ev_ms,
+                kernel_ms_single, step):
+    """the self-verifying part of the N>1 line: which backend really carried the gathers, which physical
+    GPU every rank sat on (asserted distinct under nccl), per-rank kernel / gather / step times, and the
+    event timeline showing gather k in flight under search k+1"""
+    backend = dist.get_backend()
+    nccl = backend == "nccl"
+    npat = wl.npat
+    gather_ms = timed_sync_gather(torch, dist, pipe, gloo)
+    mine = torch.tensor([kernel_ms_single, gather_ms, dt_rank / args.steps * 1e3, ev_ms / args.steps],
+                        dtype=torch.float64, device="cpu" if gloo else wl.dev)
+    allr = torch.empty(4 * world, dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(allr, mine)
+    allr = allr.cpu().view(world, 4).tolist()
+    idents = sharding.gather_device_identities(local)
+    if nccl:                     # under gloo all ranks share cuda:0 on purpose (rehearsal)
+        sharding.assert_distinct_devices(idents)
+    # event timeline of a few traced steps (outside the timed region)
+    tr = None
+    if nccl:
+        tp = sharding.CountGatherPipeline(npat, world, wl.n, wl.dev, backend="nccl", force_collective=True, trace=True)
+        for _ in range(8):
+            tp.step(lambda out64: wl.count(out_cnt=out64))
+        tp.drain()
+        torch.cuda.synchronize()
+        tr = tp.trace_report()
+        del tp
+    # rccl_ranks: ranks of the RCCL communicator that carried the gathers -- null unless the backend is nccl
+    out["rccl_ranks"] = dist.get_world_size() if nccl else None
+    out["rccl_version"] = rccl_version_string(torch) if nccl else None
+    out["dist_backend"] = backend
+    out["devices"] = idents
+    out["per_rank"] = [{"rank": r, "kernel_ms": round(v[0], 4), "gather_ms": round(v[1], 4),
+                        "wall_ms_per_step": round(v[2], 4), "stream_ms_per_step": round(v[3], 4)}
+                       for r, v in enumerate(allr)]
+    out["gather"] = {"backend": "gloo (rehearsal through host memory)" if gloo else "nccl (RCCL)",
+                     "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
+                     "bytes_per_rank_per_step": npat * (4 if pipe.wire == torch.int32 else 8),
+                     "pipelined": pipe.nbuf > 1, "trace": tr}
+
+
+def rccl_1rank_leg(out, wl, args, dev, local):
+    """default N=1 run: the step that ships for N>1 (sharding.CountGatherPipeline + gather_positions) through
+    a 1-rank RCCL communicator on this GPU, so that the driver's single-GPU line carries hardware evidence of
+    the RCCL path (communicator, device-side all_gather_into_tensor, async Work ordering under the next
+    search) even when no multi-GPU node is available.  Counts and positions must equal the ungathered ones."""
+    import torch
+    from fm_index_amd import sharding
+    dist = open_process_group(torch, local, 0, 1, False)
+    try:
+        npat, m = wl.npat, wl.m
+        wl.count()
+        torch.cuda.synchronize()
+        ref_c = wl.d_c.clone()
+        pipe = sharding.CountGatherPipeline(npat, 1, wl.n, dev, backend="nccl", force_collective=True, trace=True)
+        for _ in range(args.warmup):
+            pipe.step(lambda o: wl.count(out_cnt=o))
+        pipe.drain()
+        torch.cuda.synchronize()
+        pipe.events.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g = pipe.step(lambda o: wl.count(out_cnt=o))
+        pipe.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool((g.to(torch.int64) == ref_c).all()), "counts gathered over RCCL differ"
+        o = {"backend": dist.get_backend(), "rccl_version": rccl_version_string(torch), "ranks": dist.get_world_size(),
+             "device": sharding.device_identity(local), "value": npat * m * args.steps / dt,
+             "unit": "pattern-chars/s", "ms_per_step": dt / args.steps * 1e3,
+             "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
+             "gather_ms": round(timed_sync_gather(torch, dist, pipe, False), 4), "trace": pipe.trace_report(),
+             "note": "config-5 step at one rank: pipelined all_gather_into_tensor of the counts over a 1-rank RCCL "
+                     "communicator on this GPU; counts identical to the ungathered run"}
+        if wl.level is not None and getattr(wl, "total_hits", None):
+            wl.locate()
+            cnt = (wl.d_e - wl.d_s)
+            goff, gpos = sharding.gather_positions(cnt, wl.d_pos[:wl.total_hits], npat)
+            torch.cuda.synchronize()
+            assert int(goff[-1].item()) == wl.total_hits and bool((gpos == wl.d_pos[:wl.total_hits]).all()), \
+                "positions gathered over RCCL differ"
+            o["positions_gathered"] = wl.total_hits
+        out["rccl_1rank"] = o
+    finally:
         dist.destroy_process_group()
 
 
@@ -817,16 +959,18 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     torch.cuda.synchronize()
     lsteps = max(3, args.steps // 2)
 
+    use_dist = dist is not None
+
     def lstep():
         wl.locate()
-        if world > 1:       # config 5: positions of every rank, in input order, on every rank
+        if use_dist:        # config 5: positions of every rank, in input order, on every rank
             cnt = (wl.d_e - wl.d_s)
             lp = wl.d_pos[:total_hits]
             if gloo:
                 cnt, lp = cnt.cpu(), lp.cpu()
             return sharding.gather_positions(cnt, lp, npat * world)
         return None
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -835,7 +979,7 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     torch.cuda.synchronize()
     ldt = time.perf_counter() - t0
     all_hits = total_hits
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([ldt], dtype=torch.float64, device="cpu" if gloo else wl.dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ldt = float(tt.item())
@@ -869,11 +1013,60 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
                                                         "fmx_locate_kernel<FMX_KIND_FM>")
     roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
                          stored_traffic(key, "locate"))
+    two = None
+    if not use_dist:
+        try:
+            two = locate_two_streams(wl, max(8, lsteps))
+        except Exception as ex:  # noqa: BLE001 -- never lose the leg to its extra measurement
+            two = {"error": repr(ex)}
     dest[legname] = {"hits_per_s": all_hits * lsteps / ldt, "hits": all_hits, "hits_per_gpu": total_hits,
                      "lf_steps": lf_steps, "level": wl.level, "ms_per_batch": ldt / lsteps * 1e3,
                      "includes": "row expansion + walk" + (" + gather of counts and positions over the ranks"
-                                                           if world > 1 else ""),
+                                                           if use_dist else ""),
                      "roofline": roof}
+    if two is not None:
+        dest[legname]["two_streams"] = two
+
+
+def locate_two_streams(wl, reps):
+    """the same batch alternating between two streams through the caller-workspace entry point
+    (fmx_locate_batch_ws_dev: kernel launches only, nothing shared between the streams but the index), so
+    that one batch's longest walks run under the next batch's bulk.  Positions of both streams must equal
+    the single-stream result."""
+    torch, lib = wl.torch, wl.lib
+    total, npat = wl.total_hits, wl.npat
+    wsb = int(lib.fmx_locate_workspace_bytes(wl.h, total))
+    streams = [torch.cuda.Stream(device=wl.dev), torch.cuda.Stream(device=wl.dev)]
+    ws = [torch.empty(wsb, dtype=torch.uint8, device=wl.dev) for _ in range(2)]
+    pos = [torch.empty(max(total, 1), dtype=torch.int64, device=wl.dev) for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def launch(i):
+        rc = lib.fmx_locate_batch_ws_dev(wl.h, C.c_void_p(wl.d_s.data_ptr()), C.c_void_p(wl.d_e.data_ptr()), npat,
+                                         C.c_void_p(wl.d_off.data_ptr()), total, C.c_void_p(pos[i].data_ptr()),
+                                         C.c_void_p(ws[i].data_ptr()), wsb, C.c_void_p(streams[i].cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+    for i in (0, 1, 0, 1):
+        launch(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(2 * reps):
+        launch(r & 1)
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / (2 * reps)
+    # one stream, same entry point (what the workspace form alone buys)
+    t0 = time.perf_counter()
+    for r in range(2 * reps):
+        launch(0)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / (2 * reps)
+    ok = bool((pos[0][:total] == wl.d_pos[:total]).all()) and bool((pos[1][:total] == wl.d_pos[:total]).all())
+    assert ok, "workspace-form locate differs from fmx_locate_batch_dev"
+    return {"ms_per_batch": dt2 * 1e3, "hits_per_s": total / dt2, "one_stream_ws_ms_per_batch": dt1 * 1e3,
+            "one_stream_ws_hits_per_s": total / dt1, "workspace_bytes": wsb,
+            "note": "fmx_locate_batch_ws_dev, batches alternating between two streams with their own workspace "
+                    "and output; positions identical to fmx_locate_batch_dev"}
 
 
 def setup_3b(wl):

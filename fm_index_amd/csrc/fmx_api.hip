@@ -261,6 +261,31 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   return fmx_launch_locate(idx, d_s, d_e, npat, d_out_off, total_hits, d_out_pos, (hipStream_t)stream);
 }
+// caller-workspace forms: kernel launches only (no stream-ordered allocation) -> graph-capturable, and
+// batches on different streams share nothing but the index
+uint64_t fmx_locate_workspace_bytes(const fmx_index *idx, uint64_t total_hits) {
+  (void)idx;
+  return fmx_locate_rows_bytes(total_hits);
+}
+uint64_t fmx_offsets_workspace_bytes(uint64_t npat) { return fmx_offsets_tile_bytes(npat); }
+int fmx_locate_batch_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                            uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,
+                            uint64_t *d_out_pos, void *d_workspace, uint64_t workspace_bytes, void *stream) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  if (npat == 0 || total_hits == 0) return FMX_OK;
+  if (!d_workspace || workspace_bytes < fmx_locate_rows_bytes(total_hits) || ((uintptr_t)d_workspace & 15u))
+    return fail(FMX_ERR_ARG, "workspace is NULL, misaligned or smaller than fmx_locate_workspace_bytes()");
+  return fmx_launch_locate(idx, d_s, d_e, npat, d_out_off, total_hits, d_out_pos, (hipStream_t)stream,
+                           (uint32_t *)d_workspace);
+}
+int fmx_offsets_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                       uint64_t *d_out_off, void *d_workspace, uint64_t workspace_bytes, void *stream) {
+  CHECK_IDX(idx);
+  if (!d_workspace || workspace_bytes < fmx_offsets_tile_bytes(npat) || ((uintptr_t)d_workspace & 7u))
+    return fail(FMX_ERR_ARG, "workspace is NULL, misaligned or smaller than fmx_offsets_workspace_bytes()");
+  return fmx_launch_offsets(d_s, d_e, npat, d_out_off, (hipStream_t)stream, (uint64_t *)d_workspace);
+}
 int fmx_get_l_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
   CHECK_IDX(idx);
   return fmx_launch_scalar(idx, 0, nullptr, d_i, k, d_out, (hipStream_t)stream);
@@ -531,16 +556,19 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   if (!out_pos) return fail(FMX_ERR_ARG, "out_pos is NULL");
   HostCall hc;
   const size_t b_in = (size_t)npat * 8, b_pos = (size_t)total * 8;
-  FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(b_in) + HostCall::pad(b_in + 8) + HostCall::pad(b_pos)));
+  const size_t b_rows = (size_t)fmx_locate_rows_bytes(total);
+  FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(b_in) + HostCall::pad(b_in + 8) + HostCall::pad(b_pos) +
+                                   HostCall::pad(b_rows)));
   uint64_t *d_s = hc.take<uint64_t>(b_in), *d_e = hc.take<uint64_t>(b_in);
   uint64_t *d_off = hc.take<uint64_t>(b_in + 8), *d_pos = hc.take<uint64_t>(b_pos);
+  uint32_t *d_rows = hc.take<uint32_t>(b_rows);   // the walk's scratch comes from the thread's retained buffer too
   hipStream_t S = hc.sx->st;
   CallStatus cs(hc.sx);
   FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, S));
   FMX_HIP(hipMemcpyAsync(d_s, s, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_e, e, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_off, out_off, b_in + 8, hipMemcpyHostToDevice, S));
-  if (int rc = fmx_launch_locate(idx, d_s, d_e, npat, d_off, total, d_pos, S)) {
+  if (int rc = fmx_launch_locate(idx, d_s, d_e, npat, d_off, total, d_pos, S, d_rows)) {
     (void)hipStreamSynchronize(S);
     return rc;
   }

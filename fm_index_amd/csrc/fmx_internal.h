@@ -167,11 +167,15 @@ static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
                      uint64_t *d_cnt, hipStream_t st);
+// rows_ws / tile_ws: caller-provided scratch (fmx_locate_rows_bytes / fmx_offsets_tile_bytes); NULL = take
+// it from the stream-ordered allocator for the duration of the call
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
-                      hipStream_t st);
+                      hipStream_t st, uint32_t *rows_ws = nullptr);
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
-                       hipStream_t st);
+                       hipStream_t st, uint64_t *tile_ws = nullptr);
+uint64_t fmx_locate_rows_bytes(uint64_t total);
+uint64_t fmx_offsets_tile_bytes(uint64_t npat);
 // fills table[code] for every k-mer code (FMX_FLAG_KMER_TABLE; the index must be complete)
 int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st);
 // op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map, 6 piece_id

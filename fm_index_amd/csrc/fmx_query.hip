@@ -2017,32 +2017,42 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   return FMX_OK;
 }
 
-int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
-                       hipStream_t st) {
+uint64_t fmx_offsets_tile_bytes(uint64_t npat) {
   uint64_t ntiles = (npat + FMX_SCAN_TILE - 1) / FMX_SCAN_TILE;
   if (ntiles == 0) ntiles = 1;
-  uint64_t *tile = nullptr;
-  FMX_HIP(hipMallocAsync((void **)&tile, (ntiles + 1) * sizeof(uint64_t), st));
+  return ((ntiles + 1) * sizeof(uint64_t) + 255u) & ~(uint64_t)255u;
+}
+uint64_t fmx_locate_rows_bytes(uint64_t total) {
+  return ((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u;
+}
+
+int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
+                       hipStream_t st, uint64_t *tile_ws) {
+  uint64_t ntiles = (npat + FMX_SCAN_TILE - 1) / FMX_SCAN_TILE;
+  if (ntiles == 0) ntiles = 1;
+  uint64_t *tile = tile_ws;
+  if (!tile_ws) FMX_HIP(hipMallocAsync((void **)&tile, (ntiles + 1) * sizeof(uint64_t), st));
   hipLaunchKernelGGL(fmx_tile_sums_kernel, dim3((unsigned)ntiles), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                      npat, tile);
   hipLaunchKernelGGL(fmx_scan_tiles_kernel, dim3(1), dim3(FMX_BLOCK), 0, st, tile, ntiles);
   hipLaunchKernelGGL(fmx_tile_scan_kernel, dim3((unsigned)ntiles), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                      npat, tile, ntiles, d_off);
   FMX_HIP(hipGetLastError());
-  FMX_HIP(hipFreeAsync(tile, st));
+  if (!tile_ws) FMX_HIP(hipFreeAsync(tile, st));
   return FMX_OK;
 }
 
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
-                      hipStream_t st) {
+                      hipStream_t st, uint32_t *rows_ws) {
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0 || total == 0) return FMX_OK;
   const FmxMwm &w = dv.bw;
   uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
-  // rows in their own read-only buffer: the walk's loads never alias its stores
-  uint32_t *rows = nullptr;
-  FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
+  // rows in their own read-only buffer: the walk's loads never alias its stores.  The caller's workspace
+  // when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
+  uint32_t *rows = rows_ws;
+  if (!rows_ws) FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
   // 1024-thread blocks that each own a slice of the hits (FmxHitQueue): `nb` blocks wanted -> slice
   // length (a multiple of the 64-row chunk, below 2^31) and the blocks that are really needed
   auto slice = [total](uint64_t nb, uint32_t chunk, uint32_t &hpb, unsigned &grid) {
@@ -2186,7 +2196,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
-  FMX_HIP(hipFreeAsync(rows, st));
+  if (!rows_ws) FMX_HIP(hipFreeAsync(rows, st));
   return FMX_OK;
 }
 

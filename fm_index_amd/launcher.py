@@ -22,6 +22,11 @@ def free_port():
 
 
 def rank_env(rank, world, port, base=None):
+    """environment of one rank.  HSA_ENABLE_IPC_MODE_LEGACY=0 is kept when the caller has it and set when
+    it is missing: on this ROCm 7 image the host driver only supports dmabuf IPC, and without the variable
+    RCCL's intra-node transport (and any device-buffer sharing between the rank processes) fails with
+    `hipIpcGetMemHandle: invalid argument`.  The image exports it already; a rank started from a scrubbed
+    environment (a test, a service manager) must still get it."""
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
                 "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),

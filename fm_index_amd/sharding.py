@@ -91,19 +91,29 @@ class CountGatherPipeline:
     """
 
     def __init__(self, npat_local, world, text_len, device, backend="nccl", pipelined=True,
-                 group=None, force_wire=None):
+                 group=None, force_wire=None, force_collective=False, trace=False):
         self.npat, self.world, self.group = npat_local, world, group
         self.device = torch.device(device)
         self.host = backend == "gloo"
         self.wire = wire_dtype(text_len, force_wire)
-        self.nbuf = 2 if (pipelined and world > 1) else 1
+        # force_collective: run the gather even on a 1-rank communicator (`bench.py --force-dist`: the
+        # RCCL code path -- communicator, device-side all_gather_into_tensor, async Work ordering --
+        # on the one GPU a test box has)
+        self.collective = world > 1 or force_collective
+        self.nbuf = 2 if (pipelined and self.collective) else 1
         self.local64 = [torch.empty(npat_local, dtype=torch.int64, device=self.device) for _ in range(self.nbuf)]
         gdev = torch.device("cpu") if self.host else self.device
         self.local_w = [torch.empty(npat_local, dtype=self.wire, device=gdev) for _ in range(self.nbuf)]
         self.gathered = [torch.empty(npat_local * world, dtype=self.wire, device=gdev)
-                         for _ in range(self.nbuf)] if world > 1 else []
+                         for _ in range(self.nbuf)] if self.collective else []
         self.pending = [None] * self.nbuf
         self.k = 0
+        # trace: HIP events around every search launch (launch stream) and behind every gather (an
+        # observer stream that waits for the collective, so the launch stream is never held up):
+        # trace_report() turns them into the evidence that gather k ran under search k+1
+        self.trace = bool(trace) and self.device.type == "cuda" and not self.host
+        self.events = []
+        self.obs = torch.cuda.Stream(device=self.device) if self.trace else None
 
     def step(self, launch):
         """one search + gather; returns the tensor that will hold all ranks' counts in input
@@ -113,14 +123,27 @@ class CountGatherPipeline:
         if self.pending[b] is not None:          # this buffer's previous gather must be done
             self.pending[b].wait()
             self.pending[b] = None
+        if self.trace:
+            ks, ke, gd = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ks.record()
         launch(self.local64[b])
-        if self.world == 1:
+        if self.trace:
+            ke.record()
+        if not self.collective:
             return self.local64[b]
         self.local_w[b].copy_(self.local64[b])   # down-cast (and D2H for gloo)
         work = dist.all_gather_into_tensor(self.gathered[b], self.local_w[b], group=self.group,
                                            async_op=self.nbuf > 1)
         if self.nbuf > 1:
             self.pending[b] = work
+        if self.trace:
+            with torch.cuda.stream(self.obs):
+                if self.nbuf > 1:
+                    work.wait()              # the OBSERVER stream waits for the collective
+                else:
+                    self.obs.wait_stream(torch.cuda.current_stream(self.device))
+                gd.record(self.obs)
+            self.events.append((ks, ke, gd))
         return self.gathered[b]
 
     def drain(self):
@@ -128,3 +151,73 @@ class CountGatherPipeline:
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
+
+    def trace_report(self):
+        """Timeline of the traced steps (call after drain() + synchronize): per step the search
+        kernel's start / end and the moment its gather had completed, in microseconds from the first
+        launch.  `gathers_under_next_search` counts the steps whose gather completed AFTER the next
+        search had started and BEFORE it ended -- the collective and the kernel were in flight
+        together; `search_gap_us` is the idle time of the launch stream between two searches (a
+        serialised gather would show up here)."""
+        ev = self.events
+        if len(ev) < 2:
+            return None
+        t0 = ev[0][0]
+        ks = [t0.elapsed_time(e[0]) * 1e3 for e in ev]
+        ke = [t0.elapsed_time(e[1]) * 1e3 for e in ev]
+        gd = [t0.elapsed_time(e[2]) * 1e3 for e in ev]
+        n = len(ev)
+        under = sum(1 for k in range(n - 1) if ks[k + 1] < gd[k] < ke[k + 1])
+        before_end = sum(1 for k in range(n - 1) if gd[k] < ke[k + 1])
+        gaps = sorted(ks[k + 1] - ke[k] for k in range(n - 1))
+        glat = sorted(gd[k] - ke[k] for k in range(n))
+        kern = sorted(ke[k] - ks[k] for k in range(n))
+        return {"steps": n, "gathers_under_next_search": under, "gathers_done_before_next_search_ends": before_end,
+                "search_gap_us_median": round(gaps[len(gaps) // 2], 2), "search_gap_us_max": round(gaps[-1], 2),
+                "gather_latency_us_median": round(glat[n // 2], 2), "search_us_median": round(kern[n // 2], 2),
+                "timeline_us": [[round(ks[k], 1), round(ke[k], 1), round(gd[k], 1)] for k in range(min(n, 8))]}
+
+
+# ---------------------------------------------------------------------------------------------
+# which physical GPU does each rank sit on?  (one process per GPU: LOCAL_RANK is only a promise)
+# ---------------------------------------------------------------------------------------------
+def device_identity(local):
+    """{"pci_bus_id", "uuid", "name"} of cuda:`local` -- the PCI bus id straight from the HIP runtime
+    this process already uses (hipDeviceGetPCIBusId), the uuid / name from torch's device properties."""
+    import ctypes as C
+    ident = {"pci_bus_id": None, "uuid": None, "name": None}
+    try:
+        props = torch.cuda.get_device_properties(local)
+        ident["name"] = getattr(props, "name", None)
+        u = getattr(props, "uuid", None)
+        ident["uuid"] = str(u) if u is not None else None
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import os
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, C.c_int(local)) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+    except Exception:  # noqa: BLE001
+        pass
+    return ident
+
+
+def gather_device_identities(local, group=None):
+    """every rank's device_identity(), in rank order, on every rank"""
+    mine = device_identity(local)
+    world = dist.get_world_size(group)
+    out = [None] * world
+    dist.all_gather_object(out, mine, group=group)
+    return out
+
+
+def assert_distinct_devices(idents):
+    """N ranks must sit on N distinct physical GPUs (PCI bus ids; uuids when no bus id is known)"""
+    keys = [i.get("pci_bus_id") or i.get("uuid") for i in idents]
+    if any(k is None for k in keys):
+        raise RuntimeError("cannot identify the GPUs of all ranks: %r" % (idents,))
+    if len(set(keys)) != len(keys):
+        raise RuntimeError("ranks share a physical GPU: %r" % (keys,))
+    return keys

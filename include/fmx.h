@@ -194,6 +194,22 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
 /* exclusive scan helper on the device: d_out_off[k] = sum_{j<k}(e[j]-s[j]), k = 0..npat */
 int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
                     uint64_t *d_out_off, void *stream);
+/* Caller-workspace forms of the two calls above.  fmx_locate_batch_dev / fmx_offsets_dev take their
+ * scratch (the expanded rows s[k]+j of wrapper.rs:203-217; the scan's tile sums) from the stream-ordered
+ * allocator, which keeps them out of hipGraph capture and couples streams that share the pool.  With a
+ * workspace of fmx_locate_workspace_bytes(idx, total_hits) / fmx_offsets_workspace_bytes(npat) bytes of
+ * device memory (256-byte aligned, owned by the caller, reusable across calls ON THE SAME STREAM) these
+ * forms only launch kernels: no allocation, no synchronisation, capturable into a hipGraph, and batches
+ * on different streams with different workspaces run concurrently (one batch's long walks under the
+ * other's bulk).  Same results, same errors; a workspace that is NULL or too small is FMX_ERR_ARG. */
+uint64_t fmx_locate_workspace_bytes(const fmx_index *idx, uint64_t total_hits);
+int fmx_locate_batch_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
+                            uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,
+                            uint64_t *d_out_pos, void *d_workspace, uint64_t workspace_bytes,
+                            void *stream);
+uint64_t fmx_offsets_workspace_bytes(uint64_t npat);
+int fmx_offsets_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                       uint64_t *d_out_off, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* ---- multi-pieces index (src/multi_pieces.rs, frontend.rs:46-68, 100-104) --- */
 /* SearchIndexWithMultiPieces::search_prefix / search_suffix / search_exact are the same

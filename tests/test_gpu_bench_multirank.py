@@ -28,7 +28,11 @@ def _run(extra, tmp_path, tag):
 def test_two_ranks_equal_one_process(tmp_path):
     two, c2 = _run(["--gpus", "2", "--dist-backend", "gloo", "--npat", "4096"], tmp_path, "two")
     one, c1 = _run(["--gpus", "1", "--npat", "8192"], tmp_path, "one")
-    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and one["n_gpus"] == 1
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    # the gloo rehearsal must not claim RCCL ranks (the driver reads rccl_ranks as "RCCL saw N ranks")
+    assert two["rccl_ranks"] is None and two["rccl_version"] is None and two["dist_backend"] == "gloo"
+    assert len(two["devices"]) == 2 and len(two["per_rank"]) == 2
+    assert all(r["kernel_ms"] > 0 and r["gather_ms"] > 0 for r in two["per_rank"])
     assert two["gather"]["counts_wire_dtype"] == "int32"
     assert c2.shape == c1.shape == (8192,)
     assert (c2 == c1).all()
@@ -37,3 +41,33 @@ def test_two_ranks_equal_one_process(tmp_path):
     # the locate leg gathered every rank's positions
     assert two["locate"]["hits"] == one["locate"]["hits"]
     assert two["locate"]["hits_per_gpu"] <= two["locate"]["hits"]
+
+
+def test_one_rank_rccl_communicator_carries_the_gathers(tmp_path):
+    """RCCL on the hardware a test box has: `--force-dist` opens a 1-rank nccl (= RCCL)
+    process group on this GPU and drives the step that ships for N > 1 -- pipelined device-side
+    all_gather_into_tensor of the counts, counts-then-positions gather of locate -- through it.  The line must
+    say so itself (backend, RCCL version, the physical device), the gathered counts must equal the run without
+    any process group, and the event timeline must show gather k finishing under search k+1."""
+    big = ["--log2n", "24", "--npat", "262144", "--steps", "6"]
+    forced, cf = _run(["--gpus", "1", "--force-dist"] + big, tmp_path, "forced")
+    plain, cp = _run(["--gpus", "1"] + big, tmp_path, "plain")
+    assert forced["dist_backend"] == "nccl" and forced["rccl_ranks"] == 1 and forced["rccl_version"]
+    assert forced["n_gpus"] == 1 and forced["gather"]["pipelined"] is True
+    dev = forced["devices"]
+    assert len(dev) == 1 and (dev[0]["pci_bus_id"] or dev[0]["uuid"])
+    assert (cf == cp).all() and cf.shape == (262144,)
+    assert forced["locate"]["hits"] == plain["locate"]["hits"]
+    assert "gather of counts and positions" in forced["locate"]["includes"]
+    pr = forced["per_rank"]
+    assert len(pr) == 1 and pr[0]["kernel_ms"] > 0 and pr[0]["gather_ms"] > 0
+    tr = forced["gather"]["trace"]
+    assert tr and tr["steps"] == 8
+    # no search waited for its predecessor's gather: every gather was complete before the NEXT search ended,
+    # and the launch stream's idle gap between two searches is far below one search
+    assert tr["gathers_done_before_next_search_ends"] == tr["steps"] - 1, tr
+    assert tr["search_gap_us_median"] < 0.5 * tr["search_us_median"], tr
+    # the default single-GPU line carries the same evidence in its rccl_1rank object
+    r1 = plain["rccl_1rank"]
+    assert r1.get("backend") == "nccl" and r1["ranks"] == 1 and r1["value"] > 0, r1
+    assert r1["positions_gathered"] == plain["locate"]["hits"]

@@ -129,6 +129,86 @@ def test_count_dev_is_graph_capturable():
     assert (d_e.cpu().numpy().view(np.uint64) == e0).all()
 
 
+def _locate_ws_setup(kind="fm", n=1 << 17, npat=4096, plen=6):
+    import torch
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    if kind == "fm":
+        t = W.dna_text_np(n, 5)
+        gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+        oi = O.OracleIndex(t, 4, level=2)
+    else:
+        t = W.byte_text_np(n, 4)
+        gi = F.RLFMIndexWithLocate(F.Text(t), 2)
+        oi = O.OracleIndex(t, 255, level=2, kind="rlfm")
+    flat, off, _ = W.substring_patterns_np(t, npat, plen, 3)
+    s0, e0 = oi.count_batch(flat, off)
+    ooff, opos = oi.locate_batch(s0, e0, nthreads=4)
+    d_s = torch.from_numpy(s0.view(np.int64)).to(dev)
+    d_e = torch.from_numpy(e0.view(np.int64)).to(dev)
+    return lib, dev, gi, d_s, d_e, ooff, opos
+
+
+@pytest.mark.parametrize("kind", ["fm", "rlfm"])
+def test_locate_workspace_form_is_graph_capturable_and_stream_independent(kind):
+    """fmx_offsets_ws_dev + fmx_locate_batch_ws_dev launch kernels only (scratch = the caller's workspace,
+    no stream-ordered allocation): the pair can be captured into a hipGraph and replayed, two batches on two
+    streams with their own workspaces give the reference's exact position sequence, and a missing / short
+    workspace is FMX_ERR_ARG."""
+    import torch
+    lib, dev, gi, d_s, d_e, ooff, opos = _locate_ws_setup(kind)
+    h, npat, total = gi.handle(), d_s.numel(), int(ooff[-1])
+    wsb = int(lib.fmx_locate_workspace_bytes(h, total))
+    osb = int(lib.fmx_offsets_workspace_bytes(npat))
+    assert wsb >= 4 * total and wsb % 256 == 0 and osb % 256 == 0
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(2)]
+    ows = [torch.empty(osb, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_off = [torch.zeros(npat + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    d_pos = [torch.zeros(total, dtype=torch.int64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def enqueue(i, sp):
+        assert lib.fmx_offsets_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                      C.c_void_p(d_off[i].data_ptr()), C.c_void_p(ows[i].data_ptr()), osb, sp) == 0
+        assert lib.fmx_locate_batch_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                           C.c_void_p(d_off[i].data_ptr()), total, C.c_void_p(d_pos[i].data_ptr()),
+                                           C.c_void_p(ws[i].data_ptr()), wsb, sp) == 0
+    # two streams, interleaved batches
+    for r in range(6):
+        i = r & 1
+        enqueue(i, C.c_void_p(streams[i].cuda_stream))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert (d_off[i].cpu().numpy().view(np.uint64) == ooff).all()
+        assert (d_pos[i].cpu().numpy().view(np.uint64) == opos).all()
+    # hipGraph capture + replay of the same pair of calls
+    side = streams[0]
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            enqueue(0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        d_pos[0].zero_()
+        d_off[0].zero_()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+    assert (d_off[0].cpu().numpy().view(np.uint64) == ooff).all()
+    assert (d_pos[0].cpu().numpy().view(np.uint64) == opos).all()
+    assert lib.fmx_stream_status(h) == 0
+    # a workspace that is missing or too small is refused before anything is launched
+    sp = C.c_void_p(streams[0].cuda_stream)
+    assert lib.fmx_locate_batch_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                       C.c_void_p(d_off[0].data_ptr()), total, C.c_void_p(d_pos[0].data_ptr()),
+                                       None, wsb, sp) == L.ERR_ARG
+    assert lib.fmx_locate_batch_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                       C.c_void_p(d_off[0].data_ptr()), total, C.c_void_p(d_pos[0].data_ptr()),
+                                       C.c_void_p(ws[0].data_ptr()), 4 * total - 4, sp) == L.ERR_ARG
+    assert lib.fmx_offsets_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
+                                  C.c_void_p(d_off[0].data_ptr()), None, osb, sp) == L.ERR_ARG
+    gi.close()
+
+
 def test_large_host_pointer_batch_is_chunked_consistently():
     """Host-pointer batches >= 2^17 patterns are uploaded / searched / downloaded in two
     overlapping halves; the answers must equal the same patterns asked in small batches,

@@ -134,3 +134,51 @@ def test_count_gather_pipeline_over_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def _one_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from fm_index_amd import sharding as S
+    pipe = S.CountGatherPipeline(100, 1, 1 << 20, "cpu", backend="gloo", force_collective=True)
+    assert pipe.collective and pipe.nbuf == 2 and len(pipe.gathered) == 2
+    plain = S.CountGatherPipeline(100, 1, 1 << 20, "cpu", backend="gloo")
+    assert not plain.collective and plain.nbuf == 1
+    outs = []
+    for k in range(4):
+        outs.append(pipe.step(lambda o, k=k: o.copy_(torch.arange(100, dtype=torch.int64) + k)))
+    pipe.drain()
+    ok = bool((outs[3].to(torch.int64) == torch.arange(100) + 3).all())
+    ok = ok and bool((outs[2].to(torch.int64) == torch.arange(100) + 2).all())
+    off, pos = S.gather_positions(torch.tensor([2, 0, 1]), torch.tensor([7, 8, 9]), 3)
+    ok = ok and off.tolist() == [0, 2, 2, 3] and pos.tolist() == [7, 8, 9]
+    q.put(ok)
+    dist.destroy_process_group()
+
+
+def test_forced_collective_on_a_one_rank_group():
+    """`bench.py --force-dist`: the gather really runs (double-buffered, async) on a 1-rank group"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
+def test_distinct_device_check():
+    from fm_index_amd import sharding as S
+    a = {"pci_bus_id": "0000:05:00.0", "uuid": None, "name": "x"}
+    b = {"pci_bus_id": "0000:15:00.0", "uuid": None, "name": "x"}
+    assert S.assert_distinct_devices([a, b]) == ["0000:05:00.0", "0000:15:00.0"]
+    with pytest.raises(RuntimeError, match="share a physical GPU"):
+        S.assert_distinct_devices([a, dict(a)])
+    with pytest.raises(RuntimeError, match="cannot identify"):
+        S.assert_distinct_devices([a, {"pci_bus_id": None, "uuid": None}])
+    # the rank environment always carries the dmabuf-IPC switch RCCL needs on this image
+    from fm_index_amd import launcher
+    assert launcher.rank_env(1, 2, 1234, base={})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launcher.rank_env(1, 2, 1234, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"

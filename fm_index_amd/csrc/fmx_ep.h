@@ -239,9 +239,6 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)            rlfmi.rs:136
   const uint32_t lo = j - 1u + bit;                          // b.rank1(i + 1) - 1    rlfmi.rs:124
-  // run start b.select1(j) = first one at or after i: usually in the piece; else one more probe,
-  // issued now so that it travels under the rank rounds
-  const FmxSel ss = fmx_ep_select_issue<SM, true>(ix.b, j, nx == FMX_NONE, live);
   uint32_t pos = lo, r = 0, m = 1u;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
 #pragma unroll
@@ -253,6 +250,10 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map2(const FmxDev &ix, uint32
     pos = r;                                                 // C_l[code] is folded into the counters
   }
   const uint32_t nr = kc + r + (bit ? 0u : m);               // cs[c] + s.rank(j, c)  rlfmi.rs:137,139
+  // run start b.select1(j) = first one at or after i: usually in the piece; else one more probe, issued
+  // TOGETHER with the B' select (both are consumed below, so it adds no dependent stage; issued ahead of
+  // the rank rounds, as in round 2, its block sat in 5 registers through both rounds for nothing)
+  const FmxSel ss = fmx_ep_select_issue<SM, true>(ix.b, j, nx == FMX_NONE, live);
   const FmxSel sf = fmx_ep_select_issue<SM, true>(ix.bp, nr, true, live);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);          // bp.select1(cs[c] + nr)
   uint32_t st = nx;
@@ -274,7 +275,6 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
   uint32_t bit, nx;
   const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)
   const uint32_t lo = j - 1u + bit;
-  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, j, nx == FMX_NONE, live);
   uint32_t pos = lo, r = 0;
   sym = 0;
   const uint32_t nl = NL ? (uint32_t)NL : ix.bw.nlevels;
@@ -287,6 +287,7 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
     pos = r;
   }
   const uint32_t nr = kt[sym] + r + (bit ? 0u : 1u);         // cs[c] + s.rank(j, c)   rlfmi.rs:129-130
+  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, j, nx == FMX_NONE, live);   // with the B' select
   const FmxSel sf = fmx_ep_select_issue<SM, false>(ix.bp, nr, true, live);
   uint32_t f = fmx_ep_select_finish<SM>(ix.bp, sf);
   uint32_t st = nx;

@@ -962,6 +962,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 #define FMX_LCHUNK 64u
 #define FMX_NOCHUNK 0xFFFFFFFFu
 #define FMX_LOC_BLOCK 1024
+// LWIN: the rows of the two resident chunks live in LDS (2 x 64 words per wave, `lwin`) instead of two
+// registers per lane -- for the one-walk-per-lane kernel, which is short of registers; handing out a hit is
+// then one ds_read instead of two ds_bpermutes.
+template <bool LWIN = false>
 struct FmxHitQueue {
   const uint32_t *rows;   // rows of this block's slice
   uint64_t lo;            // first hit of the slice (index into out_pos)
@@ -971,7 +975,9 @@ struct FmxHitQueue {
                           // latency-bound, and two walks in a row per slot are twice the chain)
   uint32_t lane;
   uint32_t c0, c1;        // resident chunks of the slice (FMX_NOCHUNK once it is exhausted), wave-uniform
-  uint32_t win0, win1;    // rows of the resident chunks, one per lane (lanes >= chunk unused)
+  uint32_t win0, win1;    // rows of the resident chunks, one per lane (lanes >= chunk unused)     [!LWIN]
+  volatile uint32_t *lwin;  // this wave's 2 x 64 words of LDS; chunk c0 sits in half w0, c1 in the other [LWIN]
+  uint32_t w0;
   uint32_t used;          // hits already handed out of c0|c1
   __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
     const uint32_t x = c * chunk + lane;
@@ -986,28 +992,24 @@ struct FmxHitQueue {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   }
   __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t rows_per_ticket,
-                                       uint32_t ln, unsigned int &counter) {
+                                       uint32_t ln, unsigned int &counter, volatile uint32_t *lds_win = nullptr) {
     rows = r; lo = first; nhits = count; chunk = rows_per_ticket; lane = ln;
+    lwin = lds_win; w0 = 0; win0 = 0; win1 = 0;
     // every wave of the block draws its FIRST ticket before any draws a second one (called by all
     // threads of the block at kernel start): with fewer tickets than 2 x waves, no wave goes without
     c0 = valid(draw(counter, 1u));
-    win0 = load_win(c0);
+    if (LWIN) lwin[lane] = load_win(c0); else win0 = load_win(c0);
     __syncthreads();
     c1 = valid(draw(counter, 1u));
-    win1 = load_win(c1);
+    if (LWIN) lwin[64u + lane] = load_win(c1); else win1 = load_win(c1);
     used = 0;
   }
   // the hit with index `used + rank` (< 2 * chunk): returns false when the slice has run dry
   __device__ __forceinline__ bool take(uint32_t rank, uint64_t &h, uint32_t &row) const {
-    const uint32_t idx = used + rank;
-    const bool first = idx < chunk;
-    const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
-    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
-    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
-    const uint32_t x = c * chunk + within;
+    uint32_t x;
+    const bool ok = take32(rank, x, row);
     h = lo + x;
-    row = first ? v0 : v1;
-    return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
+    return ok;
   }
   // the same with the hit as an index into the slice (out_pos index = lo + x): 32-bit state for the kernels
   // that keep one walk per lane
@@ -1020,22 +1022,32 @@ struct FmxHitQueue {
     const uint32_t idx = used + rank;
     first = idx < chunk;
     const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
-    const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
-    const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
+    if (LWIN) {
+      row = lwin[((first ? w0 : w0 ^ 1u) << 6) + (within & 63u)];
+    } else {
+      const uint32_t v0 = (uint32_t)__shfl((int)win0, (int)(within & 63u));
+      const uint32_t v1 = (uint32_t)__shfl((int)win1, (int)(within & 63u));
+      row = first ? v0 : v1;
+    }
     x = c * chunk + within;
-    row = first ? v0 : v1;
     return idx < 2u * chunk && c != FMX_NOCHUNK && x < nhits;
   }
   // `count` hits were handed out (wave-uniform, count <= chunk)
   // returns true when the window slid: c1 became c0 and a new c1 was drawn (wave-uniform)
   __device__ __forceinline__ bool advance(uint32_t count, unsigned int &counter) {
+    FMX_CHECK(count <= chunk && used < chunk);       // at most one slide per call
     used += count;
     if (used >= chunk) {                             // wave-uniform: slide
       used -= chunk;
       c0 = c1;
-      win0 = win1;
       c1 = c1 != FMX_NOCHUNK ? valid(draw(counter, 1u)) : FMX_NOCHUNK;
-      win1 = load_win(c1);
+      if (LWIN) {
+        lwin[(w0 << 6) + lane] = load_win(c1);       // the half the old c0 occupied
+        w0 ^= 1u;
+      } else {
+        win0 = win1;
+        win1 = load_win(c1);
+      }
       return true;
     }
     return false;
@@ -1071,7 +1083,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
   const uint32_t grp = lane >> 3;
   const uint32_t lmask = (1u << sa_level) - 1u;
   const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
-  FmxHitQueue hq;
+  FmxHitQueue<> hq;
   hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
 
   uint64_t h[Q], pend_h[Q], pend_v[Q];
@@ -1216,7 +1228,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3q_kernel(
                                                                                 : 0xFFFFFFFFFFFFFFFFull;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row (n < 2^32 - 16)
   const uint32_t lmask = (1u << sa_level) - 1u;
-  FmxHitQueue hq;
+  FmxHitQueue<> hq;
   hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
   // the first 8 hits go to walk 0 of the wave's 8 groups, the next 8 to walk 1, ...: a wave that gets few
   // hits has few live walk slots and skips the others' loads and decodes
@@ -1354,7 +1366,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
                                                 : 0xFFFFFFFFFFFFFFFFull;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample / no position (n < 2^32 - 16)
   const uint32_t lmask = (1u << sa_level) - 1u;
-  FmxHitQueue hq;
+  FmxHitQueue<> hq;
   hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   // write-combining ring of this wave: slot r holds ticket ring_tag[r]; entry i of it = position of hit
@@ -1478,14 +1490,27 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
 // locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
 // probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects; FM over several wavelet
 // levels: one access+rank round per level (eight records in flight per lane).  Lanes take
-// their hits from the global queue (FmxHitQueue) as they finish.  K[] is staged in LDS when the
+// their hits from the block's queue (FmxHitQueue) as they finish.  K[] is staged in LDS when the
 // alphabet is small (it is read with a data-dependent symbol in every step).
-template <int KIND, int NL, int SM, bool KLDS>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
+// TEXT (compile time since round 3): text-order sampling (FmxDev::phase).  The walk state of a lane is
+// packed: row, hit (32-bit index into the block's slice), ring slot, and ONE control word -- the step
+// count in row order; stage | steps left | phase in text order (a text-order walk is exactly `phase`
+// steps long, so no separate counter) -- 4-5 registers where round 2 kept 8.
+// WC: positions leave through the write-combining ring of the DNA walk kernel (fmx_locate_f3p_kernel):
+// tickets are 64 consecutive hits = 512 contiguous bytes of out_pos, a finished walk drops its position
+// into its ticket's ring slot while that ticket is resident, and a recycled slot is stored with one
+// contiguous 64 x 8-byte store.  Round 2 stored every position on its own: an 8-byte store in
+// completion order is one 32-byte sector and one request at the memory side (config 4: 22.5 MB written
+// for 8.4 MB of positions).
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_kernel(
     FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
   __shared__ unsigned int lds_q;
+  __shared__ uint32_t hq_win[(FMX_LOC_BLOCK / 64) * 128];     // rows of each wave's two resident tickets
+  __shared__ uint32_t wc_ring[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS * 64 : 1];
+  __shared__ uint32_t wc_tag[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS : 1];
   if (threadIdx.x == 0) lds_q = 0;
   if (KLDS) {
     for (uint32_t t = threadIdx.x; t <= ix.max_character; t += blockDim.x) kt_lds[t] = ix.K[t];
@@ -1497,80 +1522,137 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_ep_kernel(
   const uint32_t *kt = KLDS ? kt_lds : ix.K;
   const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
-  FmxHitQueue hq;
-  hq.init(rows + blo, blo, bn, FMX_LCHUNK, lane, lds_q);
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no position (n < 2^32 - 16)
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of the block (scalar)
+  FmxHitQueue<true> hq;
+  hq.init(rows + blo, blo, bn, FMX_LCHUNK, lane, lds_q, hq_win + wv * 128u);
+  uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
+  // write-combining ring of this wave (see fmx_locate_f3p_kernel): slot r holds ticket ring_tag[r]
+  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + wv * (FMX_WC_SLOTS * 64);
+  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + wv * FMX_WC_SLOTS;
+  [[maybe_unused]] uint32_t rseq = 2;                 // tickets drawn so far (ticket k of the wave -> ring slot k & 3)
+  static_assert(FMX_WC_SLOTS == 4, "the tag lookup below reads four tags");
+  if (WC) {
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) ring[r * 64u + lane] = NONE;
+    if (lane < FMX_WC_SLOTS) ring_tag[lane] = lane == 0 ? hq.c0 : (lane == 1 ? hq.c1 : FMX_NOCHUNK);
+  }
   // the first 8 hits of a chunk go to lane 0 of the wave's 8 groups, the next 8 to lane 1, ...: a wave
   // that gets few hits (small batches) has few live endpoint positions and its rank rounds skip the rest
-  uint64_t h;
-  uint32_t row;
-  bool active = hq.take((g << 3) | (lane >> 3), h, row);
-  hq.advance(64u, lds_q);
+  uint32_t hx, row;                                   // hit (index into the slice) and current row of the walk
+  bool active = hq.take32((g << 3) | (lane >> 3), hx, row);     // the whole first ticket (c0, ring slot 0)
+  {
+    const bool slid = hq.advance(64u, lds_q);
+    if (WC && slid) {
+      const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+      if (lane == 0) ring_tag[ns] = hq.c1;            // slot ns is still empty (all NONE)
+      rseq++;
+    }
+  }
   if (!active) row = 0u;
-  uint32_t steps = 0, nsteps = 0;
-  // text-order sampling (FmxDev::phase; wave-uniform): stage of the lane's walk -- 0 phase piece of the
-  // start row, 1 LF steps (`rem` of them, no test in between), 2 phase piece of the final row for its
-  // rank among the sampled rows, 3 the sample.
+  uint32_t nsteps = 0;
+  // control word.  Row order: LF steps done so far.  Text order: bits 0-3 steps still to do, bits 4-7 the
+  // walk's phase (= its length), bits 8-9 the stage -- 0 phase piece of the start row, 1 LF steps (no test
+  // in between), 2 phase piece of the final row for its rank among the sampled rows, 3 the sample.
   // One round = the lane-wise probes of the lanes that need them, chained (phase piece -> sample ->
   // position -> next hit), THEN one LF step of every walking lane: a hit costs `steps` rounds (+ 1 in
   // text order) of its lane instead of one round per stage, and no LF step runs with idle probing lanes.
-  const bool text = ix.phase != nullptr;
-  uint32_t st = 0, rem = 0, sidx = 0;
+  uint32_t ctl = 0;
+  [[maybe_unused]] uint32_t sidx = 0;                 // text order: index of the sample
   while (__any(active)) {
-    if (text) {
+    if (TEXT) {
+      const uint32_t st = ctl >> 8;
       const bool probing = active && (st == 0u || st == 2u);
       if (__any(probing)) {                           // wave-uniform
-        uint32_t pt = 0;
-        uint4 pc = make_uint4(0u, 0u, 0u, 0u);
         if (probing) {
+          uint32_t pt = 0;
           const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
           FMX_TOUCH(&ix.phase[pi]);
-          pc = ix.phase[pi];
+          const uint4 pc = ix.phase[pi];
           uint32_t rank0;
           const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
           sidx = rank0;
-          rem = phi;
-          st = (st == 2u || phi == 0u) ? 3u : 1u;
+          if (st == 0u) ctl = phi | (phi << 4) | ((phi == 0u ? 3u : 1u) << 8);   // start row: phase -> walk length
+          else ctl = (ctl & 0xFFu) | (3u << 8);                                  // final row: its sample is next
         }
       }
     }
     // walks standing on their sampled row: sample -> position; their lanes take the next hits
-    const bool sampled = active && (text ? st == 3u : (row & lmask) == 0u);
+    const bool sampled = active && (TEXT ? (ctl >> 8) == 3u : (row & lmask) == 0u);
     const unsigned long long fmask = __ballot(sampled);
     if (fmask) {                                      // wave-uniform
       uint32_t sa = 0;
       if (sampled) {                                  // sample.rs:46-60 Some(sa)
-        const uint32_t si = text ? sidx : row >> ix.sa_level;
+        const uint32_t si = TEXT ? sidx : row >> ix.sa_level;
         FMX_CHECK(si < ix.nsamples);
         FMX_TOUCH(&ix.samples[si]);
         sa = ix.samples[si];
       }
-      uint64_t h_new;
-      uint32_t r_new;
-      const bool ok = hq.take((uint32_t)__popcll(fmask & ((1ull << lane) - 1ull)), h_new, r_new);
+      uint32_t x_new, r_new;
+      const bool ok = hq.take32((uint32_t)__popcll(fmask & ((1ull << lane) - 1ull)), x_new, r_new);
       if (sampled) {
-        uint64_t v = (uint64_t)sa + steps;            // rlfmi.rs:181: (sa + steps) % len
-        if (v >= ix.n) v -= ix.n;
-        out_pos[h] = v;
-        h = h_new;
+        // rlfmi.rs:181 / fm_index.rs:131-133: (sa + steps) % len, in 32 bits: sa < n, steps < n, so one
+        // subtraction of n (modulo 2^32) is exact whether or not the addition wrapped
+        const uint32_t stp = TEXT ? (ctl >> 4) & 15u : ctl;
+        uint32_t v = sa + stp;
+        if (v < sa || v >= ix.n) v -= ix.n;
+        FMX_CHECK(hx < bn);
+        // the ring slot that holds the hit's ticket, if it is still resident (the four tags in one LDS read;
+        // a ticket id appears in at most one slot)
+        uint32_t rslot = FMX_WC_SLOTS;
+        if (WC) {
+          const uint32_t t = hx >> 6;
+          const uint32_t t0 = ring_tag[0], t1 = ring_tag[1], t2 = ring_tag[2], t3 = ring_tag[3];
+          rslot = t == t0 ? 0u : t == t1 ? 1u : t == t2 ? 2u : t == t3 ? 3u : (uint32_t)FMX_WC_SLOTS;
+        }
+        if (WC && rslot < FMX_WC_SLOTS) ring[rslot * 64u + (hx & 63u)] = v;
+        else out[hx] = (uint64_t)v;
+        nsteps += stp;
+        hx = x_new;
         active = ok;
-        steps = 0;
-        st = 0;
+        ctl = 0;
         row = ok ? r_new : 0u;
       }
-      hq.advance((uint32_t)__popcll(fmask), lds_q);
+      const bool slid = hq.advance((uint32_t)__popcll(fmask), lds_q);
+      if (WC && slid) {
+        // a new ticket was drawn: it gets the ring slot of the oldest one, whose arrived positions leave
+        // now in one contiguous store (hit index = 64 * ticket + lane)
+        const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+        const uint32_t old_tag = ring_tag[ns];
+        const uint32_t v = ring[ns * 64u + lane];
+        FMX_CHECK(old_tag == FMX_NOCHUNK || v == NONE || old_tag * 64u + lane < bn);
+        if (old_tag != FMX_NOCHUNK && v != NONE) out[old_tag * 64u + lane] = (uint64_t)v;
+        ring[ns * 64u + lane] = NONE;
+        if (lane == 0) ring_tag[ns] = hq.c1;
+        rseq++;
+      }
     }
     // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186 -- a hit taken above walks in this same round
     // (row order) or after its phase piece in the next (text order)
-    const bool walking = active && (text ? st == 1u : (row & lmask) != 0u);
+    const bool walking = active && (TEXT ? (ctl >> 8) == 1u : (row & lmask) != 0u);
     if (__any(walking)) {
       uint32_t sym;
       const uint32_t nrow = KIND == FMX_KIND_RLFM
                                 ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
                                 : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
       if (walking) {
-        row = nrow; steps++; nsteps++;
-        if (text && --rem == 0u) st = 2u;
+        row = nrow;
+        if (TEXT) {
+          ctl -= 1u;                                  // one step less to do
+          if ((ctl & 15u) == 0u) ctl = (ctl & 0xFFu) | (2u << 8);
+        } else {
+          ctl++;
+        }
       }
+    }
+  }
+  if (WC) {                                           // what is still in the ring
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) {
+      const uint32_t tag = ring_tag[r];
+      const uint32_t v = ring[r * 64u + lane];
+      FMX_CHECK(tag == FMX_NOCHUNK || v == NONE || tag * 64u + lane < bn);
+      if (tag != FMX_NOCHUNK && v != NONE) out[tag * 64u + lane] = (uint64_t)v;
     }
   }
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
@@ -2169,14 +2251,20 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       slice((uint64_t)fmx_env_long("FMX_EP_LOC_BLOCKS", big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       const bool klds = dv.max_character < 1024u;
+#define FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, WCF)                                                   \
+  hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, KL, TX, WCF>), dim3(gr), dim3(ep_threads), 0, \
+                     st, dv, total, hpb, rows, d_pos, steps)
+#ifdef FMX_MEASURE   // FMX_VARIANT=26: positions stored directly (no write-combining ring)
+#define FMX_EPL_LAUNCH2(KIND, NL, SM, KL, TX)                                                        \
+  do { if (fmx_variant() == 26) FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, false);                        \
+       else FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, true); } while (0)
+#else
+#define FMX_EPL_LAUNCH2(KIND, NL, SM, KL, TX) FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, true)
+#endif
 #define FMX_EPL_LAUNCH(KIND, NL, SM)                                                                 \
   do {                                                                                               \
-    if (klds)                                                                                        \
-      hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, true>), dim3(gr), dim3(ep_threads), 0,    \
-                         st, dv, total, hpb, rows, d_pos, steps);                                     \
-    else                                                                                             \
-      hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, false>), dim3(gr), dim3(ep_threads), 0,   \
-                         st, dv, total, hpb, rows, d_pos, steps);                                     \
+    if (klds) { if (dv.phase) FMX_EPL_LAUNCH2(KIND, NL, SM, true, true); else FMX_EPL_LAUNCH2(KIND, NL, SM, true, false); } \
+    else { if (dv.phase) FMX_EPL_LAUNCH2(KIND, NL, SM, false, true); else FMX_EPL_LAUNCH2(KIND, NL, SM, false, false); }   \
   } while (0)
 #define FMX_EPL_SM(KIND, SM)                                                                         \
   do {                                                                                               \

@@ -78,16 +78,64 @@ def wire_dtype(text_len, force=None):
     return torch.int32 if text_len < (1 << 31) else torch.int64
 
 
+def pick_concurrent_stream(device, other=None, tries=8, spin_cycles=400000):
+    """A stream that REALLY runs concurrently with `other` (default: the current stream).
+
+    HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that
+    land on the same queue execute in submission order, however independent they look
+    (profiles/r03/rccl_overlap_probe_hwqueues.jsonl: the count gather of step k then runs BETWEEN
+    searches k and k+1 instead of under k+1).  So candidates are tested: one single-thread spin kernel
+    on each stream -- together they take one spin when the queues differ, two when they alias.
+    Returns (stream, {"tried", "concurrent", "ratio"}); the last candidate is returned even when none
+    overlapped (the pipeline stays correct, just serialised)."""
+    device = torch.device(device)
+    other = other or torch.cuda.current_stream(device)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize(device)
+    # duration of one spin
+    e[0].record(other)
+    with torch.cuda.stream(other):
+        torch.cuda._sleep(spin_cycles)
+    e[1].record(other)
+    torch.cuda.synchronize(device)
+    one = max(e[0].elapsed_time(e[1]), 1e-3)
+    info = {"tried": 0, "concurrent": False, "ratio": None}
+    cand = None
+    keep = []                                   # rejected candidates stay alive so that the pool moves on
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device)
+        info["tried"] += 1
+        cand.wait_stream(other)
+        e[2].record(other)
+        with torch.cuda.stream(other):
+            torch.cuda._sleep(spin_cycles)
+        with torch.cuda.stream(cand):
+            torch.cuda._sleep(spin_cycles)
+        other.wait_stream(cand)
+        e[3].record(other)
+        torch.cuda.synchronize(device)
+        ratio = e[2].elapsed_time(e[3]) / one
+        info["ratio"] = round(ratio, 2)
+        if ratio < 1.5:
+            info["concurrent"] = True
+            break
+        keep.append(cand)
+    return cand, info
+
+
 class CountGatherPipeline:
     """The N > 1 step of bench.py (BASELINE config 5): search this rank's shard, all-gather the
     per-pattern counts of every rank.
 
-    Two result buffers alternate: the gather of step k is issued asynchronously (on RCCL's stream
-    it starts once the kernel that produced its input has finished) and runs under the search
-    kernel of step k+1; a buffer is reused only after its gather has completed.  `launch(out64)`
-    must enqueue the count of this rank's shard on the current stream, writing int64 counts into
-    `out64` (the ABI's u64 counts).  With backend "gloo" (CPU tests, single-GPU rehearsal) the
-    counts go through host memory.
+    Two result buffers alternate.  The launch stream only ever runs the search kernels: the down-cast to
+    the wire dtype and the collective of step k go to the pipeline's own communication stream (picked so
+    that it does not share a hardware queue with the launch stream, pick_concurrent_stream), which waits
+    for search k through an event and runs under search k+1; a buffer is reused only after its gather has
+    completed (event wait on the launch stream, two steps later).  `launch(out64)` must enqueue the count
+    of this rank's shard on the current stream, writing int64 counts into `out64` (the ABI's u64 counts).
+    With backend "gloo" (CPU tests, single-GPU rehearsal) the counts go through host memory and the
+    gather is torch.distributed's async Work.
     """
 
     def __init__(self, npat_local, world, text_len, device, backend="nccl", pipelined=True,
@@ -97,8 +145,8 @@ class CountGatherPipeline:
         self.host = backend == "gloo"
         self.wire = wire_dtype(text_len, force_wire)
         # force_collective: run the gather even on a 1-rank communicator (`bench.py --force-dist`: the
-        # RCCL code path -- communicator, device-side all_gather_into_tensor, async Work ordering --
-        # on the one GPU a test box has)
+        # RCCL code path -- communicator, device-side all_gather_into_tensor, ordering against the next
+        # search -- on the one GPU a test box has)
         self.collective = world > 1 or force_collective
         self.nbuf = 2 if (pipelined and self.collective) else 1
         self.local64 = [torch.empty(npat_local, dtype=torch.int64, device=self.device) for _ in range(self.nbuf)]
@@ -108,49 +156,73 @@ class CountGatherPipeline:
                          for _ in range(self.nbuf)] if self.collective else []
         self.pending = [None] * self.nbuf
         self.k = 0
-        # trace: HIP events around every search launch (launch stream) and behind every gather (an
-        # observer stream that waits for the collective, so the launch stream is never held up):
-        # trace_report() turns them into the evidence that gather k ran under search k+1
-        self.trace = bool(trace) and self.device.type == "cuda" and not self.host
+        # device-side pipeline: own communication stream + events
+        self.on_device = self.collective and not self.host and self.device.type == "cuda"
+        self.comm, self.comm_info = None, None
+        if self.on_device and self.nbuf > 1:
+            with torch.cuda.device(self.device):
+                self.comm, self.comm_info = pick_concurrent_stream(self.device)
+        # trace: HIP events around every search launch (launch stream) and behind every gather
+        # (communication stream): trace_report() turns them into the evidence that gather k ran under
+        # search k+1
+        self.trace = bool(trace) and self.on_device
         self.events = []
-        self.obs = torch.cuda.Stream(device=self.device) if self.trace else None
+
+    def _wait(self, b):
+        p = self.pending[b]
+        if p is None:
+            return
+        if isinstance(p, torch.cuda.Event):
+            torch.cuda.current_stream(self.device).wait_event(p)
+        else:
+            p.wait()
+        self.pending[b] = None
 
     def step(self, launch):
         """one search + gather; returns the tensor that will hold all ranks' counts in input
         order (complete after drain(), or after the next step() on the same buffer)."""
         b = self.k % self.nbuf
         self.k += 1
-        if self.pending[b] is not None:          # this buffer's previous gather must be done
-            self.pending[b].wait()
-            self.pending[b] = None
+        self._wait(b)                            # this buffer's previous gather must be done
+        ks = ke = None
         if self.trace:
-            ks, ke, gd = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ks.record()
         launch(self.local64[b])
         if self.trace:
             ke.record()
         if not self.collective:
             return self.local64[b]
+        if self.comm is not None:
+            # searched[b] -> communication stream: down-cast + collective there, launch stream moves on
+            cur = torch.cuda.current_stream(self.device)
+            searched = ke if ke is not None else torch.cuda.Event()
+            if ke is None:
+                searched.record(cur)
+            done = torch.cuda.Event(enable_timing=self.trace)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(searched)
+                self.local_w[b].copy_(self.local64[b])
+                dist.all_gather_into_tensor(self.gathered[b], self.local_w[b], group=self.group)
+                done.record(self.comm)
+            self.pending[b] = done
+            if self.trace:
+                self.events.append((ks, ke, done))
+            return self.gathered[b]
         self.local_w[b].copy_(self.local64[b])   # down-cast (and D2H for gloo)
         work = dist.all_gather_into_tensor(self.gathered[b], self.local_w[b], group=self.group,
                                            async_op=self.nbuf > 1)
         if self.nbuf > 1:
             self.pending[b] = work
         if self.trace:
-            with torch.cuda.stream(self.obs):
-                if self.nbuf > 1:
-                    work.wait()              # the OBSERVER stream waits for the collective
-                else:
-                    self.obs.wait_stream(torch.cuda.current_stream(self.device))
-                gd.record(self.obs)
+            gd = torch.cuda.Event(enable_timing=True)
+            gd.record()
             self.events.append((ks, ke, gd))
         return self.gathered[b]
 
     def drain(self):
         for b in range(self.nbuf):
-            if self.pending[b] is not None:
-                self.pending[b].wait()
-                self.pending[b] = None
+            self._wait(b)
 
     def trace_report(self):
         """Timeline of the traced steps (call after drain() + synchronize): per step the search
@@ -175,6 +247,7 @@ class CountGatherPipeline:
         return {"steps": n, "gathers_under_next_search": under, "gathers_done_before_next_search_ends": before_end,
                 "search_gap_us_median": round(gaps[len(gaps) // 2], 2), "search_gap_us_max": round(gaps[-1], 2),
                 "gather_latency_us_median": round(glat[n // 2], 2), "search_us_median": round(kern[n // 2], 2),
+                "comm_stream": self.comm_info,
                 "timeline_us": [[round(ks[k], 1), round(ke[k], 1), round(gd[k], 1)] for k in range(min(n, 8))]}
 
 

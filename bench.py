@@ -28,6 +28,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Process-level runtime settings, fixed before torch, HIP or OpenMP are initialised (none is a machine setting):
+#  * HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  Streams that share one run in
+#    submission order: the count gather of step k then sits BETWEEN searches k and k+1 instead of under k+1
+#    (profiles/r03/rccl_overlap_probe_hwqueues.jsonl).  8 queues; the headline is unaffected
+#    (profiles/r03/hw_queues_ab.txt).
+# (The CPU baseline's threads are placed by the oracle itself, per batch -- OMP_PROC_BIND would narrow the
+# affinity mask of this Python thread for good, and with it the mask of every HIP / RCCL helper thread.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 GATHER_CEILING_GLINES = 55.0  # profiles/microbench/gather_r02.txt: dependent random lines the memory
 #                               system sustains (16..128-byte requests alike, 128 MiB..2 GiB tables)
@@ -238,9 +247,12 @@ def run_census(wl, launch, cap_entries):
     requested = int(cnt.item())
     if requested > cap_entries:
         return {"requested_lines": requested, "distinct_lines": None, "note": "log capacity exceeded"}
-    distinct = int(torch.unique(log[:requested]).numel())
-    del log
-    return {"requested_lines": requested, "distinct_lines": distinct}
+    ent = log[:requested]
+    narrow = int((ent < 0).sum().item())          # bit 63: a lane-wise probe of <= 16 bytes (fmx_device.h)
+    distinct = int(torch.unique(ent & 0x7FFFFFFFFFFFFFFF).numel())
+    del log, ent
+    return {"requested_lines": requested, "distinct_lines": distinct, "requested_records": requested - narrow,
+            "requested_probes": narrow}
 
 
 # --------------------------------------------------------------------------------------------
@@ -282,38 +294,70 @@ def set_miss_lines(r, traffic_bytes, stream_bytes, fetch_kb_raw=None):
     r["frac_of_gather_ceiling"] = round(req / t_s / (GATHER_CEILING_GLINES * 1e9), 4)
 
 
+def price_traffic(roof, ent):
+    """HBM-side bytes of one launch from its counters (`ent`: fetch_kb_raw, write_kb, source) -> roof["traffic"],
+    "achieved", "frac".  gfx950's FETCH_SIZE reports 64 B per fabric request whatever its size.  A request
+    for a whole 128-byte record therefore moved twice what the counter says; a lane-wise probe (<= 16 bytes:
+    B / B' pieces, select blocks, positions, phase pieces, samples) moved the 64 B it reports.  The census
+    (same kernels, every request logged with its width) gives the share of record requests among the
+    requests of this launch, and
+        traffic = FETCH_SIZE x (1 + record share) + WRITE_SIZE.
+    For the all-record kernels (DNA count) that is the guide's 2 x FETCH_SIZE; for the run-length kernels,
+    half of whose requests are 16-byte probes, 2 x FETCH_SIZE overstated the bytes -- it is
+    kept as `traffic_upper`.  Without a census the upper bound is all there is, and `frac` says so."""
+    if not roof or not ent or not ent.get("fetch_kb_raw"):
+        return
+    t_s = roof["avg_kernel_ms"] / 1e3
+    fetch, write = ent["fetch_kb_raw"] * 1024.0, (ent.get("write_kb") or 0.0) * 1024.0
+    rec, prb = roof.get("requested_records"), roof.get("requested_probes")
+    share = rec / (rec + prb) if rec is not None and prb is not None and rec + prb > 0 else None
+    upper = int(2.0 * fetch + write)
+    tb = int(fetch * (1.0 + share) + write) if share is not None else upper
+    roof["traffic"] = tb
+    roof["traffic_upper"] = upper
+    roof["record_share_of_requests"] = round(share, 4) if share is not None else None
+    roof["traffic_source"] = ent.get("source")
+    if ent.get("kernel"):
+        roof["traffic_kernel"] = ent["kernel"]
+    roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent.get("write_kb")
+    roof["achieved"] = round(tb / t_s / 1e9, 1)
+    roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+    roof["frac_upper"] = round(upper / t_s / 1e9 / HBM_PEAK_GBS, 4)
+    set_miss_lines(roof, tb, roof.get("stream_bytes", 0), ent["fetch_kb_raw"])
+    roof["basis"] = ("HBM-side bytes of the PMC counters: FETCH_SIZE x (1 + share of 128-byte record requests, from "
+                     "the census) + WRITE_SIZE, over the kernel time" if share is not None else
+                     "UPPER BOUND: 2 x FETCH_SIZE + WRITE_SIZE (no census of request widths in this run)")
+    if roof.get("min_bytes"):
+        roof["traffic_over_min_bytes"] = round(tb / roof["min_bytes"], 3)
+
+
 def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes, census, traffic):
     """HBM roofline of one kernel.  `achieved` / `frac` use what the memory system really moved
-    when it was measured (PMC passes), else the lines the kernel REQUESTS (census) -- both are real
-    bytes of this layout and stay below the peak; the SURVEY 8d figure (the reference layout's 64-byte
-    blocks) is kept as `algorithmic_ref_bytes` for information only."""
+    when it was measured (PMC passes, priced by price_traffic) -- real bytes of this layout, below the peak;
+    the SURVEY 8d figure (the reference layout's 64-byte blocks) is kept as `algorithmic_ref_bytes` for
+    information only."""
     t_s = avg_kernel_ms / 1e3
     r = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "avg_kernel_ms": round(avg_kernel_ms, 4), "stream_bytes": stream_bytes}
-    req_bytes = None
     if census and census.get("requested_lines") is not None:
-        req_bytes = census["requested_lines"] * LINE + stream_bytes
         r["requested_lines"] = census["requested_lines"]
-        r["requested_bytes"] = req_bytes
+        r["requested_records"] = census.get("requested_records")
+        r["requested_probes"] = census.get("requested_probes")
+        nrec = census.get("requested_records")
+        nprb = census.get("requested_probes") or 0
+        r["requested_bytes"] = (nrec * LINE + nprb * 16 if nrec is not None else census["requested_lines"] * LINE) \
+            + stream_bytes
         r["requested_lines_per_s"] = census["requested_lines"] / t_s     # L2 hits included
         if census.get("distinct_lines") is not None:
             r["min_bytes"] = census["distinct_lines"] * LINE + stream_bytes
-    tb = traffic.get("bytes") if traffic else None
-    r["traffic"] = tb
-    if tb:
-        r["traffic_source"] = traffic.get("source")
-        r["achieved"] = round(tb / t_s / 1e9, 1)
-        set_miss_lines(r, tb, stream_bytes, traffic.get("fetch_kb_raw"))
-        r["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
-        if r.get("min_bytes"):
-            r["traffic_over_min_bytes"] = round(tb / r["min_bytes"], 3)
-    else:
-        # the census counts L2 hits too, so requested bytes are not HBM-side traffic: no number is
-        # better than one that can exceed the peak
-        r["achieved"] = None
-        r["basis"] = "no PMC traffic for this build (rocprofv3 unavailable and no profiles/traffic.json entry " \
-                     "measured on these sources)"
-    r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4) if r["achieved"] else None
+    r["traffic"] = None
+    r["achieved"] = None
+    r["frac"] = None
+    # the census counts L2 hits too, so requested bytes are not HBM-side traffic: no number is
+    # better than one that can exceed the peak
+    r["basis"] = "no PMC traffic for this build (rocprofv3 unavailable and no profiles/traffic.json entry " \
+                 "measured on these sources)"
+    price_traffic(r, traffic)
     r["algorithmic_ref_bytes"] = units * ref_bytes_per_unit
     r["algorithmic_ref_bytes_per_unit"] = ref_bytes_per_unit
     return r
@@ -467,7 +511,6 @@ def run_pmc_passes(args):
         # gfx950: FETCH_SIZE tallies 128-byte requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section;
         # re-calibrated below on a kernel with a known byte count); WRITE_SIZE reads exactly
         out[leg] = {"fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb or 0.0, 1),
-                    "bytes": int((2.0 * fetch_kb + (write_kb or 0.0)) * 1024),
                     "kernel": kn.split("(")[0].replace("void ", ""),
                     "source": "live rocprofv3 --pmc passes of this run"}
     # calibration in our own access pattern: k_mwm_pieces<3> reads the n-byte BWT exactly once
@@ -482,7 +525,62 @@ def run_pmc_passes(args):
 # --------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (port of the reference algorithm) on this box's cores
 # --------------------------------------------------------------------------------------------
+def host_cpu():
+    """what the CPU column really ran on: the cores this process may use (affinity mask, capped by the
+    cgroup CPU quota -- os.cpu_count() sees neither), the CPU model, sockets and threads per core"""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = os.cpu_count() or 1
+    quota = None
+    try:                                    # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_cpu_quota"] = quota
+    cores = info["affinity"]
+    if quota is not None:
+        cores = max(1, min(cores, int(quota)))
+    info["effective_cpus"] = cores
+    model, phys, siblings, cpu_cores = None, set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys.add(v)
+            elif k == "siblings" and siblings is None:
+                siblings = int(v)
+            elif k == "cpu cores" and cpu_cores is None:
+                cpu_cores = int(v)
+    except (OSError, ValueError):
+        pass
+    info["cpu_model"] = model
+    info["sockets"] = len(phys) or None
+    info["threads_per_core"] = (siblings // cpu_cores) if siblings and cpu_cores else None
+    info["physical_cores"] = (len(phys) * cpu_cores) if phys and cpu_cores else None
+    return info
+
+
 def cpu_baseline(wl, args, kind):
+    """the oracle (CPU port of the reference algorithm) on this box's cores: the headline number on the CPUs this
+    process may really use (affinity mask capped by the cgroup CPU quota), a thread sweep through and beyond that
+    number with the parallel efficiency, and the single-thread rate (the reference itself is single-threaded).
+    The threads of a batch pin themselves one per CPU, spread evenly over the allowed CPUs
+    (oracle/fm_oracle.c: orc_set_thread_spread); the oracle's bit planes are first touched by the static thread
+    decomposition that fills them, so their pages are spread over the sockets like the threads that probe them
+    at random."""
     import numpy as np
     from oracle import fm_oracle as O
     t0 = time.time()
@@ -491,7 +589,9 @@ def cpu_baseline(wl, args, kind):
     oi = O.OracleIndex.from_bwt(bwt, cs, wl.maxc, native=True, kind=kind)
     del bwt
     t_ob = time.time() - t0
-    cores = os.cpu_count() or 1
+    host = host_cpu()
+    cores = host["effective_cpus"]
+    oi.set_thread_spread(True)
     m = wl.m
     pat_h = wl.pat.cpu().numpy()
     s_h = wl.d_s.cpu().numpy().view(np.uint64)
@@ -502,23 +602,53 @@ def cpu_baseline(wl, args, kind):
         t = time.perf_counter()
         so, eo = oi.count_batch(pat_h[:k * m], offk, nthreads=threads)
         return time.perf_counter() - t, so, eo
+    budget = args.cpu_seconds
     k0 = 1 << 14
     t_probe, so, eo = cpu_run(k0, cores)
-    k = int(min(wl.npat, max(k0, k0 * args.cpu_seconds / 4 / max(t_probe, 1e-6))))
+    k = int(min(wl.npat, max(k0, k0 * budget / 5 / max(t_probe, 1e-6))))
     t_all, so, eo = cpu_run(k, cores)
     assert (so == s_h[:k]).all() and (eo == e_h[:k]).all(), "GPU != oracle on the CPU sample"
     times = [t_all]
-    while sum(times) < args.cpu_seconds and len(times) < 25:
+    while sum(times) < budget * 0.5 and len(times) < 25:
         times.append(cpu_run(k, cores)[0])
     t_all = sorted(times)[len(times) // 2]
-    k1 = max(1024, k // cores)
+    value = k * m / t_all
+    # one thread, then the sweep: each point ~ budget / 12 seconds of work at the rate of the point before
+    k1 = max(1024, int(k0 * (budget / 12) / max(t_probe * cores, 1e-6)))
+    k1 = min(k1, wl.npat)
     t_one, _, _ = cpu_run(k1, 1)
+    one = k1 * m / t_one
+    sweep = [{"threads": 1, "value": one, "scaling_vs_1t": 1.0, "parallel_efficiency": 1.0}]
+    rate = one
+    # through the effective CPU count and beyond it, up to every CPU the affinity mask shows: where the curve
+    # flattens is what this box gives this process, whatever os.cpu_count() says
+    phys = host.get("physical_cores") or cores
+    limit = host["affinity"]
+    eff_cores = min(cores, phys)
+    for th in sorted({t for t in (2, 4, 8, 16, 32, 64, 128, phys, cores, limit) if 1 < t <= limit}):
+        kk = int(min(wl.npat, max(2048, rate * min(th / sweep[-1]["threads"], 2.0) * (budget / 16) / m)))
+        dt, _, _ = cpu_run(kk, th)
+        rate = kk * m / dt
+        sweep.append({"threads": th, "value": rate, "scaling_vs_1t": round(rate / one, 2),
+                      "parallel_efficiency": round(rate / one / min(th, eff_cores), 3)})
+    best = max(sweep, key=lambda p: p["value"])
+    team = oi.team_size(cores)
+    oi.set_thread_spread(False)
     oi.close()
-    return {"value": k * m / t_all, "unit": "pattern-chars/s", "cores": cores, "kind": "port",
+    return {"value": max(value, best["value"]), "unit": "pattern-chars/s", "cores": cores, "threads_used": team or cores,
+            "kind": "port", "cpu_model": host["cpu_model"], "sockets": host["sockets"],
+            "physical_cores": host["physical_cores"], "threads_per_core": host["threads_per_core"],
+            "host": {k_: host[k_] for k_ in ("os_cpu_count", "affinity", "cgroup_cpu_quota", "effective_cpus")},
+            "placement": "one thread per CPU, spread evenly over the allowed CPUs (sched_setaffinity per batch)",
             "sample": "first %d of the %d patterns (same text, same %s built from the index's exported "
                       "BWT), median of %d runs of %.2f s on %d threads; GPU (s,e) bit-identical on the sample"
                       % (k, wl.npat, "RLFM structure" if kind == "rlfm" else "wavelet matrix", len(times), t_all, cores),
-            "single_thread_value": k1 * m / t_one, "oracle_build_s": round(t_ob, 1)}
+            "all_threads_value": value, "best_threads": best["threads"],
+            "single_thread_value": one, "scaling_vs_1t": round(max(value, best["value"]) / one, 2),
+            "parallel_efficiency": round(max(value, best["value"]) / one / eff_cores, 3),
+            "parallel_efficiency_note": "best rate / (single-thread rate x effective CPUs = min(affinity, cgroup quota, "
+                                        "physical cores))",
+            "thread_sweep": sweep, "oracle_build_s": round(t_ob, 1)}
 
 
 # --------------------------------------------------------------------------------------------
@@ -680,6 +810,13 @@ def run(args, world, pmc=None):
     # ---- locate (config 3; gathered over the ranks for N > 1) ----
     if wl.level is not None:
         locate_leg(out, wl, args, world, rank, dist, gloo, key)
+
+    # ---- opt-in text-order sampling on the one-level index (FMX_FLAG_TEXT_ORDER): same positions ----
+    if single and wl.dna and wl.level is not None and not args.no_accel:
+        try:
+            locate_text_order_leg(out, wl, args)
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
+            out["locate_text_order"] = {"error": repr(ex)}
 
     # ---- the config-5 step through a 1-rank RCCL communicator on this GPU (default N=1 run) ----
     if single and not args.no_rccl_check:
@@ -867,26 +1004,14 @@ def rccl_1rank_leg(out, wl, args, dev, local):
 
 
 def apply_pmc(out, pmc, cal):
-    def redo(roof, ent):
-        if not roof or not ent:
-            return
-        t_s = roof["avg_kernel_ms"] / 1e3
-        roof["traffic"] = ent["bytes"]
-        roof["traffic_source"] = ent["source"]
-        roof["traffic_kernel"] = ent["kernel"]
-        roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent["write_kb"]
-        roof["achieved"] = round(ent["bytes"] / t_s / 1e9, 1)
-        roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-        set_miss_lines(roof, ent["bytes"], roof.get("stream_bytes", 0), ent["fetch_kb_raw"])
-        roof["basis"] = "HBM-side bytes of the PMC counters (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"
-        if roof.get("min_bytes"):
-            roof["traffic_over_min_bytes"] = round(ent["bytes"] / roof["min_bytes"], 3)
+    redo = price_traffic
     if isinstance(cal, str):
         out["pmc"] = {"status": cal}
     elif pmc:
         out["pmc"] = {"status": "ok", "calibration": cal,
                       "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel-trace only) over "
-                              "`bench.py --pmc-child`; gfx950: FETCH_SIZE x 2"}
+                              "`bench.py --pmc-child`; gfx950: FETCH_SIZE reports 64 B per request -> x (1 + share of "
+                              "128-byte record requests), see roofline.basis"}
     else:
         out["pmc"] = {"status": "no counters collected"}
     redo(out.get("roofline"), pmc.get("dna_count"))
@@ -1028,6 +1153,47 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
         dest[legname]["two_streams"] = two
 
 
+def locate_text_order_leg(out, wl, args):
+    """config 3 on an index built with FMX_FLAG_TEXT_ORDER (opt-in for one-level indexes): the rows whose SA
+    value is a multiple of 2^level carry the samples and every walk is exactly SA[row] mod 2^level steps.
+    Positions must equal the row-order index's (the reference's answers) on every hit."""
+    torch, F, lib = wl.torch, wl.F, wl.lib
+    tix = F.FMIndexWithLocate.from_device_text(wl.text.data_ptr(), wl.n, wl.maxc, level=wl.level, device=wl.local,
+                                               sampling="text")
+    try:
+        assert tix.text_order()
+        total, npat = wl.total_hits, wl.npat
+        pos = torch.empty(max(total, 1), dtype=torch.int64, device=wl.dev)
+
+        def lstep():
+            rc = lib.fmx_locate_batch_dev(tix.handle(), C.c_void_p(wl.d_s.data_ptr()), C.c_void_p(wl.d_e.data_ptr()),
+                                          npat, C.c_void_p(wl.d_off.data_ptr()), total, C.c_void_p(pos.data_ptr()), wl.sp)
+            assert rc == 0
+        for _ in range(3):
+            lstep()
+        torch.cuda.synchronize()
+        reps = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lstep()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        lib.fmx_set_timing(tix.handle(), 1)
+        lstep()
+        torch.cuda.synchronize()
+        kms, steps = lib.fmx_last_kernel_ms(tix.handle()), int(lib.fmx_last_steps(tix.handle()))
+        lib.fmx_set_timing(tix.handle(), 0)
+        assert bool((pos[:total] == wl.d_pos[:total]).all()), "text-order index locates differently"
+        out["locate_text_order"] = {"hits_per_s": total / dt, "ms_per_batch": dt * 1e3, "walk_kernel_ms": round(kms, 4),
+                                    "hits": total, "lf_steps": steps, "index_bytes": tix.heap_size(),
+                                    "row_order_index_bytes": wl.index.heap_size(),
+                                    "build_ms": round(float(lib.fmx_build_ms(tix.handle())), 1),
+                                    "note": "opt-in FMX_FLAG_TEXT_ORDER on the config-3 index; positions identical "
+                                            "to the row-order index on every hit"}
+    finally:
+        tix.close()
+
+
 def locate_two_streams(wl, reps):
     """the same batch alternating between two streams through the caller-workspace entry point
     (fmx_locate_batch_ws_dev: kernel launches only, nothing shared between the streams but the index), so
@@ -1132,8 +1298,11 @@ def locate_3b(out, wl, args, key):
                         "count_min": int(cnts.min().item()), "count_median": int(cnts.median().item()),
                         "count_max": int(cnts.max().item())}
     # HBM-side traffic of this launch (told from the config-3 launches of the same kernel by its grid)
+    # request widths by construction (what the census counts for config 3): one record per LF step, one sample per hit
+    widths = {"requested_lines": lf_steps + total, "requested_records": lf_steps, "requested_probes": total,
+              "distinct_lines": None}
     out["locate_3b"]["roofline"] = make_roofline("fmx_locate_f3p_kernel<4>", kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
-                                                 total * 4 + total * 8, None, stored_traffic(key, "locate_3b"))
+                                                 total * 4 + total * 8, widths, stored_traffic(key, "locate_3b"))
 
 
 def d2h_leg(out, wl, args):
@@ -1186,9 +1355,10 @@ def d2h_leg(out, wl, args):
                        "value_is": "pinned" if dt <= dtp else "pageable",
                        "bytes_in": npat * m + (npat + 1) * 8, "bytes_out": 3 * npat * 8,
                        "note": "fmx_count_batch (host pointers): upload, count, download, synchronise per call; "
-                               "caller-owned arrays reused across calls, page-locked and pageable (this runtime "
-                               "copies pageable memory faster than it DMAs page-locked memory); value_incl_d2h "
-                               "is the better of the two; never the headline value"}
+                               "caller-owned arrays reused across calls.  Page-locked arrays: 8-chunk pipeline over "
+                               "three streams (DMA upload, search, download by copy kernels); pageable arrays: the "
+                               "runtime's pin-copy-unpin copies in two chunks.  value_incl_d2h is the better of the "
+                               "two; never the headline value"}
     del hp, ho, hs, he, hc
 
 

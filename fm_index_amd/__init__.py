@@ -106,10 +106,21 @@ class Text:
         return self._max
 
 
+def _flags(keep_sa, pair_index, kmer_table, sampling):
+    """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
+    (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
+    if sampling not in (None, "text", "row"):
+        raise ValueError("sampling must be None, 'text' or 'row'")
+    return ((L.FLAG_KEEP_SA if keep_sa else 0) | (L.FLAG_PAIR_INDEX if pair_index else 0) |
+            (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
+            (L.FLAG_ROW_ORDER if sampling == "row" else 0))
+
+
 class _Index:
     _kind = L.KIND_FM
 
-    def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False):
+    def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False,
+                 sampling=None):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -119,14 +130,13 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
                                  text.max_character(),
-                                 self._kind, lvl, (L.FLAG_KEEP_SA if keep_sa else 0) |
-                                 (L.FLAG_PAIR_INDEX if pair_index else 0) |
-                                 (L.FLAG_KMER_TABLE if kmer_table else 0), device, C.byref(self._h))
+                                 self._kind, lvl, _flags(keep_sa, pair_index, kmer_table, sampling), device,
+                                 C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
-                         pair_index=False, sym_bytes=1, kmer_table=False):
+                         pair_index=False, sym_bytes=1, kmer_table=False, sampling=None):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -134,9 +144,7 @@ class _Index:
         self._dtype = np.dtype(_DTYPES[sym_bytes])
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
-                                       (L.FLAG_KEEP_SA if keep_sa else 0) |
-                                       (L.FLAG_PAIR_INDEX if pair_index else 0) |
-                                       (L.FLAG_KMER_TABLE if kmer_table else 0), device,
+                                       _flags(keep_sa, pair_index, kmer_table, sampling), device,
                                        C.byref(self._h)))
         return self
 
@@ -275,6 +283,10 @@ class _Index:
     def has_pair_index(self):
         return bool(self._lib.fmx_has_pair_index(self._h))
 
+    def text_order(self):
+        """suffix-array samples kept in text order (FMX_FLAG_TEXT_ORDER or the builder's default)?"""
+        return bool(self._lib.fmx_text_order(self._h))
+
     def kmer_k(self):
         """k of the opt-in k-mer start table (0 = none)."""
         return int(self._lib.fmx_kmer_k(self._h))
@@ -310,8 +322,8 @@ class FMIndexWithLocate(_Index):
     """FMIndexWithLocate::new(&text, level) (frontend.rs:205-221)."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False):
-        super().__init__(text, level, device, keep_sa, pair_index, kmer_table)
+    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False, sampling=None):
+        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling)
 
 
 class RLFMIndex(_Index):
@@ -326,8 +338,8 @@ class RLFMIndexWithLocate(_Index):
     """RLFMIndexWithLocate::new(&text, level) (frontend.rs:233-243)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False):
-        super().__init__(text, level, device, keep_sa, False, kmer_table)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None):
+        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling)
 
 
 class FMIndexMultiPieces(_Index):
@@ -357,8 +369,8 @@ class FMIndexMultiPieces(_Index):
 class FMIndexMultiPiecesWithLocate(FMIndexMultiPieces):
     """FMIndexMultiPiecesWithLocate::new(&text, level) (frontend.rs:255-267)."""
 
-    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False):
-        _Index.__init__(self, text, level, device, keep_sa, False, kmer_table)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None):
+        _Index.__init__(self, text, level, device, keep_sa, False, kmer_table, sampling)
 
 
 class Search:

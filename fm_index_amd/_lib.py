@@ -24,6 +24,8 @@ NO_LOCATE = 0xFFFFFFFF
 FLAG_KEEP_SA = 1
 FLAG_PAIR_INDEX = 2
 FLAG_KMER_TABLE = 4
+FLAG_TEXT_ORDER = 8
+FLAG_ROW_ORDER = 16
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
@@ -92,6 +94,7 @@ SYMBOLS = [
     ("fmx_match_rows", _I, [_V, _V, _V, _U64, _I, _V, _V]),
     ("fmx_sym_bytes", _U32, [_V]),
     ("fmx_has_pair_index", _I, [_V]),
+    ("fmx_text_order", _I, [_V]),
     ("fmx_kmer_k", _U32, [_V]),
 ]
 

@@ -193,6 +193,7 @@ uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0;
 uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
 uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
+int fmx_text_order(const fmx_index *idx) { return idx && idx->dev.phase ? 1 : 0; }
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
@@ -324,8 +325,11 @@ namespace {
 const size_t kSmallCap = 256u << 10;
 const size_t kSmallUse = kSmallCap - 64;   // the last 64 bytes of both staging buffers hold the call's status word
 const size_t kRetainCap = 1ull << 30;   // larger batch scratch is allocated and freed per call
+const int kPipeEvents = 16;              // chunks of a pipelined host-pointer batch
+const unsigned kPipeSearchBlocks = 1792; // grid cap of a chunk's search: 7 x 256 CUs
 struct SmallCtx {
-  hipStream_t st = nullptr, st2 = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr;
+  hipEvent_t ev_in[kPipeEvents], ev_k[kPipeEvents];   // upload done / kernel done, per chunk (no timing)
   uint8_t *h = nullptr, *d = nullptr;
   uint8_t *big = nullptr;
   size_t big_cap = 0;
@@ -339,6 +343,8 @@ struct SmallCtxSet {  // released when the owning thread exits
       if (hipSetDevice(dvc) != hipSuccess) continue;
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
+      (void)hipStreamDestroy(c.st3);
+      for (int k = 0; k < kPipeEvents; k++) { (void)hipEventDestroy(c.ev_in[k]); (void)hipEventDestroy(c.ev_k[k]); }
       (void)hipHostFree(c.h);
       (void)hipFree(c.d);
       if (c.big) (void)hipFree(c.big);
@@ -357,10 +363,22 @@ SmallCtx *small_ctx(int device) {
       c.st = nullptr;
       return nullptr;
     }
-    if (hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c.st3, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipStreamDestroy(c.st);
+      (void)hipStreamDestroy(c.st2);
+      c.st = nullptr;
+      return nullptr;
+    }
+    bool ok = true;
+    int made = 0;
+    for (; made < kPipeEvents && ok; made++)
+      ok = hipEventCreateWithFlags(&c.ev_in[made], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&c.ev_k[made], hipEventDisableTiming) == hipSuccess;
+    if (!ok || hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c.d, kSmallCap) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
+      (void)hipStreamDestroy(c.st3);
       c.st = nullptr;
       return nullptr;
     }
@@ -447,6 +465,58 @@ int finish_host_call(SmallCtx *sx, hipStream_t other = nullptr) {
 }
 }  // namespace
 uint32_t *fmx_call_status(void) { return t_call_status; }
+// ---- page-locked caller memory: seen from the device, moved by kernels ----------------------------------
+// device address of a host pointer when the GPU can reach it (hipHostMalloc / hipHostRegister memory), else NULL
+static void *device_view(const void *p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (at.type != hipMemoryTypeHost) return nullptr;
+  void *d = nullptr;                       // the address of THIS pointer (interior pointers included), not of its allocation
+  if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
+// dst[0, n) = src[0, n); both sides aligned alike modulo 16 (the callers see to that): bytes up to the first
+// 16-byte boundary, 16-byte vectors, bytes again
+__global__ __launch_bounds__(256) void fmx_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                       size_t n) {
+  size_t head = (16u - ((uintptr_t)src & 15u)) & 15u;
+  if (head > n) head = n;
+  const size_t body = (n - head) >> 4, tail = (n - head) & 15u;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  if (tid < head) dst[tid] = src[tid];
+  const uint4 *s4 = (const uint4 *)(src + head);
+  uint4 *d4 = (uint4 *)(dst + head);
+  for (size_t i = tid; i < body; i += nth) d4[i] = s4[i];
+  if (tid < tail) dst[head + (body << 4) + tid] = src[head + (body << 4) + tid];
+}
+// 8-byte words whose two sides differ by 8 modulo 16 (u64 arrays at an odd word of the caller's buffer)
+__global__ __launch_bounds__(256) void fmx_copy8_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src,
+                                                        size_t nwords) {
+  const size_t nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += nth) dst[i] = src[i];
+}
+// 256 blocks move 56 GB/s over the host link and leave the CUs to the search kernels (pcie_probe: 64 blocks the
+// same rate alone, 1024 slower)
+static unsigned g_copy_blocks = 32;   // 32 x 256 lanes x 16 B in flight carry 56 GB/s over the host link
+static void launch_copy(void *dst, const void *src, size_t bytes, hipStream_t S) {
+  if (!bytes) return;
+  size_t blocks = (bytes / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > g_copy_blocks) blocks = g_copy_blocks;
+  if ((((uintptr_t)dst ^ (uintptr_t)src) & 15u) == 0)
+    hipLaunchKernelGGL(fmx_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, S, (uint8_t *)dst, (const uint8_t *)src, bytes);
+  else   // only the 8-byte arrays can get here: symbols are copied with matching alignment
+    hipLaunchKernelGGL(fmx_copy8_kernel, dim3((unsigned)blocks), dim3(256), 0, S, (uint64_t *)dst, (const uint64_t *)src,
+                       bytes / 8);
+}
+
 
 int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_off, uint64_t npat,
                     const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count) {
@@ -480,9 +550,7 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       return rc;
     }
   }
-  // batches: pattern bytes go in and (s, e, count) come out in chunks that alternate between the
-  // context's two streams, so chunk k's kernel runs under chunk k+1's upload and chunk k-1's
-  // download
+  // batches
   std::vector<uint32_t> narrow;
   const uint8_t *src = (const uint8_t *)pat;
   if (idx->sym_bytes_abi == 8 && total) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
@@ -491,24 +559,112 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     for (uint64_t i = 0; i < total; i++) narrow[i] = p64[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p64[i];
     src = (const uint8_t *)narrow.data();
   }
-  const size_t b_pat = (size_t)total * sb, b_off = (size_t)(npat + 1) * 8, b_out = (size_t)npat * 8;
+  // Page-locked caller arrays (hipHostMalloc / hipHostRegister / torch pin_memory) are visible to the GPU:
+  // chunks are moved by COPY KERNELS in the chunk's own stream -- symbols and offsets in, search, (s, e, count)
+  // out -- and three streams keep both directions of the host link and the search busy at once.  The runtime's
+  // DMA copies of page-locked memory run at the same 56 GB/s per direction (benchmarks/gpu/pcie_probe.hip), but
+  // every hand-over between a DMA copy and a kernel of the same stream costs tens of microseconds here: the
+  // same pipeline built from hipMemcpyAsync took 4.0 ms per 2^20 x 32 call, two chunks 2.0 ms.
+  const bool all_pinned = idx->sym_bytes_abi != 8 && !idx->timing && npat >= (1u << 16) &&
+                          device_view(pat) && device_view(pat_off) && (!s0e0 || device_view(s0e0)) &&
+                          (!out_s || device_view(out_s)) && (!out_e || device_view(out_e)) &&
+                          (!out_count || device_view(out_count));
+  const size_t b_pat = (size_t)total * sb, b_out = (size_t)npat * 8;
+  const uint64_t max_ch = 8;
+  const size_t b_off = (size_t)(npat + 1 + max_ch) * 8;      // every chunk gets its own slice of the offsets
   HostCall hc;
-  FMX_HIP(hc.open(idx->device, HostCall::pad(b_pat ? b_pat : 8) + HostCall::pad(b_off) +
+  FMX_HIP(hc.open(idx->device, HostCall::pad(b_pat + 32) + HostCall::pad(b_off) +
                                    (s0e0 ? HostCall::pad(2 * b_out) : 0) + 3 * HostCall::pad(b_out)));
-  uint8_t *d_pat = hc.take<uint8_t>(b_pat);
+  uint8_t *d_pat = hc.take<uint8_t>(b_pat + 32);
   uint64_t *d_off = hc.take<uint64_t>(b_off);
   uint64_t *d_se = s0e0 ? hc.take<uint64_t>(2 * b_out) : nullptr;
   uint64_t *d_s = hc.take<uint64_t>(b_out), *d_e = hc.take<uint64_t>(b_out), *d_c = hc.take<uint64_t>(b_out);
-  hipStream_t st[2] = {hc.sx->st, hc.sx->st2};
-  CallStatus cs(hc.sx);
-  FMX_HIP(hipMemsetAsync(status_dev(hc.sx), 0, 4, st[0]));   // ordered before every chunk by the wait below
-  // two halves: every host copy has a fixed cost of 50-80 us on this runtime, so more, smaller chunks
-  // lose (pageable arrays at 2^20 x 32: 1 chunk 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13;
-  // page-locked arrays: 2 chunks 2.0 ms, 8 chunks 3.7 ms -- their DMA copies are slower than the
-  // runtime's staged copies of pageable memory, so pinning buys nothing here)
+  SmallCtx *sx = hc.sx;
+  CallStatus cs(sx);
+  if (all_pinned) {
+    // three ROLE streams linked by events: upload of chunk k+1, search of chunk k and download of chunk k-1
+    // run at the same time, each stage at its full rate.  (One stream per CHUNK was measured first: the
+    // chunks then march in step -- three uploads share the link, then three searches share the CUs -- and
+    // nothing overlaps: 1.75 ms, the sum of the stages.  benchmarks/gpu/hostpipe_trace.sh)
+    hipStream_t s_k = sx->st, s_in = sx->st2, s_out = sx->st3;
+    auto drain = [&]() { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_k); (void)hipStreamSynchronize(s_out); };
+    // eight chunks from 2^19 patterns: the upload is the slowest stage (40 MB at 56 GB/s against 0.65 ms of
+    // search and 24 MB out for 2^20 x 32) and every DMA copy costs ~20 us on top of its bytes; with 4 or 8 equal
+    // chunks a call takes 1.34-1.39 ms, with all offsets in one copy ahead of the chunks or with chunks that
+    // shrink towards the end 1.46-1.6 ms (benchmarks/gpu/hostpipe_sweep.sh, profiles/r03/hostpipe_*.txt)
+    uint64_t nch = npat >= (1u << 19) ? max_ch : 4;
+    unsigned search_blocks = kPipeSearchBlocks;
+    bool h2d_dma = true;
+#ifdef FMX_TUNE_HOSTPIPE   // benchmarks/gpu/hostpipe_sweep.sh only: never defined for the shipped library
+    if (const char *v = getenv("FMX_PIPE_CHUNKS")) { const uint64_t u = (uint64_t)atoi(v); if (u >= 1 && u <= max_ch) nch = u; }
+    if (const char *v = getenv("FMX_PIPE_BLOCKS")) search_blocks = (unsigned)atoi(v);
+    if (const char *v = getenv("FMX_PIPE_COPY_BLOCKS")) g_copy_blocks = (unsigned)atoi(v);
+    if (const char *v = getenv("FMX_PIPE_H2D")) h2d_dma = atoi(v) != 0;
+#endif
+    auto cut = [&](uint64_t k) { return npat * k / nch; };
+    FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, s_k));   // ahead of every search in the search stream
+    // the device copy of the symbols keeps the caller's alignment modulo 16, so that both sides of every
+    // chunk's copy are aligned alike whatever pa is
+    uint8_t *d_pat_al = d_pat + ((uintptr_t)src & 15u);
+    const uint8_t *v_pat = (const uint8_t *)device_view(src);
+    const uint64_t *v_off = (const uint64_t *)device_view(pat_off);
+    const uint64_t *v_se = s0e0 ? (const uint64_t *)device_view(s0e0) : nullptr;
+    uint64_t *v_os = out_s ? (uint64_t *)device_view(out_s) : nullptr;
+    uint64_t *v_oe = out_e ? (uint64_t *)device_view(out_e) : nullptr;
+    uint64_t *v_oc = out_count ? (uint64_t *)device_view(out_count) : nullptr;
+    for (uint64_t k = 0; k < nch; k++) {
+      const uint64_t a = cut(k), b = cut(k + 1);
+      if (b == a) continue;
+      const uint64_t pa = pat_off[a], pb = pat_off[b];
+      if (pb < pa || pb > total) {
+        drain();
+        return fail(FMX_ERR_ARG, "pat_off is not non-decreasing");
+      }
+      // upload by DMA: the stream holds nothing but copies, so none of them waits for a kernel (a DMA copy that
+      // depends on a kernel is handed over by the host: tens of microseconds each); the search's wait for the
+      // copy is a barrier on the GPU side.  Upload by copy kernels was measured too: host reads in flight slow
+      // the concurrent search five-fold (benchmarks/gpu/hostpipe_trace.sh)
+      uint64_t *off_k = d_off + a + k;               // entries a..b of the caller's offsets, this chunk's own copy
+      if (h2d_dma) {
+        FMX_HIP(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice, s_in));
+        if (pb > pa)
+          FMX_HIP(hipMemcpyAsync(d_pat_al + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, s_in));
+        if (s0e0) FMX_HIP(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, s_in));
+      } else {
+        launch_copy(off_k, v_off + a, (size_t)(b - a + 1) * 8, s_in);
+        if (pb > pa) launch_copy(d_pat_al + pa * sb, v_pat + pa * sb, (size_t)(pb - pa) * sb, s_in);
+        if (s0e0) launch_copy(d_se + 2 * a, v_se + 2 * a, (size_t)(b - a) * 16, s_in);
+      }
+      FMX_HIP(hipEventRecord(sx->ev_in[k], s_in));
+      FMX_HIP(hipStreamWaitEvent(s_k, sx->ev_in[k], 0));
+      // the kernel bounds every pattern's offsets by the last entry it is given: pb <= total.  Fewer blocks than
+      // the CUs have slots for: the download kernels of the chunk before need somewhere to run WHILE this
+      // search runs (a persistent 2048-block grid holds every slot until its last pattern)
+      if (int rc = fmx_launch_count(idx, d_pat_al, off_k, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a, d_e + a,
+                                    d_c + a, s_k, search_blocks)) {
+        drain();
+        return rc;
+      }
+      FMX_HIP(hipEventRecord(sx->ev_k[k], s_k));
+      FMX_HIP(hipStreamWaitEvent(s_out, sx->ev_k[k], 0));
+      // download by copy kernels: kernel after kernel, no hand-over to a DMA engine
+      if (v_os) launch_copy(v_os + a, d_s + a, (size_t)(b - a) * 8, s_out);
+      if (v_oe) launch_copy(v_oe + a, d_e + a, (size_t)(b - a) * 8, s_out);
+      if (v_oc) launch_copy(v_oc + a, d_c + a, (size_t)(b - a) * 8, s_out);
+    }
+    FMX_HIP(hipGetLastError());
+    FMX_HIP(hipStreamSynchronize(s_in));
+    FMX_HIP(hipStreamSynchronize(s_out));            // s_k == sx->st is waited for below
+    return finish_host_call(sx);
+  }
+  // pageable arrays: the runtime's copies (pin, copy, unpin), each chunk chained in one of two streams.  Two
+  // halves: every such copy has a fixed cost of 50-80 us, so more, smaller chunks lose (2^20 x 32: 1 chunk
+  // 1.92 ms, 2: 1.42, 4: 1.52, 8: 2.76, 16: 3.13)
+  hipStream_t st[2] = {sx->st, sx->st2};
+  FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, st[0]));   // ordered before every chunk by the wait below
   uint64_t nch = (npat >= (1u << 17) && !idx->timing) ? 2 : 1;
   // all offsets first (every chunk's kernel reads its own slice plus one entry)
-  FMX_HIP(hipMemcpyAsync(d_off, pat_off, b_off, hipMemcpyHostToDevice, st[0]));
+  FMX_HIP(hipMemcpyAsync(d_off, pat_off, (size_t)(npat + 1) * 8, hipMemcpyHostToDevice, st[0]));
   FMX_HIP(hipStreamSynchronize(st[0]));
   auto download = [&](uint64_t k) -> hipError_t {
     const uint64_t a = npat * k / nch, b = npat * (k + 1) / nch;
@@ -542,7 +698,7 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   }
   FMX_HIP(download(nch - 1));
   FMX_HIP(hipStreamSynchronize(st[1]));              // st[0] == sx->st is waited for below
-  return finish_host_call(hc.sx);
+  return finish_host_call(sx);
 }
 
 int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,

@@ -1001,13 +1001,11 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     // row-order sampling and no geometric tail -- at the price of two phase-piece reads.  One-level
     // indexes (DNA) keep row-order sampling: their LF step is ONE request, so the two extra reads cost
     // more than the saved steps (2^20 hits 0.255 ms against 0.158 ms, profiles/r02/sweeps.md).
-    bool text_order = level >= 1 && level <= FMX_PHASE_MAX_LEVEL && (idx->kind == FMX_KIND_RLFM || L > 4);
-#ifdef FMX_MEASURE
-    if (const char *v = getenv("FMX_VARIANT")) {
-      if (atoi(v) == 18) text_order = false;                                          // sampled rows everywhere
-      if (atoi(v) == 19) text_order = level >= 1 && level <= FMX_PHASE_MAX_LEVEL;     // text order everywhere
-    }
-#endif
+    // FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER override that choice (include/fmx.h).
+    const bool can_text = level >= 1 && level <= FMX_PHASE_MAX_LEVEL;
+    bool text_order = can_text && (idx->kind == FMX_KIND_RLFM || L > 4);
+    if (idx->flags & FMX_FLAG_TEXT_ORDER) text_order = can_text;
+    if (idx->flags & FMX_FLAG_ROW_ORDER) text_order = false;
     if (text_order) {
       // sample the rows whose SA value is a multiple of 2^level (same number of samples), in row order,
       // and keep every row's phase SA[row] mod 2^level with a rank over the phase-0 rows (fmx_internal.h)

@@ -26,17 +26,23 @@
 #ifdef FMX_CENSUS
 struct FmxCensusDev { unsigned long long *log; unsigned long long *count; unsigned long long cap; };
 static __device__ FmxCensusDev fmx_census_dev;
-__device__ __forceinline__ void fmx_touch(const void *p) {
+// A log entry is the 128-byte line address; bit 63 marks a NARROW request (a lane-wise probe of at most 16
+// bytes: B / B' pieces, select blocks, stored positions, phase pieces, samples, k-mer entries) as opposed to a
+// whole 128-byte record fetched by the 8 lanes of a group -- bench.py prices the two differently.
+__device__ __forceinline__ void fmx_touch(const void *p, bool narrow) {
   if (fmx_census_dev.log) {
     const unsigned long long i = atomicAdd(fmx_census_dev.count, 1ull);
-    if (i < fmx_census_dev.cap) fmx_census_dev.log[i] = (unsigned long long)(uintptr_t)p >> 7;
+    if (i < fmx_census_dev.cap)
+      fmx_census_dev.log[i] = ((unsigned long long)(uintptr_t)p >> 7) | (narrow ? 1ull << 63 : 0ull);
   }
 }
-#define FMX_TOUCH(p) fmx_touch((const void *)(p))
-#define FMX_TOUCH_G0(g, p) do { if ((g) == 0) fmx_touch((const void *)(p)); } while (0)
+#define FMX_TOUCH(p) fmx_touch((const void *)(p), true)                                        // lane-wise probe
+#define FMX_TOUCH_G0(g, p) do { if ((g) == 0) fmx_touch((const void *)(p), false); } while (0)  // 128-byte record
+#define FMX_TOUCH_G0N(g, p) do { if ((g) == 0) fmx_touch((const void *)(p), true); } while (0)  // one word / block, read by the group
 #else
 #define FMX_TOUCH(p) do { } while (0)
 #define FMX_TOUCH_G0(g, p) do { } while (0)
+#define FMX_TOUCH_G0N(g, p) do { } while (0)
 #endif
 
 // pattern / text symbol i of a buffer whose symbols are sb bytes wide (Character, character.rs)
@@ -428,15 +434,15 @@ __device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k, ui
 // select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint32_t fmx_bits_select(const FmxBits &bv, uint32_t k, uint32_t g) {
   if (k >= bv.ones) return bv.len;
-  if (bv.pos) { FMX_TOUCH_G0(g, &bv.pos[k]); return bv.pos[k]; }   // sparse vector: the positions are stored
+  if (bv.pos) { FMX_TOUCH_G0N(g, &bv.pos[k]); return bv.pos[k]; }   // sparse vector: the positions are stored
   if (bv.dsel) {                              // dense vector: one 16-byte block answers it
-    FMX_TOUCH_G0(g, &bv.dsel[k >> bv.dsel_shift]);
+    FMX_TOUCH_G0N(g, &bv.dsel[k >> bv.dsel_shift]);
     const uint4 blk = bv.dsel[k >> bv.dsel_shift];
     if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k, bv.dsel_shift);
   }
   uint32_t h = k / FMX_SEL_STEP;
   FMX_CHECK(h + 1 < bv.nsel);
-  FMX_TOUCH_G0(g, &bv.sel[h]);
+  FMX_TOUCH_G0N(g, &bv.sel[h]);
   uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
   FMX_CHECK(lo < bv.nrec && hi < bv.nrec);
   while (lo < hi) {  // group-uniform binary search over record bases
@@ -471,16 +477,16 @@ __device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k
   const bool v0 = k0 < A.ones, v1 = k1 < B.ones;
   const uint32_t q0 = v0 ? k0 : 0u, q1 = v1 ? k1 : 0u;
   if (SM == 1 || (SM < 0 && A.pos && B.pos)) {   // sparse vectors: the positions are stored
-    FMX_TOUCH_G0(g, &A.pos[q0]);
-    FMX_TOUCH_G0(g, &B.pos[q1]);
+    FMX_TOUCH_G0N(g, &A.pos[q0]);
+    FMX_TOUCH_G0N(g, &B.pos[q1]);
     const uint32_t a0 = A.pos[q0], a1 = B.pos[q1];
     out0 = v0 ? a0 : A.len;
     out1 = v1 ? a1 : B.len;
     return;
   }
   if (SM == 2 || (SM < 0 && A.dsel && B.dsel)) {   // dense vectors: one 16-byte block per select
-    FMX_TOUCH_G0(g, &A.dsel[q0 >> A.dsel_shift]);
-    FMX_TOUCH_G0(g, &B.dsel[q1 >> B.dsel_shift]);
+    FMX_TOUCH_G0N(g, &A.dsel[q0 >> A.dsel_shift]);
+    FMX_TOUCH_G0N(g, &B.dsel[q1 >> B.dsel_shift]);
     const uint4 b0 = A.dsel[q0 >> A.dsel_shift], b1 = B.dsel[q1 >> B.dsel_shift];
     if (b0.x != 0xFFFFFFFFu && b1.x != 0xFFFFFFFFu) {
       out0 = v0 ? fmx_dsel_pos(b0, q0, A.dsel_shift) : A.len;
@@ -489,8 +495,8 @@ __device__ __forceinline__ void fmx_bits_select_two(const FmxBits &A, uint32_t k
     }
   }
   FMX_CHECK(q0 / FMX_SEL_STEP + 1 < A.nsel && q1 / FMX_SEL_STEP + 1 < B.nsel);
-  FMX_TOUCH_G0(g, &A.sel[q0 / FMX_SEL_STEP]);
-  FMX_TOUCH_G0(g, &B.sel[q1 / FMX_SEL_STEP]);
+  FMX_TOUCH_G0N(g, &A.sel[q0 / FMX_SEL_STEP]);
+  FMX_TOUCH_G0N(g, &B.sel[q1 / FMX_SEL_STEP]);
   uint32_t lo0 = A.sel[q0 / FMX_SEL_STEP], hi0 = A.sel[q0 / FMX_SEL_STEP + 1];
   uint32_t lo1 = B.sel[q1 / FMX_SEL_STEP], hi1 = B.sel[q1 / FMX_SEL_STEP + 1];
   FMX_CHECK(hi0 < A.nrec && hi1 < B.nrec);

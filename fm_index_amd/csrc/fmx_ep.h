@@ -35,7 +35,7 @@ __device__ __forceinline__ void fmx_touch_lane(const void *p, bool want = true) 
     const bool same = lo == (uint32_t)line && hi == (uint32_t)(line >> 32);
     if (same && (threadIdx.x & 1u)) log = false;
   }
-  if (log) fmx_touch(p);
+  if (log) fmx_touch(p, true);
 }
 #define FMX_TOUCH_LANE(PAIRED, p, want) fmx_touch_lane<PAIRED>((const void *)(p), (want))
 #else

@@ -164,9 +164,11 @@ static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
   return FMX_OK;
 }
 
+// max_blocks (0 = the kernel's own choice): cap of the 256-thread grid of the group-per-pattern kernels, for a
+// caller that wants workgroup slots left free for kernels of its other streams (fmx_count_batch's copy kernels)
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
-                     uint64_t *d_cnt, hipStream_t st);
+                     uint64_t *d_cnt, hipStream_t st, unsigned max_blocks = 0);
 // rows_ws / tile_ws: caller-provided scratch (fmx_locate_rows_bytes / fmx_offsets_tile_bytes); NULL = take
 // it from the stream-ordered allocator for the duration of the call
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,

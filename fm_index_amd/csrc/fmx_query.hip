@@ -19,42 +19,12 @@
 #define FMX_BLOCK 256
 #define FMX_MAX_BLOCKS 2048  // 256 CUs x 8 resident 256-thread blocks
 
-// Kernel variant selector.  The SHIPPED library (libfmx.so) has one path per index kind: this
-// function is the constant 1 there and no environment variable is read on any launch path.
-// Measurement builds (make measure / make debug, -DFMX_MEASURE) read FMX_VARIANT once, so that the
-// alternatives DESIGN.md section 4.1 quotes stay reproducible:
-//   unset / 1  the shipped paths
-//   0          force the round-1 generic group-per-pattern kernels (any kind / any number of levels)
-//   2, 5       DNA count with 2 / 4 independent chains per group            (slower: 0.78 / 1.00 ms)
-//   3, 4       DNA count skipping the 2nd load when both ends share a record (slower: 0.74 / 0.80 ms)
-//   6          ignore the k-mer start table even when it was built
-//   7          ignore the pair index even when it was built
-//   8, 9       lane-per-pattern / wavefront-per-pattern DNA count kernels
-//   11, 12, 14, 15  DNA locate with 1 / 2 / 4 / 8 walks per group
-//   16, 17     (builder) do not store the positions of sparse / the select blocks of dense RLFM bit vectors
-//   18, 19     (builder) row-order / text-order suffix-array sampling for every index kind
-//   20         endpoint-per-lane count on FM indexes;  21  one-walk-per-lane locate on the one-level index
-//   22         DNA walk kernel of rounds 1-2 (state repeated in all 8 lanes);  23  hand-over at the end of the round
-//   24, 25     distributed-state DNA count kernel with 4 / 2 patterns per group;  26  positions stored directly
-// and the grid knobs FMX_EP_BLOCKS, FMX_LOC_BLOCKS, FMX_LOC_THREADS, FMX_EP_LOC_BLOCKS, FMX_RL_EP_MIN, FMX_FM_EP_MIN
-// (benchmarks/gpu/README.md).
-#ifdef FMX_MEASURE
-static inline int fmx_variant() {
-  static const int cached = [] {
-    const char *v = getenv("FMX_VARIANT");
-    return v ? atoi(v) : 1;
-  }();
-  return cached;
+static inline unsigned fmx_grid_for_groups(uint64_t units);
+// the same, but never more blocks than `cap` (a caller that wants CU slots left free for its copy kernels)
+static inline unsigned fmx_grid_capped(uint64_t units, unsigned cap) {
+  const unsigned g = fmx_grid_for_groups(units);
+  return g < cap ? g : cap;
 }
-static inline long fmx_env_long(const char *name, long dflt) {
-  const char *v = getenv(name);
-  return v ? atol(v) : dflt;
-}
-#else
-static constexpr int fmx_variant() { return 1; }
-static constexpr long fmx_env_long(const char *, long dflt) { return dflt; }
-#endif
-
 static inline unsigned fmx_grid_for_groups(uint64_t units) {
   uint64_t blocks = (units * FMX_GROUP + FMX_BLOCK - 1) / FMX_BLOCK;
   if (blocks < 1) blocks = 1;
@@ -154,7 +124,7 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
           uint32_t code;
           if (fmx_kmer_code((const uint8_t *)pat, pbeg + j, ix.kmer_k, ix.kmer_bits, ix.max_character, g,
                             code)) {
-            FMX_TOUCH_G0(g, &ix.kmer[code]);
+            FMX_TOUCH_G0N(g, &ix.kmer[code]);
             const uint2 se = ix.kmer[code];
             s = se.x;
             e = se.y;
@@ -281,7 +251,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
           if (KM && j[q] >= kmer_k) {                  // the first kmer_k steps from the table
             uint32_t code;
             if (fmx_kmer_code(pat, pbeg[q] + j[q], kmer_k, kmer_bits, max_character, g, code)) {
-              FMX_TOUCH_G0(g, &kmer[code]);
+              FMX_TOUCH_G0N(g, &kmer[code]);
               const uint2 se = kmer[code];
               s[q] = se.x;
               e[q] = se.y;
@@ -356,208 +326,6 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// ---------------------------------------------------------------------------
-// The same count with the PATTERN STATE DISTRIBUTED over the lanes of a group (the form the DNA walk
-// kernel takes, fmx_locate_f3p_kernel): a group of 8 lanes still reads one 128-byte record per interval
-// end, but it advances Q patterns at a time and lane q of each quad keeps pattern q -- its offsets, the
-// symbols still to consume, (s, e) -- so fetching the next symbol, the early exit (wrapper.rs:111-113),
-// the outputs and the start of the next pattern run once per round for all Q, lane-wise, and only the
-// two record loads + the two rank decodes run per pattern (s, e, c broadcast inside the quad).
-// No k-mer table here (that lookup is cooperative over the group): fmx_count_f3_kernel serves it.
-// ---------------------------------------------------------------------------
-template <int Q>
-__device__ __forceinline__ uint32_t fmx_slot_bcast(uint32_t v, int q) {
-  return Q == 1 ? v : fmx_quad_bcast(v, q);
-}
-template <int Q>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3d_kernel(
-    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
-    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
-    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
-    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
-  static_assert(Q == 2 || Q == 4, "patterns per group");
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  [[maybe_unused]] const uint32_t nrec = n / 256u + 1u;
-  const uint32_t slot = g & (uint32_t)(Q - 1);        // the pattern whose state this lane keeps (8 / Q replicas)
-  const bool owner = g < (uint32_t)Q;                 // the replica that stores and counts
-  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
-  constexpr uint32_t NONE = 0xFFFFFFFFu;              // not a position (n < 2^32 - 16)
-  const uint64_t ptot = npat ? off[npat] : 0;         // symbols the caller declares behind `pat`
-
-  uint64_t k = gid * (uint64_t)Q + slot;              // a group's Q patterns are neighbours: their offsets,
-  const uint64_t kstride = ngroups * (uint64_t)Q;     // symbols and outputs share cache lines
-  bool active = k < npat, fresh = true;
-  uint64_t pbeg = 0;
-  uint32_t j = 0, s = 0, e = 0, c = 0, nsteps = 0;
-  while (__any(active)) {
-    if (active && fresh) {
-      pbeg = off[k];
-      const uint64_t pend = off[k + 1];
-      j = (uint32_t)(pend - pbeg);
-      // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
-      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
-      if (badoff) j = 0;
-      bool bad = badoff;
-      if (s0e0) {              // Search::search on an existing Search (wrapper.rs:105-106)
-        const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
-        s = (uint32_t)s64;
-        e = (uint32_t)e64;
-        if (s64 > n || e64 > n || badoff) {            // not a range of this index: refuse, do not read
-          bad = true;
-          s = 0; e = 0; j = 0;
-        }
-      } else {                 // (0, len)   wrapper.rs:41
-        s = 0;
-        e = badoff ? 0u : n;
-      }
-      if (bad && owner) atomicOr(status, 1u << FMX_ERR_ARG);
-      c = j ? pat[pbeg + j - 1] : 0u;                  // last symbol: pattern.iter().rev()
-      fresh = false;
-    }
-    const bool stepping = active && j != 0 && c <= max_character;
-    // the next symbol rides along with this round's record loads
-    uint32_t cn = 0;
-    if (stepping && j > 1) cn = pat[pbeg + j - 2];
-    const uint32_t sx = stepping ? s : NONE;
-    const unsigned long long wm = __ballot(stepping);
-    uint4 a[Q], b[Q];
-    uint32_t sq[Q], eq[Q], cq[Q];
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      sq[q] = NONE; eq[q] = 0; cq[q] = 0;
-      if (!(wm & (SLOT0 << q))) continue;              // pattern q idle in every group of the wave
-      sq[q] = fmx_slot_bcast<Q>(sx, q);
-      eq[q] = fmx_slot_bcast<Q>(e, q);
-      cq[q] = fmx_slot_bcast<Q>(c, q);
-      if (sq[q] != NONE) {                             // group-uniform
-        const uint32_t rs = sq[q] >> 8, re = eq[q] >> 8;
-        FMX_CHECK(rs < nrec && re < nrec);
-        FMX_TOUCH_G0(g, &rec[(size_t)rs * 8u]);
-        if (re != rs) FMX_TOUCH_G0(g, &rec[(size_t)re * 8u]);   // both ends in one record: ONE line
-        a[q] = rec[(size_t)rs * 8u + g];
-        b[q] = rec[(size_t)re * 8u + g];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      if (!(wm & (SLOT0 << q))) continue;
-      if (sq[q] != NONE) {
-        const uint32_t ns = fmx_group_sum(fmx_piece_rank<3>(a[q], sq[q] & 255u, cq[q], g));  // wrapper.rs:109
-        const uint32_t ne = fmx_group_sum(fmx_piece_rank<3>(b[q], eq[q] & 255u, cq[q], g));  // wrapper.rs:110
-        if (slot == (uint32_t)q) { s = ns; e = ne; }
-      }
-    }
-    if (active) {
-      bool done = j == 0;
-      if (!done) {
-        if (!stepping) {                               // reference: panic on cs[c]
-          if (owner) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
-          s = 0; e = 0; done = true;
-        } else {
-          c = cn;
-          j--;
-          nsteps++;
-          if (s == e || j == 0) done = true;           // wrapper.rs:111-113
-        }
-      }
-      if (done) {
-        if (owner) {
-          if (out_s) out_s[k] = s;
-          if (out_e) out_e[k] = e;
-          if (out_cnt) out_cnt[k] = (uint64_t)(e - s);  // wrapper.rs:132-134
-        }
-        k += kstride;
-        active = k < npat;
-        fresh = true;
-      }
-    }
-  }
-  if (steps_out && owner && nsteps)
-    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-
-#ifdef FMX_MEASURE
-// ---------------------------------------------------------------------------
-// Measurement-only alternatives to the 8-lane-group shape (selected
-// with FMX_VARIANT=8 / 9, never used by default):
-//   fmx_count_f3_lane_kernel  -- one LANE owns one pattern and reads both 128-B records itself
-//                                (8 dwordx4 loads per record, no cross-lane traffic)
-//   fmx_count_f3_wave_kernel  -- one WAVEFRONT owns one pattern (lanes 0-7 fetch the record of s,
-//                                lanes 8-15 the record of e, the other 48 lanes idle)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fmx_rank_whole_record(const uint4 *__restrict__ r, uint32_t off,
-                                                          uint32_t c) {
-  uint32_t acc = r[c].x;  // absolute counter of symbol c
-#pragma unroll
-  for (uint32_t g = 0; g < 8; g++) {
-    const uint4 p = r[g];
-    int nb = (int)off - (int)(g * 32);
-    nb = nb < 0 ? 0 : (nb > 32 ? 32 : nb);
-    acc += __popc(fmx_piece_match<3>(p, c) & (uint32_t)((1ull << nb) - 1ull));
-  }
-  return acc;
-}
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_lane_kernel(
-    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
-    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
-    uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt,
-    uint64_t *__restrict__ steps_out) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  uint32_t nsteps = 0;
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < npat; k += stride) {
-    const uint64_t pbeg = off[k];
-    uint32_t j = (uint32_t)(off[k + 1] - pbeg), s = 0, e = n;
-    while (j) {
-      nsteps++;
-      const uint32_t c = pat[pbeg + --j];
-      if (c > max_character) { atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE); s = e = 0; break; }
-      s = fmx_rank_whole_record(rec + (size_t)(s >> 8) * 8u, s & 255u, c);
-      e = fmx_rank_whole_record(rec + (size_t)(e >> 8) * 8u, e & 255u, c);
-      if (s == e) break;
-    }
-    if (out_s) out_s[k] = s;
-    if (out_e) out_e[k] = e;
-    if (out_cnt) out_cnt[k] = (uint64_t)(e - s);
-  }
-  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_wave_kernel(
-    const uint4 *__restrict__ rec, uint32_t n, uint32_t max_character, uint32_t *status,
-    const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
-    uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt,
-    uint64_t *__restrict__ steps_out) {
-  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u;
-  if (lane >= 16u) return;                 // 48 of the 64 lanes have nothing to fetch
-  const bool is_e = lane >= 8u;
-  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  uint32_t nsteps = 0;
-  for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < npat; k += nwaves) {
-    const uint64_t pbeg = off[k];
-    uint32_t j = (uint32_t)(off[k + 1] - pbeg);
-    uint32_t v = is_e ? n : 0u;            // lanes 0-7 carry s, lanes 8-15 carry e
-    bool dead = false;
-    while (j && !dead) {
-      const uint32_t c = pat[pbeg + --j];
-      if (c > max_character) { if (lane == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE); v = 0; break; }
-      const uint4 p = rec[(size_t)(v >> 8) * 8u + g];
-      v = fmx_group_sum(fmx_piece_rank<3>(p, v & 255u, c, g));
-      const uint32_t other = (uint32_t)__shfl((int)v, (int)(lane ^ 8u));
-      dead = (v == other);
-      nsteps++;
-    }
-    if (g == 0) {
-      if (!is_e && out_s) out_s[k] = v;
-      if (is_e && out_e) out_e[k] = v;
-    }
-    const uint32_t sv = (uint32_t)__shfl((int)v, (int)(lane & 7u));
-    if (lane == 8 && out_cnt) out_cnt[k] = (uint64_t)(v - sv);
-  }
-  if (steps_out && lane == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-
-#endif  // FMX_MEASURE
 
 // ---------------------------------------------------------------------------
 // count with the opt-in pair index (FMX_FLAG_PAIR_INDEX): while at least two symbols remain
@@ -611,7 +379,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
         if (KM && j >= kmer_k) {                       // the first kmer_k steps from the table
           uint32_t code;
           if (fmx_kmer_code(pat, pbeg + j, kmer_k, kmer_bits, max_character, g, code)) {
-            FMX_TOUCH_G0(g, &kmer[code]);
+            FMX_TOUCH_G0N(g, &kmer[code]);
             const uint2 se = kmer[code];
             s = se.x;
             e = se.y;
@@ -861,7 +629,7 @@ __device__ __forceinline__ uint64_t fmx_get_sa_text(const FmxDev &ix, uint32_t r
                                                     uint32_t &nsteps) {
   uint32_t t, rank0;
   uint32_t p = fmx_phase_piece(row, ix.sa_level, t);
-  FMX_TOUCH_G0(g, &ix.phase[p]);
+  FMX_TOUCH_G0N(g, &ix.phase[p]);
   const uint32_t phi = fmx_phase_decode(ix.phase[p], t, ix.sa_level, rank0);
   for (uint32_t k = 0; k < phi; k++) {               // i = lf_map(i); steps += 1     fm_index.rs:134-137
     uint32_t sym;
@@ -870,11 +638,11 @@ __device__ __forceinline__ uint64_t fmx_get_sa_text(const FmxDev &ix, uint32_t r
   nsteps += phi;
   if (phi) {
     p = fmx_phase_piece(row, ix.sa_level, t);
-    FMX_TOUCH_G0(g, &ix.phase[p]);
+    FMX_TOUCH_G0N(g, &ix.phase[p]);
     (void)fmx_phase_decode(ix.phase[p], t, ix.sa_level, rank0);
   }
   FMX_CHECK(rank0 < ix.nsamples);
-  FMX_TOUCH_G0(g, &ix.samples[rank0]);
+  FMX_TOUCH_G0N(g, &ix.samples[rank0]);
   return (uint64_t)ix.samples[rank0] + phi;          // fm_index.rs:131-133 (sa + steps)
 }
 
@@ -917,7 +685,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
       if ((row & lmask) == 0) {
         // sample.rs:46-60 Some(sa): fm_index.rs:131-133  (sa + steps) % len
         FMX_CHECK((row >> ix.sa_level) < ix.nsamples);
-        FMX_TOUCH_G0(g, &ix.samples[row >> ix.sa_level]);
+        FMX_TOUCH_G0N(g, &ix.samples[row >> ix.sa_level]);
         uint64_t v = (uint64_t)ix.samples[row >> ix.sa_level] + steps;
         if (v >= ix.n) v -= ix.n;  // steps < n, sa < n
         if (g == 0) out_pos[h] = v;
@@ -1054,146 +822,6 @@ struct FmxHitQueue {
   }
 };
 
-#ifdef FMX_MEASURE   // the round-1/2 form of the DNA walk, kept for A/B runs (FMX_VARIANT=22)
-// locate walk, single 3-bit level (DNA).  The wave's 8 groups take hits from the queue above as they
-// finish (ballot + prefix popcount), so the wave runs sum(work) / (8 Q) iterations, not max over its
-// groups; a finishing group takes its next row from the register window with a ds_bpermute -- no
-// dependent memory access to start a walk.  Every iteration a group issues exactly ONE 16-B load per
-// lane whose address depends on its state -- a record piece while walking (fm_index.rs:134-137) or
-// the aligned chunk holding its SA sample once the row is sampled (sample.rs:46-60) -- so walking
-// and finishing groups of one wave overlap their latencies instead of serialising two branches.
-// TEXT: text-order sampling (FmxDev::phase).  A walk is then four kinds of iteration, each ONE 16-byte
-// load per lane like before: read the row's phase piece -> `phase` LF steps (no test in between) ->
-// read the final row's phase piece for its rank among the sampled rows -> read the sample.
-template <int Q, bool TEXT>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3w_kernel(
-    const uint4 *__restrict__ rec, const uint32_t *__restrict__ samples, const uint4 *__restrict__ phase,
-    uint32_t n, uint32_t sa_level, uint64_t total, uint32_t hits_per_block, uint32_t chunk,
-    const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  __shared__ unsigned int lds_q;
-  if (threadIdx.x == 0) lds_q = 0;
-  __syncthreads();
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  // Q independent walks per group: Q record loads in flight per lane (the longest single walk of
-  // the batch still bounds the kernel from below).
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = lane & (FMX_GROUP - 1);
-  const uint32_t grp = lane >> 3;
-  const uint32_t lmask = (1u << sa_level) - 1u;
-  const uint4 *samp4 = reinterpret_cast<const uint4 *>(samples);
-  FmxHitQueue<> hq;
-  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
-
-  uint64_t h[Q], pend_h[Q], pend_v[Q];
-  uint32_t row[Q], steps[Q];
-  // TEXT: stage of the walk (0 phase of the start row, 1 LF steps, 2 rank at the final row, 3 sample),
-  // LF steps still to do, index of the sample
-  [[maybe_unused]] uint32_t st[Q], rem[Q], sidx[Q];
-  bool active[Q], pending[Q];
-  uint32_t nsteps = 0;
-#pragma unroll
-  for (int q = 0; q < Q; q++) {
-    active[q] = hq.take(grp, h[q], row[q]);
-    hq.advance(8u, lds_q);
-    if (!active[q]) row[q] = 0u;
-    steps[q] = 0;
-    st[q] = 0; rem[q] = 0; sidx[q] = 0;
-    pending[q] = false;
-    pend_h[q] = 0;
-    pend_v[q] = 0;
-  }
-  for (;;) {
-    // slots that are dead in EVERY group of the wave are skipped altogether (wave-uniform): towards
-    // the end of a batch a wave holds one or two long walks, and an iteration then costs one
-    // slot's instructions instead of Q slots' -- the tail runs at memory latency, not at issue rate
-    bool live[Q];
-    bool any = false;
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      live[q] = __any(active[q]) != 0;
-      any |= live[q] || __any(pending[q]) != 0;
-    }
-    if (!any) break;
-    // issue every load of this round
-    uint4 p[Q];
-    bool sampled[Q];
-    [[maybe_unused]] uint32_t pt[Q];               // TEXT: the row's index inside its phase piece
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      sampled[q] = TEXT ? st[q] == 3u : (row[q] & lmask) == 0;
-      p[q] = make_uint4(0u, 0u, 0u, 0u);
-      pt[q] = 0;
-      if (live[q] && active[q]) {
-        const uint32_t si = TEXT ? sidx[q] : row[q] >> sa_level;
-        FMX_CHECK(row[q] < n && (row[q] >> 8) < n / 256u + 1u);
-        FMX_CHECK(!sampled[q] || (uint64_t)si <= (((uint64_t)n - 1) >> sa_level));
-        const uint4 *addr = sampled[q] ? (samp4 + (si >> 2)) : (rec + ((size_t)(row[q] >> 8) * 8u + g));
-        if (TEXT && (st[q] == 0u || st[q] == 2u)) addr = phase + fmx_phase_piece(row[q], sa_level, pt[q]);
-        FMX_TOUCH_G0(g, (!TEXT || st[q] == 1u) && !sampled[q] ? addr - g : addr);
-        p[q] = *addr;
-      }
-    }
-    // positions finished in the previous round are stored behind these loads
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      if (pending[q] && g == 0) out_pos[pend_h[q]] = pend_v[q];
-      pending[q] = false;
-    }
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      if (!live[q]) continue;                                     // wave-uniform
-      bool fin = false;
-      if (active[q]) {
-        if (sampled[q]) {
-          const uint32_t w = (TEXT ? sidx[q] : row[q] >> sa_level) & 3u;
-          const uint32_t p0 = p[q].x, p1 = p[q].y, p2 = p[q].z, p3 = p[q].w;
-          const uint32_t sa = w == 0 ? p0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
-          uint64_t v = (uint64_t)sa + steps[q];     // fm_index.rs:131-133: (sa + steps) % len
-          if (v >= n) v -= n;
-          pend_v[q] = v;
-          pend_h[q] = h[q];
-          pending[q] = true;
-          fin = true;
-        } else if (TEXT && st[q] != 1u) {           // phase piece: of the start row (0) or the final row (2)
-          uint32_t rank0;
-          const uint32_t phi = fmx_phase_decode(p[q], pt[q], sa_level, rank0);
-          sidx[q] = rank0;
-          rem[q] = phi;
-          st[q] = (st[q] == 2u || phi == 0u) ? 3u : 1u;
-        } else {
-          const uint32_t off = row[q] & 255u;
-          const uint32_t sym =
-              fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
-          row[q] = fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));  // lf_map (absolute counters)
-          steps[q]++;
-          nsteps++;
-          if (TEXT && --rem[q] == 0u) st[q] = 2u;
-        }
-      }
-      const unsigned long long fmask = __ballot(fin && g == 0);  // one bit per finishing group
-      if (fmask) {                                                // wave-uniform
-        const uint32_t leader = lane & ~7u;
-        const uint32_t my_rank = (uint32_t)__popcll(fmask & ((1ull << leader) - 1ull));
-        uint64_t h_new;
-        uint32_t r_new;
-        const bool ok = hq.take(my_rank, h_new, r_new);
-        if (fin) {
-          h[q] = h_new;
-          active[q] = ok;
-          row[q] = ok ? r_new : 0u;
-          steps[q] = 0;
-          st[q] = 0;
-        }
-        hq.advance((uint32_t)__popcll(fmask), lds_q);
-      }
-    }
-  }
-  if (steps_out && g == 0 && nsteps)
-    atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-#endif  // FMX_MEASURE
 
 // locate walk, single 3-bit level (DNA), walk state DISTRIBUTED over the lanes of a group.  A group of 8
 // lanes still serves Q walks at a time with one 128-byte record per LF step (fm_index.rs:134-137), but the
@@ -1960,12 +1588,163 @@ static void fmx_time_end(const fmx_index *idx, hipStream_t st) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Dispatch choices.  The SHIPPED library (libfmx.so) has one path per index kind and reads no environment
+// variable on any launch path: fmx_tune() is a constant there and every test on it folds away.  The
+// measurement builds (-DFMX_MEASURE: make measure / make debug) fill the same struct from FMX_VARIANT and
+// the grid knobs and add the alternative kernels DESIGN.md section 4.1 quotes -- all of that lives in
+// fmx_measure.inc, which only those builds include.
+// ---------------------------------------------------------------------------
+struct FmxTune {
+  bool generic = false;          // round-1 group-per-pattern / group-per-walk kernels for every kind
+  bool use_kmer = true;          // honour the k-mer start table when the index has one
+  bool use_pair = true;          // honour the pair index when the index has one
+  bool wc = true;                // locate: positions through the write-combining ring
+  int alt = 0;                   // measurement-only kernel (fmx_measure.inc), 0 = none
+  int walks = 0;                 // DNA locate: walks per group, 0 = by batch size
+  long ep_blocks = 1024;         // count, endpoint per lane: grid cap (4 waves per SIMD saturate the memory system)
+  long loc_blocks = 0;           // DNA locate: blocks, 0 = by batch size
+  long loc_threads = FMX_LOC_BLOCK;
+  long ep_loc_blocks = 0;        // one-walk-per-lane locate: blocks, 0 = by batch size
+  long ep_loc_threads = 0;       // ... threads per block, 0 = by batch size
+  long rl_ep_min = 1l << 18;     // RLFM: one walk per lane from this many hits
+  long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
+};
+// everything a count / locate launch needs, for the launch helpers below and in fmx_measure.inc
+struct FmxCountCall {
+  const fmx_index *idx; FmxDev dv; const void *pat; const uint64_t *off; uint64_t npat; const uint64_t *s0e0;
+  uint64_t *s, *e, *cnt, *steps; hipStream_t st; bool km; unsigned grid;
+};
+struct FmxLocateCall {
+  const fmx_index *idx; FmxDev dv; uint64_t total; const uint32_t *rows; uint64_t *pos, *steps; hipStream_t st;
+  // 1024-thread blocks that each own a slice of the hits (FmxHitQueue): `nb` blocks wanted -> slice
+  // length (a multiple of the ticket size, below 2^31) and the blocks that are really needed
+  void slice(uint64_t nb, uint32_t chunk, uint32_t &hpb, unsigned &grid) const {
+    const uint64_t min_nb = (total >> 31) + 1;
+    if (nb < min_nb) nb = min_nb;
+    uint64_t per = (total + nb - 1) / nb;
+    per = (per + chunk - 1) / chunk * chunk;
+    hpb = (uint32_t)per;
+    grid = (unsigned)((total + per - 1) / per);
+  }
+};
+// select structure of an RLFM index's B / B': 1 stored positions, 2 select blocks, 0 hints + records; -1 not RLFM
+static inline int fmx_select_mode(const fmx_index *idx, const FmxDev &dv) {
+  return idx->kind != FMX_KIND_RLFM ? -1 : (dv.b.pos && dv.bp.pos) ? 1 : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
+}
+
+// ---- count launch helpers (c = FmxCountCall) ----
+#define FMX_F3_LAUNCH(c, PPG, SKIP, KM)                                                              \
+  hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP, KM>),                                             \
+                     dim3(fmx_grid_capped(((c).npat + PPG - 1) / PPG, (c).grid)), dim3(FMX_BLOCK), 0, (c).st, \
+                     (c).dv.bw.lv[0].rec, (c).dv.n, (c).dv.max_character, (c).dv.status, (c).dv.kmer,  \
+                     (c).dv.kmer_k, (c).dv.kmer_bits, (const uint8_t *)(c).pat, (c).off, (c).npat,     \
+                     (c).s0e0, (c).s, (c).e, (c).cnt, (c).steps)
+#define FMX_PAIR_LAUNCH(c, KM)                                                                       \
+  hipLaunchKernelGGL(fmx_count_pair_kernel<KM>, dim3((c).grid), dim3(FMX_BLOCK), 0, (c).st,            \
+                     (c).dv.bw.lv[0].rec, (c).dv.pair_rec, (c).dv.n, (c).dv.max_character,             \
+                     (c).dv.pair_row0, (c).dv.pair_row1, (c).dv.status, (c).dv.kmer, (c).dv.kmer_k,    \
+                     (c).dv.kmer_bits, (const uint8_t *)(c).pat, (c).off, (c).npat, (c).s0e0, (c).s,   \
+                     (c).e, (c).cnt, (c).steps)
+// group per pattern; number of wavelet levels fixed at compile time for the common cases (1, 2)
+#define FMX_COUNT_LAUNCH(c, KIND, NL, SM)                                                            \
+  do {                                                                                               \
+    if ((c).km && (c).idx->sym_bytes == 1)                                                           \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true, SM>), dim3((c).grid), dim3(FMX_BLOCK), 0,   \
+                         (c).st, (c).dv, (c).pat, (c).off, (c).npat, (c).s0e0, (c).s, (c).e, (c).cnt,  \
+                         (c).steps);                                                                 \
+    else                                                                                             \
+      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false, SM>), dim3((c).grid), dim3(FMX_BLOCK), 0,  \
+                         (c).st, (c).dv, (c).pat, (c).off, (c).npat, (c).s0e0, (c).s, (c).e, (c).cnt,  \
+                         (c).steps);                                                                 \
+  } while (0)
+#define FMX_COUNT_KIND(c, KIND, SM)                                                                  \
+  do {                                                                                               \
+    if ((c).dv.bw.nlevels == 1) FMX_COUNT_LAUNCH(c, KIND, 1, SM);                                    \
+    else if ((c).dv.bw.nlevels == 2) FMX_COUNT_LAUNCH(c, KIND, 2, SM);                               \
+    else FMX_COUNT_LAUNCH(c, KIND, 0, SM);                                                           \
+  } while (0)
+// endpoint per lane: one pattern per group while the grid lasts, `cap` blocks at most
+#define FMX_EP_LAUNCH(c, eb, KIND, NL, SM)                                                           \
+  do {                                                                                               \
+    if ((c).km && (c).idx->sym_bytes == 1)                                                           \
+      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, true>), dim3((unsigned)(eb)),              \
+                         dim3(FMX_BLOCK), 0, (c).st, (c).dv, (c).pat, (c).off, (c).npat, (c).s0e0,     \
+                         (c).s, (c).e, (c).cnt, (c).steps);                                          \
+    else                                                                                             \
+      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, false>), dim3((unsigned)(eb)),             \
+                         dim3(FMX_BLOCK), 0, (c).st, (c).dv, (c).pat, (c).off, (c).npat, (c).s0e0,     \
+                         (c).s, (c).e, (c).cnt, (c).steps);                                          \
+  } while (0)
+#define FMX_EP_SM(c, eb, KIND, SM)                                                                   \
+  do {                                                                                               \
+    if ((c).dv.bw.nlevels == 1) FMX_EP_LAUNCH(c, eb, KIND, 1, SM);                                   \
+    else if ((c).dv.bw.nlevels == 2) FMX_EP_LAUNCH(c, eb, KIND, 2, SM);                              \
+    else FMX_EP_LAUNCH(c, eb, KIND, 0, SM);                                                          \
+  } while (0)
+static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
+  uint64_t eb = (npat + FMX_BLOCK / 8 - 1) / (FMX_BLOCK / 8);
+  return eb > (uint64_t)cap ? (uint64_t)cap : eb;
+}
+
+// ---- locate launch helpers (c = FmxLocateCall) ----
+#define FMX_LOCQ_LAUNCH(c, gr, thr, hpb, chunk, Q, TEXT)                                             \
+  hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(thr), 0, (c).st,                 \
+                     (c).dv.bw.lv[0].rec, (c).dv.samples, (c).dv.phase, (c).dv.n, (c).dv.sa_level,     \
+                     (c).total, hpb, chunk, (c).rows, (c).pos, (c).steps)
+#define FMX_LOCP_LAUNCH(c, gr, thr, hpb, chunk, Q, WCF)                                              \
+  hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, WCF>), dim3(gr), dim3(thr), 0, (c).st,                  \
+                     (c).dv.bw.lv[0].rec, (c).dv.samples, (c).dv.n, (c).dv.sa_level, (c).total, hpb,   \
+                     chunk, (c).rows, (c).pos, (c).steps)
+// group per walk (any kind / any number of levels)
+#define FMX_LOCATE_LAUNCH(c, grid, hpw, KIND, NL, SM)                                                \
+  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, (c).st,        \
+                     (c).dv, (c).total, hpw, (c).rows, (c).pos, (c).steps)
+#define FMX_LOCATE_KIND(c, grid, hpw, KIND, SM)                                                      \
+  do {                                                                                               \
+    if ((c).dv.bw.nlevels == 1) FMX_LOCATE_LAUNCH(c, grid, hpw, KIND, 1, SM);                        \
+    else if ((c).dv.bw.nlevels == 2) FMX_LOCATE_LAUNCH(c, grid, hpw, KIND, 2, SM);                   \
+    else FMX_LOCATE_LAUNCH(c, grid, hpw, KIND, 0, SM);                                               \
+  } while (0)
+// one walk per lane
+#define FMX_EPL_LAUNCH3(c, gr, thr, hpb, KIND, NL, SM, KL, TX, WCF)                                  \
+  hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, KL, TX, WCF>), dim3(gr), dim3(thr), 0,        \
+                     (c).st, (c).dv, (c).total, hpb, (c).rows, (c).pos, (c).steps)
+#ifdef FMX_MEASURE   // direct stores instead of the write-combining ring (FMX_VARIANT=26)
+#define FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, KL, TX)                                  \
+  do { if (wcf) FMX_EPL_LAUNCH3(c, gr, thr, hpb, KIND, NL, SM, KL, TX, true);                        \
+       else FMX_EPL_LAUNCH3(c, gr, thr, hpb, KIND, NL, SM, KL, TX, false); } while (0)
+#else
+#define FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, KL, TX)                                  \
+  FMX_EPL_LAUNCH3(c, gr, thr, hpb, KIND, NL, SM, KL, TX, true)
+#endif
+#define FMX_EPL_LAUNCH(c, gr, thr, hpb, wcf, KIND, NL, SM)                                           \
+  do {                                                                                               \
+    const bool klds_ = (c).dv.max_character < 1024u, text_ = (c).dv.phase != nullptr;                \
+    if (klds_) { if (text_) FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, true, true);         \
+                 else FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, true, false); }            \
+    else { if (text_) FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, false, true);              \
+           else FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, false, false); }                 \
+  } while (0)
+#define FMX_EPL_SM(c, gr, thr, hpb, wcf, KIND, SM)                                                   \
+  do {                                                                                               \
+    if ((c).dv.bw.nlevels == 1) FMX_EPL_LAUNCH(c, gr, thr, hpb, wcf, KIND, 1, SM);                   \
+    else if ((c).dv.bw.nlevels == 2) FMX_EPL_LAUNCH(c, gr, thr, hpb, wcf, KIND, 2, SM);              \
+    else FMX_EPL_LAUNCH(c, gr, thr, hpb, wcf, KIND, 0, SM);                                          \
+  } while (0)
+
+#ifdef FMX_MEASURE
+#include "fmx_measure.inc"       // fmx_tune() from the environment, fmx_measure_count(), fmx_measure_locate()
+#else
+static constexpr FmxTune fmx_tune() { return FmxTune{}; }
+#endif
+
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
-                     uint64_t *d_cnt, hipStream_t st) {
+                     uint64_t *d_cnt, hipStream_t st, unsigned max_blocks) {
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
-  unsigned grid = fmx_grid_for_groups(npat);
+  if (max_blocks == 0 || max_blocks > FMX_MAX_BLOCKS) max_blocks = FMX_MAX_BLOCKS;
   if (idx->n == 0) {                                 // no record of any structure may be probed
     hipLaunchKernelGGL(fmx_count_empty_kernel, dim3(fmx_grid_for_groups((npat + 7) / 8)), dim3(FMX_BLOCK), 0,
                        st, dv.max_character, idx->sym_bytes, dv.status, d_pat, d_off, npat, d_s0e0, d_s, d_e,
@@ -1974,125 +1753,36 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
     return FMX_OK;
   }
   fmx_time_begin(idx, st);
-  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
+  const FmxTune tn = fmx_tune();
+  const FmxCountCall c{idx, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr,
+                       st, dv.kmer != nullptr && tn.use_kmer, fmx_grid_capped(npat, max_blocks)};
   const FmxMwm &w = dv.bw;
-  int variant = fmx_variant();
-  const uint8_t *d_pat8 = (const uint8_t *)d_pat;
-  const bool km = dv.kmer != nullptr && variant != 6;   // FMX_VARIANT=6: ignore the k-mer table
-  if (dv.pair_rec && idx->sym_bytes == 1 && variant != 0 && variant != 7) {
-#define FMX_PAIR_LAUNCH(KM)                                                                          \
-  hipLaunchKernelGGL(fmx_count_pair_kernel<KM>, dim3(grid), dim3(FMX_BLOCK), 0, st, w.lv[0].rec,      \
-                     dv.pair_rec, dv.n, dv.max_character, dv.pair_row0,       \
-                     dv.pair_row1, dv.status, dv.kmer, dv.kmer_k,             \
-                     dv.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
-    if (km) FMX_PAIR_LAUNCH(true);
-    else FMX_PAIR_LAUNCH(false);
-  } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 &&
-             variant != 0 && variant != 20) {
-#define FMX_F3_LAUNCH(PPG, SKIP, KM)                                                               \
-  hipLaunchKernelGGL((fmx_count_f3_kernel<PPG, SKIP, KM>),                                           \
-                     dim3(fmx_grid_for_groups((npat + PPG - 1) / PPG)), dim3(FMX_BLOCK), 0, st,       \
-                     w.lv[0].rec, dv.n, dv.max_character, dv.status, dv.kmer, \
-                     dv.kmer_k, dv.kmer_bits, d_pat8, d_off, npat, d_s0e0, d_s, d_e,      \
-                     d_cnt, steps)
-    switch (variant) {
+  const int sm = fmx_select_mode(idx, dv);
+  bool done = false;
 #ifdef FMX_MEASURE
-      case 8:  // measurement only: lane per pattern
-        if (d_s0e0) return FMX_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(fmx_count_f3_lane_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
-                           w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8, d_off,
-                           npat, d_s, d_e, d_cnt, steps);
-        break;
-      case 9:  // measurement only: wavefront per pattern
-        if (d_s0e0) return FMX_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(fmx_count_f3_wave_kernel, dim3(FMX_MAX_BLOCKS), dim3(FMX_BLOCK), 0, st,
-                           w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8, d_off,
-                           npat, d_s, d_e, d_cnt, steps);
-        break;
-      case 2: FMX_F3_LAUNCH(2, false, false); break;
-      case 3: FMX_F3_LAUNCH(1, true, false); break;
-      case 4: FMX_F3_LAUNCH(2, true, false); break;
-      case 5: FMX_F3_LAUNCH(4, false, false); break;
+  done = fmx_measure_count(c, tn, sm);               // the alternative kernels, when one was asked for
 #endif
-#define FMX_F3D_LAUNCH(Q)                                                                          \
-  hipLaunchKernelGGL((fmx_count_f3d_kernel<Q>), dim3(fmx_grid_for_groups((npat + Q - 1) / Q)),        \
-                     dim3(FMX_BLOCK), 0, st, w.lv[0].rec, dv.n, dv.max_character, dv.status, d_pat8,  \
-                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps)
-#ifdef FMX_MEASURE
-      case 24: FMX_F3D_LAUNCH(4); break;
-      case 25: FMX_F3D_LAUNCH(2); break;
-#endif
-      default:
-        if (km) FMX_F3_LAUNCH(1, false, true);
-        else FMX_F3_LAUNCH(1, false, false);
-        break;
-    }
-  } else {
-    // number of wavelet levels fixed at compile time for the common cases (1, 2), runtime otherwise
-#define FMX_COUNT_LAUNCH(KIND, NL, SM)                                                              \
-  do {                                                                                              \
-    if (km && idx->sym_bytes == 1)                                                                  \
-      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, true, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
-                         dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
-    else                                                                                            \
-      hipLaunchKernelGGL((fmx_count_kernel<KIND, NL, false, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, \
-                         dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
-  } while (0)
-#define FMX_COUNT_KIND(KIND, SM)                                                                    \
-  do {                                                                                              \
-    if (w.nlevels == 1) FMX_COUNT_LAUNCH(KIND, 1, SM);                                              \
-    else if (w.nlevels == 2) FMX_COUNT_LAUNCH(KIND, 2, SM);                                         \
-    else FMX_COUNT_LAUNCH(KIND, 0, SM);                                                             \
-  } while (0)
-    // RLFM: the select structure of B / B' (positions, select blocks, hints + records) is fixed at
-    // compile time as well, so the search loop holds no branch on it.  With positions or select
-    // blocks every select is one lane-wise load and the endpoint-per-lane kernel runs (fmx_ep.h);
-    // mixed-density indexes (hints + record search) keep the group-per-pattern kernel.
-    const int sm = idx->kind != FMX_KIND_RLFM ? -1
-                   : (dv.b.pos && dv.bp.pos) ? 1
-                   : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
+  if (done) {
+  } else if (dv.pair_rec && idx->sym_bytes == 1 && tn.use_pair && !tn.generic) {
+    // opt-in pair index: two symbols per probe
+    if (c.km) FMX_PAIR_LAUNCH(c, true); else FMX_PAIR_LAUNCH(c, false);
+  } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic) {
+    // DNA (one 3-bit level): one 128-byte line per interval end and step, group per pattern
+    if (c.km) FMX_F3_LAUNCH(c, 1, false, true); else FMX_F3_LAUNCH(c, 1, false, false);
+  } else if (sm > 0 && !tn.generic) {
+    // RLFM whose B / B' have a one-load select (stored positions or select blocks -- every index the
+    // builder makes today): endpoint per lane (fmx_ep.h), 64 probes in flight per wave and stage.
     // FM indexes keep the group-per-pattern kernels: their steps are one light record probe per level
-    // and those kernels already run at the request ceiling; the endpoint-per-lane shape measured
-    // slower there (DNA 1.11 vs 0.67 ms, sigma = 255 two levels 0.97 vs 0.74 ms:
-    // benchmarks/gpu/ep_fm_count.sh, FMX_VARIANT=20 in measurement builds)
-#ifdef FMX_MEASURE
-    const bool fm_ep = idx->kind == FMX_KIND_FM && variant == 20;
-#else
-    constexpr bool fm_ep = false;
-#endif
-    if ((sm > 0 || fm_ep) && variant != 0) {
-      // 64 probes in flight per wave and stage: 4 waves per SIMD saturate the memory system
-      const uint64_t ep_cap = (uint64_t)fmx_env_long("FMX_EP_BLOCKS", 1024);
-      uint64_t eb = (npat + FMX_BLOCK / 8 - 1) / (FMX_BLOCK / 8);   // one pattern per group while the grid lasts
-      if (eb > ep_cap) eb = ep_cap;
-#define FMX_EP_LAUNCH(KIND, NL, SM)                                                                  \
-  do {                                                                                               \
-    if (km && idx->sym_bytes == 1)                                                                   \
-      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, true>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
-    else                                                                                             \
-      hipLaunchKernelGGL((fmx_count_ep_kernel<KIND, NL, SM, false>), dim3((unsigned)eb), dim3(FMX_BLOCK), \
-                         0, st, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, steps);              \
-  } while (0)
-#define FMX_EP_SM(KIND, SM)                                                                          \
-  do {                                                                                               \
-    if (w.nlevels == 1) FMX_EP_LAUNCH(KIND, 1, SM);                                                  \
-    else if (w.nlevels == 2) FMX_EP_LAUNCH(KIND, 2, SM);                                             \
-    else FMX_EP_LAUNCH(KIND, 0, SM);                                                                 \
-  } while (0)
-#ifdef FMX_MEASURE
-      if (fm_ep) FMX_EP_SM(FMX_KIND_FM, 0); else
-#endif
-      if (sm == 1) FMX_EP_SM(FMX_KIND_RLFM, 1);
-      else FMX_EP_SM(FMX_KIND_RLFM, 2);
-    }
-    else if (idx->kind == FMX_KIND_FM) FMX_COUNT_KIND(FMX_KIND_FM, -1);
-    else if (idx->kind == FMX_KIND_MULTI) FMX_COUNT_KIND(FMX_KIND_MULTI, -1);
-#ifdef FMX_MEASURE   // round-1 group-per-pattern RLFM kernels, per select structure (FMX_VARIANT=0)
-    else if (sm == 1) FMX_COUNT_KIND(FMX_KIND_RLFM, 1);
-    else if (sm == 2) FMX_COUNT_KIND(FMX_KIND_RLFM, 2);
-#endif
-    else FMX_COUNT_KIND(FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
+    // and those kernels already run at the request ceiling (endpoint per lane measured slower there:
+    // DNA 1.11 vs 0.67 ms, sigma = 255 two levels 0.97 vs 0.74 ms, benchmarks/gpu/ep_fm_count.sh)
+    const uint64_t eb = fmx_ep_count_blocks(npat, tn.ep_blocks);
+    if (sm == 1) FMX_EP_SM(c, eb, FMX_KIND_RLFM, 1); else FMX_EP_SM(c, eb, FMX_KIND_RLFM, 2);
+  } else if (idx->kind == FMX_KIND_FM) {
+    FMX_COUNT_KIND(c, FMX_KIND_FM, -1);
+  } else if (idx->kind == FMX_KIND_MULTI) {
+    FMX_COUNT_KIND(c, FMX_KIND_MULTI, -1);
+  } else {
+    FMX_COUNT_KIND(c, FMX_KIND_RLFM, 0);             // hints + record search: valid for every vector
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
@@ -2130,157 +1820,89 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0 || total == 0) return FMX_OK;
   const FmxMwm &w = dv.bw;
-  uint64_t *steps = idx->timing ? idx->d_steps : nullptr;
   // rows in their own read-only buffer: the walk's loads never alias its stores.  The caller's workspace
   // when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
   uint32_t *rows = rows_ws;
   if (!rows_ws) FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
-  // 1024-thread blocks that each own a slice of the hits (FmxHitQueue): `nb` blocks wanted -> slice
-  // length (a multiple of the 64-row chunk, below 2^31) and the blocks that are really needed
-  auto slice = [total](uint64_t nb, uint32_t chunk, uint32_t &hpb, unsigned &grid) {
-    const uint64_t min_nb = (total >> 31) + 1;
-    if (nb < min_nb) nb = min_nb;
-    uint64_t per = (total + nb - 1) / nb;
-    per = (per + chunk - 1) / chunk * chunk;
-    hpb = (uint32_t)per;
-    grid = (unsigned)((total + per - 1) / per);
-  };
   {
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                        d_off, npat, rows, total, dv.n, dv.status);
   }
-  uint64_t nwaves = (total + 7) / 8;
-  const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
-  if (nwaves > max_waves) nwaves = max_waves;
-  const uint64_t hpw = (total + nwaves - 1) / nwaves;
-  const unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
   fmx_time_begin(idx, st);
-  if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 &&
-      fmx_variant() != 0 && fmx_variant() != 21) {
-    // walks per group: 4 when the batch is large enough to keep every group busy with them
-    const int v = fmx_variant();
-    const int q = (v == 11) ? 1 : (v == 12) ? 2 : (v == 14) ? 4 : (v == 15) ? 8 : (total >= (1u << 16) ? 4 : 1);
-    uint32_t hpb;
-    unsigned gr;
-    const unsigned lthreads = (unsigned)fmx_env_long("FMX_LOC_THREADS", FMX_LOC_BLOCK);
+  const FmxTune tn = fmx_tune();
+  const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing ? idx->d_steps : nullptr, st};
+  const int sm = fmx_select_mode(idx, dv);
+  bool done = false;
+#ifdef FMX_MEASURE
+  done = fmx_measure_locate(c, tn, sm);              // the alternative kernels, when one was asked for
+#endif
+  if (done) {
+  } else if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic) {
+    // DNA (one 3-bit level): walk state distributed over the lanes of a group, 4 walks per group when the
+    // batch is large enough to keep every group busy with them
+    const int q = tn.walks ? tn.walks : (total >= (1u << 16) ? 4 : 1);
+    const unsigned lthreads = (unsigned)tn.loc_threads;
     // 1024-thread blocks (one LDS hit queue per 16 waves); 50 VGPRs at Q = 4, so two of them fit a CU.
     // Batches of millions of hits want both (config 3b: 14.7 ms on 512 blocks, 18.7 on 256); a 2^20-hit
     // batch is bound by the chain of its longest walks and as fast on one (benchmarks/gpu/f3q_grid_sweep.sh)
-    const uint64_t nb = (uint64_t)fmx_env_long("FMX_LOC_BLOCKS", total >= (4u << 20) && v != 22 ? 512 : 256);
+    const uint64_t nb = tn.loc_blocks ? (uint64_t)tn.loc_blocks : (total >= (4u << 20) ? 512 : 256);
     // rows per ticket: 64 once every wave gets that many; below, one hit per slot of every wave
     // (mid-size batches are latency-bound: 1.3e5 hits 54 us against 84 us with 64-row tickets)
     const uint64_t per_wave = (total + nb * (lthreads / 64) - 1) / (nb * (lthreads / 64));
     uint32_t chunk = (uint32_t)((per_wave + 7) / 8 * 8);
-    if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
     if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;      // the first round hands out 8 q hits at once
     if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
-    slice(nb, chunk, hpb, gr);
-#define FMX_LOC_LAUNCH(Q, TEXT)                                                                    \
-  hipLaunchKernelGGL((fmx_locate_f3w_kernel<Q, TEXT>), dim3(gr), dim3(FMX_LOC_BLOCK), 0, st,        \
-                     w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
-                     d_pos, steps)
-#define FMX_LOCQ_LAUNCH(Q, TEXT)                                                                   \
-  hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(lthreads), 0, st,             \
-                     w.lv[0].rec, dv.samples, dv.phase, dv.n, dv.sa_level, total, hpb, chunk, rows, \
-                     d_pos, steps)
-    // positions through the write-combining ring when the tickets are whole 64-hit chunks
-    const bool wc = chunk == FMX_LCHUNK && v != 26;   // FMX_VARIANT=26 (measurement build): direct stores
-#define FMX_LOCP_LAUNCH(Q)                                                                         \
-  do {                                                                                             \
-    if (wc)                                                                                        \
-      hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, true>), dim3(gr), dim3(lthreads), 0, st,         \
-                         w.lv[0].rec, dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps); \
-    else                                                                                           \
-      hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, false>), dim3(gr), dim3(lthreads), 0, st,        \
-                         w.lv[0].rec, dv.samples, dv.n, dv.sa_level, total, hpb, chunk, rows, d_pos, steps); \
-  } while (0)
-    if (v != 22) {          // walk state distributed over the lanes of a group
-      if (dv.phase) {
-        if (q == 4) FMX_LOCQ_LAUNCH(4, true); else if (q == 2) FMX_LOCQ_LAUNCH(2, true); else FMX_LOCQ_LAUNCH(1, true);
-      }
-#ifdef FMX_MEASURE
-      else if (v == 23) {   // hand-over at the end of the round
-        if (q == 4) FMX_LOCQ_LAUNCH(4, false); else if (q == 2) FMX_LOCQ_LAUNCH(2, false); else FMX_LOCQ_LAUNCH(1, false);
-      }
-#endif
-      else {
-#ifdef FMX_MEASURE   // 8 walks per group (FMX_VARIANT=15): 16 % fewer instructions per walk, 71 VGPRs, no faster
-        if (q == 8) FMX_LOCP_LAUNCH(8); else
-#endif
-        if (q == 4) FMX_LOCP_LAUNCH(4); else if (q == 2) FMX_LOCP_LAUNCH(2); else FMX_LOCP_LAUNCH(1);
-      }
-    }
-#ifdef FMX_MEASURE
-    else if (dv.phase) {    // FMX_VARIANT=22: walk state repeated in all 8 lanes
-      if (q == 4) FMX_LOC_LAUNCH(4, true); else if (q == 2) FMX_LOC_LAUNCH(2, true); else FMX_LOC_LAUNCH(1, true);
+    uint32_t hpb;
+    unsigned gr;
+    c.slice(nb, chunk, hpb, gr);
+    if (dv.phase) {         // text-order sampling (FMX_FLAG_TEXT_ORDER, or a file written that way)
+      if (q == 4) FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 4, true);
+      else if (q == 2) FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 2, true);
+      else FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 1, true);
+    } else if (chunk == FMX_LCHUNK && tn.wc) {   // whole 64-hit tickets: positions through the write-combining ring
+      if (q == 4) FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 4, true);
+      else if (q == 2) FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 2, true);
+      else FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 1, true);
     } else {
-      if (q == 4) FMX_LOC_LAUNCH(4, false); else if (q == 2) FMX_LOC_LAUNCH(2, false); else FMX_LOC_LAUNCH(1, false);
+      if (q == 4) FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 4, false);
+      else if (q == 2) FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 2, false);
+      else FMX_LOCP_LAUNCH(c, gr, lthreads, hpb, chunk, 1, false);
     }
-#endif
   } else {
-#define FMX_LOCATE_LAUNCH(KIND, NL, SM)                                                             \
-  hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, st, dv, \
-                     total, hpw, rows, d_pos, steps)
-#define FMX_LOCATE_KIND(KIND, SM)                                                                   \
-  do {                                                                                              \
-    if (w.nlevels == 1) FMX_LOCATE_LAUNCH(KIND, 1, SM);                                             \
-    else if (w.nlevels == 2) FMX_LOCATE_LAUNCH(KIND, 2, SM);                                        \
-    else FMX_LOCATE_LAUNCH(KIND, 0, SM);                                                            \
-  } while (0)
-    const int sm = idx->kind != FMX_KIND_RLFM ? -1
-                   : (dv.b.pos && dv.bp.pos) ? 1
-                   : (dv.b.dsel && dv.bp.dsel) ? 2 : 0;
-    // FM over several levels: the endpoint-per-lane walk pays once the batch is throughput-bound
+    // FM over several levels: the one-walk-per-lane kernel pays once the batch is throughput-bound
     // (7.9e8 hits: 7.4e9 hits/s against 5.9e9); up to 2^20 hits the group-per-walk kernel has the shorter
     // step (benchmarks/gpu/small_shapes.py: 175 vs 187 us at n = 2^16, 247 vs 297 us at n = 2^27)
-    const bool fm_ep = idx->kind == FMX_KIND_FM &&
-                       ((w.nlevels >= 2 && total >= (uint64_t)fmx_env_long("FMX_FM_EP_MIN", 4l << 20)) || fmx_variant() == 21);
+    const bool fm_ep = idx->kind == FMX_KIND_FM && w.nlevels >= 2 && total >= (uint64_t)tn.fm_ep_min;
     // RLFM: one walk per lane wins once there are enough hits to keep its 64-wide rounds busy: 2^20 hits
     // 0.22-0.38 ms against 0.44-0.67 ms, but 2^16 hits 0.10-0.16 against 0.09-0.12 ms and fewer about
     // equal (benchmarks/gpu/small_shapes.py) -- below 2^18 hits the group-per-walk kernel runs
-    const bool rl_ep = sm > 0 && total >= (uint64_t)fmx_env_long("FMX_RL_EP_MIN", 1l << 18);
-    if ((rl_ep || fm_ep) && fmx_variant() != 0) {
-      // one walk per lane: 64 walks per wave.  2^20 hits finish soonest on one 1024-thread block per CU
-      // (0.435 ms; 0.52 on 128 blocks); large batches want every wave the registers admit (94 VGPRs ->
-      // 5 per SIMD): two 640-thread blocks per CU (config 4b, 7.9e8 hits: 84 ms against 100 ms)
+    const bool rl_ep = sm > 0 && total >= (uint64_t)tn.rl_ep_min;
+    if ((rl_ep || fm_ep) && !tn.generic) {
+      // 2^20 hits finish soonest on one 1024-thread block per CU; large batches want every wave the
+      // registers admit (96 VGPRs -> 5 per SIMD): two 640-thread blocks per CU
       const bool big = total >= (4u << 20);
-      const unsigned ep_threads = big ? 640u : (unsigned)FMX_LOC_BLOCK;
+      const unsigned thr = tn.ep_loc_threads ? (unsigned)tn.ep_loc_threads : (big ? 640u : (unsigned)FMX_LOC_BLOCK);
       uint32_t hpb;
       unsigned gr;
-      slice((uint64_t)fmx_env_long("FMX_EP_LOC_BLOCKS", big ? 512 : 256), FMX_LCHUNK, hpb, gr);
-      const bool klds = dv.max_character < 1024u;
-#define FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, WCF)                                                   \
-  hipLaunchKernelGGL((fmx_locate_ep_kernel<KIND, NL, SM, KL, TX, WCF>), dim3(gr), dim3(ep_threads), 0, \
-                     st, dv, total, hpb, rows, d_pos, steps)
-#ifdef FMX_MEASURE   // FMX_VARIANT=26: positions stored directly (no write-combining ring)
-#define FMX_EPL_LAUNCH2(KIND, NL, SM, KL, TX)                                                        \
-  do { if (fmx_variant() == 26) FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, false);                        \
-       else FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, true); } while (0)
-#else
-#define FMX_EPL_LAUNCH2(KIND, NL, SM, KL, TX) FMX_EPL_LAUNCH3(KIND, NL, SM, KL, TX, true)
-#endif
-#define FMX_EPL_LAUNCH(KIND, NL, SM)                                                                 \
-  do {                                                                                               \
-    if (klds) { if (dv.phase) FMX_EPL_LAUNCH2(KIND, NL, SM, true, true); else FMX_EPL_LAUNCH2(KIND, NL, SM, true, false); } \
-    else { if (dv.phase) FMX_EPL_LAUNCH2(KIND, NL, SM, false, true); else FMX_EPL_LAUNCH2(KIND, NL, SM, false, false); }   \
-  } while (0)
-#define FMX_EPL_SM(KIND, SM)                                                                         \
-  do {                                                                                               \
-    if (w.nlevels == 1) FMX_EPL_LAUNCH(KIND, 1, SM);                                                 \
-    else if (w.nlevels == 2) FMX_EPL_LAUNCH(KIND, 2, SM);                                            \
-    else FMX_EPL_LAUNCH(KIND, 0, SM);                                                                \
-  } while (0)
-      if (fm_ep) FMX_EPL_SM(FMX_KIND_FM, 0);
-      else if (sm == 1) FMX_EPL_SM(FMX_KIND_RLFM, 1);
-      else FMX_EPL_SM(FMX_KIND_RLFM, 2);
+      c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
+      if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
+      else if (sm == 1) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_RLFM, 1);
+      else FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_RLFM, 2);
+    } else {
+      // group per walk: a wave owns a contiguous share of the hits
+      uint64_t nwaves = (total + 7) / 8;
+      const uint64_t max_waves = (uint64_t)FMX_MAX_BLOCKS * (FMX_BLOCK / 64);
+      if (nwaves > max_waves) nwaves = max_waves;
+      const uint64_t hpw = (total + nwaves - 1) / nwaves;
+      const unsigned grid = (unsigned)((nwaves + FMX_BLOCK / 64 - 1) / (FMX_BLOCK / 64));
+      if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(c, grid, hpw, FMX_KIND_FM, -1);
+      else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(c, grid, hpw, FMX_KIND_MULTI, -1);
+      else if (sm == 1) FMX_LOCATE_KIND(c, grid, hpw, FMX_KIND_RLFM, 1);   // per select structure
+      else if (sm == 2) FMX_LOCATE_KIND(c, grid, hpw, FMX_KIND_RLFM, 2);
+      else FMX_LOCATE_KIND(c, grid, hpw, FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
     }
-    else if (idx->kind == FMX_KIND_FM) FMX_LOCATE_KIND(FMX_KIND_FM, -1);
-    else if (idx->kind == FMX_KIND_MULTI) FMX_LOCATE_KIND(FMX_KIND_MULTI, -1);
-    else if (sm == 1) FMX_LOCATE_KIND(FMX_KIND_RLFM, 1);   // group per walk, per select structure
-    else if (sm == 2) FMX_LOCATE_KIND(FMX_KIND_RLFM, 2);
-    else FMX_LOCATE_KIND(FMX_KIND_RLFM, 0);   // hints + record search: valid for every vector
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());

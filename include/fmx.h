@@ -81,6 +81,19 @@ typedef struct fmx_index fmx_index;
  * stepwise path.  Ignored when not applicable (wide symbols, texts too short for k >= 2, FM over
  * larger alphabets where the lookup costs more than the steps it replaces). */
 #define FMX_FLAG_KMER_TABLE 4u
+/* Which rows carry a suffix-array sample (levels 1..4; get_sa() returns SA[i] either way, and
+ * fmx_export_sa_samples() always yields the reference's samples SA[k << level], sample.rs:33-37):
+ *   text order: the rows whose SA VALUE is a multiple of 2^level (as many samples), plus every row's
+ *     phase SA[row] mod 2^level in 16-byte pieces -- a walk is exactly `phase` LF steps, (2^level - 1) / 2
+ *     on average and never more than 2^level - 1, where row-order walks are 2^level - 1 on average with a
+ *     geometric tail; costs two 16-byte reads per hit and 128 / rows-per-piece bits per row of HBM;
+ *   row order: the rows i with i mod 2^level == 0, exactly as SOSampledSuffixArray (sample.rs:21-44).
+ * Default: text order for RLFM indexes and FM / multi-pieces indexes over two or more wavelet levels
+ * (an LF step there is several dependent requests), row order for one-level indexes (DNA: an LF step is
+ * ONE request, the two extra reads cost more than the steps they save on large batches).  These flags
+ * override the default either way; both set, or a level outside 1..4, means row order. */
+#define FMX_FLAG_TEXT_ORDER 8u
+#define FMX_FLAG_ROW_ORDER 16u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
@@ -257,6 +270,7 @@ uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r 
 uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol width in HBM / *_dev */
 uint32_t fmx_kmer_k(const fmx_index *idx);   /* k of the FMX_FLAG_KMER_TABLE table, 0 = none */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
+int fmx_text_order(const fmx_index *idx);     /* 1: suffix-array samples in text order (FMX_FLAG_TEXT_ORDER) */
 
 #ifdef __cplusplus
 }

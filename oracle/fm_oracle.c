@@ -12,6 +12,7 @@
 #include "fm_oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -34,6 +35,47 @@ int orc_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+/* Thread placement for the batch drivers (bench.py's cpu_baseline): when switched on, the threads of a batch
+ * pin themselves one per CPU, spread evenly over the CPUs this process is allowed to use (so over both sockets
+ * and, while there are fewer threads than cores, one per core); the calling thread gets its own mask back when
+ * the batch is done.  Done here rather than with OMP_PROC_BIND because that also narrows the mask of the calling
+ * (Python) thread for good -- and with it the mask every thread created later inherits. */
+static int g_spread = 0;
+void orc_set_thread_spread(int on) { g_spread = on; }
+typedef struct { cpu_set_t orig; int cpus[CPU_SETSIZE]; int ncpu; int on; } orc_place;
+static void orc_place_begin(orc_place *p) {
+  p->on = 0;
+  p->ncpu = 0;
+  if (!g_spread || sched_getaffinity(0, sizeof p->orig, &p->orig) != 0) return;
+  for (int c = 0; c < CPU_SETSIZE; c++)
+    if (CPU_ISSET(c, &p->orig)) p->cpus[p->ncpu++] = c;
+  p->on = p->ncpu > 1;
+}
+static void orc_place_thread(const orc_place *p, int t, int nt) {
+  if (!p->on) return;
+  cpu_set_t one;
+  CPU_ZERO(&one);
+  CPU_SET(p->cpus[(int)(((long long)t * p->ncpu) / (nt > 0 ? nt : 1)) % p->ncpu], &one);
+  (void)sched_setaffinity(0, sizeof one, &one);
+}
+static void orc_place_end(const orc_place *p) {
+  if (p->on) (void)sched_setaffinity(0, sizeof p->orig, &p->orig);
+}
+
+/* threads an OpenMP team of `nthreads` really gets here (bench.py's cpu_baseline reports it) */
+int orc_team_size(int nthreads) {
+  int t = 1;
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+  {
+#pragma omp single
+    t = omp_get_num_threads();
+  }
+#endif
+  return t;
 }
 
 /* util.rs:1-3 */
@@ -780,17 +822,26 @@ int orc_count_batch(const orc_backend *b, const uint8_t *pat, const uint64_t *of
   int err = 0;
   uint64_t n = b->len(b->self);
   if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-  for (int64_t k = 0; k < (int64_t)npat; k++) {
-    uint64_t s = s0e0 ? s0e0[2 * k] : 0, e = s0e0 ? s0e0[2 * k + 1] : n, st = 0; /* wrapper.rs:41 */
-    int rc = orc_search(b, pat + off[k], off[k + 1] - off[k], &s, &e, &st);
-    if (rc) {
+  orc_place pl;
+  orc_place_begin(&pl);
+#pragma omp parallel num_threads(nthreads)
+  {
+#ifdef _OPENMP
+    orc_place_thread(&pl, omp_get_thread_num(), omp_get_num_threads());
+#endif
+#pragma omp for schedule(static)
+    for (int64_t k = 0; k < (int64_t)npat; k++) {
+      uint64_t s = s0e0 ? s0e0[2 * k] : 0, e = s0e0 ? s0e0[2 * k + 1] : n, st = 0; /* wrapper.rs:41 */
+      int rc = orc_search(b, pat + off[k], off[k + 1] - off[k], &s, &e, &st);
+      if (rc) {
 #pragma omp atomic write
-      err = rc;
+        err = rc;
+      }
+      out_s[k] = s; out_e[k] = e;
+      if (out_steps) out_steps[k] = st;
     }
-    out_s[k] = s; out_e[k] = e;
-    if (out_steps) out_steps[k] = st;
   }
+  orc_place_end(&pl);
   return err;
 }
 void orc_locate_batch(const orc_backend *b, const uint64_t *s, const uint64_t *e,

@@ -200,6 +200,8 @@ uint64_t orc_naive_search(const uint8_t *text, uint64_t n, const uint8_t *pat, u
                           uint64_t *out, uint64_t cap);
 
 int orc_max_threads(void);
+int orc_team_size(int nthreads);
+void orc_set_thread_spread(int on);
 
 /* ---- wide symbols: Character = u16 / u32 (character.rs:38-42) as uint32_t arrays ------ */
 /* Same algorithms as above with 32-bit symbols; max_character < 2^32, bits = max_bits. */

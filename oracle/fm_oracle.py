@@ -82,6 +82,10 @@ def _bind(lib):
     lib.orc_naive_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_uint64]
     lib.orc_max_threads.restype = C.c_int
+    lib.orc_team_size.restype = C.c_int
+    lib.orc_team_size.argtypes = [C.c_int]
+    lib.orc_set_thread_spread.argtypes = [C.c_int]
+    lib.orc_set_thread_spread.restype = None
     # wide symbols (u16 / u32 texts as uint32 arrays)
     lib.orc_suffix_array_naive_w.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     lib.orc_suffix_array_w.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -266,6 +270,14 @@ class OracleIndex:
         if want_steps:
             return s[:npat], e[:npat], st[:npat]
         return s[:npat], e[:npat]
+
+    def set_thread_spread(self, on):
+        """pin the threads of count_batch one per CPU, spread over the allowed CPUs (cpu_baseline)"""
+        self._l.orc_set_thread_spread(1 if on else 0)
+
+    def team_size(self, nthreads):
+        """threads an OpenMP team of `nthreads` really gets on this box"""
+        return int(self._l.orc_team_size(int(nthreads)))
 
     def locate_batch(self, s, e, nthreads=1):
         s = np.ascontiguousarray(s, dtype=np.uint64)

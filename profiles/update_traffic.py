@@ -13,7 +13,7 @@ from fm_index_amd import _lib as L   # noqa: E402
 
 def ent(r, src):
     assert r.get("traffic") and r.get("fetch_kb_raw"), "the bench line has no live PMC traffic"
-    return {"fetch_kb_raw": r["fetch_kb_raw"], "write_kb": r["write_kb"], "bytes": r["traffic"],
+    return {"fetch_kb_raw": r["fetch_kb_raw"], "write_kb": r["write_kb"],
             "kernel": r.get("traffic_kernel"), "source": src + " (live rocprofv3 --pmc passes of that run)"}
 
 
@@ -24,8 +24,8 @@ def main():
     h = L.csrc_hash()
     cfg = d["config"]
     key = "dna:%d:%d:%d" % (cfg["patterns_per_gpu"], cfg["pattern_len"], cfg["text_len"].bit_length() - 1)
-    t = {"_comment": "Fallback for bench.py when rocprofv3 is not available: HBM-side bytes per launch (2 x FETCH_SIZE + "
-                     "WRITE_SIZE, gfx950 correction) from the live PMC passes of the named run.  An entry is only used "
+    t = {"_comment": "Fallback for bench.py when rocprofv3 is not available: raw FETCH_SIZE / WRITE_SIZE per launch from the "
+                     "live PMC passes of the named run (bench.py prices them: price_traffic).  An entry is only used "
                      "when `csrc_hash` equals the hash of the current fm_index_amd/csrc sources "
                      "(fm_index_amd/_lib.py::csrc_hash); regenerate with profiles/update_traffic.py.",
          key: {"csrc_hash": h, "count": ent(d["roofline"], src), "locate": ent(d["locate"]["roofline"], src)}}

@@ -244,6 +244,61 @@ def test_large_host_pointer_batch_is_chunked_consistently():
     assert (again.counts == big.counts).all()
 
 
+def test_page_locked_host_arrays_take_the_copy_kernel_pipeline():
+    """fmx_count_batch on page-locked caller arrays (torch pin_memory = hipHostMalloc): chunks are moved by copy
+    kernels over three streams.  Same answers as the pageable call for ragged patterns, with the caller's buffers
+    starting at odd bytes / odd words INSIDE their allocations (interior pointers, every alignment case of the
+    copy kernels), with refinement ranges, and with outputs the caller does not want (NULL)."""
+    import torch
+    lib = L.lib()
+    t = W.dna_text_np(300000, 23)
+    idx = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2)
+    npat = (1 << 19) + 777                       # >= 2^19: eight chunks
+    flat, off = W.ragged_patterns_np(npat, 11, 4, 29)
+    want = idx.search_many(flat=flat, off=off)   # pageable numpy arrays
+    total = int(off[-1])
+    for pad_b, pad_w in ((0, 0), (3, 1), (13, 1)):
+        hp = torch.zeros(total + 64, dtype=torch.uint8, pin_memory=True)
+        ho = torch.zeros(npat + 1 + 4, dtype=torch.int64, pin_memory=True)
+        hs = torch.zeros(npat + 4, dtype=torch.int64, pin_memory=True)
+        he = torch.zeros(npat + 4, dtype=torch.int64, pin_memory=True)
+        hc = torch.zeros(npat + 4, dtype=torch.int64, pin_memory=True)
+        hp[pad_b:pad_b + total] = torch.from_numpy(flat)
+        ho[pad_w:pad_w + npat + 1] = torch.from_numpy(off.astype(np.int64))
+        rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr() + pad_b), C.c_void_p(ho.data_ptr() + 8 * pad_w),
+                                 npat, None, C.c_void_p(hs.data_ptr() + 8 * pad_w), C.c_void_p(he.data_ptr()),
+                                 C.c_void_p(hc.data_ptr() + 8 * pad_w))
+        assert rc == 0, lib.fmx_last_error()
+        assert (hs[pad_w:pad_w + npat].numpy().view(np.uint64) == want.s).all()
+        assert (he[:npat].numpy().view(np.uint64) == want.e).all()
+        assert (hc[pad_w:pad_w + npat].numpy().view(np.uint64) == want.counts).all()
+        assert int(hs[pad_w + npat]) == 0 and int(he[npat]) == 0      # nothing written behind the arrays
+    # refinement from given ranges, only the counts wanted
+    se = torch.zeros(2 * npat, dtype=torch.int64, pin_memory=True)
+    se[:] = torch.from_numpy(np.stack([want.s, want.e], axis=1).reshape(-1).astype(np.int64))
+    one = torch.full((npat,), 2, dtype=torch.uint8).pin_memory()
+    off1 = torch.arange(npat + 1, dtype=torch.int64).pin_memory()
+    hc = torch.zeros(npat, dtype=torch.int64, pin_memory=True)
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(one.data_ptr()), C.c_void_p(off1.data_ptr()), npat,
+                             C.c_void_p(se.data_ptr()), None, None, C.c_void_p(hc.data_ptr()))
+    assert rc == 0
+    ref = idx.search_many(flat=one.numpy(), off=off1.numpy().astype(np.uint64),
+                          s0e0=se.numpy().view(np.uint64).copy())
+    assert (hc.numpy().view(np.uint64) == ref.counts).all()
+    # offsets that go backwards are refused on this path too, and an out-of-range symbol is reported
+    bad = ho.clone().pin_memory()
+    bad[pad_w + npat // 2] = int(off[-1]) + 5
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr() + pad_b), C.c_void_p(bad.data_ptr() + 8 * pad_w),
+                             npat, None, C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), None)
+    assert rc == L.ERR_ARG
+    k0 = int(np.nonzero(off[1:] > off[:-1])[0][0])           # last symbol of the first non-empty pattern: always consumed
+    hp[pad_b + int(off[k0 + 1]) - 1] = 9
+    rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr() + pad_b), C.c_void_p(ho.data_ptr() + 8 * pad_w),
+                             npat, None, C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), None)
+    assert rc == L.ERR_SYMBOL_RANGE
+    idx.close()
+
+
 def test_concurrent_builds_and_queries_in_threads():
     """Builds are not required to run in parallel, but several host threads building and querying
     their own indexes at the same time must all get the right answers."""

@@ -95,13 +95,14 @@ def test_save_load_keeps_text_order(kind, tmp_path):
 
 
 def test_text_order_forced_on_one_level_indexes():
-    """The measurement build with FMX_VARIANT=19 samples in text order on one-level indexes as well: the
-    text-order branches of the DNA walk kernel stay correct although the shipped builder never picks them."""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "fm_index_amd", "libfmx_measure.so")
-    assert os.path.exists(lib), "libfmx_measure.so is built by __graft_entry__.build()"
-    env = dict(os.environ, FMX_LIB=lib, FMX_VARIANT="19", PYTHONPATH=root)
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "text_order_forced.py")], env=env,
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip().startswith("OK 12")
+    """FMX_FLAG_TEXT_ORDER (opt-in, shipped library): one-level indexes sampled in text order -- the text-order
+    branches of the DNA walk kernel and of the generic walk against the oracle, levels 1-4, FM and multi-pieces."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import text_order_forced
+    assert text_order_forced.main() == 12
+
+
+def test_row_order_can_be_forced_where_text_order_is_the_default():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import text_order_forced
+    assert text_order_forced.row_order_forced()

@@ -1,7 +1,7 @@
-"""Run with FMX_LIB=<libfmx_measure.so> FMX_VARIANT=19: text-order sampling forced on ONE-level indexes too
-(the shipped builder keeps row-order there), so the text-order branch of the one-level DNA walk kernel
-(fmx_locate_f3q_kernel<Q, true>) and of the generic walk at one level are checked against the oracle.
-Prints "OK <cases>" on success."""
+"""Text-order sampling on ONE-level indexes (opt-in FMX_FLAG_TEXT_ORDER; the builder's default there is row
+order): the text-order branch of the one-level DNA walk kernel (fmx_locate_f3q_kernel<Q, true>) and of the
+generic walk at one level against the oracle, and FMX_FLAG_ROW_ORDER on the index kinds whose default is
+text order.  Imported by tests/test_gpu_text_order.py; `python tests/text_order_forced.py` prints "OK <cases>"."""
 import sys
 
 import numpy as np
@@ -20,7 +20,8 @@ def main():
             if kind == "multi":
                 t[np.arange(101, n - 1, 307)] = 0
             cls = F.FMIndexWithLocate if kind == "fm" else F.FMIndexMultiPiecesWithLocate
-            gi = cls(F.Text.with_max_character(t, 4), level)
+            gi = cls(F.Text.with_max_character(t, 4), level, sampling="text")
+            assert gi.text_order()
             oi = O.OracleIndex(t, 4, level=level, kind=kind)
             rows = np.arange(n)
             want = oi.get_sa(rows).astype(np.uint64)
@@ -37,7 +38,28 @@ def main():
             assert (gi.export_sa_samples() == want[::1 << level]).all()
             cases += 1
     print("OK", cases)
+    return cases
+
+
+def row_order_forced():
+    """FMX_FLAG_ROW_ORDER on a run-length index and on a two-level FM index (default: text order)"""
+    for kind, cls, maxc in (("rlfm", F.RLFMIndexWithLocate, 255), ("fm", F.FMIndexWithLocate, 255)):
+        n = 40000
+        t = (W.splitmix64_np(77, 0, n) % np.uint64(200)).astype(np.uint8) + 1
+        t[-1] = 0
+        oi = O.OracleIndex(t, maxc, level=2, kind=kind)
+        want = oi.get_sa(np.arange(n)).astype(np.uint64)
+        for sampling, expect_text in (("row", False), (None, True), ("text", True)):
+            gi = cls(F.Text(t), 2, sampling=sampling)
+            assert gi.text_order() == expect_text, (kind, sampling)
+            _, pos = gi.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))
+            assert (pos == want).all(), (kind, sampling)
+            assert (gi.export_sa_samples() == want[::4]).all()
+            gi.close()
+    return True
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    main()
+    row_order_forced()
+    sys.exit(0)

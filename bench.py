@@ -485,18 +485,29 @@ def run_pmc_passes(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
-            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                               timeout=420)
-            if p.returncode != 0:
-                return {}, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode,
-                                                                     p.stderr.decode(errors="replace")[-300:])
+            # its own session: on a timeout the WHOLE group goes (rocprofv3 and the `bench.py --pmc-child` under
+            # it, which holds a 2^30 index) and is waited for before the timed run starts
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                    start_new_session=True)
+            try:
+                _, perr = proc.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, 9)
+                except OSError:
+                    pass
+                proc.communicate()
+                return {}, "rocprofv3 --pmc %s pass timed out after 420 s (process group killed)" % counter
+            if proc.returncode != 0:
+                return {}, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, proc.returncode,
+                                                                     perr.decode(errors="replace")[-300:])
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     rows.extend(csv.DictReader(fh))
             raw[counter] = pmc_aggregate(rows, counter)
-    except (subprocess.TimeoutExpired, OSError) as ex:
-        return {}, "rocprofv3 pass did not finish: %r" % (ex,)
+    except OSError as ex:
+        return {}, "rocprofv3 pass did not start: %r" % (ex,)
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -934,15 +945,7 @@ def dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, 
     if nccl:                     # under gloo all ranks share cuda:0 on purpose (rehearsal)
         sharding.assert_distinct_devices(idents)
     # event timeline of a few traced steps (outside the timed region)
-    tr = None
-    if nccl:
-        tp = sharding.CountGatherPipeline(npat, world, wl.n, wl.dev, backend="nccl", force_collective=True, trace=True)
-        for _ in range(8):
-            tp.step(lambda out64: wl.count(out_cnt=out64))
-        tp.drain()
-        torch.cuda.synchronize()
-        tr = tp.trace_report()
-        del tp
+    tr = traced_steps(torch, sharding, wl, world) if nccl else None
     # rccl_ranks: ranks of the RCCL communicator that carried the gathers -- null unless the backend is nccl
     out["rccl_ranks"] = dist.get_world_size() if nccl else None
     out["rccl_version"] = rccl_version_string(torch) if nccl else None
@@ -955,6 +958,16 @@ def dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, 
                      "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
                      "bytes_per_rank_per_step": npat * (4 if pipe.wire == torch.int32 else 8),
                      "pipelined": pipe.nbuf > 1, "trace": tr}
+
+
+def traced_steps(torch, sharding, wl, world, steps=8):
+    """event timeline of a few steps of the count + gather pipeline (sharding.CountGatherPipeline.trace_report)"""
+    tp = sharding.CountGatherPipeline(wl.npat, world, wl.n, wl.dev, backend="nccl", force_collective=True, trace=True)
+    for _ in range(steps):
+        tp.step(lambda out64: wl.count(out_cnt=out64))
+    tp.drain()
+    torch.cuda.synchronize()
+    return tp.trace_report()
 
 
 def rccl_1rank_leg(out, wl, args, dev, local):
@@ -970,12 +983,11 @@ def rccl_1rank_leg(out, wl, args, dev, local):
         wl.count()
         torch.cuda.synchronize()
         ref_c = wl.d_c.clone()
-        pipe = sharding.CountGatherPipeline(npat, 1, wl.n, dev, backend="nccl", force_collective=True, trace=True)
+        pipe = sharding.CountGatherPipeline(npat, 1, wl.n, dev, backend="nccl", force_collective=True)
         for _ in range(args.warmup):
             pipe.step(lambda o: wl.count(out_cnt=o))
         pipe.drain()
         torch.cuda.synchronize()
-        pipe.events.clear()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             g = pipe.step(lambda o: wl.count(out_cnt=o))
@@ -987,7 +999,7 @@ def rccl_1rank_leg(out, wl, args, dev, local):
              "device": sharding.device_identity(local), "value": npat * m * args.steps / dt,
              "unit": "pattern-chars/s", "ms_per_step": dt / args.steps * 1e3,
              "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
-             "gather_ms": round(timed_sync_gather(torch, dist, pipe, False), 4), "trace": pipe.trace_report(),
+             "gather_ms": round(timed_sync_gather(torch, dist, pipe, False), 4), "trace": traced_steps(torch, sharding, wl, 1),
              "note": "config-5 step at one rank: pipelined all_gather_into_tensor of the counts over a 1-rank RCCL "
                      "communicator on this GPU; counts identical to the ungathered run"}
         if wl.level is not None and getattr(wl, "total_hits", None):

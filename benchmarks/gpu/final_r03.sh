@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-3 evidence run (through gpurun, from the repo root): the GPU suite on the shipped library, the default
+# bench line, rocprofv3 --kernel-trace --stats of the bench command, and the range-checked library on the walk
+# kernels with the write-combining ring on and off (FMX_VARIANT=26)
+OUT=gpurun_out/final_r03
+mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+bash profiles/run_rocprof.sh r03 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
+if [ -f fm_index_amd/libfmx_debug.so ]; then
+  T="tests/test_gpu_large_batches.py tests/test_gpu_rlfm.py tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_naive_fixtures.py"
+  FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1200 python -m pytest $T -m gpu -q > $OUT/pytest_debuglib_ring_on.txt 2>&1; tail -2 $OUT/pytest_debuglib_ring_on.txt
+  FMX_VARIANT=26 FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1200 python -m pytest $T -m gpu -q > $OUT/pytest_debuglib_ring_off.txt 2>&1; tail -2 $OUT/pytest_debuglib_ring_off.txt
+fi

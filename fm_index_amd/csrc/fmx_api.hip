@@ -927,12 +927,29 @@ int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
     FMX_HIP(hipMemcpy(host_out, idx->dev.samples, idx->nsamples * 4, hipMemcpyDeviceToHost));
     return FMX_OK;
   }
-  const uint64_t k = idx->nsamples, step = 1ull << idx->dev.sa_level;
-  std::vector<uint64_t> rows((size_t)k), vals((size_t)k);
-  for (uint64_t j = 0; j < k; j++) rows[j] = j * step;
-  if (int rc = fmx_get_sa_batch(idx, rows.data(), k, vals.data())) return rc;
-  for (uint64_t j = 0; j < k; j++) host_out[j] = (uint32_t)vals[j];
-  return FMX_OK;
+  // text-order sampling: the values are computed, get_sa(k << level), in chunks of 2^22 rows through the
+  // device entry point (16 B of device scratch + 16 B of pinned-free host staging per row of a CHUNK, not
+  // of the whole array; nothing that can throw crosses the C ABI)
+  const uint64_t k = idx->nsamples, step = 1ull << idx->dev.sa_level, chunk = 1ull << 22;
+  const uint64_t cap = k < chunk ? k : chunk;
+  uint64_t *d_rows = nullptr, *d_vals = nullptr;
+  uint64_t *h_buf = (uint64_t *)malloc((size_t)cap * 8);
+  if (!h_buf) return fail(FMX_ERR_ARG, "out of host memory");
+  hipError_t e = hipMalloc((void **)&d_rows, (size_t)cap * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, (size_t)cap * 8);
+  int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "hipMalloc(export scratch)", __LINE__);
+  for (uint64_t a = 0; a < k && rc == FMX_OK; a += chunk) {
+    const uint64_t m = k - a < chunk ? k - a : chunk;
+    for (uint64_t j = 0; j < m; j++) h_buf[j] = (a + j) * step;
+    if ((e = hipMemcpy(d_rows, h_buf, (size_t)m * 8, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
+    if ((rc = fmx_launch_scalar(idx, 3, nullptr, d_rows, m, d_vals, 0)) != FMX_OK) break;
+    if ((e = hipMemcpy(h_buf, d_vals, (size_t)m * 8, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
+    for (uint64_t j = 0; j < m; j++) host_out[a + j] = (uint32_t)h_buf[j];
+  }
+  if (d_rows) (void)hipFree(d_rows);
+  if (d_vals) (void)hipFree(d_vals);
+  free(h_buf);
+  return rc;
 }
 int fmx_export_sa(const fmx_index *idx, uint32_t *host_out) {
   CHECK_IDX(idx);

@@ -1052,6 +1052,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
         const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
         const uint32_t old_tag = ring_tag[ns];
         const uint32_t v = ring[ns * 64u + lane];
+        FMX_CHECK(old_tag == FMX_NOCHUNK || v == NONE || old_tag * 64u + lane < bn);
         if (old_tag != FMX_NOCHUNK && v != NONE) out[old_tag * 64u + lane] = (uint64_t)v;
         ring[ns * 64u + lane] = NONE;
         if (lane == 0) ring_tag[ns] = hq.c1;
@@ -1100,6 +1101,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
       // one subtraction of n (modulo 2^32) is exact whether or not the addition wrapped
       uint32_t v = sa + fin_steps;
       if (v < sa || v >= n) v -= n;
+      FMX_CHECK(fin_x < bn && fin_slot < FMX_WC_SLOTS);
       if (WC && ring_tag[fin_slot] == (fin_x >> 6)) ring[fin_slot * 64u + (fin_x & 63u)] = v;   // its ticket is resident
       else out[fin_x] = (uint64_t)v;
     }
@@ -1109,6 +1111,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
     for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) {
       const uint32_t tag = ring_tag[r];
       const uint32_t v = ring[r * 64u + lane];
+      FMX_CHECK(tag == FMX_NOCHUNK || v == NONE || tag * 64u + lane < bn);
       if (tag != FMX_NOCHUNK && v != NONE) out[tag * 64u + lane] = (uint64_t)v;
     }
   }

@@ -162,6 +162,10 @@ class CountGatherPipeline:
         if self.on_device and self.nbuf > 1:
             with torch.cuda.device(self.device):
                 self.comm, self.comm_info = pick_concurrent_stream(self.device)
+            # one pair of events per buffer, reused (an event per step made the runtime grow its signal pool
+            # in the middle of a run: one 22 ms stall of the launch stream in every 50-step measurement)
+            self._searched = [torch.cuda.Event() for _ in range(self.nbuf)]
+            self._done = [torch.cuda.Event() for _ in range(self.nbuf)]
         # trace: HIP events around every search launch (launch stream) and behind every gather
         # (communication stream): trace_report() turns them into the evidence that gather k ran under
         # search k+1
@@ -196,10 +200,10 @@ class CountGatherPipeline:
         if self.comm is not None:
             # searched[b] -> communication stream: down-cast + collective there, launch stream moves on
             cur = torch.cuda.current_stream(self.device)
-            searched = ke if ke is not None else torch.cuda.Event()
+            searched = ke if ke is not None else self._searched[b]
             if ke is None:
                 searched.record(cur)
-            done = torch.cuda.Event(enable_timing=self.trace)
+            done = torch.cuda.Event(enable_timing=True) if self.trace else self._done[b]
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(searched)
                 self.local_w[b].copy_(self.local64[b])

@@ -697,6 +697,8 @@ def run(args, world, pmc=None):
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:            # the ranks share one stdout: only rank 0 may write to it (libraries' banners included)
+        os.dup2(2, 1)
     gloo = args.dist_backend == "gloo"
     use_dist = world > 1 or args.force_dist      # the N>1 step, also on a 1-rank communicator when forced
     if use_dist:
@@ -872,12 +874,13 @@ def run(args, world, pmc=None):
     if pmc is not None and rank == 0:
         apply_pmc(out, pmc[0], pmc[1])
 
+    if use_dist:             # every rank is done before the line is printed; nothing follows it on stdout
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def open_process_group(torch, local, rank, world, gloo):
@@ -896,7 +899,15 @@ def open_process_group(torch, local, rank, world, gloo):
     else:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    flush_c_stdio()      # RCCL's version banner (C stdio, buffered) leaves NOW, not behind the result line at exit
     return dist
+
+
+def flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def rccl_version_string(torch):

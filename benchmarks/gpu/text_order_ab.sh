@@ -1,22 +1,12 @@
 #!/bin/bash
-# text-order sampling against row-order sampling on one box, through the measurement build:
-# FMX_VARIANT=18 row order everywhere, 19 text order everywhere (the shipped builder picks per index kind)
-O=gpurun_out/r02ab; mkdir -p $O
-export FMX_LIB=$PWD/fm_index_amd/libfmx_measure.so
-for v in 18 19; do
-  FMX_VARIANT=$v timeout 900 python bench.py --no-pmc --no-census --no-cpu-baseline --no-accel --no-early-exit --no-d2h $1 > $O/v$v.json 2> $O/v$v.err
-done
+# text-order against row-order sampling of the one-level DNA index on one box: since round 3 a build flag of the
+# shipped library (FMX_FLAG_TEXT_ORDER), reported by bench.py itself as the `locate_text_order` leg next to `locate`
+O=gpurun_out/text_order_ab; mkdir -p $O
+timeout 900 python bench.py --no-pmc --no-census --no-cpu-baseline --no-early-exit --no-d2h --no-rlfm --no-3b $1 > $O/bench.json 2> $O/bench.err
 python - <<'PY'
 import json
-for name in ('v18', 'v19'):
-    try:
-        d = json.loads(open('gpurun_out/r02ab/%s.json' % name).read().strip().splitlines()[-1])
-        l, b, r = d['locate'], d.get('locate_3b') or {}, d.get('rlfm') or {}
-        print(name, 'count ms', d['ms_per_step'], 'index_bytes', d['config'].get('index_bytes'))
-        print('  locate', {k: l.get(k) for k in ('ms_per_batch', 'hits_per_s', 'lf_steps')})
-        print('  3b', {k: b.get(k) for k in ('ms_per_batch', 'hits_per_s', 'lf_steps')})
-        print('  rlfm count ms', r.get('ms_per_step'), 'locate', {k: (r.get('locate') or {}).get(k) for k in ('ms_per_batch', 'hits_per_s', 'lf_steps')})
-    except Exception as ex:
-        print(name, 'ERR', ex)
+d = json.loads(open('gpurun_out/text_order_ab/bench.json').read().strip().splitlines()[-1])
+l, t = d['locate'], d['locate_text_order']
+print('row order ', {k: l.get(k) for k in ('ms_per_batch', 'hits_per_s', 'lf_steps')}, 'index_bytes', d['config']['index_bytes'])
+print('text order', {k: t.get(k) for k in ('ms_per_batch', 'hits_per_s', 'lf_steps', 'index_bytes')})
 PY
-tail -n 3 $O/v18.err $O/v19.err

@@ -106,21 +106,21 @@ class Text:
         return self._max
 
 
-def _flags(keep_sa, pair_index, kmer_table, sampling):
+def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False):
     """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
     (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
     if sampling not in (None, "text", "row"):
         raise ValueError("sampling must be None, 'text' or 'row'")
     return ((L.FLAG_KEEP_SA if keep_sa else 0) | (L.FLAG_PAIR_INDEX if pair_index else 0) |
             (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
-            (L.FLAG_ROW_ORDER if sampling == "row" else 0))
+            (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0))
 
 
 class _Index:
     _kind = L.KIND_FM
 
     def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False,
-                 sampling=None):
+                 sampling=None, force_wide=False):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -130,13 +130,13 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
                                  text.max_character(),
-                                 self._kind, lvl, _flags(keep_sa, pair_index, kmer_table, sampling), device,
-                                 C.byref(self._h))
+                                 self._kind, lvl, _flags(keep_sa, pair_index, kmer_table, sampling, force_wide),
+                                 device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
-                         pair_index=False, sym_bytes=1, kmer_table=False, sampling=None):
+                         pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -144,7 +144,7 @@ class _Index:
         self._dtype = np.dtype(_DTYPES[sym_bytes])
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
-                                       _flags(keep_sa, pair_index, kmer_table, sampling), device,
+                                       _flags(keep_sa, pair_index, kmer_table, sampling, force_wide), device,
                                        C.byref(self._h)))
         return self
 
@@ -266,9 +266,15 @@ class _Index:
         return out
 
     def export_sa_samples(self):
-        out = np.zeros(max(int(self._lib.fmx_num_samples(self._h)), 1), dtype=np.uint32)
+        """SOSampledSuffixArray's payload SA[k << level] (sample.rs:33-37); uint64 for texts of 2^32 symbols and more"""
+        k = int(self._lib.fmx_num_samples(self._h))
+        if self.is_wide():
+            out = np.zeros(max(k, 1), dtype=np.uint64)
+            _check(self._lib.fmx_export_sa_samples64(self._h, _p(out)))
+            return out[:k]
+        out = np.zeros(max(k, 1), dtype=np.uint32)
         _check(self._lib.fmx_export_sa_samples(self._h, _p(out)))
-        return out[:int(self._lib.fmx_num_samples(self._h))]
+        return out[:k]
 
     def export_sa(self):
         out = np.zeros(max(self.len(), 1), dtype=np.uint32)
@@ -282,6 +288,10 @@ class _Index:
 
     def has_pair_index(self):
         return bool(self._lib.fmx_has_pair_index(self._h))
+
+    def is_wide(self):
+        """served by the 64-bit engine (n >= 2^32 - 16, or FMX_FLAG_FORCE_WIDE)?"""
+        return bool(self._lib.fmx_is_wide(self._h))
 
     def text_order(self):
         """suffix-array samples kept in text order (FMX_FLAG_TEXT_ORDER or the builder's default)?"""
@@ -314,16 +324,17 @@ class FMIndex(_Index):
     """FMIndex::new(&text) (frontend.rs:195-203) -- count only."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, device=0, keep_sa=False, pair_index=False, kmer_table=False):
-        super().__init__(text, None, device, keep_sa, pair_index, kmer_table)
+    def __init__(self, text, device=0, keep_sa=False, pair_index=False, kmer_table=False, force_wide=False):
+        super().__init__(text, None, device, keep_sa, pair_index, kmer_table, None, force_wide)
 
 
 class FMIndexWithLocate(_Index):
     """FMIndexWithLocate::new(&text, level) (frontend.rs:205-221)."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False, sampling=None):
-        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling)
+    def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False, sampling=None,
+                 force_wide=False):
+        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling, force_wide)
 
 
 class RLFMIndex(_Index):

@@ -26,6 +26,7 @@ FLAG_PAIR_INDEX = 2
 FLAG_KMER_TABLE = 4
 FLAG_TEXT_ORDER = 8
 FLAG_ROW_ORDER = 16
+FLAG_FORCE_WIDE = 32
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
@@ -80,6 +81,7 @@ SYMBOLS = [
     ("fmx_export_bwt", _I, [_V, _V]),
     ("fmx_export_cs", _I, [_V, _V]),
     ("fmx_export_sa_samples", _I, [_V, _V]),
+    ("fmx_export_sa_samples64", _I, [_V, _V]),
     ("fmx_num_samples", _U64, [_V]),
     ("fmx_export_sa", _I, [_V, _V]),
     ("fmx_verify_sa", _I, [_V, C.POINTER(_U64)]),
@@ -94,6 +96,7 @@ SYMBOLS = [
     ("fmx_match_rows", _I, [_V, _V, _V, _U64, _I, _V, _V]),
     ("fmx_sym_bytes", _U32, [_V]),
     ("fmx_has_pair_index", _I, [_V]),
+    ("fmx_is_wide", _I, [_V]),
     ("fmx_text_order", _I, [_V]),
     ("fmx_kmer_k", _U32, [_V]),
 ]

@@ -108,7 +108,11 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
-  if (n >= 0xFFFFFFF0ull) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 is not supported");
+  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate over a one-level alphabet
+  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) &&
+      !(kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 7 && n >= 2))
+    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM over u8 symbols with max_character <= 7 only");
+  if (n >= (1ull << 40)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^40 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
   DeviceGuard dg;
@@ -193,6 +197,7 @@ uint64_t fmx_num_samples(const fmx_index *idx) { return idx ? idx->nsamples : 0;
 uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
 uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
+int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
 int fmx_text_order(const fmx_index *idx) { return idx && idx->dev.phase ? 1 : 0; }
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
@@ -265,7 +270,7 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64
 // caller-workspace forms: kernel launches only (no stream-ordered allocation) -> graph-capturable, and
 // batches on different streams share nothing but the index
 uint64_t fmx_locate_workspace_bytes(const fmx_index *idx, uint64_t total_hits) {
-  (void)idx;
+  if (idx && idx->is_wide) return 256;     // a wide locate expands the rows into the position array itself
   return fmx_locate_rows_bytes(total_hits);
 }
 uint64_t fmx_offsets_workspace_bytes(uint64_t npat) { return fmx_offsets_tile_bytes(npat); }
@@ -275,7 +280,7 @@ int fmx_locate_batch_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uin
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   if (npat == 0 || total_hits == 0) return FMX_OK;
-  if (!d_workspace || workspace_bytes < fmx_locate_rows_bytes(total_hits) || ((uintptr_t)d_workspace & 15u))
+  if (!d_workspace || workspace_bytes < fmx_locate_workspace_bytes(idx, total_hits) || ((uintptr_t)d_workspace & 15u))
     return fail(FMX_ERR_ARG, "workspace is NULL, misaligned or smaller than fmx_locate_workspace_bytes()");
   return fmx_launch_locate(idx, d_s, d_e, npat, d_out_off, total_hits, d_out_pos, (hipStream_t)stream,
                            (uint32_t *)d_workspace);
@@ -920,9 +925,25 @@ int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {
 // SOSampledSuffixArray's payload (sample.rs:33-37): SA[k << level] for k = 0 .. ((n-1) >> level).  With
 // text-order sampling the stored samples are other rows', so the values are computed: get_sa of
 // those rows (same numbers, whatever is sampled inside).
+int fmx_export_sa_samples64(const fmx_index *idx, uint64_t *host_out) {
+  CHECK_IDX(idx);
+  if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  if (idx->is_wide) {
+    FMX_HIP(hipMemcpy(host_out, idx->wide.samples, idx->nsamples * 8, hipMemcpyDeviceToHost));
+    return FMX_OK;
+  }
+  uint32_t *tmp = (uint32_t *)malloc((size_t)(idx->nsamples ? idx->nsamples : 1) * 4);
+  if (!tmp) return fail(FMX_ERR_ARG, "out of host memory");
+  const int rc = fmx_export_sa_samples(idx, tmp);
+  if (rc == FMX_OK)
+    for (uint64_t j = 0; j < idx->nsamples; j++) host_out[j] = tmp[j];
+  free(tmp);
+  return rc;
+}
 int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
+  if (idx->is_wide) return fail(FMX_ERR_UNSUPPORTED, "the samples of an index with n >= 2^32 need fmx_export_sa_samples64");
   if (!idx->dev.phase) {
     FMX_HIP(hipMemcpy(host_out, idx->dev.samples, idx->nsamples * 4, hipMemcpyDeviceToHost));
     return FMX_OK;
@@ -953,12 +974,17 @@ int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
 }
 int fmx_export_sa(const fmx_index *idx, uint32_t *host_out) {
   CHECK_IDX(idx);
+  if (idx->is_wide) return fail(FMX_ERR_UNSUPPORTED, "the suffix array of an index with n >= 2^32 does not fit 32 bits");
   if (!idx->d_sa) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
   if (idx->n) FMX_HIP(hipMemcpy(host_out, idx->d_sa, idx->n * 4, hipMemcpyDeviceToHost));
   return FMX_OK;
 }
 int fmx_verify_sa(const fmx_index *idx, uint64_t *violations) {
   CHECK_IDX(idx);
+  if (idx->is_wide) {
+    if (!idx->d_sa64 || !idx->d_text) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
+    return fmxw_verify_sa(idx, violations);
+  }
   if (!idx->d_sa || !idx->d_text) return fail(FMX_ERR_ARG, "index was built without FMX_FLAG_KEEP_SA");
   return fmx_verify_sa_impl(idx, violations);
 }
@@ -1054,6 +1080,7 @@ const uint32_t kFileVersion = 8;   // 2: select hints every 64 ones (was 512); 3
 }  // namespace
 
 int fmx_save(const fmx_index *idx, const char *path) {
+  if (idx && idx->is_wide) return fail(FMX_ERR_UNSUPPORTED, "an index with n >= 2^32 cannot be saved yet");
   CHECK_IDX(idx);
   if (!path) return fail(FMX_ERR_ARG, "path is NULL");
   FILE *f = fopen(path, "wb");

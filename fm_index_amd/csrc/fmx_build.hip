@@ -223,7 +223,7 @@ __global__ __launch_bounds__(BLK) void k_bwt2(const uint8_t *__restrict__ t,
 // ---- multi-ary wavelet matrix levels --------------------------------------------
 // one thread per 16-B piece; planes written now, counters after the scan
 template <int FMT, typename T>
-__global__ __launch_bounds__(BLK) void k_mwm_pieces(const T *__restrict__ cur, uint32_t n,
+__global__ __launch_bounds__(BLK) void k_mwm_pieces(const T *__restrict__ cur, uint64_t n,
                                                      uint32_t shift, uint32_t mask, uint32_t nrec,
                                                      uint4 *__restrict__ rec,
                                                      uint32_t *__restrict__ hist) {
@@ -1194,7 +1194,345 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
 }
 
 // Character = u8 / u16 / u32 (character.rs:38-42); u64 texts are narrowed by the caller
+
+// ===========================================================================================================
+// WIDE indexes: n >= 2^32 - 16 (fmx_internal.h, FmxWideDev).  FMIndex / FMIndexWithLocate over a one-level
+// alphabet.  Same construction as above with 64-bit suffix-array entries and ranks:
+//   * prefix doubling cannot pack (rank[i], rank[i+h] + 1) into one 64-bit radix key any more (33-bit ranks), so a
+//     round is two stable radix passes over (u64 key, u64 suffix) pairs -- by rank[i+h] + 1, then by rank[i] --
+//     with the ranks in their own array: 40 bytes of scratch per symbol (24 in the 32-bit builder);
+//   * the record counters are the exclusive scan over [code][record] in 64 bits -- which for a single level IS
+//     cs[code] + rank, sais.rs:9-32 -- stored relative to the superblock start, the superblock starts in `base`.
+// ===========================================================================================================
+namespace {
+// HIP refuses a launch whose grid x block exceeds 2^32 - 1 threads -- exactly what one thread per symbol would be
+// here -- so every kernel over the symbols is a grid-stride loop on at most 2^22 blocks
+#define KW_FOR(v, count) \
+  for (uint64_t v = (uint64_t)blockIdx.x * BLK + threadIdx.x; v < (count); v += (uint64_t)gridDim.x * BLK)
+inline unsigned wblocks(uint64_t n) {
+  const uint64_t b = (n + BLK - 1) / BLK;
+  return (unsigned)(b < 1 ? 1 : (b > (1u << 22) ? (1u << 22) : b));
+}
+__global__ __launch_bounds__(BLK) void kw_init_keys(const uint8_t *__restrict__ t, uint64_t n, uint32_t bits,
+                                                     uint32_t k, uint64_t *__restrict__ keys,
+                                                     uint64_t *__restrict__ idx) {
+  KW_FOR(i, n) {
+    uint64_t key = 0;
+    for (uint32_t j = 0; j < k; j++) {
+      const uint64_t p = i + j;
+      key = (key << bits) | (uint64_t)(p < n ? t[p] : 0);
+    }
+    keys[i] = key;
+    idx[i] = i;
+  }
+}
+// head[p] = p when sorted position p starts a new group of equal keys (ka, and kb when given), else 0
+__global__ __launch_bounds__(BLK) void kw_flag_heads(const uint64_t *__restrict__ ka, const uint64_t *__restrict__ kb,
+                                                      uint64_t n, uint64_t *__restrict__ head, unsigned int *dup) {
+  KW_FOR(p, n) {
+    const bool is_head = p == 0 || ka[p] != ka[p - 1] || (kb && kb[p] != kb[p - 1]);
+    head[p] = is_head ? p : 0ull;
+    if (!is_head) *dup = 1u;
+  }
+}
+struct MaxOp64 {
+  __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
+};
+__global__ __launch_bounds__(BLK) void kw_scatter_rank(const uint64_t *__restrict__ sa, const uint64_t *__restrict__ head,
+                                                        uint64_t n, uint64_t *__restrict__ rank) {
+  KW_FOR(p, n) rank[sa[p]] = head[p];
+}
+// second = rank[i + h] + 1, or 0 when the suffix ends first; first = rank[i]
+__global__ __launch_bounds__(BLK) void kw_key_second(const uint64_t *__restrict__ sa, const uint64_t *__restrict__ rank,
+                                                      uint64_t n, uint64_t h, uint64_t *__restrict__ keys) {
+  KW_FOR(p, n) {
+    const uint64_t j = sa[p] + h;
+    keys[p] = j < n ? rank[j] + 1ull : 0ull;
+  }
+}
+__global__ __launch_bounds__(BLK) void kw_key_first(const uint64_t *__restrict__ sa, const uint64_t *__restrict__ rank,
+                                                     uint64_t n, uint64_t *__restrict__ keys) {
+  KW_FOR(p, n) keys[p] = rank[sa[p]];
+}
+__global__ __launch_bounds__(BLK) void kw_bwt(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa, uint64_t n,
+                                               uint8_t *__restrict__ bwt) {
+  KW_FOR(p, n) {
+    const uint64_t k = sa[p];
+    bwt[p] = k > 0 ? t[k - 1] : (uint8_t)0;   // fm_index.rs:50-55
+  }
+}
+__global__ __launch_bounds__(BLK) void kw_samples(const uint64_t *__restrict__ sa, uint64_t nsamp, uint32_t level,
+                                                   uint64_t *__restrict__ out) {
+  KW_FOR(j, nsamp) out[j] = sa[j << level];   // sample.rs:35-37
+}
+// scan = exclusive sum (64-bit) over the per-record histograms laid out [code][record]: scan[c][r] = cs[c] +
+// #{c before record r}.  Counter of a record = that value minus the value at its superblock's first record.
+__global__ __launch_bounds__(BLK) void kw_counters(const uint64_t *__restrict__ scan, uint32_t nrec, uint32_t sb_recs,
+                                                    uint4 *__restrict__ rec) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t >= (uint64_t)nrec * 8) return;
+  const uint32_t g = (uint32_t)(t & 7), r = (uint32_t)(t >> 3);
+  const uint32_t r0 = (r >> sb_recs) << sb_recs;
+  uint4 p = rec[t];
+  p.x = (uint32_t)(scan[(size_t)g * nrec + r] - scan[(size_t)g * nrec + r0]);
+  rec[t] = p;
+}
+__global__ void kw_bases(const uint64_t *__restrict__ scan, uint32_t nrec, uint32_t nsb, uint32_t sb_recs,
+                         uint64_t *__restrict__ base) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nsb * 8u) return;
+  const uint32_t sb = t >> 3, g = t & 7u;
+  base[t] = scan[(size_t)g * nrec + ((size_t)sb << sb_recs)];
+}
+__global__ __launch_bounds__(BLK) void kw_verify_sa(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa,
+                                                     uint64_t n, uint32_t *__restrict__ mark, unsigned long long *bad) {
+  KW_FOR(p, n) {
+    const uint64_t b = sa[p];
+    if (b >= n) { atomicAdd(bad, 1ull); continue; }
+    atomicAdd(&mark[b >> 2], 1u << (8u * (uint32_t)(b & 3u)));     // one byte per index, four to a word
+    if (p == 0) continue;
+    const uint64_t a = sa[p - 1];
+    if (a >= n) continue;
+    for (uint64_t j = 0;; j++) {   // suffix a must be < suffix b (a suffix that ends first is smaller)
+      const uint64_t pa = a + j, pb = b + j;
+      if (pa >= n) break;
+      if (pb >= n) { atomicAdd(bad, 1ull); break; }
+      const uint8_t ca = t[pa], cb = t[pb];
+      if (ca < cb) break;
+      if (ca > cb) { atomicAdd(bad, 1ull); break; }
+    }
+  }
+}
+__global__ __launch_bounds__(BLK) void kw_count_not_one(const uint8_t *mark, uint64_t n, unsigned long long *bad) {
+  KW_FOR(p, n) if (mark[p] != 1u) atomicAdd(bad, 1ull);
+}
+
+int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
+  uint64_t *keys_a, *keys_b, *vals_b, *rank;
+  unsigned int *d_ng;
+  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  auto ts0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what, uint64_t h) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[fmx build]   wide sort: %-10s h=%-10llu %8.1f ms\n", what, (unsigned long long)h,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
+  };
+  FMX_HIP(pool.get(&keys_a, n));
+  FMX_HIP(pool.get(&keys_b, n));
+  FMX_HIP(pool.get(&vals_b, n));
+  FMX_HIP(pool.get(&rank, n));
+  FMX_HIP(pool.get(&d_ng, 1));
+  uint32_t k = 63 / sym_bits;
+  if (k > 32) k = 32;
+  unsigned rank_bits = 1;                                 // bits of the largest key of a doubling pass: n
+  while ((n >> rank_bits) != 0) rank_bits++;
+  size_t tmp_sort = 0, tmp_scan = 0;
+  {
+    rocprim::double_buffer<uint64_t> kb(keys_a, keys_b);
+    rocprim::double_buffer<uint64_t> vb(d_sa, vals_b);
+    FMX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort, kb, vb, (size_t)n, 0u, 64u, (hipStream_t)0));
+    FMX_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, MaxOp64(),
+                                    (hipStream_t)0));
+  }
+  const size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tmp_bytes));
+  mark("alloc", 0);
+  const unsigned nb = wblocks(n);
+  hipLaunchKernelGGL(kw_init_keys, dim3(nb), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a, d_sa);
+  FMX_HIP(hipGetLastError());
+  uint64_t *keys_cur = keys_a, *keys_alt = keys_b, *sa_cur = d_sa, *sa_alt = vals_b;
+  auto sort_pass = [&](unsigned end_bit) -> int {
+    rocprim::double_buffer<uint64_t> kb(keys_cur, keys_alt);
+    rocprim::double_buffer<uint64_t> vb(sa_cur, sa_alt);
+    size_t tb = tmp_bytes;
+    FMX_HIP(rocprim::radix_sort_pairs(tmp, tb, kb, vb, (size_t)n, 0u, end_bit, (hipStream_t)0));
+    keys_cur = kb.current(); keys_alt = kb.alternate();
+    sa_cur = vb.current();   sa_alt = vb.alternate();
+    return FMX_OK;
+  };
+  if (int rc = sort_pass(k * sym_bits)) return rc;
+  uint64_t h = k;
+  bool two_keys = false;
+  for (;;) {
+    // the radix sort's alternate buffers are free between two sorts: second keys in keys_alt, heads in sa_alt
+    uint64_t *head = sa_alt;
+    if (two_keys) hipLaunchKernelGGL(kw_key_second, dim3(nb), dim3(BLK), 0, 0, sa_cur, rank, n, h / 2, keys_alt);
+    FMX_HIP(hipMemsetAsync(d_ng, 0, sizeof(unsigned int), 0));
+    hipLaunchKernelGGL(kw_flag_heads, dim3(nb), dim3(BLK), 0, 0, keys_cur, two_keys ? keys_alt : nullptr, n, head, d_ng);
+    unsigned int dup = 0;
+    FMX_HIP(hipMemcpy(&dup, d_ng, sizeof dup, hipMemcpyDeviceToHost));
+    mark("round", h);
+    if (!dup) break;
+    if (h >= n) {
+      fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
+      return FMX_ERR_HIP;
+    }
+    size_t tb = tmp_bytes;
+    FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp64(), (hipStream_t)0));
+    hipLaunchKernelGGL(kw_scatter_rank, dim3(nb), dim3(BLK), 0, 0, sa_cur, head, n, rank);
+    // two stable passes: by rank[i + h] + 1, then by rank[i]
+    hipLaunchKernelGGL(kw_key_second, dim3(nb), dim3(BLK), 0, 0, sa_cur, rank, n, h, keys_cur);
+    if (int rc = sort_pass(rank_bits + 1)) return rc;
+    hipLaunchKernelGGL(kw_key_first, dim3(nb), dim3(BLK), 0, 0, sa_cur, rank, n, keys_cur);
+    FMX_HIP(hipGetLastError());
+    if (int rc = sort_pass(rank_bits)) return rc;
+    two_keys = true;
+    h *= 2;
+  }
+  if (sa_cur != d_sa) FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0));
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(keys_a); pool.release(keys_b); pool.release(vals_b); pool.release(rank);
+  pool.release(tmp); pool.release(d_ng);
+  return FMX_OK;
+}
+}  // namespace
+
+int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
+  auto t0 = std::chrono::steady_clock::now();
+  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[fmx build wide] %-14s %8.1f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  DevPool pool;
+  const uint64_t n = idx->n;
+  const uint32_t maxc = (uint32_t)idx->max_character;
+  const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);   // text.rs:61-63
+  // -- statistics + validation (sais.rs:115-139) --
+  std::vector<uint64_t> hist;
+  TextStats st;
+  if (int rc = symbol_histogram<uint8_t>(d_text, n, maxc, hist, &st, pool)) return rc;
+  if (st.max_sym > maxc) {
+    fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
+    return FMX_ERR_SYMBOL_RANGE;
+  }
+  uint8_t first = 0;
+  FMX_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
+  if (first == 0) {
+    fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
+    return FMX_ERR_TEXT_START_ZERO;
+  }
+  if (st.last_nonzero_plus1 != (unsigned long long)n - 1) {   // rposition == n - 2
+    fmx_set_error(FMX_ERR_TEXT_END_ZERO, nullptr);
+    return FMX_ERR_TEXT_END_ZERO;
+  }
+  idx->h_cs = (uint64_t *)calloc((size_t)maxc + 1, sizeof(uint64_t));   // sais.rs:9-32
+  {
+    uint64_t sum = 0;
+    for (uint32_t c = 0; c <= maxc; c++) { idx->h_cs[c] = sum; sum += hist[c]; }
+  }
+  mark("stats");
+  // -- suffix array --
+  uint64_t *d_sa;
+  FMX_HIP(pool.get(&d_sa, n));
+  if (int rc = suffix_sort_wide(d_text, n, L, d_sa, pool)) return rc;
+  mark("suffix sort");
+  FmxWideDev &w = idx->wide;
+  w.n = n;
+  w.max_character = maxc;
+  w.status = idx->dev.status;
+  w.sa_level = FMX_NO_LOCATE;
+  idx->dev.sa_level = FMX_NO_LOCATE;
+  idx->dev.kind = idx->kind;
+  idx->dev.sym_bytes = 1;
+  // -- SA samples (sample.rs:21-44) --
+  if (idx->level_requested != FMX_NO_LOCATE) {
+    uint32_t level = idx->level_requested;
+    if (level >= 63 || n <= (1ull << level)) level = 0;            // sample.rs:28-31
+    const uint64_t nsamp = ((n - 1) >> level) + 1;                 // sample.rs:33
+    uint64_t *d_samp;
+    FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
+    if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
+    hipLaunchKernelGGL(kw_samples, dim3(wblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    w.samples = d_samp;
+    w.sa_level = level;
+    idx->dev.sa_level = level;
+    idx->nsamples = nsamp;
+  }
+  mark("samples");
+  // -- BWT (fm_index.rs:44-58) --
+  uint8_t *d_bwt;
+  FMX_HIP(pool.get(&d_bwt, n));
+  hipLaunchKernelGGL(kw_bwt, dim3(wblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+  FMX_HIP(hipGetLastError());
+  if (idx->flags & FMX_FLAG_KEEP_SA) {
+    uint8_t *kt;
+    FMX_HIP(hipMalloc((void **)&kt, n));
+    FMX_HIP(hipMemcpy(kt, d_text, (size_t)n, hipMemcpyDeviceToDevice));
+    if (int rc = keep(idx, kt, n)) return rc;
+    idx->d_text = kt;
+    for (size_t i = 0; i < pool.v.size(); i++)
+      if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
+    if (int rc = keep(idx, d_sa, n * 8)) return rc;
+    idx->d_sa64 = d_sa;
+  } else {
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(d_sa);
+  }
+  // -- records: planes + per-record histograms, 64-bit scan, relative counters + superblock bases --
+  const uint32_t nrec = (uint32_t)(n / 256u + 1u);
+  const uint32_t sb_shift = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST, sb_recs = sb_shift - 8u;
+  const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
+  uint4 *d_rec;
+  uint32_t *d_hist;
+  uint64_t *d_scan, *d_base;
+  FMX_HIP(hipMalloc((void **)&d_rec, (size_t)nrec * 128));
+  if (int rc = keep(idx, d_rec, (uint64_t)nrec * 128)) return rc;
+  FMX_HIP(hipMalloc((void **)&d_base, (size_t)nsb * 8 * sizeof(uint64_t)));
+  if (int rc = keep(idx, d_base, (uint64_t)nsb * 64)) return rc;
+  FMX_HIP(pool.get(&d_hist, (size_t)nrec * 8));
+  FMX_HIP(pool.get(&d_scan, (size_t)nrec * 8));
+  hipLaunchKernelGGL((k_mwm_pieces<3, uint8_t>), dim3(nblocks((uint64_t)nrec * 8)), dim3(BLK), 0, 0, d_bwt, n, 0u, 7u,
+                     nrec, d_rec, d_hist);
+  {
+    size_t tb = 0;
+    FMX_HIP(exclusive_sum(nullptr, tb, d_hist, d_scan, (size_t)nrec * 8));
+    uint8_t *tmp;
+    FMX_HIP(pool.get(&tmp, tb));
+    FMX_HIP(exclusive_sum(tmp, tb, d_hist, d_scan, (size_t)nrec * 8));
+    pool.release(tmp);
+  }
+  hipLaunchKernelGGL(kw_counters, dim3(nblocks((uint64_t)nrec * 8)), dim3(BLK), 0, 0, d_scan, nrec, sb_recs, d_rec);
+  hipLaunchKernelGGL(kw_bases, dim3((nsb * 8 + 63) / 64), dim3(64), 0, 0, d_scan, nrec, nsb, sb_recs, d_base);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  w.rec = d_rec;
+  w.base = d_base;
+  w.nsb = nsb;
+  w.sb_shift = sb_shift;
+  idx->is_wide = 1;
+  mark("records");
+  idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return FMX_OK;
+}
+
+int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations) {
+  const uint64_t n = idx->n;
+  *violations = 0;
+  uint32_t *mark;
+  unsigned long long *bad;
+  const size_t words = (size_t)(n / 4 + 1);
+  FMX_HIP(hipMalloc((void **)&mark, words * 4));
+  FMX_HIP(hipMalloc((void **)&bad, 8));
+  FMX_HIP(hipMemset(mark, 0, words * 4));
+  FMX_HIP(hipMemset(bad, 0, 8));
+  hipLaunchKernelGGL(kw_verify_sa, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)idx->d_text, idx->d_sa64, n, mark,
+                     bad);
+  hipLaunchKernelGGL(kw_count_not_one, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)mark, n, bad);
+  unsigned long long hb = 0;
+  FMX_HIP(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(mark);
+  (void)hipFree(bad);
+  *violations = hb;
+  return FMX_OK;
+}
+
 int fmx_build_impl(fmx_index *idx, const void *d_text) {
+  if (fmx_wide_build(idx)) return fmx_build_wide(idx, (const uint8_t *)d_text);   // eligibility checked by the caller
   switch (idx->sym_bytes) {
     case 1: return build_impl_t<uint8_t>(idx, (const uint8_t *)d_text);
     case 2: return build_impl_t<uint16_t>(idx, (const uint16_t *)d_text);

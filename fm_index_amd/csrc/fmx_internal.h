@@ -109,8 +109,32 @@ struct FmxDev {  // passed BY VALUE to every query kernel
 };
 #define FMX_PHASE_MAX_LEVEL 4u
 
+// ---- wide indexes: n >= 2^32 - 16 (usize rows of the reference, fm_index.rs:86-95) ------------------------
+// FMIndex / FMIndexWithLocate over a one-level alphabet (max_character <= 7: DNA), rows and positions 64 bits wide.
+// Same 128-byte fmt-3 records, but a record's eight counters are RELATIVE to the start of its superblock
+// (2^31 entries = 2^23 records) and a small table holds the 64-bit absolute value at every superblock start:
+//     lf_map2(c, i) = base[i >> 31][c] + cnt32[record(i)][c] + popcount          (cs[] folded into base)
+// so a rank still costs one 128-byte line (+ 8 bytes of a table that lives in the caches), the in-group sums
+// stay 32 bits wide, and the u32 engine is untouched.  Samples are u64.
+#define FMX_WIDE_SB_SHIFT 31u      // log2(rows per superblock); FMX_FLAG_FORCE_WIDE (tests) uses FMX_WIDE_SB_SHIFT_TEST so
+#define FMX_WIDE_SB_SHIFT_TEST 12u // that a small text has many superblocks
+struct FmxWideDev {  // passed BY VALUE to the wide kernels
+  const uint4 *rec;          // n / 256 + 1 records (row n is addressable)
+  const uint64_t *base;      // [nsb][8]
+  const uint64_t *samples;   // SA[k << level], k = 0 .. (n - 1) >> level       (sample.rs:33-37)
+  uint32_t *status;          // sticky device-side error bits
+  uint64_t n;                // len incl. terminator
+  uint32_t max_character;
+  uint32_t sa_level;         // effective level; FMX_NO_LOCATE when absent
+  uint32_t nsb;
+  uint32_t sb_shift;         // log2(rows per superblock), >= 8
+};
+
 struct fmx_index {
   FmxDev dev;
+  FmxWideDev wide;       // valid when is_wide
+  int is_wide;
+  uint64_t *d_sa64;      // wide + FMX_FLAG_KEEP_SA
   int device;
   uint64_t n;
   uint32_t sym_bytes;      // width on the device (1, 2, 4)
@@ -146,6 +170,21 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// wide indexes (fmx_wide.hip / the wide section of fmx_build.hip)
+static inline bool fmx_wide_n(uint64_t n) { return n >= 0xFFFFFFF0ull; }
+static inline bool fmx_wide_build(const fmx_index *idx) { return fmx_wide_n(idx->n) || (idx->flags & FMX_FLAG_FORCE_WIDE); }
+int fmx_build_wide(fmx_index *idx, const uint8_t *d_text);
+int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off, uint64_t npat,
+                      const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e, uint64_t *d_cnt, hipStream_t st);
+int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
+                       const uint64_t *d_off, uint64_t total, uint64_t *d_pos, hipStream_t st);
+int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i, uint64_t k,
+                       uint64_t *d_out, hipStream_t st);
+int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
+int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations);
+// rows s[k] + j of every interval, 64 bits each (wrapper.rs:203-217), written to out[off[k] + j]
+int fmx_launch_expand64(const uint64_t *d_s, const uint64_t *d_e, const uint64_t *d_off, uint64_t npat,
+                        uint64_t *d_out, uint64_t total, uint64_t n, uint32_t *status, hipStream_t st);
 // The FmxDev a launcher hands to its kernels: idx->dev, with `status` replaced by the calling
 // thread's own status word while a host-pointer call is in progress (so that two threads querying
 // one handle never read each other's error); the *_dev entry points report into the handle's

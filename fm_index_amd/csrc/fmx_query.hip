@@ -574,7 +574,7 @@ template <typename T>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
     const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos, uint64_t total,
-    uint32_t n, uint32_t *status) {
+    uint64_t n, uint32_t *status) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_export_l_kernel(FmxDev ix, void
   }
 }
 int fmx_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
+  if (idx->is_wide) return fmxw_launch_export_l(idx, d_out, st);
   const FmxDev dv = fmx_launch_dev(idx);
   if (idx->n == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM || idx->kind == FMX_KIND_MULTI)
@@ -1543,6 +1544,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_match_rows_kernel(
 }
 int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                             uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st) {
+  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_counts_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
@@ -1553,6 +1555,7 @@ int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uin
 int fmx_launch_match_rows(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                           uint64_t npat, int prefix_only, const uint64_t *d_off, uint64_t *d_rows,
                           hipStream_t st) {
+  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_rows_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
@@ -1745,6 +1748,7 @@ static constexpr FmxTune fmx_tune() { return FmxTune{}; }
 int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off,
                      uint64_t npat, const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e,
                      uint64_t *d_cnt, hipStream_t st, unsigned max_blocks) {
+  if (idx->is_wide) return fmxw_launch_count(idx, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, st);
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   if (max_blocks == 0 || max_blocks > FMX_MAX_BLOCKS) max_blocks = FMX_MAX_BLOCKS;
@@ -1820,6 +1824,7 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
                       hipStream_t st, uint32_t *rows_ws) {
+  if (idx->is_wide) return fmxw_launch_locate(idx, d_s, d_e, npat, d_off, total, d_pos, st);   // rows live in d_pos
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0 || total == 0) return FMX_OK;
   const FmxMwm &w = dv.bw;
@@ -1913,8 +1918,19 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   return FMX_OK;
 }
 
+int fmx_launch_expand64(const uint64_t *d_s, const uint64_t *d_e, const uint64_t *d_off, uint64_t npat,
+                        uint64_t *d_out, uint64_t total, uint64_t n, uint32_t *status, hipStream_t st) {
+  uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
+  if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
+  hipLaunchKernelGGL(fmx_expand_kernel<uint64_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e, d_off, npat,
+                     d_out, total, n, status);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 int fmx_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i,
                       uint64_t k, uint64_t *d_out, hipStream_t st) {
+  if (idx->is_wide) return fmxw_launch_scalar(idx, op, d_c, d_i, k, d_out, st);
   const FmxDev dv = fmx_launch_dev(idx);
   if (k == 0) return FMX_OK;
   if (idx->kind == FMX_KIND_FM)
@@ -1950,6 +1966,7 @@ static int fmx_launch_extract_t(const fmx_index *idx, const uint64_t *d_rows, ui
 int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
                        int forward, void *d_out, uint64_t *d_out_len, uint64_t *d_out_next,
                        hipStream_t st) {
+  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
   if (nrows == 0) return FMX_OK;
   if (idx->sym_bytes == 1) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint8_t *)d_out, d_out_len, d_out_next, st);
   if (idx->sym_bytes == 2) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint16_t *)d_out, d_out_len, d_out_next, st);

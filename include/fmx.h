@@ -12,8 +12,12 @@
  * shim a maintainer would add.
  *
  * Conventions
- *  - rows / positions / counts are uint64_t (= Rust usize); the engine keeps
- *    uint32_t internally and rejects texts with n >= 2^32 (FMX_ERR_UNSUPPORTED).
+ *  - rows / positions / counts are uint64_t (= Rust usize).  Texts below 2^32 - 16 symbols run on the
+ *    32-bit engine (every kind, every alphabet).  Longer texts are taken by the WIDE engine (64-bit rows,
+ *    positions and samples) for FMX_KIND_FM with or without locate over u8 symbols with max_character <= 7
+ *    (DNA): build, count, locate, offsets, the trait calls get_l / lf_map / lf_map2 / get_sa and the exports
+ *    marked "wide" below; every other combination at that size, and the remaining entry points on a wide
+ *    index, report FMX_ERR_UNSUPPORTED.
  *  - symbols are `sym_bytes` wide: Character = u8 / u16 / u32 / u64 (character.rs:38-42) =
  *    1 / 2 / 4 / 8.  u64 texts and patterns are narrowed to u32 on the host (host-pointer entry
  *    points only); the *_dev entry points take 1-, 2- or 4-byte symbols (fmx_sym_bytes()).
@@ -94,6 +98,10 @@ typedef struct fmx_index fmx_index;
  * override the default either way; both set, or a level outside 1..4, means row order. */
 #define FMX_FLAG_TEXT_ORDER 8u
 #define FMX_FLAG_ROW_ORDER 16u
+/* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
+ * superblocks of 2^12 rows instead of 2^31, so that a small text exercises every part of it.  Same eligibility
+ * (FMX_KIND_FM, u8 symbols, max_character <= 7, n >= 2); same results. */
+#define FMX_FLAG_FORCE_WIDE 32u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
@@ -260,7 +268,8 @@ uint64_t fmx_last_steps(const fmx_index *idx);
 double fmx_build_ms(const fmx_index *idx);
 int fmx_export_bwt(const fmx_index *idx, void *host_out);            /* n symbols of fmx_sym_bytes() */
 int fmx_export_cs(const fmx_index *idx, uint64_t *host_out);         /* max_character+1 (sais.rs:9-32) */
-int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out); /* ((n-1)>>level)+1 */
+int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out); /* ((n-1)>>level)+1; n < 2^32 */
+int fmx_export_sa_samples64(const fmx_index *idx, uint64_t *host_out); /* the same, 64 bits each; also wide indexes */
 uint64_t fmx_num_samples(const fmx_index *idx);
 int fmx_export_sa(const fmx_index *idx, uint32_t *host_out);         /* needs FMX_FLAG_KEEP_SA */
 /* needs FMX_FLAG_KEEP_SA: number of adjacent suffix pairs out of order + number of
@@ -270,6 +279,7 @@ uint64_t fmx_num_runs(const fmx_index *idx);                         /* RLFM: r 
 uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol width in HBM / *_dev */
 uint32_t fmx_kmer_k(const fmx_index *idx);   /* k of the FMX_FLAG_KMER_TABLE table, 0 = none */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
+int fmx_is_wide(const fmx_index *idx);        /* 1: served by the wide (64-bit rows) engine */
 int fmx_text_order(const fmx_index *idx);     /* 1: suffix-array samples in text order (FMX_FLAG_TEXT_ORDER) */
 
 #ifdef __cplusplus

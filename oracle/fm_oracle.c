@@ -372,6 +372,12 @@ static void ssa_init(orc_ssa *s, uint64_t n, uint64_t level) {
   s->nsamples = ((n - 1) >> level) + 1; /* sample.rs:33 */
   s->bits = (uint64_t *)calloc((s->nsamples * s->word_size + 63) / 64 + 1, sizeof(uint64_t));
 }
+void orc_ssa_from_samples64(orc_ssa *s, const uint64_t *samples, uint64_t n, uint64_t level) {
+  ssa_init(s, n, level);
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < s->nsamples; i++)
+    bv_append_bits(s->bits, &pos, samples[i], s->word_size);
+}
 void orc_ssa_sample(orc_ssa *s, const uint32_t *sa, uint64_t n, uint64_t level) {
   ssa_init(s, n, level);
   uint64_t pos = 0;
@@ -484,6 +490,23 @@ int orc_fm_from_bwt(orc_fm **out, const uint8_t *bwt, uint64_t n, uint64_t max_c
   orc_wm_build(&f->bw, bwt, n, orc_max_bits(max_character));
   if (level >= 0 && samples) {
     orc_ssa_from_samples(&f->ssa, samples, n, (uint64_t)level);
+    f->has_locate = 1;
+  }
+  *out = f;
+  return ORC_OK;
+}
+/* the same with 64-bit sample values: texts of 2^32 symbols and more (the reference is usize throughout) */
+int orc_fm_from_bwt64(orc_fm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                    const uint64_t *cs, const uint64_t *samples, int level) {
+  *out = NULL;
+  if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
+  orc_fm *f = (orc_fm *)calloc(1, sizeof(orc_fm));
+  f->max_character = max_character;
+  f->cs = (uint64_t *)calloc(max_character + 1, sizeof(uint64_t));
+  memcpy(f->cs, cs, (max_character + 1) * sizeof(uint64_t));
+  orc_wm_build(&f->bw, bwt, n, orc_max_bits(max_character));
+  if (level >= 0 && samples) {
+    orc_ssa_from_samples64(&f->ssa, samples, n, (uint64_t)level);
     f->has_locate = 1;
   }
   *out = f;

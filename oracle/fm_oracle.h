@@ -93,6 +93,7 @@ typedef struct orc_ssa {
 void orc_ssa_sample(orc_ssa *s, const uint32_t *sa, uint64_t n, uint64_t level);
 /* sample.rs:21-44 fed from an already subsampled array (samples[k] = sa[k<<level]) */
 void orc_ssa_from_samples(orc_ssa *s, const uint32_t *samples, uint64_t n, uint64_t level);
+void orc_ssa_from_samples64(orc_ssa *s, const uint64_t *samples, uint64_t n, uint64_t level);
 void orc_ssa_free(orc_ssa *s);
 /* returns 1 and *out when Some, 0 when None (sample.rs:46-60) */
 int orc_ssa_get(const orc_ssa *s, uint64_t i, uint64_t *out);
@@ -130,6 +131,8 @@ int orc_fm_new(orc_fm **out, const uint8_t *text, uint64_t n, uint64_t max_chara
  * sorter would take too long */
 int orc_fm_from_bwt(orc_fm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
                     const uint64_t *cs, const uint32_t *samples, int level);
+int orc_fm_from_bwt64(orc_fm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                    const uint64_t *cs, const uint64_t *samples, int level);
 void orc_fm_free(orc_fm *f);
 orc_backend orc_fm_backend(orc_fm *f);
 uint64_t orc_fm_heap_bytes(const orc_fm *f);

@@ -49,6 +49,7 @@ def _bind(lib):
     lib.orc_fm_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     lib.orc_fm_from_bwt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_fm_from_bwt64.argtypes = lib.orc_fm_from_bwt.argtypes
     lib.orc_fm_free.argtypes = [C.c_void_p]
     lib.orc_fm_backend.restype = _Backend
     lib.orc_fm_backend.argtypes = [C.c_void_p]
@@ -207,12 +208,17 @@ class OracleIndex:
             b, cs, samples = _from_bwt
             b = _u8(b)
             cs = np.ascontiguousarray(cs, dtype=np.uint64)
-            sp = _p(np.ascontiguousarray(samples, dtype=np.uint32)) if samples is not None else None
+            big = len(b) >= (1 << 32)        # sample values need more than 32 bits (the reference is usize)
+            sdt = np.uint64 if big else np.uint32
+            sarr = np.ascontiguousarray(samples, dtype=sdt) if samples is not None else None
+            sp = _p(sarr) if sarr is not None else None
             if kind == "rlfm":   # run-length structure of the same L column (rlfmi.rs:41-96)
+                if big:
+                    raise ValueError("the oracle's RLFM import takes 32-bit samples: n < 2^32")
                 rc = self._l.orc_rlfm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, sp, lvl)
             else:
-                rc = self._l.orc_fm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, _p(cs),
-                                             sp, lvl)
+                fn = self._l.orc_fm_from_bwt64 if big else self._l.orc_fm_from_bwt
+                rc = fn(C.byref(h), _p(b), len(b), self.max_character, _p(cs), sp, lvl)
         elif _is_wide(text):
             t = _u32(text)
             self._text_keep = t

@@ -1,0 +1,167 @@
+"""n >= 2^32: the reference's rows and positions are `usize` (fm_index.rs:86-95, 127-140; sample.rs:21-44) and so are
+the wide engine's.  A DNA FMIndexWithLocate over n = 2^32 + 2^20 symbols is built on the GPU (64-bit suffix sort,
+superblock-relative record counters, 64-bit samples) and held to the protocol of tests/test_gpu_fullsize.py: the
+suffix array IS the suffix array (sortedness + permutation on the device), substrings occur, every located position
+holds its pattern and the source position is among the hits -- with patterns whose intervals lie beyond row 2^32 and
+patterns taken from beyond position 2^32 -- and (s, e), the ordered positions and the trait methods at rows beyond
+2^32 are identical to the CPU oracle fed the exported L column and the exported 64-bit samples.
+Needs ~185 GB of HBM for the build and ~35 GB of host memory for the oracle.
+`python tests/test_gpu_beyond_4g.py` prints the JSON summary kept under profiles/."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fm_index_amd as F  # noqa: E402
+from fm_index_amd import _lib as L  # noqa: E402
+from fm_index_amd import workload as W  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N = (1 << 32) + (1 << 20)
+
+
+def _run():
+    import torch
+    from oracle import fm_oracle as O
+    torch.cuda.empty_cache()
+    dev = torch.device("cuda", 0)
+    lib = L.lib()
+    m, level = 30, 2
+    text = W.dna_text_torch(N, 17, dev)
+    t0 = time.time()
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=level, keep_sa=True)
+    build_s = time.time() - t0
+    h = index.handle()
+    assert index.len() == N and index.is_wide() and index.level() == level
+    t0 = time.time()
+    assert index.verify_sa() == 0                       # sorted, and every index exactly once
+    verify_s = time.time() - t0
+    # patterns = substrings from (A) uniform positions, (B) positions whose suffix starts with seven 4s -- the top
+    # 4^-7 of the rows, all beyond row 2^32 --, (C) positions beyond 2^32 in the text
+    win = text[:1 << 28]
+    hi = win[:-8] == 4
+    for j in range(1, 7):
+        hi &= win[j:j - 8] == 4
+    src_b = torch.nonzero(hi).flatten()[:1 << 13]
+    assert src_b.numel() >= 1 << 12
+    del hi, win
+    src_a = W.umod_torch(W.splitmix64_torch(13, 0, 1 << 15, dev), N - 1 - m)
+    src_c = (1 << 32) + W.umod_torch(W.splitmix64_torch(14, 0, 1 << 14, dev), (1 << 20) - 1 - m)
+    src = torch.cat([src_b, src_a, src_c])
+    npat = int(src.numel())
+    pat = text[src[:, None] + torch.arange(m, dtype=torch.int64, device=dev)[None, :]].reshape(-1).contiguous()
+    off = (torch.arange(npat + 1, dtype=torch.int64, device=dev) * m).contiguous()
+    s = torch.empty(npat, dtype=torch.int64, device=dev)
+    e = torch.empty(npat, dtype=torch.int64, device=dev)
+    c = torch.empty(npat, dtype=torch.int64, device=dev)
+    assert lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                   C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), C.c_void_p(c.data_ptr()),
+                                   None) == 0
+    torch.cuda.synchronize()
+    assert lib.fmx_stream_status(h) == 0
+    assert bool((c >= 1).all())
+    rows_hi = int((e > (1 << 32)).sum().item())
+    assert rows_hi >= int(src_b.numel())
+    d_off = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+    assert lib.fmx_offsets_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                               C.c_void_p(d_off.data_ptr()), None) == 0
+    total = int(d_off[-1].item())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    assert lib.fmx_locate_batch_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                                    C.c_void_p(d_off.data_ptr()), total, C.c_void_p(d_pos.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert lib.fmx_stream_status(h) == 0
+    hit = torch.repeat_interleave(torch.arange(npat, device=dev), c)
+    ok = torch.ones(total, dtype=torch.bool, device=dev)
+    for j in range(m):
+        ok &= text[d_pos + j] == pat.view(npat, m)[hit, j]
+    assert bool(ok.all())
+    found = torch.zeros(npat, dtype=torch.bool, device=dev)
+    found[hit[d_pos == src[hit]]] = True
+    assert bool(found.all())
+    pos_hi = int((d_pos >= (1 << 32)).sum().item())
+    assert pos_hi >= int(src_c.numel())
+    # ---- the oracle, from the exported L column and the exported 64-bit samples ----
+    t0 = time.time()
+    samples = index.export_sa_samples()
+    assert samples.dtype == np.uint64 and int(samples.max()) >= (1 << 32)
+    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4, samples=samples, level=level)
+    del samples
+    oracle_s = time.time() - t0
+    k = 1 << 12
+    so, eo = oi.count_batch(pat[:k * m].cpu().numpy(), np.arange(k + 1, dtype=np.uint64) * np.uint64(m), nthreads=16)
+    assert (so == s[:k].cpu().numpy().view(np.uint64)).all()
+    assert (eo == e[:k].cpu().numpy().view(np.uint64)).all()
+    ooff, opos = oi.locate_batch(so[:1024], eo[:1024], nthreads=16)
+    assert (opos == d_pos[:int(ooff[-1])].cpu().numpy().view(np.uint64)).all()
+    rows = (np.uint64(1 << 32) + W.splitmix64_np(21, 0, 2048) % np.uint64(1 << 20)).astype(np.uint64)
+    syms = (np.uint64(1) + W.splitmix64_np(22, 0, 2048) % np.uint64(4)).astype(np.uint64)
+    rows2 = rows.copy()
+    rows2[0] = N
+    assert (index.lf_map2(syms, rows2) == oi.lf_map2(syms, rows2)).all()
+    assert (index.lf_map(rows) == oi.lf_map(rows)).all() and (index.get_l(rows) == oi.get_l(rows)).all()
+    assert (index.get_sa(rows[:256]) == oi.get_sa(rows[:256])).all()
+    oi.close()
+    # ---- for the record: what the wide engine's simple kernels do on the config-2 / config-3 shapes ----
+    kp, mp = 1 << 20, 32
+    srcp = W.umod_torch(W.splitmix64_torch(3, 0, kp, dev), N - 1 - mp)
+    patp = text[srcp[:, None] + torch.arange(mp, dtype=torch.int64, device=dev)[None, :]].reshape(-1).contiguous()
+    offp = (torch.arange(kp + 1, dtype=torch.int64, device=dev) * mp).contiguous()
+    sp_, ep_ = (torch.empty(kp, dtype=torch.int64, device=dev) for _ in range(2))
+
+    def count_p():
+        assert lib.fmx_count_batch_dev(h, C.c_void_p(patp.data_ptr()), C.c_void_p(offp.data_ptr()), kp, None,
+                                       C.c_void_p(sp_.data_ptr()), C.c_void_p(ep_.data_ptr()), None, None) == 0
+    count_p()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        count_p()
+    ev1.record()
+    torch.cuda.synchronize()
+    count_ms = ev0.elapsed_time(ev1) / 10
+    offh = torch.empty(kp + 1, dtype=torch.int64, device=dev)
+    lib.fmx_offsets_dev(h, C.c_void_p(sp_.data_ptr()), C.c_void_p(ep_.data_ptr()), kp, C.c_void_p(offh.data_ptr()), None)
+    tot_p = int(offh[-1].item())
+    posp = torch.empty(tot_p, dtype=torch.int64, device=dev)
+
+    def locate_p():
+        assert lib.fmx_locate_batch_dev(h, C.c_void_p(sp_.data_ptr()), C.c_void_p(ep_.data_ptr()), kp,
+                                        C.c_void_p(offh.data_ptr()), tot_p, C.c_void_p(posp.data_ptr()), None) == 0
+    locate_p()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(10):
+        locate_p()
+    ev1.record()
+    torch.cuda.synchronize()
+    locate_ms = ev0.elapsed_time(ev1) / 10
+    perf = {"count_2^20x32_ms": round(count_ms, 4), "count_pattern_chars_per_s": kp * mp / (count_ms / 1e3),
+            "locate_hits": tot_p, "locate_ms": round(locate_ms, 4), "locate_hits_per_s": tot_p / (locate_ms / 1e3)}
+    del patp, posp
+    out = {"kind": "fm", "n": N, "level": level, "perf": perf, "patterns": npat, "pattern_len": m, "hits": total,
+           "intervals_with_e_beyond_2^32": rows_hi, "positions_beyond_2^32": pos_hi,
+           "max_row": int(e.max().item()), "max_position": int(d_pos.max().item()),
+           "verify_sa_violations": 0, "oracle_patterns_identical": k, "oracle_located_patterns_identical": 1024,
+           "trait_rows_checked_beyond_2^32": int(len(rows)), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
+           "build_wall_s": round(build_s, 2), "verify_sa_s": round(verify_s, 2), "oracle_import_s": round(oracle_s, 1),
+           "index_bytes": index.heap_size(), "wide": index.is_wide()}
+    index.close()
+    del text, pat, d_pos
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_dna_index_beyond_4g_symbols():
+    _run()
+
+
+if __name__ == "__main__":
+    print(json.dumps(_run()))

@@ -1,0 +1,104 @@
+"""The WIDE engine (64-bit rows, positions and samples: the reference's `usize`, fm_index.rs:86-95, 127-140) on
+texts small enough for the oracle to answer every question: FMX_FLAG_FORCE_WIDE builds the index the wide builder
+makes for n >= 2^32 - 16 -- 64-bit suffix sort in two radix passes per round, record counters relative to their
+superblock, 64-bit bases and samples -- with superblocks of 2^12 rows, so that a text of 10^5 symbols crosses
+dozens of them.  tests/test_gpu_beyond_4g.py runs the same engine at n = 2^32 + 2^20."""
+import numpy as np
+import pytest
+
+import fm_index_amd as F
+from fm_index_amd import _lib as L
+from fm_index_amd import workload as W
+from oracle import fm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dna(n, seed, sigma=4):
+    t = (W.splitmix64_np(seed, 0, n) % np.uint64(sigma)).astype(np.uint8) + 1
+    t[-1] = 0
+    return t
+
+
+@pytest.mark.parametrize("n,sigma,level", [(5000, 4, 2), (70001, 4, 2), ((1 << 17) + 5, 4, 3), (40000, 7, 1), (9000, 2, 0)])
+def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level):
+    t = _dna(n, 100 + n % 97, sigma)
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True)
+    assert gi.is_wide() and gi.len() == n and gi.level() == level
+    oi = O.OracleIndex(t, sigma, level=level)
+    assert gi.verify_sa() == 0                                    # the 64-bit suffix sort
+    # backward search: ragged patterns (empty ones included), substrings, early exit
+    flat, off = W.ragged_patterns_np(3000, 14, sigma, 7)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts == oe - os_).all()
+    flat2, off2, _ = W.substring_patterns_np(t, 2000, 9, 3)
+    gb2 = gi.search_many(flat=flat2, off=off2)
+    os2, oe2 = oi.count_batch(flat2, off2)
+    assert (gb2.s == os2).all() and (gb2.e == oe2).all()
+    # refinement from given ranges (wrapper.rs:99-124)
+    se = np.stack([os2, oe2], axis=1).reshape(-1).copy()
+    one = np.full(len(os2), 2, dtype=np.uint8)
+    off1 = np.arange(len(os2) + 1, dtype=np.uint64)
+    ref = gi.search_many(flat=one, off=off1, s0e0=se)
+    rs, re_ = oi.count_batch(one, off1, s0e0=se)
+    assert (ref.s == rs).all() and (ref.e == re_).all()
+    # locate: exact sequences, suffix-array order (wrapper.rs:203-217, 238-242)
+    goff, gpos = gb2.locate()
+    ooff, opos = oi.locate_batch(os2, oe2, nthreads=4)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    goff, gpos = gi.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))    # every row
+    rows = np.arange(n, dtype=np.uint64)
+    want = oi.get_sa(rows).astype(np.uint64)
+    assert (gpos == want).all()
+    # the trait methods: every (c, i) with i == n included; every row
+    for c in range(0, sigma + 1):
+        i = np.arange(n + 1, dtype=np.uint64)
+        cc = np.full(n + 1, c, dtype=np.uint64)
+        assert (gi.lf_map2(cc, i) == oi.lf_map2(cc, i)).all(), c
+    assert (gi.lf_map(rows) == oi.lf_map(rows)).all() and (gi.get_l(rows) == oi.get_l(rows)).all()
+    assert (gi.get_sa(rows[:4000]) == want[:4000]).all()
+    samp = gi.export_sa_samples()
+    assert samp.dtype == np.uint64 and (samp == want[::1 << level]).all()
+    assert (gi.export_bwt() == oi.get_l(rows).astype(np.uint8)).all()
+    gi.close()
+
+
+def test_wide_engine_errors_and_refusals(tmp_path):
+    t = _dna(30000, 5)
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, force_wide=True)
+    lib = gi._lib
+    # a pattern symbol beyond max_character: reported, not dereferenced (the reference panics on cs[c])
+    with pytest.raises(F.Error):
+        gi.search_many(flat=np.array([1, 2, 9], dtype=np.uint8), off=np.array([0, 3], dtype=np.uint64))
+    # offsets that go backwards, ranges and rows that are not of this index
+    with pytest.raises(F.Error):
+        gi.search_many(flat=np.array([1, 2, 3], dtype=np.uint8), off=np.array([0, 3, 2], dtype=np.uint64))
+    with pytest.raises(F.Error):
+        gi.search_many(flat=np.array([1], dtype=np.uint8), off=np.array([0, 1], dtype=np.uint64),
+                       s0e0=np.array([0, 30001], dtype=np.uint64))
+    with pytest.raises(F.Error):
+        gi.get_sa(np.array([30000], dtype=np.uint64))
+    assert gi.search(bytes([1, 2])).count() >= 1                    # and the handle still works
+    # what the wide engine does not have says so
+    assert lib.fmx_save(gi.handle(), str(tmp_path / "x.fmx").encode()) == L.ERR_UNSUPPORTED
+    with pytest.raises(F.Error):
+        gi.get_f(np.array([5], dtype=np.uint64))
+    out = np.zeros(8, dtype=np.uint32)
+    assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
+    gi.close()
+    # eligibility: one-level u8 alphabets of FMX_KIND_FM only
+    with pytest.raises(F.Error):
+        F.FMIndexWithLocate(F.Text(W.byte_text_np(5000, 3)), 2, force_wide=True)
+    # a count-only wide index has no locate
+    ci = F.FMIndex(F.Text.with_max_character(t, 4), force_wide=True)
+    assert ci.is_wide() and ci.search(bytes([1, 2])).count() == gi_count(t, [1, 2])
+    ci.close()
+
+
+def gi_count(t, pat):
+    m = len(pat)
+    hits = np.ones(len(t) - m + 1, dtype=bool)
+    for j, c in enumerate(pat):
+        hits &= t[j:len(t) - m + 1 + j] == c
+    return int(hits.sum())

@@ -873,6 +873,8 @@ def run(args, world, pmc=None):
     # ---- HBM-side traffic measured by the counter passes at the start of this run ----
     if pmc is not None and rank == 0:
         apply_pmc(out, pmc[0], pmc[1])
+    two_stream_roofline(out.get("locate"))
+    two_stream_roofline((out.get("rlfm") or {}).get("locate"))
 
     if use_dist:             # every rank is done before the line is printed; nothing follows it on stdout
         dist.barrier()
@@ -1215,6 +1217,23 @@ def locate_text_order_leg(out, wl, args):
                                             "to the row-order index on every hit"}
     finally:
         tix.close()
+
+
+def two_stream_roofline(leg):
+    """the walk kernel's roofline figures at the rate of two batches in flight: same bytes and requests per launch
+    as `roofline` (one launch at a time), over the per-batch time of the two-stream run -- with launches that
+    overlap, a launch's share of the wall clock is its duration"""
+    if not leg or "two_streams" not in leg or "ms_per_batch" not in leg["two_streams"]:
+        return
+    r, two = leg.get("roofline") or {}, leg["two_streams"]
+    if not r.get("traffic"):
+        return
+    t_s = two["ms_per_batch"] / 1e3
+    two["roofline"] = {"traffic": r["traffic"], "achieved": round(r["traffic"] / t_s / 1e9, 1),
+                       "frac": round(r["traffic"] / t_s / 1e9 / HBM_PEAK_GBS, 4),
+                       "frac_of_gather_ceiling": round(r.get("fabric_requests", 0) / t_s / (GATHER_CEILING_GLINES * 1e9), 4),
+                       "basis": "bytes and fabric requests per launch of `roofline`, over the per-batch time of two "
+                                "batches in flight (includes the row expansion)"}
 
 
 def locate_two_streams(wl, reps):

@@ -44,11 +44,24 @@ __device__ __forceinline__ uint64_t fmxw_lf_map(const FmxWideDev &w, uint64_t i,
   return b + fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));
 }
 
-// SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern
+// the superblock bases in LDS (they are read with a data-dependent symbol in every step): up to FMXW_LDS_SB
+// superblocks = n < 2^37; beyond that the kernels read them from global memory
+#define FMXW_LDS_SB 64u
+__device__ __forceinline__ const uint64_t *fmxw_stage_bases(const FmxWideDev &w, uint64_t *lds) {
+  if (w.nsb > FMXW_LDS_SB) return w.base;
+  for (uint32_t t = threadIdx.x; t < w.nsb * 8u; t += blockDim.x) lds[t] = w.base[t];
+  __syncthreads();
+  return lds;
+}
+
+// SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern.  Per step the two record loads and
+// the NEXT pattern symbol are requested together and waited for once; the base of the step's symbol comes from LDS.
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
     FmxWideDev w, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  __shared__ uint64_t lds_base[FMXW_LDS_SB * 8u];
+  const uint64_t *base = fmxw_stage_bases(w, lds_base);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
@@ -69,19 +82,21 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
       s = 0; e = 0; j = 0;
     }
-    while (j) {                                     // for c in pattern.iter().rev()          wrapper.rs:108
-      const uint32_t c = pat[pbeg + j - 1];
+    uint32_t c = j ? pat[pbeg + j - 1] : 0u;        // for c in pattern.iter().rev()          wrapper.rs:108
+    while (j) {
       if (c > w.max_character) {                    // reference: panic on cs[c]
         if (g == 0) atomicOr(w.status, 1u << FMX_ERR_SYMBOL_RANGE);
         s = 0; e = 0;
         break;
       }
-      // both records and both bases are requested before either is used
+      FMX_CHECK((e >> 8) < w.n / 256u + 1u && (s >> w.sb_shift) < w.nsb && (e >> w.sb_shift) < w.nsb);
       const uint4 pa = w.rec[(size_t)(s >> 8) * 8u + g], pb = w.rec[(size_t)(e >> 8) * 8u + g];
-      const uint64_t ba = w.base[(size_t)(s >> w.sb_shift) * 8u + c];
-      const uint64_t bb = w.base[(size_t)(e >> w.sb_shift) * 8u + c];
+      const uint32_t cn = j > 1 ? pat[pbeg + j - 2] : 0u;      // rides along with the record loads
+      const uint64_t ba = base[(size_t)(s >> w.sb_shift) * 8u + c];
+      const uint64_t bb = base[(size_t)(e >> w.sb_shift) * 8u + c];
       s = ba + fmx_group_sum(fmx_piece_rank<3>(pa, (uint32_t)s & 255u, c, g));      // wrapper.rs:109
       e = bb + fmx_group_sum(fmx_piece_rank<3>(pb, (uint32_t)e & 255u, c, g));      // wrapper.rs:110
+      c = cn;
       j--;
       nsteps++;
       if (s == e) break;                            // wrapper.rs:111-113
@@ -95,31 +110,68 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60): a group per walk.  `io` holds the row on
-// entry and the position on exit -- the expanded rows of iter_matches (wrapper.rs:203-217) are written straight
-// into the caller's position array, so a wide locate needs no workspace.
+// get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60).  `io` holds the row on entry and the position
+// on exit -- the expanded rows of iter_matches (wrapper.rs:203-217) are written straight into the caller's
+// position array, so a wide locate needs no workspace.  A group runs FMXW_WALKS walks at a time (their record loads
+// are requested together) and takes the next hit for a slot the moment its walk ends.
+#define FMXW_WALKS 4
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
                                                                 uint64_t *__restrict__ steps_out) {
+  __shared__ uint64_t lds_base[FMXW_LDS_SB * 8u];
+  const uint64_t *base = fmxw_stage_bases(w, lds_base);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   const uint64_t lmask = (1ull << w.sa_level) - 1ull;
-  uint64_t nsteps = 0;
-  for (uint64_t h = gid; h < total; h += ngroups) {
-    uint64_t row = io[h], steps = 0;
-    if (row >= w.n) {                               // not a row of this index: refuse, do not read
-      if (g == 0) { atomicOr(w.status, 1u << FMX_ERR_ARG); io[h] = ~0ull; }
-      continue;
+  constexpr uint64_t NONE = ~0ull;
+  uint64_t h[FMXW_WALKS], row[FMXW_WALKS], steps[FMXW_WALKS];
+  uint64_t next = gid, nsteps = 0;                  // hits gid, gid + ngroups, ... belong to this group
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < FMXW_WALKS; q++) {
+    h[q] = NONE; row[q] = 0; steps[q] = 0;
+    if (next < total) { h[q] = next; row[q] = io[next]; next += ngroups; any = true; }
+  }
+  while (any) {
+    // rows that are not of this index, walks that stand on a sampled row: finish, hand the slot to the next hit
+#pragma unroll
+    for (int q = 0; q < FMXW_WALKS; q++) {
+      if (h[q] == NONE) continue;
+      bool done = false;
+      uint64_t v = NONE;
+      if (row[q] >= w.n) {                          // refuse, do not read
+        if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+        done = true;
+      } else if ((row[q] & lmask) == 0) {           // Some(sa): (sa + steps) % len           fm_index.rs:131-133
+        v = w.samples[row[q] >> w.sa_level] + steps[q];
+        if (v >= w.n) v -= w.n;
+        done = true;
+      }
+      if (done) {
+        if (g == 0) io[h[q]] = v;
+        nsteps += steps[q];
+        h[q] = NONE; steps[q] = 0;
+        if (next < total) { h[q] = next; row[q] = io[next]; next += ngroups; }
+      }
     }
-    while (row & lmask) {                           // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
-      uint32_t sym;
-      row = fmxw_lf_map(w, row, g, sym);
-      steps++;
+    // one LF step of every walk that is not on a sampled row: the record loads first, then the decodes
+    uint4 p[FMXW_WALKS];
+    bool walk[FMXW_WALKS];
+    any = false;
+#pragma unroll
+    for (int q = 0; q < FMXW_WALKS; q++) {
+      walk[q] = h[q] != NONE && row[q] < w.n && (row[q] & lmask) != 0;
+      any |= h[q] != NONE;
+      if (walk[q]) p[q] = w.rec[(size_t)(row[q] >> 8) * 8u + g];
     }
-    uint64_t v = w.samples[row >> w.sa_level] + steps;   // Some(sa): (sa + steps) % len     fm_index.rs:131-133
-    if (v >= w.n) v -= w.n;
-    if (g == 0) io[h] = v;
-    nsteps += steps;
+#pragma unroll
+    for (int q = 0; q < FMXW_WALKS; q++) {
+      if (!walk[q]) continue;                       // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
+      const uint32_t off = (uint32_t)row[q] & 255u;
+      const uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
+      row[q] = base[(size_t)(row[q] >> w.sb_shift) * 8u + sym] + fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));
+      steps[q]++;
+    }
   }
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }

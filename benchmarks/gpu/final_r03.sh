@@ -8,7 +8,7 @@ timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 bash profiles/run_rocprof.sh r03 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 if [ -f fm_index_amd/libfmx_debug.so ]; then
-  T="tests/test_gpu_large_batches.py tests/test_gpu_rlfm.py tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_naive_fixtures.py"
+  T="tests/test_gpu_wide.py tests/test_gpu_large_batches.py tests/test_gpu_rlfm.py tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_naive_fixtures.py"
   FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1200 python -m pytest $T -m gpu -q > $OUT/pytest_debuglib_ring_on.txt 2>&1; tail -2 $OUT/pytest_debuglib_ring_on.txt
   FMX_VARIANT=26 FMX_LIB=$PWD/fm_index_amd/libfmx_debug.so timeout 1200 python -m pytest $T -m gpu -q > $OUT/pytest_debuglib_ring_off.txt 2>&1; tail -2 $OUT/pytest_debuglib_ring_off.txt
 fi

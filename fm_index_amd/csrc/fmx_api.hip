@@ -1079,8 +1079,42 @@ const size_t kChunk = 64u << 20;
 const uint32_t kFileVersion = 8;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
 }  // namespace
 
+// wide indexes (n >= 2^32 - 16): header (dev_struct_bytes carries kWideMark) | FmxWideDev with presence flags for
+// pointers | cs[] | records | bases | samples
+namespace {
+const uint32_t kWideMark = 0x80000000u;
+struct WideBlobs { const void **field[3]; uint64_t bytes[3]; int n; };
+WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
+  WideBlobs b;
+  b.n = 0;
+  b.field[b.n] = (const void **)&w.rec;  b.bytes[b.n++] = (w.n / 256u + 1u) * 128ull;
+  b.field[b.n] = (const void **)&w.base; b.bytes[b.n++] = (uint64_t)w.nsb * 64ull;
+  if (w.sa_level != FMX_NO_LOCATE) { b.field[b.n] = (const void **)&w.samples; b.bytes[b.n++] = nsamples * 8ull; }
+  return b;
+}
+}  // namespace
+static int save_wide(const fmx_index *idx, FILE *f, FileHeader &h) {
+  h.dev_struct_bytes = (uint32_t)sizeof(FmxWideDev) | kWideMark;
+  FmxWideDev src = idx->wide, wfile = idx->wide;
+  WideBlobs bs = wide_blobs(src, idx->nsamples), bf = wide_blobs(wfile, idx->nsamples);
+  for (int b = 0; b < bf.n; b++) *bf.field[b] = (const void *)(uintptr_t)1;
+  if (wfile.sa_level == FMX_NO_LOCATE) wfile.samples = nullptr;
+  wfile.status = nullptr;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&wfile, sizeof wfile, 1, f) == 1 &&
+            fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
+  std::string buf(kChunk, '\0');
+  for (int b = 0; ok && b < bs.n; b++) {
+    const uint8_t *p = (const uint8_t *)*bs.field[b];
+    for (uint64_t o = 0; ok && o < bs.bytes[b]; o += kChunk) {
+      const size_t m = (size_t)(bs.bytes[b] - o < kChunk ? bs.bytes[b] - o : kChunk);
+      if (hipMemcpy(&buf[0], p + o, m, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+      ok = fwrite(&buf[0], 1, m, f) == m;
+    }
+  }
+  return ok ? FMX_OK : FMX_ERR_ARG;
+}
+
 int fmx_save(const fmx_index *idx, const char *path) {
-  if (idx && idx->is_wide) return fail(FMX_ERR_UNSUPPORTED, "an index with n >= 2^32 cannot be saved yet");
   CHECK_IDX(idx);
   if (!path) return fail(FMX_ERR_ARG, "path is NULL");
   FILE *f = fopen(path, "wb");
@@ -1094,6 +1128,11 @@ int fmx_save(const fmx_index *idx, const char *path) {
   h.runs = idx->runs; h.bytes = idx->bytes;
   h.sym_bytes = idx->sym_bytes; h.sym_bytes_abi = idx->sym_bytes_abi; h.kind = idx->kind;
   h.level_requested = idx->level_requested;
+  if (idx->is_wide) {
+    const int rc = save_wide(idx, f, h);
+    const bool closed = fclose(f) == 0;
+    return rc == FMX_OK && closed ? FMX_OK : fail(FMX_ERR_ARG, "write failed");
+  }
   FmxDev d = idx->dev;
   Blob blobs[64];
   int nb = enumerate_blobs(d, idx->nsamples, blobs);
@@ -1121,6 +1160,67 @@ int fmx_save(const fmx_index *idx, const char *path) {
   return ok ? FMX_OK : fail(FMX_ERR_ARG, "write failed");
 }
 
+// a wide index file: every size / bound field is checked against the header and the builder's formulas, the array
+// sizes against the file size, before anything is allocated or indexed
+static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
+  FmxWideDev w;
+  if (fread(&w, sizeof w, 1, f) != 1) return fail(FMX_ERR_ARG, "truncated index file");
+  const bool locate = w.sa_level != FMX_NO_LOCATE;
+  const char *bad = nullptr;
+  if (h.kind != FMX_KIND_FM || h.sym_bytes != 1 || h.sym_bytes_abi != 1) bad = "kind / symbol width";
+  else if (h.n < 2 || h.n >= (1ull << 40) || w.n != h.n) bad = "n";
+  else if (h.max_character == 0 || h.max_character > 7 || w.max_character != h.max_character) bad = "max_character";
+  else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";
+  else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";
+  else if (!w.rec || !w.base || (locate && !w.samples)) bad = "array presence";
+  if (bad) {
+    char msg[128];
+    snprintf(msg, sizeof msg, "corrupt index file: inconsistent %s", bad);
+    return fail(FMX_ERR_ARG, msg);
+  }
+  idx->device = device;
+  idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = locate ? h.nsamples : 0; idx->runs = 0;
+  idx->sym_bytes = 1; idx->sym_bytes_abi = 1; idx->kind = FMX_KIND_FM;
+  idx->level_requested = h.level_requested;
+  idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
+  if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) return fail(FMX_ERR_ARG, "truncated index file");
+  WideBlobs bs = wide_blobs(w, idx->nsamples);
+  uint64_t need = sizeof(FileHeader) + sizeof(FmxWideDev) + (h.max_character + 1) * 8;
+  for (int b = 0; b < bs.n; b++) { *bs.field[b] = nullptr; need += bs.bytes[b]; }
+  w.samples = nullptr; w.status = nullptr;
+  {
+    const long at = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const uint64_t have = (uint64_t)ftell(f);
+    fseek(f, at, SEEK_SET);
+    if (have != need) return fail(FMX_ERR_ARG, "corrupt index file: array sizes do not add up to the file size");
+  }
+  hipError_t e;
+  if ((e = hipMalloc((void **)&idx->dev.status, 4)) != hipSuccess || (e = hipMalloc((void **)&idx->d_steps, 8)) != hipSuccess ||
+      (e = hipMemset(idx->dev.status, 0, 4)) != hipSuccess || (e = hipMemset(idx->d_steps, 0, 8)) != hipSuccess ||
+      (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess)
+    return fmx_hip_fail(e, "handle resources", __LINE__);
+  std::string buf(kChunk, '\0');
+  for (int b = 0; b < bs.n; b++) {
+    void *p = nullptr;
+    if ((e = hipMalloc(&p, bs.bytes[b] ? bs.bytes[b] : 8)) != hipSuccess) return fmx_hip_fail(e, "hipMalloc", __LINE__);
+    if (int rc = fmx_keep(idx, p, bs.bytes[b])) { (void)hipFree(p); return rc; }
+    *bs.field[b] = p;
+    for (uint64_t o = 0; o < bs.bytes[b]; o += kChunk) {
+      const size_t m = (size_t)(bs.bytes[b] - o < kChunk ? bs.bytes[b] - o : kChunk);
+      if (fread(&buf[0], 1, m, f) != m) return fail(FMX_ERR_ARG, "truncated index file");
+      if ((e = hipMemcpy((uint8_t *)p + o, &buf[0], m, hipMemcpyHostToDevice)) != hipSuccess) return fmx_hip_fail(e, "hipMemcpy", __LINE__);
+    }
+  }
+  w.status = idx->dev.status;
+  idx->wide = w;
+  idx->is_wide = 1;
+  idx->dev.sa_level = w.sa_level;
+  idx->dev.kind = FMX_KIND_FM;
+  idx->dev.sym_bytes = 1;
+  return FMX_OK;
+}
+
 int fmx_load(const char *path, int device, fmx_index **out) {
   if (!out || !path) return fail(FMX_ERR_ARG, "NULL argument");
   *out = nullptr;
@@ -1133,8 +1233,15 @@ int fmx_load(const char *path, int device, fmx_index **out) {
   fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
   int rc = FMX_OK;
   do {
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "FMXIDX01", 8) != 0 || h.version != kFileVersion ||
-        h.dev_struct_bytes != sizeof(FmxDev)) { rc = fail(FMX_ERR_ARG, "not an fmx index file (or another version)"); break; }
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "FMXIDX01", 8) != 0 || h.version != kFileVersion) {
+      rc = fail(FMX_ERR_ARG, "not an fmx index file (or another version)");
+      break;
+    }
+    if (h.dev_struct_bytes == ((uint32_t)sizeof(FmxWideDev) | kWideMark)) {   // an index of the wide engine
+      rc = load_wide(f, h, device, idx);
+      break;
+    }
+    if (h.dev_struct_bytes != sizeof(FmxDev)) { rc = fail(FMX_ERR_ARG, "not an fmx index file (or another version)"); break; }
     if (fread(&idx->dev, sizeof(FmxDev), 1, f) != 1) { rc = fail(FMX_ERR_ARG, "truncated index file"); break; }
     if (const char *what = validate_loaded(h, idx->dev)) {
       char msg[128];

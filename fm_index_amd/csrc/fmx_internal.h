@@ -181,6 +181,8 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
 int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i, uint64_t k,
                        uint64_t *d_out, hipStream_t st);
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
+int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len, int forward,
+                        void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st);
 int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations);
 // rows s[k] + j of every interval, 64 bits each (wrapper.rs:203-217), written to out[off[k] + j]
 int fmx_launch_expand64(const uint64_t *d_s, const uint64_t *d_e, const uint64_t *d_off, uint64_t npat,

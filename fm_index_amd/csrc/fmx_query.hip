@@ -1966,7 +1966,7 @@ static int fmx_launch_extract_t(const fmx_index *idx, const uint64_t *d_rows, ui
 int fmx_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len,
                        int forward, void *d_out, uint64_t *d_out_len, uint64_t *d_out_next,
                        hipStream_t st) {
-  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
+  if (idx->is_wide) return fmxw_launch_extract(idx, d_rows, nrows, len, forward, d_out, d_out_len, d_out_next, st);
   if (nrows == 0) return FMX_OK;
   if (idx->sym_bytes == 1) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint8_t *)d_out, d_out_len, d_out_next, st);
   if (idx->sym_bytes == 2) return fmx_launch_extract_t(idx, d_rows, nrows, len, forward, (uint16_t *)d_out, d_out_len, d_out_next, st);

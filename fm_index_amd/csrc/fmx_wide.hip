@@ -44,6 +44,40 @@ __device__ __forceinline__ uint64_t fmxw_lf_map(const FmxWideDev &w, uint64_t i,
   return b + fmx_group_sum(fmx_piece_rank<3>(p, off, sym, g));
 }
 
+// get_f(i) and fl_map(i) (fm_index.rs:97-120): the greatest c with cs[c] <= i -- cs[c] is the base of superblock 0 --
+// and the position of the (i - cs[c])-th c of the BWT: the last superblock, then the last record of it, whose
+// absolute counter of c is <= i, then the entry inside that record.  (Plain binary searches: the extract path is
+// not the hot path.)
+__device__ __forceinline__ uint64_t fmxw_fl_map(const FmxWideDev &w, uint64_t i, uint32_t g, uint32_t &sym) {
+  uint32_t c = 0;
+  for (uint32_t t = 1; t <= w.max_character; t++)
+    if (w.base[t] <= i) c = t;                      // cs[] is non-decreasing
+  sym = c;
+  uint32_t sb = 0;
+  for (uint32_t t = 1; t < w.nsb; t++)
+    if (w.base[(size_t)t * 8u + c] <= i) sb = t;
+  const uint64_t b = w.base[(size_t)sb * 8u + c];
+  const uint32_t nrec = (uint32_t)(w.n / 256u + 1u), recs = w.sb_shift - 8u;
+  uint32_t lo = sb << recs, hi = ((sb + 1u) << recs) - 1u;
+  if (hi > nrec - 1u) hi = nrec - 1u;
+  while (lo < hi) {                                 // last record whose counter <= i
+    const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+    if (b + w.rec[(size_t)mid * 8u + c].x <= i) lo = mid; else hi = mid - 1u;
+  }
+  const uint32_t rem = (uint32_t)(i - (b + w.rec[(size_t)lo * 8u + c].x));   // rem-th match inside the record
+  const uint32_t m = fmx_piece_match<3>(w.rec[(size_t)lo * 8u + g], c);
+  const uint32_t mine = __popc(m);
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < FMX_GROUP; q++) {
+    const uint32_t cq = fmx_group_sum(g == q ? mine : 0u);
+    before += (q < g) ? cq : 0u;
+  }
+  const bool here = rem >= before && rem < before + mine;
+  const uint32_t pos = here ? g * 32u + fmx_select32(m, rem - before) : 0u;
+  return (uint64_t)lo * 256u + fmx_group_sum(pos);
+}
+
 // the superblock bases in LDS (they are read with a data-dependent symbol in every step): up to FMXW_LDS_SB
 // superblocks = n < 2^37; beyond that the kernels read them from global memory
 #define FMXW_LDS_SB 64u
@@ -176,7 +210,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_walk_kernel(FmxWideDev w, uin
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// the trait methods, batched (backend.rs:9-15, 29-31).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa
+// the trait methods, batched (backend.rs:9-19, 29-31).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_scalar_kernel(FmxWideDev w, int op, const uint64_t *__restrict__ cc,
                                                                   const uint64_t *__restrict__ ii, uint64_t k,
                                                                   uint64_t *__restrict__ out) {
@@ -199,6 +233,10 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_scalar_kernel(FmxWideDev w, i
       uint32_t sym;
       const uint64_t r = fmxw_lf_map(w, i, g, sym);
       res = op == 0 ? (uint64_t)sym : r;
+    } else if (op == 4 || op == 5) {                // get_f / fl_map
+      uint32_t sym;
+      const uint64_t r = fmxw_fl_map(w, i, g, sym);
+      res = op == 4 ? (uint64_t)sym : r;
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
@@ -212,6 +250,33 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_scalar_kernel(FmxWideDev w, i
       res = v;
     }
     if (g == 0) out[q] = res;
+  }
+}
+
+// Match::iter_chars_backward / iter_chars_forward for many rows (wrapper.rs:154-183): one group per row
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_extract_kernel(FmxWideDev w, const uint64_t *__restrict__ rows,
+                                                                   uint64_t nrows, uint32_t len, int forward,
+                                                                   uint8_t *__restrict__ out, uint64_t *__restrict__ out_len,
+                                                                   uint64_t *__restrict__ out_next) {
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t q = gid; q < nrows; q += ngroups) {
+    uint64_t i = rows[q], next = ~0ull;
+    uint32_t t = 0;
+    if (i >= w.n) {
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    } else {
+      uint8_t *dst = out + q * (uint64_t)len;
+      for (; t < len; t++) {
+        uint32_t sym;
+        i = forward ? fmxw_fl_map(w, i, g, sym) : fmxw_lf_map(w, i, g, sym);
+        if (g == 0) dst[t] = (uint8_t)sym;
+      }
+      next = i;
+    }
+    if (g == 0 && out_len) out_len[q] = t;
+    if (g == 0 && out_next) out_next[q] = next;
   }
 }
 
@@ -276,7 +341,7 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
 
 int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i, uint64_t k,
                        uint64_t *d_out, hipStream_t st) {
-  if (op > 3) return fmxw_unsupported("get_f / fl_map / piece_id are not available on an index with n >= 2^32");
+  if (op > 5) return fmxw_unsupported("piece_id needs a multi-pieces index");
   if (k == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
   hipLaunchKernelGGL(fmxw_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
@@ -287,6 +352,16 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   const FmxWideDev w = fmxw_dev(idx);
   hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len, int forward,
+                        void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st) {
+  if (nrows == 0) return FMX_OK;
+  const FmxWideDev w = fmxw_dev(idx);
+  hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+                     (uint8_t *)d_out, d_out_len, d_out_next);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -15,9 +15,10 @@
  *  - rows / positions / counts are uint64_t (= Rust usize).  Texts below 2^32 - 16 symbols run on the
  *    32-bit engine (every kind, every alphabet).  Longer texts are taken by the WIDE engine (64-bit rows,
  *    positions and samples) for FMX_KIND_FM with or without locate over u8 symbols with max_character <= 7
- *    (DNA): build, count, locate, offsets, the trait calls get_l / lf_map / lf_map2 / get_sa and the exports
- *    marked "wide" below; every other combination at that size, and the remaining entry points on a wide
- *    index, report FMX_ERR_UNSUPPORTED.
+ *    (DNA): every entry point of an FM index works on it (build, count, locate, offsets, all six trait calls,
+ *    extract, save / load, the exports -- the samples through fmx_export_sa_samples64) except fmx_export_sa and
+ *    the opt-in accelerators (flags ignored); every other kind / alphabet at that size is
+ *    FMX_ERR_UNSUPPORTED at build time.
  *  - symbols are `sym_bytes` wide: Character = u8 / u16 / u32 / u64 (character.rs:38-42) =
  *    1 / 2 / 4 / 8.  u64 texts and patterns are narrowed to u32 on the host (host-pointer entry
  *    points only); the *_dev entry points take 1-, 2- or 4-byte symbols (fmx_sym_bytes()).

@@ -51,3 +51,44 @@ def test_roofline_fraction_never_exceeds_the_traffic_it_was_given():
     assert r["achieved"] == 4000.0 and r["frac"] == 0.5 and r["traffic"] == 4_000_000_000
     r = B.make_roofline("k", 1.0, 10, 384, 1000, {"requested_lines": 10**9}, None)
     assert r["frac"] is None and r["achieved"] is None          # requested lines alone are never a roofline fraction
+
+
+def test_counters_are_priced_by_request_width():
+    """FETCH_SIZE reports 64 B per fabric request: x 2 for a launch of 128-byte record requests only, x 1.5 when half
+    of the requests are <= 16-byte probes (the run-length kernels); 2 x FETCH stays as `traffic_upper`."""
+    ent = {"fetch_kb_raw": 1000000.0, "write_kb": 1000.0, "source": "test"}
+    all_records = {"requested_lines": 100, "requested_records": 100, "requested_probes": 0, "distinct_lines": 50}
+    half = {"requested_lines": 100, "requested_records": 50, "requested_probes": 50, "distinct_lines": 50}
+    r = B.make_roofline("k", 1.0, 10, 384, 0, all_records, ent)
+    assert r["traffic"] == r["traffic_upper"] == int(2 * 1000000.0 * 1024 + 1000.0 * 1024)
+    assert r["record_share_of_requests"] == 1.0 and r["frac"] == r["frac_upper"]
+    r = B.make_roofline("k", 1.0, 10, 384, 0, half, ent)
+    assert r["traffic"] == int(1.5 * 1000000.0 * 1024 + 1000.0 * 1024) and r["traffic_upper"] > r["traffic"]
+    assert r["record_share_of_requests"] == 0.5 and r["frac"] < r["frac_upper"]
+    assert r["requested_bytes"] == 50 * 128 + 50 * 16
+    # the request fraction does not depend on the widths
+    r2 = B.make_roofline("k", 1.0, 10, 384, 0, all_records, ent)
+    assert r["frac_of_gather_ceiling"] == r2["frac_of_gather_ceiling"]
+    # no census: the upper bound, and the basis says so
+    r = B.make_roofline("k", 1.0, 10, 384, 0, None, ent)
+    assert r["traffic"] == r["traffic_upper"] and "UPPER BOUND" in r["basis"]
+
+
+def test_two_stream_roofline_uses_the_same_bytes_over_the_shorter_time():
+    ent = {"fetch_kb_raw": 250000.0, "write_kb": 8192.0, "source": "test"}
+    cen = {"requested_lines": 4, "requested_records": 3, "requested_probes": 1, "distinct_lines": 4}
+    leg = {"roofline": B.make_roofline("walk", 0.14, 1, 1, 0, cen, ent), "two_streams": {"ms_per_batch": 0.10}}
+    B.two_stream_roofline(leg)
+    t = leg["two_streams"]["roofline"]
+    assert t["traffic"] == leg["roofline"]["traffic"] and t["frac"] > leg["roofline"]["frac"]
+    assert abs(t["frac"] / leg["roofline"]["frac"] - 1.4) < 0.01
+    B.two_stream_roofline(None)
+    B.two_stream_roofline({"roofline": {"traffic": None}, "two_streams": {"ms_per_batch": 0.1}})
+
+
+def test_host_cpu_reports_what_the_process_may_use():
+    h = B.host_cpu()
+    assert 1 <= h["effective_cpus"] <= h["affinity"] <= (h["os_cpu_count"] or h["affinity"])
+    if h["cgroup_cpu_quota"] is not None:
+        assert h["effective_cpus"] <= max(1, int(h["cgroup_cpu_quota"]))
+    assert "cpu_model" in h and "physical_cores" in h

@@ -21,7 +21,7 @@ def _dna(n, seed, sigma=4):
 
 
 @pytest.mark.parametrize("n,sigma,level", [(5000, 4, 2), (70001, 4, 2), ((1 << 17) + 5, 4, 3), (40000, 7, 1), (9000, 2, 0)])
-def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level):
+def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path):
     t = _dna(n, 100 + n % 97, sigma)
     gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True)
     assert gi.is_wide() and gi.len() == n and gi.level() == level
@@ -61,6 +61,33 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level):
     samp = gi.export_sa_samples()
     assert samp.dtype == np.uint64 and (samp == want[::1 << level]).all()
     assert (gi.export_bwt() == oi.get_l(rows).astype(np.uint8)).all()
+    # the extract path: get_f / fl_map on every row, iter_chars_backward / _forward (wrapper.rs:154-183)
+    assert (gi.get_f(rows) == oi.get_f(rows)).all() and (gi.fl_map(rows) == oi.fl_map(rows)).all()
+    some = rows[::97][:300]
+    for forward in (False, True):
+        syms, lens, nxt = gi.extract_many(some, 9, forward=forward)
+        i = some.copy()
+        for t_ in range(9):
+            want_sym = oi.get_f(i) if forward else oi.get_l(i)
+            assert (syms[:, t_] == want_sym).all(), (forward, t_)
+            i = (oi.fl_map(i) if forward else oi.lf_map(i)).astype(np.uint64)
+        assert (lens == 9).all() and (nxt == i).all()
+    # the index file: saved, loaded, same answers, same size; a damaged file is refused
+    path = str(tmp_path / "wide.fmx")
+    gi.save(path)
+    li = type(gi).load(path)
+    assert li.is_wide() and li.len() == n and li.level() == level and li.heap_size() == gi.heap_size()
+    lb = li.search_many(flat=flat2, off=off2)
+    assert (lb.s == os2).all() and (lb.e == oe2).all()
+    _, lpos = lb.locate()
+    assert (lpos == opos).all()
+    assert (li.fl_map(rows[:2000]) == oi.fl_map(rows[:2000])).all()
+    li.close()
+    blob = bytearray(open(path, "rb").read())
+    with open(path, "wb") as fh:
+        fh.write(blob[:-16])
+    with pytest.raises(F.Error):
+        type(gi).load(path)
     gi.close()
 
 
@@ -81,9 +108,6 @@ def test_wide_engine_errors_and_refusals(tmp_path):
         gi.get_sa(np.array([30000], dtype=np.uint64))
     assert gi.search(bytes([1, 2])).count() >= 1                    # and the handle still works
     # what the wide engine does not have says so
-    assert lib.fmx_save(gi.handle(), str(tmp_path / "x.fmx").encode()) == L.ERR_UNSUPPORTED
-    with pytest.raises(F.Error):
-        gi.get_f(np.array([5], dtype=np.uint64))
     out = np.zeros(8, dtype=np.uint32)
     assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
     gi.close()

@@ -895,13 +895,22 @@ def open_process_group(torch, local, rank, world, gloo):
         os.environ["MASTER_PORT"] = str(launcher.free_port())
     os.environ.setdefault("RANK", str(rank))
     os.environ.setdefault("WORLD_SIZE", str(world))
-    if gloo:
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    flush_c_stdio()      # RCCL's version banner (C stdio, buffered) leaves NOW, not behind the result line at exit
+    # RCCL prints a version banner through C stdio to stdout; the result line must be alone there: while the group
+    # comes up, file descriptor 1 points at stderr, and the C buffer is flushed before it is put back
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if gloo:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        flush_c_stdio()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist
 
 

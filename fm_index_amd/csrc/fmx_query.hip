@@ -1190,24 +1190,27 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
   // text order) of its lane instead of one round per stage, and no LF step runs with idle probing lanes.
   uint32_t ctl = 0;
   [[maybe_unused]] uint32_t sidx = 0;                 // text order: index of the sample
-  while (__any(active)) {
-    if (TEXT) {
-      const uint32_t st = ctl >> 8;
-      const bool probing = active && (st == 0u || st == 2u);
-      if (__any(probing)) {                           // wave-uniform
-        if (probing) {
-          uint32_t pt = 0;
-          const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
-          FMX_TOUCH(&ix.phase[pi]);
-          const uint4 pc = ix.phase[pi];
-          uint32_t rank0;
-          const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
-          sidx = rank0;
-          if (st == 0u) ctl = phi | (phi << 4) | ((phi == 0u ? 3u : 1u) << 8);   // start row: phase -> walk length
-          else ctl = (ctl & 0xFFu) | (3u << 8);                                  // final row: its sample is next
-        }
+  // text order: the phase piece of the lane's row -- of a start row (stage 0: phase -> walk length) or of the
+  // final row (stage 2: its rank among the sampled rows) -- one lane-wise 16-byte probe
+  auto probe = [&]() {
+    const uint32_t st = ctl >> 8;
+    const bool probing = active && (st == 0u || st == 2u);
+    if (__any(probing)) {                             // wave-uniform
+      if (probing) {
+        uint32_t pt = 0;
+        const uint32_t pi = fmx_phase_piece(row, ix.sa_level, pt);
+        FMX_TOUCH(&ix.phase[pi]);
+        const uint4 pc = ix.phase[pi];
+        uint32_t rank0;
+        const uint32_t phi = fmx_phase_decode(pc, pt, ix.sa_level, rank0);
+        sidx = rank0;
+        if (st == 0u) ctl = phi | (phi << 4) | ((phi == 0u ? 3u : 1u) << 8);   // start row: phase -> walk length
+        else ctl = (ctl & 0xFFu) | (3u << 8);                                  // final row: its sample is next
       }
     }
+  };
+  while (__any(active)) {
+    if (TEXT) probe();
     // walks standing on their sampled row: sample -> position; their lanes take the next hits
     const bool sampled = active && (TEXT ? (ctl >> 8) == 3u : (row & lmask) == 0u);
     const unsigned long long fmask = __ballot(sampled);
@@ -1258,8 +1261,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         rseq++;
       }
     }
+    // text order: the hits just taken read their start row's phase piece at once, so that they walk in THIS round
+    // like the hits of row order do (round 2 left it to the next round: 2.5 rounds of its lane per hit at level 2,
+    // now 1.75, for one more lane-wise probe stage per round)
+    if (TEXT && fmask) probe();
     // None: i = lf_map(i); steps += 1   rlfmi.rs:183-186 -- a hit taken above walks in this same round
-    // (row order) or after its phase piece in the next (text order)
     const bool walking = active && (TEXT ? (ctl >> 8) == 1u : (row & lmask) != 0u);
     if (__any(walking)) {
       uint32_t sym;

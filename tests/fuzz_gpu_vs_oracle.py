@@ -61,17 +61,27 @@ def main():
         except O.OracleError:
             continue
         text = F.Text.with_max_character(t, maxc)
+        # which rows carry the samples (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER / the builder's choice), and for
+        # eligible indexes sometimes the 64-bit engine (FMX_FLAG_FORCE_WIDE)
+        sampling = [None, "text", "row"][int(rng.integers(0, 3))] if level is not None else None
+        engine64 = kind == "fm" and dtype == np.uint8 and maxc <= 7 and n >= 2 and rng.random() < 0.4
+        if engine64:
+            pair, kmer, sampling = False, False, None
         if kind == "fm":
-            gi = F.FMIndexWithLocate(text, level, pair_index=pair, kmer_table=kmer) if level is not None else \
-                F.FMIndex(text, pair_index=pair, kmer_table=kmer)
+            gi = F.FMIndexWithLocate(text, level, pair_index=pair, kmer_table=kmer, sampling=sampling,
+                                     force_wide=engine64) if level is not None else \
+                F.FMIndex(text, pair_index=pair, kmer_table=kmer, force_wide=engine64)
+            assert gi.is_wide() == engine64
         elif kind == "rlfm":
             if n < 2:
                 continue
-            gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer) if level is not None else \
+            gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer, sampling=sampling) if level is not None else \
                 F.RLFMIndex(text, kmer_table=kmer)
         else:
-            gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer) if level is not None else \
+            gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer, sampling=sampling) if level is not None else \
                 F.FMIndexMultiPieces(text, kmer_table=kmer)
+        stats["engine64"] = stats.get("engine64", 0) + int(engine64)
+        stats["text_order"] = stats.get("text_order", 0) + int(gi.text_order())
         stats[kind] += 1
         stats["pair"] += int(pair)
         stats["kmer"] = stats.get("kmer", 0) + int(gi.kmer_k() > 0)

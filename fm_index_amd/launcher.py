@@ -30,7 +30,10 @@ def rank_env(rank, world, port, base=None):
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
                 "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                # streams that share one of HIP's hardware queues (4 by default) run in submission order: the
+                # count gather would sit between two searches instead of under one
+                "GPU_MAX_HW_QUEUES": env.get("GPU_MAX_HW_QUEUES", "8")})
     return env
 
 

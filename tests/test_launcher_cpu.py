@@ -182,3 +182,5 @@ def test_distinct_device_check():
     from fm_index_amd import launcher
     assert launcher.rank_env(1, 2, 1234, base={})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert launcher.rank_env(1, 2, 1234, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    assert launcher.rank_env(0, 2, 1234, base={})["GPU_MAX_HW_QUEUES"] == "8"
+    assert launcher.rank_env(0, 2, 1234, base={"GPU_MAX_HW_QUEUES": "4"})["GPU_MAX_HW_QUEUES"] == "4"

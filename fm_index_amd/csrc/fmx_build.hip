@@ -22,20 +22,52 @@
 
 namespace {
 
+// Scratch of SMALL builds: every temporary of a text of up to kArenaMaxN symbols is carved from one buffer the
+// calling thread keeps per device, instead of ~30 hipMalloc / hipFree pairs (a hipFree waits for the device; at
+// n = 1000 they were most of the build).  Released when the thread exits.
+const uint64_t kArenaMaxN = 1ull << 17;
+const size_t kArenaBytes = 48u << 20;
+struct SmallArenaSet {
+  uint8_t *p[16] = {};
+  ~SmallArenaSet() {
+    for (int d = 0; d < 16; d++)
+      if (p[d] && hipSetDevice(d) == hipSuccess) (void)hipFree(p[d]);
+  }
+};
+inline uint8_t *small_arena(int device) {
+  static thread_local SmallArenaSet set;
+  if (device < 0 || device >= 16) return nullptr;
+  if (!set.p[device] && hipMalloc((void **)&set.p[device], kArenaBytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set.p[device] = nullptr;
+  }
+  return set.p[device];
+}
+
 struct DevPool {  // temporaries freed when the builder returns
   std::vector<void *> v;
+  uint8_t *arena = nullptr;   // small builds: bump allocation from the thread's retained buffer
+  size_t arena_cap = 0, arena_off = 0;
   ~DevPool() {
     for (void *p : v) (void)hipFree(p);
   }
+  void use_arena(uint8_t *base, size_t cap) { arena = base; arena_cap = base ? cap : 0; arena_off = 0; }
   template <typename T>
   hipError_t get(T **out, size_t count) {
+    const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255u) & ~(size_t)255u;
+    if (arena && arena_off + bytes <= arena_cap) {
+      *out = (T *)(arena + arena_off);
+      arena_off += bytes;
+      return hipSuccess;
+    }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) v.push_back(p);
     *out = (T *)p;
     return e;
   }
   void release(void *p) {
+    if (arena && (uint8_t *)p >= arena && (uint8_t *)p < arena + arena_cap) return;   // goes with the arena
     for (size_t i = 0; i < v.size(); i++)
       if (v[i] == p) {
         (void)hipFree(p);
@@ -942,6 +974,8 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
   const uint32_t n = (uint32_t)idx->n;
   const uint32_t maxc = (uint32_t)idx->max_character;
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);  // text.rs:61-63
+  // (FMX_FLAG_KEEP_SA hands the suffix array over to the index: it must be an allocation of its own)
+  if (n <= kArenaMaxN && !(idx->flags & FMX_FLAG_KEEP_SA)) pool.use_arena(small_arena(idx->device), kArenaBytes);
 
   // -- statistics + validation (sais.rs:115-139) --
   std::vector<uint64_t> hist;

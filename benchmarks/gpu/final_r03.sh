@@ -6,6 +6,7 @@ OUT=gpurun_out/final_r03
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+python benchmarks/criterion_shapes.py > $OUT/criterion_shapes.jsonl 2>/dev/null; echo "criterion rc=$?"
 bash profiles/run_rocprof.sh r03 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 if [ -f fm_index_amd/libfmx_debug.so ]; then
   T="tests/test_gpu_wide.py tests/test_gpu_large_batches.py tests/test_gpu_rlfm.py tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_naive_fixtures.py"

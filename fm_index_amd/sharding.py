@@ -117,6 +117,8 @@ def pick_concurrent_stream(device, other=None, tries=8, spin_cycles=400000):
     overlapped (the pipeline stays correct, just serialised)."""
     device = torch.device(device)
     other = other or torch.cuda.current_stream(device)
+    if not hasattr(torch.cuda, "_sleep"):       # no spin kernel in this torch build: take a stream untested
+        return torch.cuda.Stream(device=device), {"tried": 1, "concurrent": None, "ratio": None}
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     torch.cuda._sleep(1000)
     torch.cuda.synchronize(device)

@@ -571,12 +571,12 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     for (uint64_t i = 0; i < total; i++) narrow[i] = p64[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p64[i];
     src = (const uint8_t *)narrow.data();
   }
-  // Page-locked caller arrays (hipHostMalloc / hipHostRegister / torch pin_memory) are visible to the GPU:
-  // chunks are moved by COPY KERNELS in the chunk's own stream -- symbols and offsets in, search, (s, e, count)
-  // out -- and three streams keep both directions of the host link and the search busy at once.  The runtime's
-  // DMA copies of page-locked memory run at the same 56 GB/s per direction (benchmarks/gpu/pcie_probe.hip), but
-  // every hand-over between a DMA copy and a kernel of the same stream costs tens of microseconds here: the
-  // same pipeline built from hipMemcpyAsync took 4.0 ms per 2^20 x 32 call, two chunks 2.0 ms.
+  // Page-locked caller arrays (hipHostMalloc / hipHostRegister / torch pin_memory) can be DMA'd in place and are
+  // visible to the GPU: the batch goes through a chunk pipeline over three role streams (below) -- DMA upload,
+  // search, download by copy kernels -- that keeps both directions of the host link and the search busy at once.
+  // Built from hipMemcpyAsync alone it was slower than no pipeline at all: every hand-over between a DMA copy and
+  // a kernel of the same stream costs tens of microseconds on this runtime (4.0 ms per 2^20 x 32 call with eight
+  // chunks, 2.0 ms with two; benchmarks/gpu/pcie_probe.hip, hostpipe_sweep.sh).
   const bool all_pinned = idx->sym_bytes_abi != 8 && !idx->timing && npat >= (1u << 16) &&
                           device_view(pat) && device_view(pat_off) && (!s0e0 || device_view(s0e0)) &&
                           (!out_s || device_view(out_s)) && (!out_e || device_view(out_e)) &&

@@ -7,9 +7,9 @@
 // 128-byte line fetched by an 8-lane group (one dwordx4 per lane), popcount + three DPP adds in 32 bits, and
 // one 64-bit add of the base, whose 8-byte load is issued together with the record load.
 //
-// Shapes are the simple ones (a group owns a pattern / a walk from start to end): these kernels exist so that
-// an index beyond 2^32 symbols answers exactly what the reference answers; the tuned shapes of the 32-bit
-// engine (state machines, distributed walk state, write-combining ring) are not repeated here.
+// Shapes: a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel) / a walk from
+// start to end (locate: one memory round trip per iteration); the distributed walk state, the hit queue and the
+// write-combining ring of the 32-bit locate kernels are not repeated here.
 #include "fmx_device.h"
 
 #define FMXW_BLOCK 256
@@ -78,24 +78,32 @@ __device__ __forceinline__ uint64_t fmxw_fl_map(const FmxWideDev &w, uint64_t i,
   return (uint64_t)lo * 256u + fmx_group_sum(pos);
 }
 
-// the superblock bases in LDS (they are read with a data-dependent symbol in every step): up to FMXW_LDS_SB
-// superblocks = n < 2^37; beyond that the kernels read them from global memory
+// The superblock bases are read with a data-dependent symbol in every step.  Up to FMXW_LDS_SB superblocks
+// (n < 2^37) every block keeps them in LDS (kernels instantiated with LDSB = true: ds_read, 32-bit address); beyond
+// that -- and for the many tiny superblocks of FMX_FLAG_FORCE_WIDE test indexes -- the LDSB = false instantiation
+// reads them from global memory.  Two instantiations rather than one pointer that may point to either: a generic
+// pointer makes every base read a flat_load, which goes down the vector-memory path next to the record loads
+// (0.90 ms against 0.69 ms per 2^20 x 32 batch at n = 2^30, benchmarks/gpu/wide_tune.sh).
 #define FMXW_LDS_SB 64u
-__device__ __forceinline__ const uint64_t *fmxw_stage_bases(const FmxWideDev &w, uint64_t *lds) {
-  if (w.nsb > FMXW_LDS_SB) return w.base;
-  for (uint32_t t = threadIdx.x; t < w.nsb * 8u; t += blockDim.x) lds[t] = w.base[t];
-  __syncthreads();
-  return lds;
-}
+#define FMXW_BASES(w, LDSB)                                                                          \
+  __shared__ uint64_t lds_base[(LDSB) ? FMXW_LDS_SB * 8u : 1u];                                        \
+  if (LDSB) {                                                                                        \
+    for (uint32_t t_ = threadIdx.x; t_ < (w).nsb * 8u; t_ += blockDim.x) lds_base[t_] = (w).base[t_];  \
+    __syncthreads();                                                                                 \
+  }                                                                                                  \
+  auto base_at = [&](uint64_t row_, uint32_t c_) -> uint64_t {                                       \
+    const uint32_t sb_ = (uint32_t)(row_ >> (w).sb_shift);                                           \
+    if constexpr (LDSB) return lds_base[sb_ * 8u + c_]; else return (w).base[(size_t)sb_ * 8u + c_]; \
+  }
 
 // SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern.  Per step the two record loads and
 // the NEXT pattern symbol are requested together and waited for once; the base of the step's symbol comes from LDS.
+template <bool LDSB>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
     FmxWideDev w, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
-  __shared__ uint64_t lds_base[FMXW_LDS_SB * 8u];
-  const uint64_t *base = fmxw_stage_bases(w, lds_base);
+  FMXW_BASES(w, LDSB);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
@@ -126,8 +134,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
       FMX_CHECK((e >> 8) < w.n / 256u + 1u && (s >> w.sb_shift) < w.nsb && (e >> w.sb_shift) < w.nsb);
       const uint4 pa = w.rec[(size_t)(s >> 8) * 8u + g], pb = w.rec[(size_t)(e >> 8) * 8u + g];
       const uint32_t cn = j > 1 ? pat[pbeg + j - 2] : 0u;      // rides along with the record loads
-      const uint64_t ba = base[(size_t)(s >> w.sb_shift) * 8u + c];
-      const uint64_t bb = base[(size_t)(e >> w.sb_shift) * 8u + c];
+      const uint64_t ba = base_at(s, c), bb = base_at(e, c);
       s = ba + fmx_group_sum(fmx_piece_rank<3>(pa, (uint32_t)s & 255u, c, g));      // wrapper.rs:109
       e = bb + fmx_group_sum(fmx_piece_rank<3>(pb, (uint32_t)e & 255u, c, g));      // wrapper.rs:110
       c = cn;
@@ -146,65 +153,77 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
 
 // get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60).  `io` holds the row on entry and the position
 // on exit -- the expanded rows of iter_matches (wrapper.rs:203-217) are written straight into the caller's
-// position array, so a wide locate needs no workspace.  A group runs FMXW_WALKS walks at a time (their record loads
-// are requested together) and takes the next hit for a slot the moment its walk ends.
-#define FMXW_WALKS 4
-__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
-                                                                uint64_t *__restrict__ steps_out) {
-  __shared__ uint64_t lds_base[FMXW_LDS_SB * 8u];
-  const uint64_t *base = fmxw_stage_bases(w, lds_base);
+// position array, so a wide locate needs no workspace.  A group keeps WALKS walks going; slot q owns the hits
+// gid + (q + WALKS t) ngroups.  One iteration is ONE memory round trip for every slot, all requested before the one
+// wait: a walk on an unsampled row requests its record (8 lanes x 16 bytes); a walk on a sampled row requests its
+// sample on lane 0 and -- on the other lanes -- the row of the slot's next hit, so a walk of k LF steps costs k + 1
+// round trips and nothing that was loaded is waited for in a later iteration.
+template <int WALKS, bool LDSB>
+__global__ __launch_bounds__(FMXW_BLOCK, 8) void fmxw_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                   uint64_t *__restrict__ steps_out) {
+  FMXW_BASES(w, LDSB);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  const uint64_t lmask = (1ull << w.sa_level) - 1ull;
+  const uint64_t lmask = (1ull << w.sa_level) - 1ull, stride = (uint64_t)WALKS * ngroups;
   constexpr uint64_t NONE = ~0ull;
-  uint64_t h[FMXW_WALKS], row[FMXW_WALKS], steps[FMXW_WALKS];
-  uint64_t next = gid, nsteps = 0;                  // hits gid, gid + ngroups, ... belong to this group
+  uint64_t h[WALKS], row[WALKS], steps[WALKS];
+  bool fresh[WALKS];                                // the slot's first hit: its row has not been read yet
+  uint64_t nsteps = 0;
   bool any = false;
 #pragma unroll
-  for (int q = 0; q < FMXW_WALKS; q++) {
-    h[q] = NONE; row[q] = 0; steps[q] = 0;
-    if (next < total) { h[q] = next; row[q] = io[next]; next += ngroups; any = true; }
+  for (int q = 0; q < WALKS; q++) {
+    h[q] = gid + (uint64_t)q * ngroups;
+    if (h[q] >= total) h[q] = NONE;
+    row[q] = 0; steps[q] = 0;
+    fresh[q] = true;
+    any |= h[q] != NONE;
   }
   while (any) {
-    // rows that are not of this index, walks that stand on a sampled row: finish, hand the slot to the next hit
+    uint4 p[WALKS];
+    uint64_t aux[WALKS] = {};                       // lane 0: the sample; lanes 1-7: the row of the slot's next hit
+    int what[WALKS];                                // 0 idle, 1 first row, 2 not a row of this index, 3 sampled, 4 LF step
 #pragma unroll
-    for (int q = 0; q < FMXW_WALKS; q++) {
-      if (h[q] == NONE) continue;
-      bool done = false;
-      uint64_t v = NONE;
-      if (row[q] >= w.n) {                          // refuse, do not read
-        if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
-        done = true;
-      } else if ((row[q] & lmask) == 0) {           // Some(sa): (sa + steps) % len           fm_index.rs:131-133
-        v = w.samples[row[q] >> w.sa_level] + steps[q];
-        if (v >= w.n) v -= w.n;
-        done = true;
-      }
-      if (done) {
-        if (g == 0) io[h[q]] = v;
-        nsteps += steps[q];
-        h[q] = NONE; steps[q] = 0;
-        if (next < total) { h[q] = next; row[q] = io[next]; next += ngroups; }
+    for (int q = 0; q < WALKS; q++) {
+      what[q] = h[q] == NONE ? 0 : fresh[q] ? 1 : row[q] >= w.n ? 2 : (row[q] & lmask) == 0 ? 3 : 4;
+      if (what[q] == 4) {                           // None: the record of lf_map             fm_index.rs:134-135
+        p[q] = w.rec[(size_t)(row[q] >> 8) * 8u + g];
+      } else {                                      // one load instruction for both kinds of lane
+        const uint64_t want = what[q] == 1 ? h[q] : h[q] + stride;
+        const bool more = what[q] == 1 || (what[q] != 0 && total - h[q] > stride);
+        const uint64_t *from = g == 0 ? w.samples + (row[q] >> w.sa_level) : io + want;   // Some(sa)   fm_index.rs:131
+        if (g == 0 ? what[q] == 3 : more) aux[q] = *from;
       }
     }
-    // one LF step of every walk that is not on a sampled row: the record loads first, then the decodes
-    uint4 p[FMXW_WALKS];
-    bool walk[FMXW_WALKS];
     any = false;
 #pragma unroll
-    for (int q = 0; q < FMXW_WALKS; q++) {
-      walk[q] = h[q] != NONE && row[q] < w.n && (row[q] & lmask) != 0;
+    for (int q = 0; q < WALKS; q++) {
+      if (what[q] == 4) {                           // i = lf_map(i); steps += 1              fm_index.rs:135-136
+        const uint32_t off = (uint32_t)row[q] & 255u;
+        const uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
+        row[q] = base_at(row[q], sym) + fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));
+        steps[q]++;
+      } else if (what[q] != 0) {
+        if (what[q] != 1 && g == 0) {
+          uint64_t v = NONE;
+          if (what[q] == 2) {                       // refused, nothing was read
+            atomicOr(w.status, 1u << FMX_ERR_ARG);
+          } else {                                  // (sa + steps) % len                     fm_index.rs:132
+            v = aux[q] + steps[q];
+            if (v >= w.n) v -= w.n;
+          }
+          io[h[q]] = v;
+        }
+        if (what[q] != 1) {
+          nsteps += steps[q];
+          h[q] = total - h[q] > stride ? h[q] + stride : NONE;
+        }
+        // the next row stands on lanes 1-7 of the group: lane 1 / lane 5 of the two quads
+        row[q] = (uint64_t)fmx_quad_bcast_c<1>((uint32_t)aux[q]) | (uint64_t)fmx_quad_bcast_c<1>((uint32_t)(aux[q] >> 32)) << 32;
+        steps[q] = 0;
+        fresh[q] = false;
+      }
       any |= h[q] != NONE;
-      if (walk[q]) p[q] = w.rec[(size_t)(row[q] >> 8) * 8u + g];
-    }
-#pragma unroll
-    for (int q = 0; q < FMXW_WALKS; q++) {
-      if (!walk[q]) continue;                       // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
-      const uint32_t off = (uint32_t)row[q] & 255u;
-      const uint32_t sym = fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p[q], off & 31u) : 0u);
-      row[q] = base[(size_t)(row[q] >> w.sb_shift) * 8u + sym] + fmx_group_sum(fmx_piece_rank<3>(p[q], off, sym, g));
-      steps[q]++;
     }
   }
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
@@ -318,8 +337,12 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   if (npat == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
   fmxw_time_begin(idx, st);
-  hipLaunchKernelGGL(fmxw_count_kernel, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, (const uint8_t *)d_pat, d_off,
-                     npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr);
+  // group per pattern, one pattern per group at a time: two patterns per group in flight, or one record load for
+  // both ends of a narrow interval, measured slower (0.75-0.80 ms against 0.70 ms, benchmarks/gpu/wide_tune.sh)
+#define FMXW_CNT(LDSB)                                                                                             \
+  hipLaunchKernelGGL(fmxw_count_kernel<LDSB>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, (const uint8_t *)d_pat, \
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr)
+  if (w.nsb <= FMXW_LDS_SB) FMXW_CNT(true); else FMXW_CNT(false);
   fmxw_time_end(idx, st);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -332,8 +355,12 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
   // iter_matches: rows s..e-1 ascending (wrapper.rs:203-217), written where their positions will stand
   if (int rc = fmx_launch_expand64(d_s, d_e, d_off, npat, d_pos, total, w.n, w.status, st)) return rc;
   fmxw_time_begin(idx, st);
-  hipLaunchKernelGGL(fmxw_walk_kernel, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
-                     idx->timing ? idx->d_steps : nullptr);
+  // one walk per group at a time: with 2 / 3 / 4 the kernel executes the instructions of every slot for every group
+  // of a wave and is issue-bound (0.196 / 0.204 / 0.226 ms against 0.181 ms per 2^20 hits, wide_tune.sh)
+#define FMXW_WALK(LDSB)                                                                                            \
+  hipLaunchKernelGGL((fmxw_walk_kernel<1, LDSB>), dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,  \
+                     idx->timing ? idx->d_steps : nullptr)
+  if (w.nsb <= FMXW_LDS_SB) FMXW_WALK(true); else FMXW_WALK(false);
   fmxw_time_end(idx, st);
   FMX_HIP(hipGetLastError());
   return FMX_OK;

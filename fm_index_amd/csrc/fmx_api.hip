@@ -108,10 +108,10 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
-  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate over a one-level alphabet
+  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate over byte texts
   if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) &&
-      !(kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 7 && n >= 2))
-    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM over u8 symbols with max_character <= 7 only");
+      !(kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 255 && n >= 2))
+    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM over u8 symbols only");
   if (n >= (1ull << 40)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^40 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
@@ -1103,12 +1103,21 @@ const uint32_t kFileVersion = 8;   // 2: select hints every 64 ones (was 512); 3
 // pointers | cs[] | records | bases | samples
 namespace {
 const uint32_t kWideMark = 0x80000000u;
-struct WideBlobs { const void **field[3]; uint64_t bytes[3]; int n; };
+struct WideBlobs { const void **field[4 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[4 + 2 * FMXW_MAX_LEVELS]; int n; };
 WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
   WideBlobs b;
   b.n = 0;
-  b.field[b.n] = (const void **)&w.rec;  b.bytes[b.n++] = (w.n / 256u + 1u) * 128ull;
-  b.field[b.n] = (const void **)&w.base; b.bytes[b.n++] = (uint64_t)w.nsb * 64ull;
+  if (w.generic) {
+    for (uint32_t l = 0; l < w.nlevels && l < FMXW_MAX_LEVELS; l++) {
+      b.field[b.n] = (const void **)&w.lv[l].rec;  b.bytes[b.n++] = (uint64_t)w.lv[l].nrec * 128ull;
+      b.field[b.n] = (const void **)&w.lv[l].base; b.bytes[b.n++] = (uint64_t)w.nsb * 128ull;
+    }
+    b.field[b.n] = (const void **)&w.K;  b.bytes[b.n++] = ((uint64_t)w.max_character + 1) * 8ull;
+    b.field[b.n] = (const void **)&w.cs; b.bytes[b.n++] = ((uint64_t)w.max_character + 1) * 8ull;
+  } else {
+    b.field[b.n] = (const void **)&w.rec;  b.bytes[b.n++] = (w.n / 256u + 1u) * 128ull;
+    b.field[b.n] = (const void **)&w.base; b.bytes[b.n++] = (uint64_t)w.nsb * 64ull;
+  }
   if (w.sa_level != FMX_NO_LOCATE) { b.field[b.n] = (const void **)&w.samples; b.bytes[b.n++] = nsamples * 8ull; }
   return b;
 }
@@ -1189,10 +1198,27 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   const char *bad = nullptr;
   if (h.kind != FMX_KIND_FM || h.sym_bytes != 1 || h.sym_bytes_abi != 1) bad = "kind / symbol width";
   else if (h.n < 2 || h.n >= (1ull << 40) || w.n != h.n) bad = "n";
-  else if (h.max_character == 0 || h.max_character > 7 || w.max_character != h.max_character) bad = "max_character";
+  else if (h.max_character == 0 || h.max_character > 255 || w.max_character != h.max_character) bad = "max_character";
+  else if (w.generic != (h.max_character > 7 ? 1u : 0u)) bad = "engine";
   else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";
   else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";
-  else if (!w.rec || !w.base || (locate && !w.samples)) bad = "array presence";
+  else if (!w.generic && (!w.rec || !w.base || (locate && !w.samples))) bad = "array presence";
+  else if (w.generic) {
+    // the levels must be the builder's split of max_bits (text.rs:61-63) -- the kernels index records, bases and K[]
+    // by what these fields say
+    const uint32_t L = 32u - (uint32_t)__builtin_clz((uint32_t)h.max_character);
+    const uint32_t nlv = (L + 3) / 4, lo = L / nlv, extra = L % nlv;
+    uint32_t shift = L;
+    if (w.nlevels != nlv || nlv > FMXW_MAX_LEVELS || w.rec || w.base || !w.K || !w.cs || (locate && !w.samples)) bad = "levels";
+    for (uint32_t l = 0; !bad && l < nlv; l++) {
+      const uint32_t bits = lo + (l < extra ? 1u : 0u), fmt = bits == 4 ? 4u : 3u;
+      shift -= bits;
+      const FmxWideLevel &v = w.lv[l];
+      if (v.fmt != fmt || v.shift != shift || v.mask != (1u << bits) - 1u || !v.rec || !v.base ||
+          v.nrec != (uint32_t)((h.n >> (fmt == 3 ? 8 : 7)) + 1u) || w.sb_shift < (fmt == 3 ? 8u : 7u))
+        bad = "level fields";
+    }
+  }
   if (bad) {
     char msg[128];
     snprintf(msg, sizeof msg, "corrupt index file: inconsistent %s", bad);

@@ -1318,6 +1318,33 @@ __global__ void kw_bases(const uint64_t *__restrict__ scan, uint32_t nrec, uint3
   const uint32_t sb = t >> 3, g = t & 7u;
   base[t] = scan[(size_t)g * nrec + ((size_t)sb << sb_recs)];
 }
+// the same for a level of the generic wide index (FmxWideLevel): scan laid out [code][record] over NCODE codes;
+// a record's counters are relative to its superblock's first record, base[sb][code] is the absolute value there --
+// on every level but the last including the entries with a smaller code (scan[code][0]), which makes a level's rank
+// the position in the next level
+template <int FMT>
+__global__ __launch_bounds__(BLK) void kw_counters_g(const uint64_t *__restrict__ scan, uint32_t nrec, uint32_t sb_recs,
+                                                      uint4 *__restrict__ rec) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t >= (uint64_t)nrec * 8) return;
+  const uint32_t g = (uint32_t)(t & 7), r = (uint32_t)(t >> 3);
+  const uint32_t r0 = (r >> sb_recs) << sb_recs;
+  uint4 p = rec[t];
+  if (FMT == 3) {
+    p.x = (uint32_t)(scan[(size_t)g * nrec + r] - scan[(size_t)g * nrec + r0]);
+  } else {
+    p.x = (uint32_t)(scan[(size_t)(2 * g) * nrec + r] - scan[(size_t)(2 * g) * nrec + r0]);
+    p.y = (uint32_t)(scan[(size_t)(2 * g + 1) * nrec + r] - scan[(size_t)(2 * g + 1) * nrec + r0]);
+  }
+  rec[t] = p;
+}
+__global__ void kw_bases_g(const uint64_t *__restrict__ scan, uint32_t nrec, uint32_t nsb, uint32_t sb_recs,
+                           uint32_t ncode, int fold, uint64_t *__restrict__ base) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nsb * 16u) return;
+  const uint32_t sb = t >> 4, c = t & 15u;
+  base[t] = c < ncode ? scan[(size_t)c * nrec + ((size_t)sb << sb_recs)] - (fold ? 0ull : scan[(size_t)c * nrec]) : 0ull;
+}
 __global__ __launch_bounds__(BLK) void kw_verify_sa(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa,
                                                      uint64_t n, uint32_t *__restrict__ mark, unsigned long long *bad) {
   KW_FOR(p, n) {
@@ -1507,10 +1534,90 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
     FMX_HIP(hipDeviceSynchronize());
     pool.release(d_sa);
   }
-  // -- records: planes + per-record histograms, 64-bit scan, relative counters + superblock bases --
-  const uint32_t nrec = (uint32_t)(n / 256u + 1u);
   const uint32_t sb_shift = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST, sb_recs = sb_shift - 8u;
   const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
+  if (maxc > 7) {
+    // -- generic wide index: the levels of the multi-ary wavelet matrix (as build_mwm, 64-bit scans) --
+    uint32_t nlv, bits[FMX_MAX_LEVELS];
+    split_levels(L, &nlv, bits);
+    if (nlv > FMXW_MAX_LEVELS) {
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "wide index: more wavelet levels than FMXW_MAX_LEVELS");
+      return FMX_ERR_UNSUPPORTED;
+    }
+    uint8_t *cur = d_bwt, *alt = nullptr;
+    if (nlv > 1) FMX_HIP(pool.get(&alt, n));
+    uint32_t shift = L;
+    w.generic = 1;
+    w.nlevels = nlv;
+    w.nsb = nsb;
+    w.sb_shift = sb_shift;
+    for (uint32_t l = 0; l < nlv; l++) {
+      shift -= bits[l];
+      FmxWideLevel &lv = w.lv[l];
+      lv.fmt = bits[l] == 4 ? 4u : 3u;
+      lv.shift = shift;
+      lv.mask = (1u << bits[l]) - 1u;
+      const uint32_t rec_shift = lv.fmt == 3 ? 8u : 7u, ncode = lv.fmt == 3 ? 8u : 16u;
+      lv.nrec = (uint32_t)((n >> rec_shift) + 1u);           // +1: position n itself must be addressable
+      uint4 *rec;
+      uint64_t *base, *scan;
+      uint32_t *hist;
+      FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
+      if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
+      FMX_HIP(hipMalloc((void **)&base, (size_t)nsb * 16 * sizeof(uint64_t)));
+      if (int rc = keep(idx, base, (uint64_t)nsb * 128)) return rc;
+      const size_t nh = (size_t)ncode * lv.nrec;
+      FMX_HIP(pool.get(&hist, nh));
+      FMX_HIP(pool.get(&scan, nh));
+      const unsigned grid = nblocks((uint64_t)lv.nrec * 8);
+      if (lv.fmt == 3)
+        hipLaunchKernelGGL((k_mwm_pieces<3, uint8_t>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+      else
+        hipLaunchKernelGGL((k_mwm_pieces<4, uint8_t>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+      size_t tb = 0;
+      FMX_HIP(exclusive_sum(nullptr, tb, hist, scan, nh));
+      uint8_t *tmp;
+      FMX_HIP(pool.get(&tmp, tb));
+      FMX_HIP(exclusive_sum(tmp, tb, hist, scan, nh));
+      if (lv.fmt == 3)
+        hipLaunchKernelGGL(kw_counters_g<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
+      else
+        hipLaunchKernelGGL(kw_counters_g<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
+      hipLaunchKernelGGL(kw_bases_g, dim3((nsb * 16 + 63) / 64), dim3(64), 0, 0, scan, lv.nrec, nsb, sb_shift - rec_shift,
+                         ncode, l + 1 < nlv ? 1 : 0, base);
+      FMX_HIP(hipGetLastError());
+      lv.rec = rec;
+      lv.base = base;
+      if (l + 1 < nlv) {   // stable sort of the whole sequence by this level's code -> order of the next level
+        size_t sb = 0;
+        FMX_HIP(rocprim::radix_sort_keys(nullptr, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
+        uint8_t *stmp;
+        FMX_HIP(pool.get(&stmp, sb));
+        FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
+        FMX_HIP(hipDeviceSynchronize());
+        pool.release(stmp);
+        uint8_t *x = cur; cur = alt; alt = x;
+      }
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(hist); pool.release(scan); pool.release(tmp);
+    }
+    uint64_t *d_cs, *d_K;
+    FMX_HIP(hipMalloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
+    if (int rc = keep(idx, d_cs, ((uint64_t)maxc + 1) * 8)) return rc;
+    FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * 8));
+    if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 8)) return rc;
+    FMX_HIP(hipMemcpy(d_cs, idx->h_cs, ((size_t)maxc + 1) * 8, hipMemcpyHostToDevice));
+    w.cs = d_cs;
+    w.K = d_K;
+    if (int rc = fmxw_launch_compute_K(w, d_K)) return rc;
+    FMX_HIP(hipDeviceSynchronize());
+    idx->is_wide = 1;
+    mark("levels");
+    idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FMX_OK;
+  }
+  // -- records: planes + per-record histograms, 64-bit scan, relative counters + superblock bases --
+  const uint32_t nrec = (uint32_t)(n / 256u + 1u);
   uint4 *d_rec;
   uint32_t *d_hist;
   uint64_t *d_scan, *d_base;

@@ -118,9 +118,24 @@ struct FmxDev {  // passed BY VALUE to every query kernel
 // stay 32 bits wide, and the u32 engine is untouched.  Samples are u64.
 #define FMX_WIDE_SB_SHIFT 31u      // log2(rows per superblock); FMX_FLAG_FORCE_WIDE (tests) uses FMX_WIDE_SB_SHIFT_TEST so
 #define FMX_WIDE_SB_SHIFT_TEST 12u // that a small text has many superblocks
+// Larger byte alphabets (8 <= max_character <= 255, `generic`): the multi-ary wavelet matrix of the 32-bit engine --
+// up to FMXW_MAX_LEVELS levels of 3 or 4 bits, the sequence stably sorted by the level's code between levels -- with
+// the same superblock scheme per level: lv[l].base[sb][code] is the 64-bit rank of `code` at the superblock's start,
+// plus, on every level but the last, the number of entries with a smaller code (so that a level's rank IS the
+// position in the next level, as in FmxLevel); K[c] = cs[c] - (rank chain of c at position 0), 64 bits wide:
+//     lf_map2(c, i) = K[c] + rank chain of c at i                                  (fm_index.rs:93-95)
+#define FMXW_MAX_LEVELS 2
+struct FmxWideLevel {
+  const uint4 *rec;          // n / per_rec + 1 records (per_rec = 256 for fmt 3, 128 for fmt 4)
+  const uint64_t *base;      // [nsb][16]
+  uint32_t fmt;              // 3 or 4
+  uint32_t shift;            // code = (sym >> shift) & mask
+  uint32_t mask;
+  uint32_t nrec;
+};
 struct FmxWideDev {  // passed BY VALUE to the wide kernels
-  const uint4 *rec;          // n / 256 + 1 records (row n is addressable)
-  const uint64_t *base;      // [nsb][8]
+  const uint4 *rec;          // one 3-bit level (max_character <= 7): n / 256 + 1 records (row n is addressable)
+  const uint64_t *base;      // ... [nsb][8], cs[] folded in
   const uint64_t *samples;   // SA[k << level], k = 0 .. (n - 1) >> level       (sample.rs:33-37)
   uint32_t *status;          // sticky device-side error bits
   uint64_t n;                // len incl. terminator
@@ -128,6 +143,11 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   uint32_t sa_level;         // effective level; FMX_NO_LOCATE when absent
   uint32_t nsb;
   uint32_t sb_shift;         // log2(rows per superblock), >= 8
+  uint32_t generic;          // 1: lv[] / K / cs below describe the index, rec / base above are NULL
+  uint32_t nlevels;
+  FmxWideLevel lv[FMXW_MAX_LEVELS];
+  const uint64_t *K;         // [max_character + 1]
+  const uint64_t *cs;        // [max_character + 1] C array on the device (get_f / fl_map)
 };
 
 struct fmx_index {
@@ -184,6 +204,7 @@ int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
 int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len, int forward,
                         void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st);
 int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations);
+int fmxw_launch_compute_K(const FmxWideDev &w, uint64_t *d_K);   // generic wide index: K[c] = cs[c] - rank chain of c at 0
 // rows s[k] + j of every interval, 64 bits each (wrapper.rs:203-217), written to out[off[k] + j]
 int fmx_launch_expand64(const uint64_t *d_s, const uint64_t *d_e, const uint64_t *d_off, uint64_t npat,
                         uint64_t *d_out, uint64_t total, uint64_t n, uint32_t *status, hipStream_t st);

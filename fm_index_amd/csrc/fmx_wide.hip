@@ -310,6 +310,326 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_export_l_kernel(FmxWideDev w,
   }
 }
 
+// ===========================================================================
+// Generic wide indexes (FmxWideDev::generic: byte alphabets, up to FMXW_MAX_LEVELS wavelet levels).  Same shapes as the
+// one-level kernels above -- a group per pattern / per walk --, one record round per level and interval end.
+// The level bases and K[] are read with data-dependent indices in every step: LDS (GLDS = true, up to FMXW_GLDS_SB
+// superblocks) or global memory, two instantiations as for FMXW_BASES.
+// ===========================================================================
+#define FMXW_GLDS_SB 32u
+#define FMXW_GBASES(w, GLDS)                                                                                       \
+  __shared__ uint64_t lds_gb[(GLDS) ? FMXW_MAX_LEVELS * FMXW_GLDS_SB * 16u : 1u];                                    \
+  __shared__ uint64_t lds_k[(GLDS) ? 256u : 1u];                                                                    \
+  if (GLDS) {                                                                                                      \
+    for (uint32_t l_ = 0; l_ < (w).nlevels; l_++)                                                                  \
+      for (uint32_t t_ = threadIdx.x; t_ < (w).nsb * 16u; t_ += blockDim.x)                                        \
+        lds_gb[l_ * FMXW_GLDS_SB * 16u + t_] = (w).lv[l_].base[t_];                                                 \
+    for (uint32_t t_ = threadIdx.x; t_ <= (w).max_character; t_ += blockDim.x) lds_k[t_] = (w).K[t_];              \
+    __syncthreads();                                                                                               \
+  }                                                                                                                \
+  auto gbase = [&](uint32_t l_, uint64_t pos_, uint32_t code_) -> uint64_t {                                       \
+    const uint32_t sb_ = (uint32_t)(pos_ >> (w).sb_shift);                                                         \
+    if constexpr (GLDS) return lds_gb[(l_ * FMXW_GLDS_SB + sb_) * 16u + code_];                                     \
+    else return (w).lv[l_].base[(size_t)sb_ * 16u + code_];                                                         \
+  };                                                                                                               \
+  auto gk = [&](uint32_t c_) -> uint64_t {                                                                         \
+    if constexpr (GLDS) return lds_k[c_]; else return (w).K[c_];                                                     \
+  }
+
+// this lane's piece of the record of position `pos` on level L
+__device__ __forceinline__ uint4 fmxw_g_piece(const FmxWideLevel &L, uint64_t pos, uint32_t g) {
+  FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
+  return L.rec[(size_t)(pos >> (L.fmt == 3 ? 8 : 7)) * 8u + g];
+}
+// rank of `code` among the first `pos` entries of the level, relative to the superblock start (all 8 lanes get it)
+__device__ __forceinline__ uint32_t fmxw_g_rank32(const FmxWideLevel &L, const uint4 &p, uint64_t pos, uint32_t code, uint32_t g) {
+  return L.fmt == 3 ? fmx_group_sum(fmx_piece_rank<3>(p, (uint32_t)pos & 255u, code, g))
+                    : fmx_group_sum(fmx_piece_rank<4>(p, (uint32_t)pos & 127u, code, g));
+}
+// level code of the entry at `pos` (all 8 lanes get it)
+__device__ __forceinline__ uint32_t fmxw_g_code(const FmxWideLevel &L, const uint4 &p, uint64_t pos, uint32_t g) {
+  if (L.fmt == 3) {
+    const uint32_t off = (uint32_t)pos & 255u;
+    return fmx_group_sum((g == (off >> 5)) ? fmx_piece_code<3>(p, off & 31u) : 0u);
+  }
+  const uint32_t off = (uint32_t)pos & 127u;
+  return fmx_group_sum((g == (off >> 4)) ? fmx_piece_code<4>(p, off & 15u) : 0u);
+}
+// rank chain of symbol c at position i: lf_map2(c, i) = K[c] + chain                          fm_index.rs:93-95
+template <class GB>
+__device__ __forceinline__ uint64_t fmxw_g_chain(const FmxWideDev &w, const GB &gbase, uint32_t c, uint64_t pos, uint32_t g) {
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    const uint32_t code = (c >> L.shift) & L.mask;
+    const uint4 p = fmxw_g_piece(L, pos, g);
+    pos = gbase(l, pos, code) + fmxw_g_rank32(L, p, pos, code, g);
+  }
+  return pos;
+}
+// get_l(i) and the rank chain of that symbol at i: lf_map(i) = K[sym] + chain                 fm_index.rs:82-91
+template <class GB>
+__device__ __forceinline__ uint64_t fmxw_g_lf(const FmxWideDev &w, const GB &gbase, uint64_t pos, uint32_t g, uint32_t &sym) {
+  sym = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    const uint4 p = fmxw_g_piece(L, pos, g);
+    const uint32_t code = fmxw_g_code(L, p, pos, g);
+    sym |= code << L.shift;
+    pos = gbase(l, pos, code) + fmxw_g_rank32(L, p, pos, code, g);
+  }
+  return pos;
+}
+// counter of `code` at the start of record r, absolute (in the units of the level's ranks); global bases
+__device__ __forceinline__ uint64_t fmxw_g_counter(const FmxWideDev &w, const FmxWideLevel &L, uint32_t r, uint32_t code) {
+  const uint32_t recs = w.sb_shift - (L.fmt == 3 ? 8u : 7u);
+  const uint64_t b = L.base[(size_t)(r >> recs) * 16u + code];
+  if (L.fmt == 3) return b + L.rec[(size_t)r * 8u + code].x;
+  const uint4 p = L.rec[(size_t)r * 8u + (code >> 1)];
+  return b + ((code & 1u) ? p.y : p.x);
+}
+// position of the entry with level code `code` whose rank (in the level's units) is `target`.  Binary searches over
+// the superblock bases and the record counters: the extract path is not the hot path.
+__device__ __forceinline__ uint64_t fmxw_g_select(const FmxWideDev &w, const FmxWideLevel &L, uint32_t code, uint64_t target,
+                                                  uint32_t g) {
+  const uint32_t recs = w.sb_shift - (L.fmt == 3 ? 8u : 7u);
+  uint32_t slo = 0, shi = w.nsb - 1u;
+  while (slo < shi) {                               // last superblock whose base <= target
+    const uint32_t mid = slo + (shi - slo + 1u) / 2u;
+    if (L.base[(size_t)mid * 16u + code] <= target) slo = mid; else shi = mid - 1u;
+  }
+  uint32_t lo = slo << recs, hi = ((slo + 1u) << recs) - 1u;
+  if (hi > L.nrec - 1u) hi = L.nrec - 1u;
+  while (lo < hi) {                                 // last record of it whose counter <= target
+    const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+    if (fmxw_g_counter(w, L, mid, code) <= target) lo = mid; else hi = mid - 1u;
+  }
+  const uint32_t rem = (uint32_t)(target - fmxw_g_counter(w, L, lo, code));   // rem-th match inside the record
+  const uint4 p = L.rec[(size_t)lo * 8u + g];
+  const uint32_t m = L.fmt == 3 ? fmx_piece_match<3>(p, code) : fmx_piece_match<4>(p, code);
+  const uint32_t per = L.fmt == 3 ? 32u : 16u;
+  const uint32_t mine = __popc(m);
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < FMX_GROUP; q++) {
+    const uint32_t cq = fmx_group_sum(g == q ? mine : 0u);
+    before += (q < g) ? cq : 0u;
+  }
+  const bool here = rem >= before && rem < before + mine;
+  const uint32_t pos = here ? g * per + fmx_select32(m, rem - before) : 0u;
+  return (uint64_t)lo * (per * 8u) + fmx_group_sum(pos);
+}
+// get_f(i) and fl_map(i) (fm_index.rs:97-120): the greatest c with cs[c] <= i, then the (i - cs[c])-th c of the BWT:
+// down the start chain of c, back up through the level selects (as fmx_mwm_select)
+template <class GB>
+__device__ __forceinline__ uint64_t fmxw_g_fl(const FmxWideDev &w, const GB &gbase, uint64_t i, uint32_t g, uint32_t &sym) {
+  uint32_t s = 0, e = w.max_character + 1u;
+  while (e - s > 1u) {
+    const uint32_t m = s + (e - s) / 2u;
+    if (w.cs[m] <= i) s = m; else e = m;
+  }
+  sym = s;
+  uint64_t target = fmxw_g_chain(w, gbase, s, 0, g) + (i - w.cs[s]);
+  for (uint32_t l = w.nlevels; l-- > 0;) {
+    const FmxWideLevel &L = w.lv[l];
+    target = fmxw_g_select(w, L, (s >> L.shift) & L.mask, target, g);
+  }
+  return target;
+}
+
+__global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint64_t *__restrict__ K) {
+  FMXW_GBASES(w, false);
+  (void)gk;
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  if (c > w.max_character) return;
+  const uint64_t sc = fmxw_g_chain(w, gbase, c, 0, g);
+  if (g == 0) K[c] = w.cs[c] - sc;
+}
+
+// SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern; per level the records of both
+// interval ends are requested together, the next pattern symbol with the first level's
+template <bool GLDS>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
+    FmxWideDev w, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  FMXW_GBASES(w, GLDS);
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  const uint64_t ptot = npat ? off[npat] : 0;       // symbols the caller declares behind `pat`
+  uint64_t nsteps = 0;
+  for (uint64_t k = gid; k < npat; k += ngroups) {
+    const uint64_t pbeg = off[k], pend = off[k + 1];
+    uint64_t j = pend - pbeg;
+    bool bad = pend < pbeg || pend > ptot;          // offsets that go backwards or leave the pattern buffer
+    uint64_t s = 0, e = w.n;                        // SearchIndexWrapper::search: (0, len)   wrapper.rs:41
+    if (s0e0) {                                     // Search::search on an existing Search   wrapper.rs:105-106
+      s = s0e0[2 * k];
+      e = s0e0[2 * k + 1];
+      bad |= s > w.n || e > w.n;                    // not a range of this index
+    }
+    if (bad) {                                      // refuse, do not read
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+      s = 0; e = 0; j = 0;
+    }
+    uint32_t c = j ? pat[pbeg + j - 1] : 0u;        // for c in pattern.iter().rev()          wrapper.rs:108
+    while (j) {
+      if (c > w.max_character) {                    // reference: panic on cs[c]
+        if (g == 0) atomicOr(w.status, 1u << FMX_ERR_SYMBOL_RANGE);
+        s = 0; e = 0;
+        break;
+      }
+      uint32_t cn = 0;
+      uint64_t ps = s, pe = e;
+      for (uint32_t l = 0; l < w.nlevels; l++) {
+        const FmxWideLevel &L = w.lv[l];
+        const uint32_t code = (c >> L.shift) & L.mask;
+        const uint4 pa = fmxw_g_piece(L, ps, g), pb = fmxw_g_piece(L, pe, g);
+        if (l == 0 && j > 1) cn = pat[pbeg + j - 2];             // rides along with the record loads
+        const uint64_t ba = gbase(l, ps, code), bb = gbase(l, pe, code);
+        ps = ba + fmxw_g_rank32(L, pa, ps, code, g);
+        pe = bb + fmxw_g_rank32(L, pb, pe, code, g);
+      }
+      const uint64_t kc = gk(c);
+      s = kc + ps;                                  // wrapper.rs:109
+      e = kc + pe;                                  // wrapper.rs:110
+      c = cn;
+      j--;
+      nsteps++;
+      if (s == e) break;                            // wrapper.rs:111-113
+    }
+    if (g == 0) {
+      if (out_s) out_s[k] = s;
+      if (out_e) out_e[k] = e;
+      if (out_cnt) out_cnt[k] = e - s;              // wrapper.rs:132-134
+    }
+  }
+  if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60): a group per walk, rows in, positions out
+template <bool GLDS>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                  uint64_t *__restrict__ steps_out) {
+  FMXW_GBASES(w, GLDS);
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  const uint64_t lmask = (1ull << w.sa_level) - 1ull;
+  uint64_t nsteps = 0;
+  for (uint64_t h = gid; h < total; h += ngroups) {
+    uint64_t row = io[h], steps = 0, v = ~0ull;
+    if (row >= w.n) {                               // refuse, do not read
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    } else {
+      while (row & lmask) {                         // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
+        uint32_t sym;
+        const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
+        row = gk(sym) + r;
+        steps++;
+      }
+      v = w.samples[row >> w.sa_level] + steps;     // Some(sa): (sa + steps) % len           fm_index.rs:131-133
+      if (v >= w.n) v -= w.n;
+    }
+    if (g == 0) io[h] = v;
+    nsteps += steps;
+  }
+  if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// the trait methods, batched (backend.rs:9-19, 29-31).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w, int op, const uint64_t *__restrict__ cc,
+                                                                    const uint64_t *__restrict__ ii, uint64_t k,
+                                                                    uint64_t *__restrict__ out) {
+  FMXW_GBASES(w, false);
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t q = gid; q < k; q += ngroups) {
+    const uint64_t i = ii[q];
+    uint64_t res = ~0ull;
+    if (op == 2) {                                  // lf_map2(c, i), i in [0, n]
+      const uint64_t c = cc[q];
+      if (c > w.max_character || i > w.n) {
+        if (g == 0) atomicOr(w.status, 1u << (c > w.max_character ? FMX_ERR_SYMBOL_RANGE : FMX_ERR_ARG));
+      } else {
+        res = gk((uint32_t)c) + fmxw_g_chain(w, gbase, (uint32_t)c, i, g);
+      }
+    } else if (i >= w.n) {
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    } else if (op == 0 || op == 1) {
+      uint32_t sym;
+      const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
+      res = op == 0 ? (uint64_t)sym : gk(sym) + r;
+    } else if (op == 4 || op == 5) {                // get_f / fl_map
+      uint32_t sym;
+      const uint64_t r = fmxw_g_fl(w, gbase, i, g, sym);
+      res = op == 4 ? (uint64_t)sym : r;
+    } else {                                        // get_sa
+      const uint64_t lmask = (1ull << w.sa_level) - 1ull;
+      uint64_t row = i, steps = 0;
+      while (row & lmask) {
+        uint32_t sym;
+        const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
+        row = gk(sym) + r;
+        steps++;
+      }
+      uint64_t v = w.samples[row >> w.sa_level] + steps;
+      if (v >= w.n) v -= w.n;
+      res = v;
+    }
+    if (g == 0) out[q] = res;
+  }
+}
+
+// Match::iter_chars_backward / iter_chars_forward for many rows (wrapper.rs:154-183): one group per row
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w, const uint64_t *__restrict__ rows,
+                                                                     uint64_t nrows, uint32_t len, int forward,
+                                                                     uint8_t *__restrict__ out, uint64_t *__restrict__ out_len,
+                                                                     uint64_t *__restrict__ out_next) {
+  FMXW_GBASES(w, false);
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t q = gid; q < nrows; q += ngroups) {
+    uint64_t i = rows[q], next = ~0ull;
+    uint32_t t = 0;
+    if (i >= w.n) {
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    } else {
+      uint8_t *dst = out + q * (uint64_t)len;
+      for (; t < len; t++) {
+        uint32_t sym;
+        if (forward) {
+          i = fmxw_g_fl(w, gbase, i, g, sym);
+        } else {
+          const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
+          i = gk(sym) + r;
+        }
+        if (g == 0) dst[t] = (uint8_t)sym;
+      }
+      next = i;
+    }
+    if (g == 0 && out_len) out_len[q] = t;
+    if (g == 0 && out_next) out_next[q] = next;
+  }
+}
+
+// L column of rows [0, n), one byte per row (get_l): a group per row
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, uint8_t *__restrict__ out) {
+  FMXW_GBASES(w, false);
+  (void)gk;
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t i = gid; i < w.n; i += ngroups) {
+    uint32_t sym;
+    (void)fmxw_g_lf(w, gbase, i, g, sym);
+    if (g == 0) out[i] = (uint8_t)sym;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -337,6 +657,15 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   if (npat == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
   fmxw_time_begin(idx, st);
+  if (w.generic) {
+#define FMXW_GCNT(GLDS)                                                                                            \
+  hipLaunchKernelGGL(fmxw_g_count_kernel<GLDS>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, (const uint8_t *)d_pat, \
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr)
+    if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true); else FMXW_GCNT(false);
+    fmxw_time_end(idx, st);
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
   // group per pattern, one pattern per group at a time: two patterns per group in flight, or one record load for
   // both ends of a narrow interval, measured slower (0.75-0.80 ms against 0.70 ms, benchmarks/gpu/wide_tune.sh)
 #define FMXW_CNT(LDSB)                                                                                             \
@@ -355,6 +684,17 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
   // iter_matches: rows s..e-1 ascending (wrapper.rs:203-217), written where their positions will stand
   if (int rc = fmx_launch_expand64(d_s, d_e, d_off, npat, d_pos, total, w.n, w.status, st)) return rc;
   fmxw_time_begin(idx, st);
+  if (w.generic) {
+    if (w.nsb <= FMXW_GLDS_SB)
+      hipLaunchKernelGGL(fmxw_g_walk_kernel<true>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
+                         idx->timing ? idx->d_steps : nullptr);
+    else
+      hipLaunchKernelGGL(fmxw_g_walk_kernel<false>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
+                         idx->timing ? idx->d_steps : nullptr);
+    fmxw_time_end(idx, st);
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
   // one walk per group at a time: with 2 / 3 / 4 the kernel executes the instructions of every slot for every group
   // of a wave and is issue-bound (0.196 / 0.204 / 0.226 ms against 0.181 ms per 2^20 hits, wide_tune.sh)
 #define FMXW_WALK(LDSB)                                                                                            \
@@ -371,14 +711,16 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
   if (op > 5) return fmxw_unsupported("piece_id needs a multi-pieces index");
   if (k == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
-  hipLaunchKernelGGL(fmxw_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  if (w.generic) hipLaunchKernelGGL(fmxw_g_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  else hipLaunchKernelGGL(fmxw_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   const FmxWideDev w = fmxw_dev(idx);
-  hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
+  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
+  else hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
@@ -387,8 +729,19 @@ int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t n
                         void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st) {
   if (nrows == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
-  hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
-                     (uint8_t *)d_out, d_out_len, d_out_next);
+  if (w.generic)
+    hipLaunchKernelGGL(fmxw_g_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+                       (uint8_t *)d_out, d_out_len, d_out_next);
+  else
+    hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+                       (uint8_t *)d_out, d_out_len, d_out_next);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int fmxw_launch_compute_K(const FmxWideDev &w, uint64_t *d_K) {
+  const unsigned groups = w.max_character + 1u;
+  hipLaunchKernelGGL(fmxw_g_compute_K_kernel, dim3((groups * FMX_GROUP + 63) / 64), dim3(64), 0, 0, w, d_K);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

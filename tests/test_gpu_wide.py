@@ -3,6 +3,8 @@ texts small enough for the oracle to answer every question: FMX_FLAG_FORCE_WIDE 
 makes for n >= 2^32 - 16 -- 64-bit suffix sort in two radix passes per round, record counters relative to their
 superblock, 64-bit bases and samples -- with superblocks of 2^12 rows, so that a text of 10^5 symbols crosses
 dozens of them.  tests/test_gpu_beyond_4g.py runs the same engine at n = 2^32 + 2^20."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -20,7 +22,11 @@ def _dna(n, seed, sigma=4):
     return t
 
 
-@pytest.mark.parametrize("n,sigma,level", [(5000, 4, 2), (70001, 4, 2), ((1 << 17) + 5, 4, 3), (40000, 7, 1), (9000, 2, 0)])
+# sigma <= 7: the one-level engine.  Larger byte alphabets: the generic wide engine -- one 4-bit level (12), levels of
+# 3 + 2 bits (20), 4 + 3 (100), 4 + 4 (255); (1 << 17) + 5 rows are 33 superblocks: bases from global memory
+@pytest.mark.parametrize("n,sigma,level", [(5000, 4, 2), (70001, 4, 2), ((1 << 17) + 5, 4, 3), (40000, 7, 1), (9000, 2, 0),
+                                           (30000, 12, 2), (50001, 20, 2), (60001, 100, 1), (45000, 255, 2),
+                                           ((1 << 17) + 5, 200, 3), (7000, 8, 0)])
 def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path):
     t = _dna(n, 100 + n % 97, sigma)
     gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True)
@@ -111,9 +117,12 @@ def test_wide_engine_errors_and_refusals(tmp_path):
     out = np.zeros(8, dtype=np.uint32)
     assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
     gi.close()
-    # eligibility: one-level u8 alphabets of FMX_KIND_FM only
+    # eligibility: FMX_KIND_FM over u8 symbols only
+    bt = W.byte_text_np(5000, 3)
+    h = C.c_void_p()
+    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_RLFM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
     with pytest.raises(F.Error):
-        F.FMIndexWithLocate(F.Text(W.byte_text_np(5000, 3)), 2, force_wide=True)
+        F.FMIndexWithLocate(F.Text(W.byte_text_np(5000, 3).astype(np.uint16)), 2, force_wide=True)
     # a count-only wide index has no locate
     ci = F.FMIndex(F.Text.with_max_character(t, 4), force_wide=True)
     assert ci.is_wide() and ci.search(bytes([1, 2])).count() == gi_count(t, [1, 2])

@@ -110,8 +110,8 @@ struct FmxDev {  // passed BY VALUE to every query kernel
 #define FMX_PHASE_MAX_LEVEL 4u
 
 // ---- wide indexes: n >= 2^32 - 16 (usize rows of the reference, fm_index.rs:86-95) ------------------------
-// FMIndex / FMIndexWithLocate over a one-level alphabet (max_character <= 7: DNA), rows and positions 64 bits wide.
-// Same 128-byte fmt-3 records, but a record's eight counters are RELATIVE to the start of its superblock
+// FMIndex / FMIndexWithLocate over byte texts, rows and positions 64 bits wide.  One-level alphabets
+// (max_character <= 7: DNA): the same 128-byte fmt-3 records, but a record's eight counters are RELATIVE to the start of its superblock
 // (2^31 entries = 2^23 records) and a small table holds the 64-bit absolute value at every superblock start:
 //     lf_map2(c, i) = base[i >> 31][c] + cnt32[record(i)][c] + popcount          (cs[] folded into base)
 // so a rank still costs one 128-byte line (+ 8 bytes of a table that lives in the caches), the in-group sums

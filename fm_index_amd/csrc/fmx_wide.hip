@@ -2,10 +2,11 @@
 // need the reference's `usize` (fm_index.rs:86-95, 127-140; wrapper.rs:103-134, 203-217, 238-242).
 //
 // A second instantiation next to the 32-bit engine of fmx_query.hip, which it leaves untouched: FMIndex /
-// FMIndexWithLocate over a one-level alphabet (max_character <= 7).  Layout: fmx_internal.h (FmxWideDev) -- the
-// same 128-byte records, counters relative to a 2^31-row superblock, a table of 64-bit bases.  A rank is one
-// 128-byte line fetched by an 8-lane group (one dwordx4 per lane), popcount + three DPP adds in 32 bits, and
-// one 64-bit add of the base, whose 8-byte load is issued together with the record load.
+// FMIndexWithLocate over byte texts.  Layout: fmx_internal.h (FmxWideDev) -- the same 128-byte records, counters
+// relative to a 2^31-row superblock, a table of 64-bit bases.  A rank is one 128-byte line fetched by an 8-lane
+// group (one dwordx4 per lane), popcount + three DPP adds in 32 bits, and one 64-bit add of the base.
+// First half of the file: one-level alphabets (max_character <= 7, DNA); second half: the generic kernels for
+// larger byte alphabets (the multi-ary wavelet levels of the 32-bit engine with per-level bases and a 64-bit K[]).
 //
 // Shapes: a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel) / a walk from
 // start to end (locate: one memory round trip per iteration); the distributed walk state, the hit queue and the
@@ -616,17 +617,41 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w
   }
 }
 
-// L column of rows [0, n), one byte per row (get_l): a group per row
+// L column of rows [0, n), one byte per row (get_l).  A LANE per row (consecutive lanes, consecutive rows): the
+// first level's records are read in order, and the rank that leads to the next level is taken by the lane alone
+// over the pieces in front of its entry -- one random 16-byte read per row and further level instead of a group's
+// dependent round trips (4.3e9 rows at n = 2^32).
+template <int FMT>
+__device__ __forceinline__ uint32_t fmxw_g_lane_rank(const FmxWideLevel &L, uint32_t r, uint32_t pi, uint32_t bit,
+                                                     const uint4 &piece, uint32_t code) {
+  uint32_t cnt;
+  if (FMT == 3) {
+    cnt = L.rec[(size_t)r * 8u + code].x;
+  } else {
+    const uint4 c = L.rec[(size_t)r * 8u + (code >> 1)];
+    cnt = (code & 1u) ? c.y : c.x;
+  }
+  for (uint32_t q = 0; q < pi; q++) cnt += __popc(fmx_piece_match<FMT>(L.rec[(size_t)r * 8u + q], code));
+  return cnt + __popc(fmx_piece_match<FMT>(piece, code) & ((1u << bit) - 1u));
+}
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, uint8_t *__restrict__ out) {
-  FMXW_GBASES(w, false);
-  (void)gk;
-  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
-  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
-  for (uint64_t i = gid; i < w.n; i += ngroups) {
-    uint32_t sym;
-    (void)fmxw_g_lf(w, gbase, i, g, sym);
-    if (g == 0) out[i] = (uint8_t)sym;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < w.n; i += stride) {
+    uint64_t pos = i;
+    uint32_t sym = 0;
+    for (uint32_t l = 0; l < w.nlevels; l++) {
+      const FmxWideLevel &L = w.lv[l];
+      const bool f3 = L.fmt == 3;
+      const uint32_t r = (uint32_t)(pos >> (f3 ? 8 : 7)), off = (uint32_t)pos & (f3 ? 255u : 127u);
+      const uint32_t pi = f3 ? off >> 5 : off >> 4, bit = f3 ? off & 31u : off & 15u;
+      const uint4 piece = L.rec[(size_t)r * 8u + pi];
+      const uint32_t code = f3 ? fmx_piece_code<3>(piece, bit) : fmx_piece_code<4>(piece, bit);
+      sym |= code << L.shift;
+      if (l + 1 < w.nlevels)
+        pos = L.base[(size_t)(pos >> w.sb_shift) * 16u + code] +
+              (f3 ? fmxw_g_lane_rank<3>(L, r, pi, bit, piece, code) : fmxw_g_lane_rank<4>(L, r, pi, bit, piece, code));
+    }
+    out[i] = (uint8_t)sym;
   }
 }
 
@@ -719,7 +744,7 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
+  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
   else hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;

@@ -1,5 +1,6 @@
 """n >= 2^32: the reference's rows and positions are `usize` (fm_index.rs:86-95, 127-140; sample.rs:21-44) and so are
-the wide engine's.  A DNA FMIndexWithLocate over n = 2^32 + 2^20 symbols is built on the GPU (64-bit suffix sort,
+the wide engine's.  An FMIndexWithLocate over n = 2^32 + 2^20 symbols -- a DNA text (the one-level wide engine) and a
+byte text (the generic wide engine: two wavelet levels) -- is built on the GPU (64-bit suffix sort,
 superblock-relative record counters, 64-bit samples) and held to the protocol of tests/test_gpu_fullsize.py: the
 suffix array IS the suffix array (sortedness + permutation on the device), substrings occur, every located position
 holds its pattern and the source position is among the hits -- with patterns whose intervals lie beyond row 2^32 and
@@ -26,28 +27,34 @@ pytestmark = pytest.mark.gpu
 N = (1 << 32) + (1 << 20)
 
 
-def _run():
+def _run(alphabet="dna"):
     import torch
     from oracle import fm_oracle as O
     torch.cuda.empty_cache()
     dev = torch.device("cuda", 0)
     lib = L.lib()
-    m, level = 30, 2
-    text = W.dna_text_torch(N, 17, dev)
+    dna = alphabet == "dna"
+    # DNA: the one-level engine; bytes: the generic wide engine (two 4-bit wavelet levels)
+    m, level, sigma = (30, 2, 4) if dna else (10, 3, 255)
+    text = W.dna_text_torch(N, 17, dev) if dna else W.byte_text_torch(N, 17, dev)
     t0 = time.time()
-    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=level, keep_sa=True)
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, sigma, level=level, keep_sa=True)
     build_s = time.time() - t0
     h = index.handle()
     assert index.len() == N and index.is_wide() and index.level() == level
     t0 = time.time()
     assert index.verify_sa() == 0                       # sorted, and every index exactly once
     verify_s = time.time() - t0
-    # patterns = substrings from (A) uniform positions, (B) positions whose suffix starts with seven 4s -- the top
-    # 4^-7 of the rows, all beyond row 2^32 --, (C) positions beyond 2^32 in the text
+    # patterns = substrings from (A) uniform positions, (B) positions whose suffix sorts into the last 2^20 rows, all
+    # beyond row 2^32 -- seven 4s (the top 4^-7 of the rows) / (255, >= 245) (the top 11 / 255^2) --, (C) positions
+    # beyond 2^32 in the text
     win = text[:1 << 28]
-    hi = win[:-8] == 4
-    for j in range(1, 7):
-        hi &= win[j:j - 8] == 4
+    if dna:
+        hi = win[:-8] == 4
+        for j in range(1, 7):
+            hi &= win[j:j - 8] == 4
+    else:
+        hi = (win[:-8] == 255) & (win[1:-7] >= 245)
     src_b = torch.nonzero(hi).flatten()[:1 << 13]
     assert src_b.numel() >= 1 << 12
     del hi, win
@@ -91,7 +98,7 @@ def _run():
     t0 = time.time()
     samples = index.export_sa_samples()
     assert samples.dtype == np.uint64 and int(samples.max()) >= (1 << 32)
-    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4, samples=samples, level=level)
+    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), sigma, samples=samples, level=level)
     del samples
     oracle_s = time.time() - t0
     k = 1 << 12
@@ -101,7 +108,7 @@ def _run():
     ooff, opos = oi.locate_batch(so[:1024], eo[:1024], nthreads=16)
     assert (opos == d_pos[:int(ooff[-1])].cpu().numpy().view(np.uint64)).all()
     rows = (np.uint64(1 << 32) + W.splitmix64_np(21, 0, 2048) % np.uint64(1 << 20)).astype(np.uint64)
-    syms = (np.uint64(1) + W.splitmix64_np(22, 0, 2048) % np.uint64(4)).astype(np.uint64)
+    syms = (np.uint64(1) + W.splitmix64_np(22, 0, 2048) % np.uint64(sigma)).astype(np.uint64)
     rows2 = rows.copy()
     rows2[0] = N
     assert (index.lf_map2(syms, rows2) == oi.lf_map2(syms, rows2)).all()
@@ -146,7 +153,7 @@ def _run():
     perf = {"count_2^20x32_ms": round(count_ms, 4), "count_pattern_chars_per_s": kp * mp / (count_ms / 1e3),
             "locate_hits": tot_p, "locate_ms": round(locate_ms, 4), "locate_hits_per_s": tot_p / (locate_ms / 1e3)}
     del patp, posp
-    out = {"kind": "fm", "n": N, "level": level, "perf": perf, "patterns": npat, "pattern_len": m, "hits": total,
+    out = {"kind": "fm", "alphabet": alphabet, "max_character": sigma, "n": N, "level": level, "perf": perf, "patterns": npat, "pattern_len": m, "hits": total,
            "intervals_with_e_beyond_2^32": rows_hi, "positions_beyond_2^32": pos_hi,
            "max_row": int(e.max().item()), "max_position": int(d_pos.max().item()),
            "verify_sa_violations": 0, "oracle_patterns_identical": k, "oracle_located_patterns_identical": 1024,
@@ -163,5 +170,9 @@ def test_dna_index_beyond_4g_symbols():
     _run()
 
 
+def test_byte_index_beyond_4g_symbols():
+    _run("bytes")
+
+
 if __name__ == "__main__":
-    print(json.dumps(_run()))
+    print(json.dumps(_run(sys.argv[1] if len(sys.argv) > 1 else "dna")))

@@ -1,0 +1,16 @@
+"""FMX_BUILD_TRACE of the config-2 build (n = 2^30 DNA) three times in one process: what of build_ms is the driver's
+memory management (hipMalloc / hipFree of the builder's scratch) and what is kernels"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import fm_index_amd as F
+from fm_index_amd import workload as W
+dev = torch.device("cuda", 0)
+N = 1 << 30
+text = W.dna_text_torch(N, 17, dev)
+for rep in range(3):
+    sys.stderr.write("== rep %d\n" % rep); sys.stderr.flush()
+    t0 = time.time()
+    ix = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=2)
+    sys.stderr.write("wall %.3f s\n" % (time.time() - t0))
+    ix.close()

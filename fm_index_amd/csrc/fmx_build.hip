@@ -521,6 +521,55 @@ void split_levels(uint32_t L, uint32_t *nlv, uint32_t *bits) {
   *nlv = k;
 }
 
+// ---- refinement rounds of the prefix doubling: only the suffixes whose rank is not final yet ----------------
+// grp[p] = first sorted position of the group of equal keys position p belongs to (the max-scan of k_flag_heads).
+// A position is ACTIVE while its group has more than one member.
+__global__ __launch_bounds__(BLK) void k_active_flags(const uint32_t *__restrict__ grp, uint32_t n,
+                                                       uint8_t *__restrict__ flags) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  const bool single = grp[p] == (uint32_t)p && (p + 1 == n || grp[p + 1] == (uint32_t)(p + 1));
+  flags[p] = single ? 0 : 1;
+}
+// the same over the compacted list: apos[k] = sorted position of the k-th active suffix, grp[k] its group's first position
+__global__ __launch_bounds__(BLK) void k_active_flags_c(const uint32_t *__restrict__ apos, const uint32_t *__restrict__ grp,
+                                                         uint32_t m, uint8_t *__restrict__ flags) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  const bool single = grp[k] == apos[k] && (k + 1 == m || grp[k + 1] == apos[k + 1]);
+  flags[k] = single ? 0 : 1;
+}
+// doubling key of the k-th active suffix: (its group, rank[i + h] + 1 or 0 when the suffix ends first)
+__global__ __launch_bounds__(BLK) void k_refine_keys(const uint32_t *__restrict__ apos, const uint32_t *__restrict__ sa,
+                                                      const uint32_t *__restrict__ rank, uint32_t n, uint64_t h, uint32_t m,
+                                                      uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  const uint64_t i = sa[apos[k]];
+  const uint64_t j = i + h;
+  const uint64_t lo = j < n ? (uint64_t)rank[j] + 1ull : 0ull;
+  keys[k] = ((uint64_t)rank[i] << 32) | lo;
+  vals[k] = (uint32_t)i;
+}
+// the sorted active suffixes go back to the active positions (ascending keys <-> ascending positions: a group's
+// positions are contiguous and all active); head[k] = apos[k] where a new group starts, else 0
+__global__ __launch_bounds__(BLK) void k_refine_write(const uint32_t *__restrict__ apos, const uint64_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ vals, uint32_t m,
+                                                       uint32_t *__restrict__ sa, uint32_t *__restrict__ head) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  sa[apos[k]] = vals[k];
+  head[k] = (k == 0 || keys[k] != keys[k - 1]) ? apos[k] : 0u;
+}
+__global__ __launch_bounds__(BLK) void k_refine_rank(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ grp,
+                                                      uint32_t m, uint32_t *__restrict__ rank) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k < m) rank[vals[k]] = grp[k];
+}
+struct AsU32 {
+  __device__ __forceinline__ uint32_t operator()(uint8_t f) const { return f; }
+};
+
 // suffix array of d_text[0..n) into d_sa (u32) -- prefix doubling
 template <typename T>
 int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, DevPool &pool) {
@@ -557,6 +606,83 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   FMX_HIP(pool.get(&tmp, tmp_bytes));
 
   mark("alloc", 0);
+  // rocPRIM calls of the refinement rounds: `tmp` when it is large enough, a buffer of their own otherwise
+  auto scratch = [&](size_t need, uint8_t **out, bool *own) -> hipError_t {
+    *own = need > tmp_bytes;
+    if (!*own) { *out = tmp; return hipSuccess; }
+    return pool.get(out, need);
+  };
+  auto count_flags = [&](const uint8_t *fl, uint32_t cnt, uint32_t *out) -> int {
+    auto in = rocprim::make_transform_iterator(fl, AsU32());
+    size_t need = 0;
+    FMX_HIP(rocprim::reduce(nullptr, need, in, d_ng, 0u, (size_t)cnt, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    uint8_t *t; bool own;
+    FMX_HIP(scratch(need, &t, &own));
+    FMX_HIP(rocprim::reduce(t, need, in, d_ng, 0u, (size_t)cnt, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    FMX_HIP(hipMemcpy(out, d_ng, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (own) pool.release(t);
+    return FMX_OK;
+  };
+  auto compact = [&](auto in, const uint8_t *fl, uint32_t cnt, uint32_t *out, uint32_t expect) -> int {
+    size_t need = 0;
+    FMX_HIP(rocprim::select(nullptr, need, in, fl, out, d_ng, (size_t)cnt, (hipStream_t)0));
+    uint8_t *t; bool own;
+    FMX_HIP(scratch(need, &t, &own));
+    FMX_HIP(rocprim::select(t, need, in, fl, out, d_ng, (size_t)cnt, (hipStream_t)0));
+    unsigned int got = 0;
+    FMX_HIP(hipMemcpy(&got, d_ng, sizeof got, hipMemcpyDeviceToHost));
+    if (own) pool.release(t);
+    if (got != expect) { fmx_set_error(FMX_ERR_HIP, "suffix sort: compaction lost count"); return FMX_ERR_HIP; }
+    return FMX_OK;
+  };
+  // refinement: the m suffixes at the sorted positions apos[] are still tied after h symbols; sort them inside their
+  // groups by rank[i + h], give the new groups their ranks, drop the ones that are alone now, double h
+  auto refine = [&](uint32_t *apos, uint32_t m, uint32_t *sa, uint32_t *rk, uint64_t h) -> int {
+    uint64_t *ck_a, *ck_b;
+    uint32_t *cv_a, *cv_b, *grp, *apos2;
+    uint8_t *fl;
+    FMX_HIP(pool.get(&ck_a, m)); FMX_HIP(pool.get(&ck_b, m));
+    FMX_HIP(pool.get(&cv_a, m)); FMX_HIP(pool.get(&cv_b, m));
+    FMX_HIP(pool.get(&grp, m));  FMX_HIP(pool.get(&apos2, m));
+    FMX_HIP(pool.get(&fl, m));
+    while (m) {
+      if (h >= n) {  // cannot happen for distinct suffixes; guard against an endless loop
+        fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
+        return FMX_ERR_HIP;
+      }
+      hipLaunchKernelGGL(k_refine_keys, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, sa, rk, n, h, m, ck_a, cv_a);
+      rocprim::double_buffer<uint64_t> kb(ck_a, ck_b);
+      rocprim::double_buffer<uint32_t> vb(cv_a, cv_b);
+      size_t need = 0;
+      FMX_HIP(rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)m, 0u, 64u, (hipStream_t)0));
+      uint8_t *t; bool own;
+      FMX_HIP(scratch(need, &t, &own));
+      FMX_HIP(rocprim::radix_sort_pairs(t, need, kb, vb, (size_t)m, 0u, 64u, (hipStream_t)0));
+      hipLaunchKernelGGL(k_refine_write, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, kb.current(), vb.current(), m, sa, grp);
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      size_t tb2 = 0;
+      FMX_HIP(rocprim::inclusive_scan(nullptr, tb2, grp, grp, (size_t)m, MaxOp(), (hipStream_t)0));
+      FMX_HIP(scratch(tb2, &t, &own));
+      FMX_HIP(rocprim::inclusive_scan(t, tb2, grp, grp, (size_t)m, MaxOp(), (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      hipLaunchKernelGGL(k_refine_rank, dim3(nblocks(m)), dim3(BLK), 0, 0, vb.current(), grp, m, rk);
+      hipLaunchKernelGGL(k_active_flags_c, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, grp, m, fl);
+      FMX_HIP(hipGetLastError());
+      uint32_t m2 = 0;
+      if (int rc = count_flags(fl, m, &m2)) return rc;
+      h *= 2;
+      mark("refine", h);
+      if (m2) {
+        if (int rc = compact(apos, fl, m, apos2, m2)) return rc;
+        uint32_t *x = apos; apos = apos2; apos2 = x;
+      }
+      m = m2;
+    }
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(ck_a); pool.release(ck_b); pool.release(cv_a); pool.release(cv_b);
+    pool.release(grp); pool.release(apos); pool.release(apos2); pool.release(fl);
+    return FMX_OK;
+  };
   hipLaunchKernelGGL(k_init_keys<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
                      d_sa);
   uint64_t *keys_cur = keys_a, *keys_alt = keys_b;
@@ -585,6 +711,23 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     tb = tmp_bytes;
     FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp(), (hipStream_t)0));
     hipLaunchKernelGGL(k_scatter_rank, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, head, n, rank);
+    // how many suffixes are still tied?  (the keys are spent: their buffer takes the flags)
+    uint8_t *flags = (uint8_t *)keys_cur;
+    hipLaunchKernelGGL(k_active_flags, dim3(nblocks(n)), dim3(BLK), 0, 0, head, n, flags);
+    uint32_t m = 0;
+    if (int rc = count_flags(flags, n, &m)) return rc;
+    mark("active", m);
+    if ((uint64_t)m * 4 <= n) {
+      // few enough: from here on only they are sorted, in buffers of their own (<= 41 m bytes for the 16 n released)
+      uint32_t *apos;
+      FMX_HIP(pool.get(&apos, m));
+      if (int rc = compact(rocprim::counting_iterator<uint32_t>(0), flags, n, apos, m)) return rc;
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(keys_a); pool.release(keys_b);
+      keys_a = keys_b = nullptr;
+      if (int rc = refine(apos, m, sa_cur, rank, h)) return rc;
+      break;
+    }
     hipLaunchKernelGGL(k_double_keys, dim3(nblocks(n)), dim3(BLK), 0, 0, sa_cur, rank, n, h,
                        keys_cur);
     end_bit = 64;
@@ -593,7 +736,9 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   if (sa_cur != d_sa)
     FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, 0));
   FMX_HIP(hipDeviceSynchronize());
-  pool.release(keys_a); pool.release(keys_b); pool.release(vals_b);
+  if (keys_a) pool.release(keys_a);
+  if (keys_b) pool.release(keys_b);
+  pool.release(vals_b);
   pool.release(tmp); pool.release(d_ng);
   return FMX_OK;
 }

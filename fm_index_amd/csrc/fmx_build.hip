@@ -1433,6 +1433,48 @@ __global__ __launch_bounds__(BLK) void kw_key_first(const uint64_t *__restrict__
                                                      uint64_t n, uint64_t *__restrict__ keys) {
   KW_FOR(p, n) keys[p] = rank[sa[p]];
 }
+// ---- refinement rounds (as k_refine_* of the 32-bit builder; two 64-bit keys per suffix, two stable passes) ----
+__global__ __launch_bounds__(BLK) void kwr_active_flags(const uint64_t *__restrict__ grp, uint64_t n, uint8_t *__restrict__ flags) {
+  KW_FOR(p, n) flags[p] = (grp[p] == p && (p + 1 == n || grp[p + 1] == p + 1)) ? 0 : 1;
+}
+__global__ __launch_bounds__(BLK) void kwr_active_flags_c(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ grp,
+                                                           uint64_t m, uint8_t *__restrict__ flags) {
+  KW_FOR(k, m) flags[k] = (grp[k] == apos[k] && (k + 1 == m || grp[k + 1] == apos[k + 1])) ? 0 : 1;
+}
+__global__ __launch_bounds__(BLK) void kwr_init(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ sa,
+                                                 const uint64_t *__restrict__ rank, uint64_t n, uint64_t h, uint64_t m,
+                                                 uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+  KW_FOR(k, m) {
+    const uint64_t i = sa[apos[k]], j = i + h;
+    vals[k] = i;
+    keys[k] = j < n ? rank[j] + 1ull : 0ull;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwr_first(const uint64_t *__restrict__ vals, const uint64_t *__restrict__ rank, uint64_t m,
+                                                  uint64_t *__restrict__ keys) {
+  KW_FOR(k, m) keys[k] = rank[vals[k]];
+}
+__global__ __launch_bounds__(BLK) void kwr_write(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ first,
+                                                  const uint64_t *__restrict__ vals, const uint64_t *__restrict__ rank, uint64_t n,
+                                                  uint64_t h, uint64_t m, uint64_t *__restrict__ sa, uint64_t *__restrict__ head) {
+  KW_FOR(k, m) {
+    const uint64_t i = vals[k];
+    sa[apos[k]] = i;
+    bool is_head = k == 0 || first[k] != first[k - 1];
+    if (!is_head) {
+      const uint64_t j = i + h, jp = vals[k - 1] + h;
+      is_head = (j < n ? rank[j] + 1ull : 0ull) != (jp < n ? rank[jp] + 1ull : 0ull);
+    }
+    head[k] = is_head ? apos[k] : 0ull;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwr_rank(const uint64_t *__restrict__ vals, const uint64_t *__restrict__ grp, uint64_t m,
+                                                 uint64_t *__restrict__ rank) {
+  KW_FOR(k, m) rank[vals[k]] = grp[k];
+}
+struct AsU64 {
+  __device__ __forceinline__ unsigned long long operator()(uint8_t f) const { return f; }
+};
 __global__ __launch_bounds__(BLK) void kw_bwt(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa, uint64_t n,
                                                uint8_t *__restrict__ bwt) {
   KW_FOR(p, n) {
@@ -1559,6 +1601,95 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
     return FMX_OK;
   };
   if (int rc = sort_pass(k * sym_bits)) return rc;
+  // the refinement rounds' rocPRIM calls: `tmp` when it is large enough, a buffer of their own otherwise
+  unsigned long long *d_cnt;
+  FMX_HIP(pool.get(&d_cnt, 1));
+  auto scratch = [&](size_t need, uint8_t **out, bool *own) -> hipError_t {
+    *own = need > tmp_bytes;
+    if (!*own) { *out = tmp; return hipSuccess; }
+    return pool.get(out, need);
+  };
+  auto count_flags = [&](const uint8_t *fl, uint64_t cnt, uint64_t *out) -> int {
+    auto in = rocprim::make_transform_iterator(fl, AsU64());
+    size_t need = 0;
+    FMX_HIP(rocprim::reduce(nullptr, need, in, d_cnt, 0ull, (size_t)cnt, rocprim::plus<unsigned long long>(), (hipStream_t)0));
+    uint8_t *t; bool own;
+    FMX_HIP(scratch(need, &t, &own));
+    FMX_HIP(rocprim::reduce(t, need, in, d_cnt, 0ull, (size_t)cnt, rocprim::plus<unsigned long long>(), (hipStream_t)0));
+    unsigned long long got = 0;
+    FMX_HIP(hipMemcpy(&got, d_cnt, sizeof got, hipMemcpyDeviceToHost));
+    if (own) pool.release(t);
+    *out = got;
+    return FMX_OK;
+  };
+  auto compact = [&](auto in, const uint8_t *fl, uint64_t cnt, uint64_t *out, uint64_t expect) -> int {
+    size_t need = 0;
+    FMX_HIP(rocprim::select(nullptr, need, in, fl, out, d_cnt, (size_t)cnt, (hipStream_t)0));
+    uint8_t *t; bool own;
+    FMX_HIP(scratch(need, &t, &own));
+    FMX_HIP(rocprim::select(t, need, in, fl, out, d_cnt, (size_t)cnt, (hipStream_t)0));
+    unsigned long long got = 0;
+    FMX_HIP(hipMemcpy(&got, d_cnt, sizeof got, hipMemcpyDeviceToHost));
+    if (own) pool.release(t);
+    if (got != expect) { fmx_set_error(FMX_ERR_HIP, "suffix sort: compaction lost count"); return FMX_ERR_HIP; }
+    return FMX_OK;
+  };
+  auto refine = [&](uint64_t *apos, uint64_t m, uint64_t *sa, uint64_t h) -> int {
+    uint64_t *ck_a, *ck_b, *cv_a, *cv_b, *grp, *apos2;
+    uint8_t *fl;
+    FMX_HIP(pool.get(&ck_a, m)); FMX_HIP(pool.get(&ck_b, m));
+    FMX_HIP(pool.get(&cv_a, m)); FMX_HIP(pool.get(&cv_b, m));
+    FMX_HIP(pool.get(&grp, m));  FMX_HIP(pool.get(&apos2, m));
+    FMX_HIP(pool.get(&fl, m));
+    while (m) {
+      if (h >= n) {
+        fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
+        return FMX_ERR_HIP;
+      }
+      const unsigned mb = wblocks(m);
+      uint64_t *kc = ck_a, *ka = ck_b, *vc = cv_a, *va = cv_b;
+      auto pass = [&](unsigned end_bit) -> int {
+        rocprim::double_buffer<uint64_t> kb(kc, ka);
+        rocprim::double_buffer<uint64_t> vb(vc, va);
+        size_t need = 0;
+        FMX_HIP(rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+        uint8_t *t; bool own;
+        FMX_HIP(scratch(need, &t, &own));
+        FMX_HIP(rocprim::radix_sort_pairs(t, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+        if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+        kc = kb.current(); ka = kb.alternate();
+        vc = vb.current(); va = vb.alternate();
+        return FMX_OK;
+      };
+      hipLaunchKernelGGL(kwr_init, dim3(mb), dim3(BLK), 0, 0, apos, sa, rank, n, h, m, kc, vc);
+      if (int rc = pass(rank_bits + 1)) return rc;           // by rank[i + h] + 1 ...
+      hipLaunchKernelGGL(kwr_first, dim3(mb), dim3(BLK), 0, 0, vc, rank, m, kc);
+      if (int rc = pass(rank_bits)) return rc;               // ... then, stable, by rank[i]
+      hipLaunchKernelGGL(kwr_write, dim3(mb), dim3(BLK), 0, 0, apos, kc, vc, rank, n, h, m, sa, grp);
+      size_t tb2 = 0;
+      FMX_HIP(rocprim::inclusive_scan(nullptr, tb2, grp, grp, (size_t)m, MaxOp64(), (hipStream_t)0));
+      uint8_t *t; bool own;
+      FMX_HIP(scratch(tb2, &t, &own));
+      FMX_HIP(rocprim::inclusive_scan(t, tb2, grp, grp, (size_t)m, MaxOp64(), (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      hipLaunchKernelGGL(kwr_rank, dim3(mb), dim3(BLK), 0, 0, vc, grp, m, rank);
+      hipLaunchKernelGGL(kwr_active_flags_c, dim3(mb), dim3(BLK), 0, 0, apos, grp, m, fl);
+      FMX_HIP(hipGetLastError());
+      uint64_t m2 = 0;
+      if (int rc = count_flags(fl, m, &m2)) return rc;
+      h *= 2;
+      mark("refine", h);
+      if (m2) {
+        if (int rc = compact(apos, fl, m, apos2, m2)) return rc;
+        uint64_t *x = apos; apos = apos2; apos2 = x;
+      }
+      m = m2;
+    }
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(ck_a); pool.release(ck_b); pool.release(cv_a); pool.release(cv_b);
+    pool.release(grp); pool.release(apos); pool.release(apos2); pool.release(fl);
+    return FMX_OK;
+  };
   uint64_t h = k;
   bool two_keys = false;
   for (;;) {
@@ -1578,6 +1709,25 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
     size_t tb = tmp_bytes;
     FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp64(), (hipStream_t)0));
     hipLaunchKernelGGL(kw_scatter_rank, dim3(nb), dim3(BLK), 0, 0, sa_cur, head, n, rank);
+    {
+      // how many suffixes are still tied?  (the keys are spent: their buffer takes the flags)
+      uint8_t *flags = (uint8_t *)keys_cur;
+      hipLaunchKernelGGL(kwr_active_flags, dim3(nb), dim3(BLK), 0, 0, head, n, flags);
+      uint64_t m = 0;
+      if (int rc = count_flags(flags, n, &m)) return rc;
+      mark("active", m);
+      if (m * 4 <= n) {
+        // few enough: from here on only they are sorted, in buffers of their own (49 m bytes for the 16 n released)
+        uint64_t *apos;
+        FMX_HIP(pool.get(&apos, m));
+        if (int rc = compact(rocprim::counting_iterator<uint64_t>(0), flags, n, apos, m)) return rc;
+        FMX_HIP(hipDeviceSynchronize());
+        pool.release(keys_a); pool.release(keys_b);
+        keys_a = keys_b = nullptr;
+        if (int rc = refine(apos, m, sa_cur, h)) return rc;
+        break;
+      }
+    }
     // two stable passes: by rank[i + h] + 1, then by rank[i]
     hipLaunchKernelGGL(kw_key_second, dim3(nb), dim3(BLK), 0, 0, sa_cur, rank, n, h, keys_cur);
     if (int rc = sort_pass(rank_bits + 1)) return rc;
@@ -1589,8 +1739,10 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
   }
   if (sa_cur != d_sa) FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0));
   FMX_HIP(hipDeviceSynchronize());
-  pool.release(keys_a); pool.release(keys_b); pool.release(vals_b); pool.release(rank);
-  pool.release(tmp); pool.release(d_ng);
+  if (keys_a) pool.release(keys_a);
+  if (keys_b) pool.release(keys_b);
+  pool.release(vals_b); pool.release(rank);
+  pool.release(tmp); pool.release(d_ng); pool.release(d_cnt);
   return FMX_OK;
 }
 }  // namespace

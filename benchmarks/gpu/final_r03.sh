@@ -1,12 +1,16 @@
 #!/bin/bash
 # round-3 evidence run (through gpurun, from the repo root): the GPU suite on the shipped library, the default
-# bench line, rocprofv3 --kernel-trace --stats of the bench command, and the range-checked library on the walk
-# kernels with the write-combining ring on and off (FMX_VARIANT=26)
+# bench line, the forced-RCCL and config-4b lines, rocprofv3 --kernel-trace --stats of the bench command, and the
+# range-checked library on the walk kernels with the write-combining ring on and off (FMX_VARIANT=26)
 OUT=gpurun_out/final_r03
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
+timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+python bench.py --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; echo "bench force-dist rc=$?"
+python bench.py --workload rep-rlfm --no-pmc > $OUT/bench_config4b.json 2> $OUT/bench_config4b.err; echo "bench 4b rc=$?"
 python benchmarks/criterion_shapes.py > $OUT/criterion_shapes.jsonl 2>/dev/null; echo "criterion rc=$?"
+python tests/test_gpu_beyond_4g.py dna > $OUT/beyond_4g.json 2>/dev/null; echo "beyond_4g dna rc=$?"
+python tests/test_gpu_beyond_4g.py bytes > $OUT/beyond_4g_bytes.json 2>/dev/null; echo "beyond_4g bytes rc=$?"
 bash profiles/run_rocprof.sh r03 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 if [ -f fm_index_amd/libfmx_debug.so ]; then
   T="tests/test_gpu_wide.py tests/test_gpu_large_batches.py tests/test_gpu_rlfm.py tests/test_gpu_parity.py tests/test_gpu_text_order.py tests/test_naive_fixtures.py"

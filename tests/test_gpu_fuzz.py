@@ -17,3 +17,17 @@ def test_fuzz_short(seed):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "fuzz ok" in out.stdout
+
+
+def test_fuzz_refinement_rounds_on_small_texts():
+    """the builder re-sorts only the still-tied suffixes once few are left (k_refine_*), from n = 2^19 on in the shipped
+    library; the measurement build takes the threshold from the environment, so that the random / repetitive / run-heavy
+    texts of the fuzz driver go through those rounds"""
+    lib = os.path.join(ROOT, "fm_index_amd", "libfmx_measure.so")
+    if not os.path.exists(lib):
+        pytest.skip("libfmx_measure.so not built")
+    env = dict(os.environ, FMX_LIB=lib, FMX_REFINE_MIN_N="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_gpu_vs_oracle.py"), "30", "13"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "fuzz ok" in out.stdout

@@ -566,6 +566,70 @@ __global__ __launch_bounds__(BLK) void k_refine_rank(const uint32_t *__restrict_
   uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (k < m) rank[vals[k]] = grp[k];
 }
+// ---- the first refinement round straight from the text: the key of suffix i + h over its first h symbols IS what
+// k_init_keys packs, so the tied suffixes can be told apart to depth 2h before any rank exists (no scan over all
+// positions, no scatter of all ranks -- 40 of the 54 ms those cost at n = 2^30 when a few thousand suffixes are tied)
+template <typename T>
+__device__ __forceinline__ uint64_t pack_key(const T *__restrict__ t, uint32_t n, uint64_t pos, uint32_t bits, uint32_t k) {
+  uint64_t key = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    const uint64_t p = pos + j;
+    key = (key << bits) | (uint64_t)(p < n ? t[p] : 0);
+  }
+  return key;
+}
+// tied positions from the UNSCANNED heads of k_flag_heads (head[p] = p at a group's first position, 0 elsewhere)
+__global__ __launch_bounds__(BLK) void k_active_flags_h(const uint32_t *__restrict__ head, uint32_t n, uint8_t *__restrict__ flags) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= n) return;
+  const bool h0 = p == 0 || head[p] != 0u, h1 = p + 1 == n || head[p + 1] != 0u;
+  flags[p] = (h0 && h1) ? 0 : 1;
+}
+__global__ __launch_bounds__(BLK) void k_text_round_heads(const uint32_t *__restrict__ apos, const uint32_t *__restrict__ head,
+                                                           uint32_t m, uint32_t *__restrict__ grp) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t p = apos[k];
+  grp[k] = (p == 0 || head[p] != 0u) ? p : 0u;      // position 0 starts a group whose id is 0: the max-scan keeps it
+}
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_text_round_keys(const uint32_t *__restrict__ apos, const uint32_t *__restrict__ sa,
+                                                          const T *__restrict__ t, uint32_t n, uint32_t bits, uint32_t ksym,
+                                                          uint64_t h, uint32_t m, uint64_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ idx) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  keys[k] = pack_key<T>(t, n, (uint64_t)sa[apos[k]] + h, bits, ksym);
+  idx[k] = (uint32_t)k;
+}
+__global__ __launch_bounds__(BLK) void k_text_round_group_keys(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ grp,
+                                                                uint32_t m, uint64_t *__restrict__ keys) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k < m) keys[k] = grp[idx[k]];
+}
+__global__ __launch_bounds__(BLK) void k_text_round_gather(const uint32_t *__restrict__ apos, const uint32_t *__restrict__ idx,
+                                                            const uint32_t *__restrict__ sa, uint32_t m, uint32_t *__restrict__ suf) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k < m) suf[k] = sa[apos[idx[k]]];
+}
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_text_round_write(const uint32_t *__restrict__ apos, const uint64_t *__restrict__ gkeys,
+                                                           const uint32_t *__restrict__ suf, const T *__restrict__ t, uint32_t n,
+                                                           uint32_t bits, uint32_t ksym, uint64_t h, uint32_t m,
+                                                           uint32_t *__restrict__ sa, uint32_t *__restrict__ head) {
+  uint64_t k = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t i = suf[k];
+  sa[apos[k]] = i;
+  bool is_head = k == 0 || gkeys[k] != gkeys[k - 1];
+  if (!is_head) is_head = pack_key<T>(t, n, (uint64_t)i + h, bits, ksym) != pack_key<T>(t, n, (uint64_t)suf[k - 1] + h, bits, ksym);
+  head[k] = is_head ? apos[k] : 0u;
+}
+// rank[i] = sorted position of suffix i, for every suffix (the still-tied ones get their group's afterwards)
+__global__ __launch_bounds__(BLK) void k_rank_identity(const uint32_t *__restrict__ sa, uint32_t n, uint32_t *__restrict__ rank) {
+  uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p < n) rank[sa[p]] = (uint32_t)p;
+}
 struct AsU32 {
   __device__ __forceinline__ uint32_t operator()(uint8_t f) const { return f; }
 };
@@ -691,6 +755,78 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     pool.release(grp); pool.release(apos); pool.release(apos2); pool.release(fl);
     return FMX_OK;
   };
+  // The text round (see k_text_round_*): `flags` marks the m tied positions, `head0` are the unscanned heads.  Sorts
+  // the tied suffixes inside their groups by the text key at depth h, and -- if some are still tied -- builds the
+  // ranks (identity + the tied groups') and hands over to refine() at depth 2h.  *done = 1: the order is final.
+  auto text_round = [&](const uint8_t *fl0, const uint32_t *head0, uint32_t m, uint32_t *sa, uint32_t *rk, uint64_t h,
+                        int *done) -> int {
+    uint32_t *apos, *grp0, *ix_a, *ix_b, *suf, *grp;
+    uint64_t *tk_a, *tk_b;
+    uint8_t *fl;
+    FMX_HIP(pool.get(&apos, m)); FMX_HIP(pool.get(&grp0, m));
+    if (int rc = compact(rocprim::counting_iterator<uint32_t>(0), fl0, n, apos, m)) return rc;
+    hipLaunchKernelGGL(k_text_round_heads, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, head0, m, grp0);
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(keys_a); pool.release(keys_b);               // flags and heads lived there
+    keys_a = keys_b = nullptr;
+    FMX_HIP(pool.get(&tk_a, m)); FMX_HIP(pool.get(&tk_b, m));
+    FMX_HIP(pool.get(&ix_a, m)); FMX_HIP(pool.get(&ix_b, m));
+    FMX_HIP(pool.get(&suf, m));  FMX_HIP(pool.get(&grp, m));
+    FMX_HIP(pool.get(&fl, m));
+    uint8_t *t; bool own;
+    auto scan_max = [&](uint32_t *a) -> int {
+      size_t need = 0;
+      FMX_HIP(rocprim::inclusive_scan(nullptr, need, a, a, (size_t)m, MaxOp(), (hipStream_t)0));
+      FMX_HIP(scratch(need, &t, &own));
+      FMX_HIP(rocprim::inclusive_scan(t, need, a, a, (size_t)m, MaxOp(), (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      return FMX_OK;
+    };
+    if (int rc = scan_max(grp0)) return rc;                   // grp0[k] = first position of the k-th tied suffix's group
+    uint64_t *kc = tk_a, *ka = tk_b;
+    uint32_t *vc = ix_a, *va = ix_b;
+    auto pass = [&](unsigned end_bit) -> int {
+      rocprim::double_buffer<uint64_t> kb(kc, ka);
+      rocprim::double_buffer<uint32_t> vb(vc, va);
+      size_t need = 0;
+      FMX_HIP(rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+      FMX_HIP(scratch(need, &t, &own));
+      FMX_HIP(rocprim::radix_sort_pairs(t, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      kc = kb.current(); ka = kb.alternate();
+      vc = vb.current(); va = vb.alternate();
+      return FMX_OK;
+    };
+    hipLaunchKernelGGL(k_text_round_keys<T>, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, sa, d_text, n, sym_bits, k, h, m, kc, vc);
+    if (int rc = pass(k * sym_bits)) return rc;               // by the text key at depth h ...
+    hipLaunchKernelGGL(k_text_round_group_keys, dim3(nblocks(m)), dim3(BLK), 0, 0, vc, grp0, m, kc);
+    if (int rc = pass(32u)) return rc;                        // ... then, stable, by the group
+    hipLaunchKernelGGL(k_text_round_gather, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, vc, sa, m, suf);
+    hipLaunchKernelGGL(k_text_round_write<T>, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, kc, suf, d_text, n, sym_bits, k, h, m,
+                       sa, grp);
+    if (int rc = scan_max(grp)) return rc;
+    hipLaunchKernelGGL(k_active_flags_c, dim3(nblocks(m)), dim3(BLK), 0, 0, apos, grp, m, fl);
+    FMX_HIP(hipGetLastError());
+    uint32_t m2 = 0;
+    if (int rc = count_flags(fl, m, &m2)) return rc;
+    mark("text round", m2);
+    *done = 1;
+    uint32_t *apos2 = nullptr;
+    if (m2) {
+      // some are tied beyond 2h symbols: every suffix gets its rank (its position; a tied one its group's first
+      // position), and the doubling rounds take over
+      FMX_HIP(pool.get(&apos2, m2));
+      if (int rc = compact(apos, fl, m, apos2, m2)) return rc;
+      hipLaunchKernelGGL(k_rank_identity, dim3(nblocks(n)), dim3(BLK), 0, 0, sa, n, rk);
+      hipLaunchKernelGGL(k_refine_rank, dim3(nblocks(m)), dim3(BLK), 0, 0, suf, grp, m, rk);
+      FMX_HIP(hipGetLastError());
+    }
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(tk_a); pool.release(tk_b); pool.release(ix_a); pool.release(ix_b);
+    pool.release(suf); pool.release(grp); pool.release(fl); pool.release(grp0); pool.release(apos);
+    if (m2) return refine(apos2, m2, sa, rk, 2 * h);
+    return FMX_OK;
+  };
   hipLaunchKernelGGL(k_init_keys<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a,
                      d_sa);
   uint64_t *keys_cur = keys_a, *keys_alt = keys_b;
@@ -715,6 +851,20 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
     if (h >= n) {  // cannot happen for distinct suffixes; guard against an endless loop
       fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
       return FMX_ERR_HIP;
+    }
+    if (h == k && n >= refine_min_n()) {
+      // first round: when at most an eighth of the suffixes are tied, they are told apart to depth 2h by keys
+      // packed from the text, and only if some are STILL tied does any rank get computed
+      uint8_t *flags = (uint8_t *)keys_cur;
+      uint32_t m = 0;
+      hipLaunchKernelGGL(k_active_flags_h, dim3(nblocks(n)), dim3(BLK), 0, 0, head, n, flags);
+      if (int rc = count_flags(flags, n, &m)) return rc;
+      mark("tied", m);
+      if ((uint64_t)m * 8 <= n) {
+        int done = 0;
+        if (int rc = text_round(flags, head, m, sa_cur, rank, h, &done)) return rc;
+        if (done) break;
+      }
     }
     tb = tmp_bytes;
     FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp(), (hipStream_t)0));

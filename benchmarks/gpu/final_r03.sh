@@ -7,7 +7,7 @@ mkdir -p $OUT
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 python bench.py --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; echo "bench force-dist rc=$?"
-python bench.py --workload rep-rlfm --no-pmc > $OUT/bench_config4b.json 2> $OUT/bench_config4b.err; echo "bench 4b rc=$?"
+python bench.py --workload rep-rlfm --no-pmc --no-census > $OUT/bench_config4b.json 2> $OUT/bench_config4b.err; echo "bench 4b rc=$?"
 python benchmarks/criterion_shapes.py > $OUT/criterion_shapes.jsonl 2>/dev/null; echo "criterion rc=$?"
 python tests/test_gpu_beyond_4g.py dna > $OUT/beyond_4g.json 2>/dev/null; echo "beyond_4g dna rc=$?"
 python tests/test_gpu_beyond_4g.py bytes > $OUT/beyond_4g_bytes.json 2>/dev/null; echo "beyond_4g bytes rc=$?"

@@ -112,7 +112,8 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) &&
       !(kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 255 && n >= 2))
     return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM over u8 symbols only");
-  if (n >= (1ull << 40)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^40 is not supported");
+  // the wide engine's record and superblock indices are 32 bits wide: n / 128 + 1 records, (superblock + 1) << 24
+  if (n >= (1ull << 38)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^38 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
   if (int rc = select_device(device)) return rc;
   DeviceGuard dg;
@@ -1197,7 +1198,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   const bool locate = w.sa_level != FMX_NO_LOCATE;
   const char *bad = nullptr;
   if (h.kind != FMX_KIND_FM || h.sym_bytes != 1 || h.sym_bytes_abi != 1) bad = "kind / symbol width";
-  else if (h.n < 2 || h.n >= (1ull << 40) || w.n != h.n) bad = "n";
+  else if (h.n < 2 || h.n >= (1ull << 38) || w.n != h.n) bad = "n";
   else if (h.max_character == 0 || h.max_character > 255 || w.max_character != h.max_character) bad = "max_character";
   else if (w.generic != (h.max_character > 7 ? 1u : 0u)) bad = "engine";
   else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";

@@ -1634,6 +1634,59 @@ __global__ __launch_bounds__(BLK) void kwr_rank(const uint64_t *__restrict__ val
                                                  uint64_t *__restrict__ rank) {
   KW_FOR(k, m) rank[vals[k]] = grp[k];
 }
+// ---- the first refinement round from the text (as k_text_round_* of the 32-bit builder) ----
+__device__ __forceinline__ uint64_t kw_pack_key(const uint8_t *__restrict__ t, uint64_t n, uint64_t pos, uint32_t bits, uint32_t k) {
+  uint64_t key = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    const uint64_t p = pos + j;
+    key = (key << bits) | (uint64_t)(p < n ? t[p] : 0);
+  }
+  return key;
+}
+__global__ __launch_bounds__(BLK) void kwt_active_flags_h(const uint64_t *__restrict__ head, uint64_t n, uint8_t *__restrict__ flags) {
+  KW_FOR(p, n) {
+    const bool h0 = p == 0 || head[p] != 0ull, h1 = p + 1 == n || head[p + 1] != 0ull;
+    flags[p] = (h0 && h1) ? 0 : 1;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwt_heads(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ head, uint64_t m,
+                                                  uint64_t *__restrict__ grp) {
+  KW_FOR(k, m) {
+    const uint64_t p = apos[k];
+    grp[k] = (p == 0 || head[p] != 0ull) ? p : 0ull;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwt_keys(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ sa,
+                                                 const uint8_t *__restrict__ t, uint64_t n, uint32_t bits, uint32_t ksym, uint64_t h,
+                                                 uint64_t m, uint64_t *__restrict__ keys, uint64_t *__restrict__ idx) {
+  KW_FOR(k, m) {
+    keys[k] = kw_pack_key(t, n, sa[apos[k]] + h, bits, ksym);
+    idx[k] = k;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwt_group_keys(const uint64_t *__restrict__ idx, const uint64_t *__restrict__ grp, uint64_t m,
+                                                       uint64_t *__restrict__ keys) {
+  KW_FOR(k, m) keys[k] = grp[idx[k]];
+}
+__global__ __launch_bounds__(BLK) void kwt_gather(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ idx,
+                                                   const uint64_t *__restrict__ sa, uint64_t m, uint64_t *__restrict__ suf) {
+  KW_FOR(k, m) suf[k] = sa[apos[idx[k]]];
+}
+__global__ __launch_bounds__(BLK) void kwt_write(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ gkeys,
+                                                  const uint64_t *__restrict__ suf, const uint8_t *__restrict__ t, uint64_t n,
+                                                  uint32_t bits, uint32_t ksym, uint64_t h, uint64_t m, uint64_t *__restrict__ sa,
+                                                  uint64_t *__restrict__ head) {
+  KW_FOR(k, m) {
+    const uint64_t i = suf[k];
+    sa[apos[k]] = i;
+    bool is_head = k == 0 || gkeys[k] != gkeys[k - 1];
+    if (!is_head) is_head = kw_pack_key(t, n, i + h, bits, ksym) != kw_pack_key(t, n, suf[k - 1] + h, bits, ksym);
+    head[k] = is_head ? apos[k] : 0ull;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwt_rank_identity(const uint64_t *__restrict__ sa, uint64_t n, uint64_t *__restrict__ rank) {
+  KW_FOR(p, n) rank[sa[p]] = p;
+}
 struct AsU64 {
   __device__ __forceinline__ unsigned long long operator()(uint8_t f) const { return f; }
 };
@@ -1852,6 +1905,69 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
     pool.release(grp); pool.release(apos); pool.release(apos2); pool.release(fl);
     return FMX_OK;
   };
+  auto text_round = [&](const uint8_t *fl0, const uint64_t *head0, uint64_t m, uint64_t *sa, uint64_t h) -> int {
+    uint64_t *apos, *grp0, *tk_a, *tk_b, *ix_a, *ix_b, *suf, *grp;
+    uint8_t *fl;
+    FMX_HIP(pool.get(&apos, m)); FMX_HIP(pool.get(&grp0, m));
+    if (int rc = compact(rocprim::counting_iterator<uint64_t>(0), fl0, n, apos, m)) return rc;
+    const unsigned mb = wblocks(m);
+    hipLaunchKernelGGL(kwt_heads, dim3(mb), dim3(BLK), 0, 0, apos, head0, m, grp0);
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(keys_a); pool.release(keys_b);               // flags lived there (heads in the suffix buffer's alternate)
+    keys_a = keys_b = nullptr;
+    FMX_HIP(pool.get(&tk_a, m)); FMX_HIP(pool.get(&tk_b, m));
+    FMX_HIP(pool.get(&ix_a, m)); FMX_HIP(pool.get(&ix_b, m));
+    FMX_HIP(pool.get(&suf, m));  FMX_HIP(pool.get(&grp, m));
+    FMX_HIP(pool.get(&fl, m));
+    uint8_t *t; bool own;
+    auto scan_max = [&](uint64_t *a) -> int {
+      size_t need = 0;
+      FMX_HIP(rocprim::inclusive_scan(nullptr, need, a, a, (size_t)m, MaxOp64(), (hipStream_t)0));
+      FMX_HIP(scratch(need, &t, &own));
+      FMX_HIP(rocprim::inclusive_scan(t, need, a, a, (size_t)m, MaxOp64(), (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      return FMX_OK;
+    };
+    if (int rc = scan_max(grp0)) return rc;
+    uint64_t *kc = tk_a, *ka = tk_b, *vc = ix_a, *va = ix_b;
+    auto pass = [&](unsigned end_bit) -> int {
+      rocprim::double_buffer<uint64_t> kb(kc, ka);
+      rocprim::double_buffer<uint64_t> vb(vc, va);
+      size_t need = 0;
+      FMX_HIP(rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+      FMX_HIP(scratch(need, &t, &own));
+      FMX_HIP(rocprim::radix_sort_pairs(t, need, kb, vb, (size_t)m, 0u, end_bit, (hipStream_t)0));
+      if (own) { FMX_HIP(hipDeviceSynchronize()); pool.release(t); }
+      kc = kb.current(); ka = kb.alternate();
+      vc = vb.current(); va = vb.alternate();
+      return FMX_OK;
+    };
+    hipLaunchKernelGGL(kwt_keys, dim3(mb), dim3(BLK), 0, 0, apos, sa, d_text, n, sym_bits, k, h, m, kc, vc);
+    if (int rc = pass(k * sym_bits)) return rc;               // by the text key at depth h ...
+    hipLaunchKernelGGL(kwt_group_keys, dim3(mb), dim3(BLK), 0, 0, vc, grp0, m, kc);
+    if (int rc = pass(rank_bits)) return rc;                  // ... then, stable, by the group
+    hipLaunchKernelGGL(kwt_gather, dim3(mb), dim3(BLK), 0, 0, apos, vc, sa, m, suf);
+    hipLaunchKernelGGL(kwt_write, dim3(mb), dim3(BLK), 0, 0, apos, kc, suf, d_text, n, sym_bits, k, h, m, sa, grp);
+    if (int rc = scan_max(grp)) return rc;
+    hipLaunchKernelGGL(kwr_active_flags_c, dim3(mb), dim3(BLK), 0, 0, apos, grp, m, fl);
+    FMX_HIP(hipGetLastError());
+    uint64_t m2 = 0;
+    if (int rc = count_flags(fl, m, &m2)) return rc;
+    mark("text round", m2);
+    uint64_t *apos2 = nullptr;
+    if (m2) {   // tied beyond 2h symbols: ranks for every suffix (position; a tied one its group's first position)
+      FMX_HIP(pool.get(&apos2, m2));
+      if (int rc = compact(apos, fl, m, apos2, m2)) return rc;
+      hipLaunchKernelGGL(kwt_rank_identity, dim3(nb), dim3(BLK), 0, 0, sa, n, rank);
+      hipLaunchKernelGGL(kwr_rank, dim3(mb), dim3(BLK), 0, 0, suf, grp, m, rank);
+      FMX_HIP(hipGetLastError());
+    }
+    FMX_HIP(hipDeviceSynchronize());
+    pool.release(tk_a); pool.release(tk_b); pool.release(ix_a); pool.release(ix_b);
+    pool.release(suf); pool.release(grp); pool.release(fl); pool.release(grp0); pool.release(apos);
+    if (m2) return refine(apos2, m2, sa, 2 * h);
+    return FMX_OK;
+  };
   uint64_t h = k;
   bool two_keys = false;
   for (;;) {
@@ -1867,6 +1983,19 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
     if (h >= n) {
       fmx_set_error(FMX_ERR_HIP, "suffix sort did not converge");
       return FMX_ERR_HIP;
+    }
+    if (!two_keys) {
+      // first round: when at most an eighth of the suffixes are tied, they are told apart to depth 2h by keys packed
+      // from the text, and only if some are STILL tied does any rank get computed (see the 32-bit builder)
+      uint8_t *flags = (uint8_t *)keys_cur;
+      uint64_t m = 0;
+      hipLaunchKernelGGL(kwt_active_flags_h, dim3(nb), dim3(BLK), 0, 0, head, n, flags);
+      if (int rc = count_flags(flags, n, &m)) return rc;
+      mark("tied", m);
+      if (m * 8 <= n) {
+        if (int rc = text_round(flags, head, m, sa_cur, h)) return rc;
+        break;
+      }
     }
     size_t tb = tmp_bytes;
     FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp64(), (hipStream_t)0));

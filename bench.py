@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-early-exit", action="store_true", help="skip the config-2b legs")
     ap.add_argument("--no-rlfm", action="store_true", help="skip the config-4 object of the default run")
     ap.add_argument("--no-3b", action="store_true", help="skip the config-3b object")
+    ap.add_argument("--no-wide", action="store_true", help="skip the n = 2^32 + 2^20 object (the 64-bit engine)")
     ap.add_argument("--no-d2h", action="store_true", help="skip value_incl_d2h")
     ap.add_argument("--no-census", action="store_true", help="skip the requested / distinct line census")
     ap.add_argument("--no-pmc", action="store_true",
@@ -871,6 +872,14 @@ def run(args, world, pmc=None):
             wr.close()
             del wr
 
+    # ---- beyond 2^32 rows: the 64-bit engine on the config-2 / config-3 shapes.  LAST: its builder holds ~172 GB of
+    # scratch, and a process that has cycled through the device's memory pays for every later hipMalloc / hipFree ----
+    if single and wl.dna and not args.no_wide and args.log2n >= 30:      # only next to the full-size configs
+        try:
+            wide_leg(out, args, dev)
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
+            out["wide"] = {"error": repr(ex)}
+
     # ---- HBM-side traffic measured by the counter passes at the start of this run ----
     if pmc is not None and rank == 0:
         apply_pmc(out, pmc[0], pmc[1])
@@ -1429,6 +1438,94 @@ def d2h_leg(out, wl, args):
                                "runtime's pin-copy-unpin copies in two chunks.  value_incl_d2h is the better of the "
                                "two; never the headline value"}
     del hp, ho, hs, he, hc
+
+
+def wide_leg(out, args, dev):
+    """`usize` rows (fm_index.rs:86-95): a DNA FMIndexWithLocate over n = 2^32 + 2^20 symbols on the wide engine
+    (fmx_wide.hip) -- built here, 2^20 length-32 substring patterns counted, 2^20 hits located; every count >= 1 and every
+    located position holds its pattern (checked on the device).  tests/test_gpu_beyond_4g.py is the parity test."""
+    import torch
+    import fm_index_amd as F
+    from fm_index_amd import workload as W
+    from fm_index_amd import _lib as L
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    need = 200 << 30
+    if free < need:
+        out["wide"] = {"skipped": "needs ~190 GB of free HBM for the build, %.0f GB free" % (free / 2 ** 30)}
+        return
+    lib = L.lib()
+    n, level, npat, m = (1 << 32) + (1 << 20), 2, 1 << 20, 32
+    t0 = time.perf_counter()
+    text = W.dna_text_torch(n, 17, dev)
+    torch.cuda.synchronize()
+    textgen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=level)
+    build_wall_s = time.perf_counter() - t0
+    h = index.handle()
+    assert index.is_wide() and index.len() == n
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def patterns(seed, mm):
+        src = W.umod_torch(W.splitmix64_torch(seed, 0, npat, dev), n - 1 - mm)
+        pat = text[src[:, None] + torch.arange(mm, dtype=torch.int64, device=dev)[None, :]].reshape(-1).contiguous()
+        off = (torch.arange(npat + 1, dtype=torch.int64, device=dev) * mm).contiguous()
+        return src, pat, off
+    s, e, c = (torch.empty(npat, dtype=torch.int64, device=dev) for _ in range(3))
+
+    def count(pat, off):
+        rc = lib.fmx_count_batch_dev(h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), npat, None,
+                                     C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), C.c_void_p(c.data_ptr()), sp)
+        assert rc == 0, lib.fmx_last_error().decode()
+    _src, pat, off = patterns(3, m)
+    for _ in range(args.warmup):
+        count(pat, off)
+    torch.cuda.synchronize()
+    count_ms = event_time_ms(torch, stream, lambda: count(pat, off), args.steps)
+    assert lib.fmx_stream_status(h) == 0 and bool((c >= 1).all())
+    rows_beyond = int((e > (1 << 32)).sum().item())
+    # locate: length-22 substrings (about one hit each at this n), rows expanded and walked
+    src2, pat2, off2 = patterns(5, 22)
+    count(pat2, off2)
+    d_off = torch.empty(npat + 1, dtype=torch.int64, device=dev)
+    assert lib.fmx_offsets_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat, C.c_void_p(d_off.data_ptr()), sp) == 0
+    total = int(d_off[-1].item())
+    pos = torch.empty(total, dtype=torch.int64, device=dev)
+
+    def locate():
+        rc = lib.fmx_locate_batch_dev(h, C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), npat,
+                                      C.c_void_p(d_off.data_ptr()), total, C.c_void_p(pos.data_ptr()), sp)
+        assert rc == 0, lib.fmx_last_error().decode()
+    for _ in range(args.warmup):
+        locate()
+    torch.cuda.synchronize()
+    locate_ms = event_time_ms(torch, stream, locate, args.steps)
+    assert lib.fmx_stream_status(h) == 0
+    hit = torch.repeat_interleave(torch.arange(npat, device=dev), c)
+    ok = torch.ones(total, dtype=torch.bool, device=dev)
+    for j in range(22):
+        ok &= text[pos + j] == pat2.view(npat, 22)[hit, j]
+    assert bool(ok.all()), "a located position does not hold its pattern"
+    found = torch.zeros(npat, dtype=torch.bool, device=dev)
+    found[hit[pos == src2[hit]]] = True
+    assert bool(found.all()), "a pattern's source position is not among its hits"
+    out["wide"] = {
+        "workload": "FMIndexWithLocate, n=2^32+2^20 sigma=4 DNA text: %d x len-%d substring patterns counted, %d hits located "
+                    "(level %d)" % (npat, m, total, level),
+        "text_len": n, "engine": "64-bit rows (fmx_wide.hip)", "value": npat * m / (count_ms / 1e3),
+        "unit": "pattern-chars/s", "ms_per_step": count_ms, "intervals_with_e_beyond_2^32": rows_beyond,
+        "locate": {"hits": total, "ms_per_batch": locate_ms, "hits_per_s": total / (locate_ms / 1e3),
+                   "positions_beyond_2^32": int((pos >= (1 << 32)).sum().item()),
+                   "checked": "every located position holds its pattern; every source position is among the hits"},
+        "index_bytes": index.heap_size(), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
+        "build_wall_s": round(build_wall_s, 2), "textgen_s": round(textgen_s, 2),
+        "note": "build_ms includes the driver's hipMalloc / hipFree of ~172 GB of scratch: 0.6 s on fresh device memory, "
+                "seconds once the process has cycled through it (DESIGN.md section 4.3)"}
+    index.close()
+    del text, pat, pat2, pos
+    torch.cuda.empty_cache()
 
 
 def rlfm_leg(out, args, dev, local):

@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --no-accel --no-early-exit: only config-2/3/4 launches of the headline kernels in the trace
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-3b ${2:---no-accel}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-3b --no-wide ${2:---no-accel}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_write.out 2> $OUT/pmc_write.err

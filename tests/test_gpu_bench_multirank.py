@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 COMMON = ["--log2n", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-accel", "--no-rlfm",
-          "--no-pmc", "--no-3b", "--no-d2h", "--no-early-exit", "--pattern-seed", "7"]
+          "--no-pmc", "--no-3b", "--no-d2h", "--no-early-exit", "--no-wide", "--pattern-seed", "7"]
 
 
 def _run(extra, tmp_path, tag):

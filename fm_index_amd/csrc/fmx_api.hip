@@ -108,10 +108,9 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
-  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate over byte texts
-  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) &&
-      !(kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 255 && n >= 2))
-    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM over u8 symbols only");
+  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate
+  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) && !(kind == FMX_KIND_FM && n >= 2))
+    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM only");
   // the wide engine's record and superblock indices are 32 bits wide: n / 128 + 1 records, (superblock + 1) << 24
   if (n >= (1ull << 38)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^38 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
@@ -1197,10 +1196,15 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   if (fread(&w, sizeof w, 1, f) != 1) return fail(FMX_ERR_ARG, "truncated index file");
   const bool locate = w.sa_level != FMX_NO_LOCATE;
   const char *bad = nullptr;
-  if (h.kind != FMX_KIND_FM || h.sym_bytes != 1 || h.sym_bytes_abi != 1) bad = "kind / symbol width";
+  if (h.kind != FMX_KIND_FM || (h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) ||
+      (h.sym_bytes_abi != h.sym_bytes && !(h.sym_bytes_abi == 8 && h.sym_bytes == 4)))
+    bad = "kind / symbol width";
   else if (h.n < 2 || h.n >= (1ull << 38) || w.n != h.n) bad = "n";
-  else if (h.max_character == 0 || h.max_character > 255 || w.max_character != h.max_character) bad = "max_character";
-  else if (w.generic != (h.max_character > 7 ? 1u : 0u)) bad = "engine";
+  else if (h.max_character == 0 || h.max_character >= (1ull << 26) || w.max_character != h.max_character ||
+           (h.sym_bytes < 4 && h.max_character >= (1ull << (8 * h.sym_bytes))))
+    bad = "max_character";
+  else if (w.generic != ((h.max_character > 7 || h.sym_bytes != 1) ? 1u : 0u) || (w.generic && w.sym_bytes != h.sym_bytes))
+    bad = "engine";
   else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";
   else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";
   else if (!w.generic && (!w.rec || !w.base || (locate && !w.samples))) bad = "array presence";
@@ -1227,7 +1231,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   }
   idx->device = device;
   idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = locate ? h.nsamples : 0; idx->runs = 0;
-  idx->sym_bytes = 1; idx->sym_bytes_abi = 1; idx->kind = FMX_KIND_FM;
+  idx->sym_bytes = h.sym_bytes; idx->sym_bytes_abi = h.sym_bytes_abi; idx->kind = FMX_KIND_FM;
   idx->level_requested = h.level_requested;
   idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
   if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) return fail(FMX_ERR_ARG, "truncated index file");
@@ -1264,7 +1268,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   idx->is_wide = 1;
   idx->dev.sa_level = w.sa_level;
   idx->dev.kind = FMX_KIND_FM;
-  idx->dev.sym_bytes = 1;
+  idx->dev.sym_bytes = h.sym_bytes;
   return FMX_OK;
 }
 

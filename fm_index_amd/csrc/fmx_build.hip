@@ -1554,7 +1554,8 @@ inline unsigned wblocks(uint64_t n) {
   const uint64_t b = (n + BLK - 1) / BLK;
   return (unsigned)(b < 1 ? 1 : (b > (1u << 22) ? (1u << 22) : b));
 }
-__global__ __launch_bounds__(BLK) void kw_init_keys(const uint8_t *__restrict__ t, uint64_t n, uint32_t bits,
+template <typename T>
+__global__ __launch_bounds__(BLK) void kw_init_keys(const T *__restrict__ t, uint64_t n, uint32_t bits,
                                                      uint32_t k, uint64_t *__restrict__ keys,
                                                      uint64_t *__restrict__ idx) {
   KW_FOR(i, n) {
@@ -1635,7 +1636,8 @@ __global__ __launch_bounds__(BLK) void kwr_rank(const uint64_t *__restrict__ val
   KW_FOR(k, m) rank[vals[k]] = grp[k];
 }
 // ---- the first refinement round from the text (as k_text_round_* of the 32-bit builder) ----
-__device__ __forceinline__ uint64_t kw_pack_key(const uint8_t *__restrict__ t, uint64_t n, uint64_t pos, uint32_t bits, uint32_t k) {
+template <typename T>
+__device__ __forceinline__ uint64_t kw_pack_key(const T *__restrict__ t, uint64_t n, uint64_t pos, uint32_t bits, uint32_t k) {
   uint64_t key = 0;
   for (uint32_t j = 0; j < k; j++) {
     const uint64_t p = pos + j;
@@ -1656,8 +1658,9 @@ __global__ __launch_bounds__(BLK) void kwt_heads(const uint64_t *__restrict__ ap
     grp[k] = (p == 0 || head[p] != 0ull) ? p : 0ull;
   }
 }
+template <typename T>
 __global__ __launch_bounds__(BLK) void kwt_keys(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ sa,
-                                                 const uint8_t *__restrict__ t, uint64_t n, uint32_t bits, uint32_t ksym, uint64_t h,
+                                                 const T *__restrict__ t, uint64_t n, uint32_t bits, uint32_t ksym, uint64_t h,
                                                  uint64_t m, uint64_t *__restrict__ keys, uint64_t *__restrict__ idx) {
   KW_FOR(k, m) {
     keys[k] = kw_pack_key(t, n, sa[apos[k]] + h, bits, ksym);
@@ -1672,8 +1675,9 @@ __global__ __launch_bounds__(BLK) void kwt_gather(const uint64_t *__restrict__ a
                                                    const uint64_t *__restrict__ sa, uint64_t m, uint64_t *__restrict__ suf) {
   KW_FOR(k, m) suf[k] = sa[apos[idx[k]]];
 }
+template <typename T>
 __global__ __launch_bounds__(BLK) void kwt_write(const uint64_t *__restrict__ apos, const uint64_t *__restrict__ gkeys,
-                                                  const uint64_t *__restrict__ suf, const uint8_t *__restrict__ t, uint64_t n,
+                                                  const uint64_t *__restrict__ suf, const T *__restrict__ t, uint64_t n,
                                                   uint32_t bits, uint32_t ksym, uint64_t h, uint64_t m, uint64_t *__restrict__ sa,
                                                   uint64_t *__restrict__ head) {
   KW_FOR(k, m) {
@@ -1690,11 +1694,12 @@ __global__ __launch_bounds__(BLK) void kwt_rank_identity(const uint64_t *__restr
 struct AsU64 {
   __device__ __forceinline__ unsigned long long operator()(uint8_t f) const { return f; }
 };
-__global__ __launch_bounds__(BLK) void kw_bwt(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa, uint64_t n,
-                                               uint8_t *__restrict__ bwt) {
+template <typename T>
+__global__ __launch_bounds__(BLK) void kw_bwt(const T *__restrict__ t, const uint64_t *__restrict__ sa, uint64_t n,
+                                               T *__restrict__ bwt) {
   KW_FOR(p, n) {
     const uint64_t k = sa[p];
-    bwt[p] = k > 0 ? t[k - 1] : (uint8_t)0;   // fm_index.rs:50-55
+    bwt[p] = k > 0 ? t[k - 1] : (T)0;   // fm_index.rs:50-55
   }
 }
 __global__ __launch_bounds__(BLK) void kw_samples(const uint64_t *__restrict__ sa, uint64_t nsamp, uint32_t level,
@@ -1747,7 +1752,8 @@ __global__ void kw_bases_g(const uint64_t *__restrict__ scan, uint32_t nrec, uin
   const uint32_t sb = t >> 4, c = t & 15u;
   base[t] = c < ncode ? scan[(size_t)c * nrec + ((size_t)sb << sb_recs)] - (fold ? 0ull : scan[(size_t)c * nrec]) : 0ull;
 }
-__global__ __launch_bounds__(BLK) void kw_verify_sa(const uint8_t *__restrict__ t, const uint64_t *__restrict__ sa,
+template <typename T>
+__global__ __launch_bounds__(BLK) void kw_verify_sa(const T *__restrict__ t, const uint64_t *__restrict__ sa,
                                                      uint64_t n, uint32_t *__restrict__ mark, unsigned long long *bad) {
   KW_FOR(p, n) {
     const uint64_t b = sa[p];
@@ -1760,7 +1766,7 @@ __global__ __launch_bounds__(BLK) void kw_verify_sa(const uint8_t *__restrict__ 
       const uint64_t pa = a + j, pb = b + j;
       if (pa >= n) break;
       if (pb >= n) { atomicAdd(bad, 1ull); break; }
-      const uint8_t ca = t[pa], cb = t[pb];
+      const T ca = t[pa], cb = t[pb];
       if (ca < cb) break;
       if (ca > cb) { atomicAdd(bad, 1ull); break; }
     }
@@ -1770,7 +1776,8 @@ __global__ __launch_bounds__(BLK) void kw_count_not_one(const uint8_t *mark, uin
   KW_FOR(p, n) if (mark[p] != 1u) atomicAdd(bad, 1ull);
 }
 
-int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
+template <typename T>
+int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
   uint64_t *keys_a, *keys_b, *vals_b, *rank;
   unsigned int *d_ng;
   static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
@@ -1803,7 +1810,7 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
   FMX_HIP(pool.get(&tmp, tmp_bytes));
   mark("alloc", 0);
   const unsigned nb = wblocks(n);
-  hipLaunchKernelGGL(kw_init_keys, dim3(nb), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a, d_sa);
+  hipLaunchKernelGGL(kw_init_keys<T>, dim3(nb), dim3(BLK), 0, 0, d_text, n, sym_bits, k, keys_a, d_sa);
   FMX_HIP(hipGetLastError());
   uint64_t *keys_cur = keys_a, *keys_alt = keys_b, *sa_cur = d_sa, *sa_alt = vals_b;
   auto sort_pass = [&](unsigned end_bit) -> int {
@@ -1942,12 +1949,12 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
       vc = vb.current(); va = vb.alternate();
       return FMX_OK;
     };
-    hipLaunchKernelGGL(kwt_keys, dim3(mb), dim3(BLK), 0, 0, apos, sa, d_text, n, sym_bits, k, h, m, kc, vc);
+    hipLaunchKernelGGL(kwt_keys<T>, dim3(mb), dim3(BLK), 0, 0, apos, sa, d_text, n, sym_bits, k, h, m, kc, vc);
     if (int rc = pass(k * sym_bits)) return rc;               // by the text key at depth h ...
     hipLaunchKernelGGL(kwt_group_keys, dim3(mb), dim3(BLK), 0, 0, vc, grp0, m, kc);
     if (int rc = pass(rank_bits)) return rc;                  // ... then, stable, by the group
     hipLaunchKernelGGL(kwt_gather, dim3(mb), dim3(BLK), 0, 0, apos, vc, sa, m, suf);
-    hipLaunchKernelGGL(kwt_write, dim3(mb), dim3(BLK), 0, 0, apos, kc, suf, d_text, n, sym_bits, k, h, m, sa, grp);
+    hipLaunchKernelGGL(kwt_write<T>, dim3(mb), dim3(BLK), 0, 0, apos, kc, suf, d_text, n, sym_bits, k, h, m, sa, grp);
     if (int rc = scan_max(grp)) return rc;
     hipLaunchKernelGGL(kwr_active_flags_c, dim3(mb), dim3(BLK), 0, 0, apos, grp, m, fl);
     FMX_HIP(hipGetLastError());
@@ -2038,7 +2045,8 @@ int suffix_sort_wide(const uint8_t *d_text, uint64_t n, uint32_t sym_bits, uint6
 }
 }  // namespace
 
-int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
+template <typename T>
+static int build_wide_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
   static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
   auto mark = [&](const char *what) {
@@ -2054,13 +2062,13 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   // -- statistics + validation (sais.rs:115-139) --
   std::vector<uint64_t> hist;
   TextStats st;
-  if (int rc = symbol_histogram<uint8_t>(d_text, n, maxc, hist, &st, pool)) return rc;
+  if (int rc = symbol_histogram<T>(d_text, n, maxc, hist, &st, pool)) return rc;
   if (st.max_sym > maxc) {
     fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
     return FMX_ERR_SYMBOL_RANGE;
   }
-  uint8_t first = 0;
-  FMX_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
+  T first = 0;
+  FMX_HIP(hipMemcpy(&first, d_text, sizeof(T), hipMemcpyDeviceToHost));
   if (first == 0) {
     fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
     return FMX_ERR_TEXT_START_ZERO;
@@ -2078,16 +2086,17 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   // -- suffix array --
   uint64_t *d_sa;
   FMX_HIP(pool.get(&d_sa, n));
-  if (int rc = suffix_sort_wide(d_text, n, L, d_sa, pool)) return rc;
+  if (int rc = suffix_sort_wide<T>(d_text, n, L, d_sa, pool)) return rc;
   mark("suffix sort");
   FmxWideDev &w = idx->wide;
   w.n = n;
+  w.sym_bytes = (uint32_t)sizeof(T);
   w.max_character = maxc;
   w.status = idx->dev.status;
   w.sa_level = FMX_NO_LOCATE;
   idx->dev.sa_level = FMX_NO_LOCATE;
   idx->dev.kind = idx->kind;
-  idx->dev.sym_bytes = 1;
+  idx->dev.sym_bytes = (uint32_t)sizeof(T);
   // -- SA samples (sample.rs:21-44) --
   if (idx->level_requested != FMX_NO_LOCATE) {
     uint32_t level = idx->level_requested;
@@ -2104,16 +2113,16 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   }
   mark("samples");
   // -- BWT (fm_index.rs:44-58) --
-  uint8_t *d_bwt;
+  T *d_bwt;
   FMX_HIP(pool.get(&d_bwt, n));
-  hipLaunchKernelGGL(kw_bwt, dim3(wblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
+  hipLaunchKernelGGL(kw_bwt<T>, dim3(wblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
   FMX_HIP(hipGetLastError());
   if (idx->flags & FMX_FLAG_KEEP_SA) {
-    uint8_t *kt;
-    FMX_HIP(hipMalloc((void **)&kt, n));
-    FMX_HIP(hipMemcpy(kt, d_text, (size_t)n, hipMemcpyDeviceToDevice));
-    if (int rc = keep(idx, kt, n)) return rc;
-    idx->d_text = kt;
+    T *kt;
+    FMX_HIP(hipMalloc((void **)&kt, n * sizeof(T)));
+    FMX_HIP(hipMemcpy(kt, d_text, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice));
+    if (int rc = keep(idx, kt, n * sizeof(T))) return rc;
+    idx->d_text = (uint8_t *)kt;
     for (size_t i = 0; i < pool.v.size(); i++)
       if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
     if (int rc = keep(idx, d_sa, n * 8)) return rc;
@@ -2124,7 +2133,7 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   }
   const uint32_t sb_shift = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST, sb_recs = sb_shift - 8u;
   const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
-  if (maxc > 7) {
+  if (maxc > 7 || sizeof(T) != 1) {
     // -- generic wide index: the levels of the multi-ary wavelet matrix (as build_mwm, 64-bit scans) --
     uint32_t nlv, bits[FMX_MAX_LEVELS];
     split_levels(L, &nlv, bits);
@@ -2132,7 +2141,7 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
       fmx_set_error(FMX_ERR_UNSUPPORTED, "wide index: more wavelet levels than FMXW_MAX_LEVELS");
       return FMX_ERR_UNSUPPORTED;
     }
-    uint8_t *cur = d_bwt, *alt = nullptr;
+    T *cur = d_bwt, *alt = nullptr;
     if (nlv > 1) FMX_HIP(pool.get(&alt, n));
     uint32_t shift = L;
     w.generic = 1;
@@ -2159,9 +2168,9 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
       FMX_HIP(pool.get(&scan, nh));
       const unsigned grid = nblocks((uint64_t)lv.nrec * 8);
       if (lv.fmt == 3)
-        hipLaunchKernelGGL((k_mwm_pieces<3, uint8_t>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+        hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
       else
-        hipLaunchKernelGGL((k_mwm_pieces<4, uint8_t>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+        hipLaunchKernelGGL((k_mwm_pieces<4, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
       size_t tb = 0;
       FMX_HIP(exclusive_sum(nullptr, tb, hist, scan, nh));
       uint8_t *tmp;
@@ -2184,7 +2193,7 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
         FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
         FMX_HIP(hipDeviceSynchronize());
         pool.release(stmp);
-        uint8_t *x = cur; cur = alt; alt = x;
+        T *x = cur; cur = alt; alt = x;
       }
       FMX_HIP(hipDeviceSynchronize());
       pool.release(hist); pool.release(scan); pool.release(tmp);
@@ -2215,7 +2224,7 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   if (int rc = keep(idx, d_base, (uint64_t)nsb * 64)) return rc;
   FMX_HIP(pool.get(&d_hist, (size_t)nrec * 8));
   FMX_HIP(pool.get(&d_scan, (size_t)nrec * 8));
-  hipLaunchKernelGGL((k_mwm_pieces<3, uint8_t>), dim3(nblocks((uint64_t)nrec * 8)), dim3(BLK), 0, 0, d_bwt, n, 0u, 7u,
+  hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(nblocks((uint64_t)nrec * 8)), dim3(BLK), 0, 0, d_bwt, n, 0u, 7u,
                      nrec, d_rec, d_hist);
   {
     size_t tb = 0;
@@ -2239,6 +2248,17 @@ int fmx_build_wide(fmx_index *idx, const uint8_t *d_text) {
   return FMX_OK;
 }
 
+int fmx_build_wide(fmx_index *idx, const void *d_text) {
+  switch (idx->sym_bytes) {
+    case 1: return build_wide_t<uint8_t>(idx, (const uint8_t *)d_text);
+    case 2: return build_wide_t<uint16_t>(idx, (const uint16_t *)d_text);
+    case 4: return build_wide_t<uint32_t>(idx, (const uint32_t *)d_text);
+    default:
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "sym_bytes must be 1, 2 or 4 on the device");
+      return FMX_ERR_UNSUPPORTED;
+  }
+}
+
 int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations) {
   const uint64_t n = idx->n;
   *violations = 0;
@@ -2249,8 +2269,12 @@ int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations) {
   FMX_HIP(hipMalloc((void **)&bad, 8));
   FMX_HIP(hipMemset(mark, 0, words * 4));
   FMX_HIP(hipMemset(bad, 0, 8));
-  hipLaunchKernelGGL(kw_verify_sa, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)idx->d_text, idx->d_sa64, n, mark,
-                     bad);
+  if (idx->sym_bytes == 1)
+    hipLaunchKernelGGL(kw_verify_sa<uint8_t>, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)idx->d_text, idx->d_sa64, n, mark, bad);
+  else if (idx->sym_bytes == 2)
+    hipLaunchKernelGGL(kw_verify_sa<uint16_t>, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint16_t *)idx->d_text, idx->d_sa64, n, mark, bad);
+  else
+    hipLaunchKernelGGL(kw_verify_sa<uint32_t>, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint32_t *)idx->d_text, idx->d_sa64, n, mark, bad);
   hipLaunchKernelGGL(kw_count_not_one, dim3(wblocks(n)), dim3(BLK), 0, 0, (const uint8_t *)mark, n, bad);
   unsigned long long hb = 0;
   FMX_HIP(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
@@ -2261,7 +2285,7 @@ int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations) {
 }
 
 int fmx_build_impl(fmx_index *idx, const void *d_text) {
-  if (fmx_wide_build(idx)) return fmx_build_wide(idx, (const uint8_t *)d_text);   // eligibility checked by the caller
+  if (fmx_wide_build(idx)) return fmx_build_wide(idx, d_text);   // eligibility checked by the caller
   switch (idx->sym_bytes) {
     case 1: return build_impl_t<uint8_t>(idx, (const uint8_t *)d_text);
     case 2: return build_impl_t<uint16_t>(idx, (const uint16_t *)d_text);

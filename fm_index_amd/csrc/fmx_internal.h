@@ -124,7 +124,7 @@ struct FmxDev {  // passed BY VALUE to every query kernel
 // plus, on every level but the last, the number of entries with a smaller code (so that a level's rank IS the
 // position in the next level, as in FmxLevel); K[c] = cs[c] - (rank chain of c at position 0), 64 bits wide:
 //     lf_map2(c, i) = K[c] + rank chain of c at i                                  (fm_index.rs:93-95)
-#define FMXW_MAX_LEVELS 2
+#define FMXW_MAX_LEVELS 7
 struct FmxWideLevel {
   const uint4 *rec;          // n / per_rec + 1 records (per_rec = 256 for fmt 3, 128 for fmt 4)
   const uint64_t *base;      // [nsb][16]
@@ -148,6 +148,8 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   FmxWideLevel lv[FMXW_MAX_LEVELS];
   const uint64_t *K;         // [max_character + 1]
   const uint64_t *cs;        // [max_character + 1] C array on the device (get_f / fl_map)
+  uint32_t sym_bytes;        // width of text / pattern symbols (1, 2 or 4; generic indexes only when > 1)
+  uint32_t pad;
 };
 
 struct fmx_index {
@@ -193,7 +195,7 @@ int fmx_build_impl(fmx_index *idx, const void *d_text);
 // wide indexes (fmx_wide.hip / the wide section of fmx_build.hip)
 static inline bool fmx_wide_n(uint64_t n) { return n >= 0xFFFFFFF0ull; }
 static inline bool fmx_wide_build(const fmx_index *idx) { return fmx_wide_n(idx->n) || (idx->flags & FMX_FLAG_FORCE_WIDE); }
-int fmx_build_wide(fmx_index *idx, const uint8_t *d_text);
+int fmx_build_wide(fmx_index *idx, const void *d_text);
 int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off, uint64_t npat,
                       const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e, uint64_t *d_cnt, hipStream_t st);
 int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,

@@ -317,15 +317,17 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_export_l_kernel(FmxWideDev w,
 // The level bases and K[] are read with data-dependent indices in every step: LDS (GLDS = true, up to FMXW_GLDS_SB
 // superblocks) or global memory, two instantiations as for FMXW_BASES.
 // ===========================================================================
-#define FMXW_GLDS_SB 32u
+#define FMXW_GLDS_SB 8u
 #define FMXW_GBASES(w, GLDS)                                                                                       \
   __shared__ uint64_t lds_gb[(GLDS) ? FMXW_MAX_LEVELS * FMXW_GLDS_SB * 16u : 1u];                                    \
   __shared__ uint64_t lds_k[(GLDS) ? 256u : 1u];                                                                    \
+  const bool klds_ = (GLDS) && (w).max_character < 256u;      /* K[] of a byte alphabet fits; larger ones stay global */ \
   if (GLDS) {                                                                                                      \
     for (uint32_t l_ = 0; l_ < (w).nlevels; l_++)                                                                  \
       for (uint32_t t_ = threadIdx.x; t_ < (w).nsb * 16u; t_ += blockDim.x)                                        \
         lds_gb[l_ * FMXW_GLDS_SB * 16u + t_] = (w).lv[l_].base[t_];                                                 \
-    for (uint32_t t_ = threadIdx.x; t_ <= (w).max_character; t_ += blockDim.x) lds_k[t_] = (w).K[t_];              \
+    if (klds_)                                                                                                     \
+      for (uint32_t t_ = threadIdx.x; t_ <= (w).max_character; t_ += blockDim.x) lds_k[t_] = (w).K[t_];            \
     __syncthreads();                                                                                               \
   }                                                                                                                \
   auto gbase = [&](uint32_t l_, uint64_t pos_, uint32_t code_) -> uint64_t {                                       \
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_export_l_kernel(FmxWideDev w,
     else return (w).lv[l_].base[(size_t)sb_ * 16u + code_];                                                         \
   };                                                                                                               \
   auto gk = [&](uint32_t c_) -> uint64_t {                                                                         \
-    if constexpr (GLDS) return lds_k[c_]; else return (w).K[c_];                                                     \
+    if constexpr (GLDS) { if (klds_) return lds_k[c_]; }                                                            \
+    return (w).K[c_];                                                                                              \
   }
 
 // this lane's piece of the record of position `pos` on level L
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint
 // interval ends are requested together, the next pattern symbol with the first level's
 template <bool GLDS>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
-    FmxWideDev w, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    FmxWideDev w, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
   FMXW_GBASES(w, GLDS);
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
       s = 0; e = 0; j = 0;
     }
-    uint32_t c = j ? pat[pbeg + j - 1] : 0u;        // for c in pattern.iter().rev()          wrapper.rs:108
+    uint32_t c = j ? fmx_load_sym(pat, w.sym_bytes, pbeg + j - 1) : 0u;        // for c in pattern.iter().rev()          wrapper.rs:108
     while (j) {
       if (c > w.max_character) {                    // reference: panic on cs[c]
         if (g == 0) atomicOr(w.status, 1u << FMX_ERR_SYMBOL_RANGE);
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
         const FmxWideLevel &L = w.lv[l];
         const uint32_t code = (c >> L.shift) & L.mask;
         const uint4 pa = fmxw_g_piece(L, ps, g), pb = fmxw_g_piece(L, pe, g);
-        if (l == 0 && j > 1) cn = pat[pbeg + j - 2];             // rides along with the record loads
+        if (l == 0 && j > 1) cn = fmx_load_sym(pat, w.sym_bytes, pbeg + j - 2);             // rides along with the record loads
         const uint64_t ba = gbase(l, ps, code), bb = gbase(l, pe, code);
         ps = ba + fmxw_g_rank32(L, pa, ps, code, g);
         pe = bb + fmxw_g_rank32(L, pb, pe, code, g);
@@ -585,9 +588,14 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
 }
 
 // Match::iter_chars_backward / iter_chars_forward for many rows (wrapper.rs:154-183): one group per row
+__device__ __forceinline__ void fmxw_store_sym(void *p, uint32_t sb, uint64_t i, uint32_t v) {
+  if (sb == 1) ((uint8_t *)p)[i] = (uint8_t)v;
+  else if (sb == 2) ((uint16_t *)p)[i] = (uint16_t)v;
+  else ((uint32_t *)p)[i] = v;
+}
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w, const uint64_t *__restrict__ rows,
                                                                      uint64_t nrows, uint32_t len, int forward,
-                                                                     uint8_t *__restrict__ out, uint64_t *__restrict__ out_len,
+                                                                     void *__restrict__ out, uint64_t *__restrict__ out_len,
                                                                      uint64_t *__restrict__ out_next) {
   FMXW_GBASES(w, false);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
@@ -599,7 +607,6 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w
     if (i >= w.n) {
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
     } else {
-      uint8_t *dst = out + q * (uint64_t)len;
       for (; t < len; t++) {
         uint32_t sym;
         if (forward) {
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w
           const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
           i = gk(sym) + r;
         }
-        if (g == 0) dst[t] = (uint8_t)sym;
+        if (g == 0) fmxw_store_sym(out, w.sym_bytes, q * (uint64_t)len + t, sym);
       }
       next = i;
     }
@@ -634,7 +641,7 @@ __device__ __forceinline__ uint32_t fmxw_g_lane_rank(const FmxWideLevel &L, uint
   for (uint32_t q = 0; q < pi; q++) cnt += __popc(fmx_piece_match<FMT>(L.rec[(size_t)r * 8u + q], code));
   return cnt + __popc(fmx_piece_match<FMT>(piece, code) & ((1u << bit) - 1u));
 }
-__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, uint8_t *__restrict__ out) {
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, void *__restrict__ out) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < w.n; i += stride) {
     uint64_t pos = i;
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev 
         pos = L.base[(size_t)(pos >> w.sb_shift) * 16u + code] +
               (f3 ? fmxw_g_lane_rank<3>(L, r, pi, bit, piece, code) : fmxw_g_lane_rank<4>(L, r, pi, bit, piece, code));
     }
-    out[i] = (uint8_t)sym;
+    fmxw_store_sym(out, w.sym_bytes, i, sym);
   }
 }
 
@@ -684,7 +691,7 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   fmxw_time_begin(idx, st);
   if (w.generic) {
 #define FMXW_GCNT(GLDS)                                                                                            \
-  hipLaunchKernelGGL(fmxw_g_count_kernel<GLDS>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, (const uint8_t *)d_pat, \
+  hipLaunchKernelGGL(fmxw_g_count_kernel<GLDS>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,             \
                      d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr)
     if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true); else FMXW_GCNT(false);
     fmxw_time_end(idx, st);
@@ -744,7 +751,7 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
+  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, d_out);
   else hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -756,7 +763,7 @@ int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t n
   const FmxWideDev w = fmxw_dev(idx);
   if (w.generic)
     hipLaunchKernelGGL(fmxw_g_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
-                       (uint8_t *)d_out, d_out_len, d_out_next);
+                       d_out, d_out_len, d_out_next);
   else
     hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
                        (uint8_t *)d_out, d_out_len, d_out_next);

@@ -64,7 +64,7 @@ def main():
         # which rows carry the samples (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER / the builder's choice), and for
         # eligible indexes sometimes the 64-bit engine (FMX_FLAG_FORCE_WIDE)
         sampling = [None, "text", "row"][int(rng.integers(0, 3))] if level is not None else None
-        engine64 = kind == "fm" and dtype == np.uint8 and n >= 2 and rng.random() < (0.4 if maxc <= 7 else 0.25)
+        engine64 = kind == "fm" and n >= 2 and rng.random() < (0.4 if (maxc <= 7 and dtype == np.uint8) else 0.25)
         if engine64:
             pair, kmer, sampling = False, False, None
         if kind == "fm":

@@ -16,25 +16,37 @@ from oracle import fm_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _dna(n, seed, sigma=4):
-    t = (W.splitmix64_np(seed, 0, n) % np.uint64(sigma)).astype(np.uint8) + 1
+def _dna(n, seed, sigma=4, dtype=np.uint8):
+    t = ((W.splitmix64_np(seed, 0, n) % np.uint64(sigma)) + np.uint64(1)).astype(dtype)
     t[-1] = 0
     return t
 
 
+def _ragged(npat, mmax, sigma, seed, dtype):
+    flat, off = W.ragged_patterns_np(npat, mmax, min(sigma, 255), seed)
+    if dtype == np.uint8:
+        return flat, off
+    wide = ((W.splitmix64_np(seed + 5, 0, max(len(flat), 1)) % np.uint64(sigma)) + np.uint64(1)).astype(dtype)[:len(flat)]
+    return wide, off
+
+
 # sigma <= 7: the one-level engine.  Larger byte alphabets: the generic wide engine -- one 4-bit level (12), levels of
 # 3 + 2 bits (20), 4 + 3 (100), 4 + 4 (255); (1 << 17) + 5 rows are 33 superblocks: bases from global memory
-@pytest.mark.parametrize("n,sigma,level", [(5000, 4, 2), (70001, 4, 2), ((1 << 17) + 5, 4, 3), (40000, 7, 1), (9000, 2, 0),
-                                           (30000, 12, 2), (50001, 20, 2), (60001, 100, 1), (45000, 255, 2),
-                                           ((1 << 17) + 5, 200, 3), (7000, 8, 0)])
-def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path):
-    t = _dna(n, 100 + n % 97, sigma)
+# u16 / u32 symbols: the same generic engine with up to seven levels (sigma = 70000: 4 + 4 + 3 + 3 + 3 bits), K[] in
+# global memory
+@pytest.mark.parametrize("n,sigma,level,dtype", [
+    (5000, 4, 2, np.uint8), (70001, 4, 2, np.uint8), ((1 << 17) + 5, 4, 3, np.uint8), (40000, 7, 1, np.uint8),
+    (9000, 2, 0, np.uint8), (30000, 12, 2, np.uint8), (50001, 20, 2, np.uint8), (60001, 100, 1, np.uint8),
+    (45000, 255, 2, np.uint8), ((1 << 17) + 5, 200, 3, np.uint8), (7000, 8, 0, np.uint8),
+    (30000, 1000, 2, np.uint16), (9000, 4, 1, np.uint16), (40001, 70000, 1, np.uint32), (20000, 300, 2, np.uint32)])
+def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, dtype, tmp_path):
+    t = _dna(n, 100 + n % 97, sigma, dtype)
     gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True)
     assert gi.is_wide() and gi.len() == n and gi.level() == level
-    oi = O.OracleIndex(t, sigma, level=level)
+    oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level)
     assert gi.verify_sa() == 0                                    # the 64-bit suffix sort
     # backward search: ragged patterns (empty ones included), substrings, early exit
-    flat, off = W.ragged_patterns_np(3000, 14, sigma, 7)
+    flat, off = _ragged(3000, 14, sigma, 7, dtype)
     gb = gi.search_many(flat=flat, off=off)
     os_, oe = oi.count_batch(flat, off)
     assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts == oe - os_).all()
@@ -44,7 +56,7 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path)
     assert (gb2.s == os2).all() and (gb2.e == oe2).all()
     # refinement from given ranges (wrapper.rs:99-124)
     se = np.stack([os2, oe2], axis=1).reshape(-1).copy()
-    one = np.full(len(os2), 2, dtype=np.uint8)
+    one = np.full(len(os2), 2, dtype=dtype)
     off1 = np.arange(len(os2) + 1, dtype=np.uint64)
     ref = gi.search_many(flat=one, off=off1, s0e0=se)
     rs, re_ = oi.count_batch(one, off1, s0e0=se)
@@ -58,7 +70,7 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path)
     want = oi.get_sa(rows).astype(np.uint64)
     assert (gpos == want).all()
     # the trait methods: every (c, i) with i == n included; every row
-    for c in range(0, sigma + 1):
+    for c in (range(0, sigma + 1) if sigma <= 255 else [0, 1, 2, sigma // 2, sigma - 1, sigma]):
         i = np.arange(n + 1, dtype=np.uint64)
         cc = np.full(n + 1, c, dtype=np.uint64)
         assert (gi.lf_map2(cc, i) == oi.lf_map2(cc, i)).all(), c
@@ -66,7 +78,7 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, tmp_path)
     assert (gi.get_sa(rows[:4000]) == want[:4000]).all()
     samp = gi.export_sa_samples()
     assert samp.dtype == np.uint64 and (samp == want[::1 << level]).all()
-    assert (gi.export_bwt() == oi.get_l(rows).astype(np.uint8)).all()
+    assert (gi.export_bwt() == oi.get_l(rows).astype(dtype)).all()
     # the extract path: get_f / fl_map on every row, iter_chars_backward / _forward (wrapper.rs:154-183)
     assert (gi.get_f(rows) == oi.get_f(rows)).all() and (gi.fl_map(rows) == oi.fl_map(rows)).all()
     some = rows[::97][:300]
@@ -117,12 +129,11 @@ def test_wide_engine_errors_and_refusals(tmp_path):
     out = np.zeros(8, dtype=np.uint32)
     assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
     gi.close()
-    # eligibility: FMX_KIND_FM over u8 symbols only
+    # eligibility: FMX_KIND_FM only
     bt = W.byte_text_np(5000, 3)
     h = C.c_void_p()
     assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_RLFM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
-    with pytest.raises(F.Error):
-        F.FMIndexWithLocate(F.Text(W.byte_text_np(5000, 3).astype(np.uint16)), 2, force_wide=True)
+    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_MULTI, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
     # a count-only wide index has no locate
     ci = F.FMIndex(F.Text.with_max_character(t, 4), force_wide=True)
     assert ci.is_wide() and ci.search(bytes([1, 2])).count() == gi_count(t, [1, 2])

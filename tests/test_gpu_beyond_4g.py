@@ -33,12 +33,22 @@ def _run(alphabet="dna"):
     torch.cuda.empty_cache()
     dev = torch.device("cuda", 0)
     lib = L.lib()
-    dna = alphabet == "dna"
-    # DNA: the one-level engine; bytes: the generic wide engine (two 4-bit wavelet levels)
-    m, level, sigma = (30, 2, 4) if dna else (10, 3, 255)
-    text = W.dna_text_torch(N, 17, dev) if dna else W.byte_text_torch(N, 17, dev)
+    dna, u16 = alphabet == "dna", alphabet == "u16"
+    # DNA: the one-level engine; bytes: the generic wide engine (two 4-bit wavelet levels); u16 (run by hand, not a
+    # test: `python tests/test_gpu_beyond_4g.py u16`): 2-byte symbols, sigma = 1000 (4 + 3 + 3 bits), without the
+    # oracle -- its u32 copy of the 2^32 symbols plus the exports would need ~50 GB of host memory
+    m, level, sigma = (30, 2, 4) if dna else (6, 3, 1000) if u16 else (10, 3, 255)
+    if u16:
+        text = torch.empty(N, dtype=torch.int16, device=dev)       # values 1..1000: the bit patterns of u16
+        for a in range(0, N, 1 << 26):
+            k_ = min(1 << 26, N - a)
+            text[a:a + k_] = (W.umod_torch(W.splitmix64_torch(17, a, k_, dev), 1000) + 1).to(torch.int16)
+        text[N - 1] = 0
+    else:
+        text = W.dna_text_torch(N, 17, dev) if dna else W.byte_text_torch(N, 17, dev)
     t0 = time.time()
-    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, sigma, level=level, keep_sa=True)
+    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, sigma, level=level, keep_sa=True,
+                                                 sym_bytes=2 if u16 else 1)
     build_s = time.time() - t0
     h = index.handle()
     assert index.len() == N and index.is_wide() and index.level() == level
@@ -53,6 +63,8 @@ def _run(alphabet="dna"):
         hi = win[:-8] == 4
         for j in range(1, 7):
             hi &= win[j:j - 8] == 4
+    elif u16:
+        hi = (win[:-8] == 1000) & (win[1:-7] >= 800)    # the top 201 / 1000^2 of the rows
     else:
         hi = (win[:-8] == 255) & (win[1:-7] >= 245)
     src_b = torch.nonzero(hi).flatten()[:1 << 13]
@@ -96,6 +108,12 @@ def _run(alphabet="dna"):
     assert pos_hi >= int(src_c.numel())
     # ---- the oracle, from the exported L column and the exported 64-bit samples ----
     t0 = time.time()
+    if u16:
+        return {"kind": "fm", "alphabet": alphabet, "max_character": sigma, "sym_bytes": 2, "n": N, "level": level,
+                "patterns": npat, "pattern_len": m, "hits": total, "intervals_with_e_beyond_2^32": rows_hi,
+                "positions_beyond_2^32": pos_hi, "verify_sa_violations": 0, "oracle": "not run (host memory)",
+                "build_ms": round(float(lib.fmx_build_ms(h)), 1), "verify_sa_s": round(verify_s, 2),
+                "index_bytes": index.heap_size(), "wide": index.is_wide()}
     samples = index.export_sa_samples()
     assert samples.dtype == np.uint64 and int(samples.max()) >= (1 << 32)
     oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), sigma, samples=samples, level=level)

@@ -16,6 +16,7 @@ prints ONE JSON line.
 import argparse
 import csv
 import ctypes as C
+import datetime
 import glob
 import json
 import os
@@ -49,7 +50,12 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=30, help="text length 2^k incl. terminator")
-    ap.add_argument("--npat", type=int, default=1 << 20, help="patterns per GPU")
+    ap.add_argument("--npat", type=int, default=1 << 20, help="patterns per GPU (weak scaling, the default)")
+    ap.add_argument("--total-patterns", type=int, default=None,
+                    help="strong scaling (BASELINE config 5): a FIXED global set of this many patterns (seed 7), "
+                         "rank r searching the contiguous shard [ceil(T r / G), ceil(T (r+1) / G)); --npat is ignored.  "
+                         "`--gpus G --total-patterns 8388608` is config 5; at G = 1 the step still goes through a 1-rank "
+                         "RCCL communicator so that every point of the curve includes the gather")
     ap.add_argument("--plen", type=int, default=32)
     ap.add_argument("--level", type=int, default=2, help="SA sampling level for the locate legs")
     ap.add_argument("--workload", default="dna", choices=["dna", "bytes-fm", "bytes-rlfm", "rep-fm", "rep-rlfm"],
@@ -77,6 +83,8 @@ def parse_args(argv=None):
                     help="with --gpus 1: still open the process group (a 1-rank RCCL communicator on this GPU) and "
                          "drive the N>1 step -- pipelined all-gather of the counts, counts-then-positions gather of "
                          "locate -- through it; the line is the config-5 line at one rank")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="default N=1 run: skip the `config5_g1` object (the 8 388 608-pattern set of config 5 on one GPU)")
     ap.add_argument("--no-rccl-check", action="store_true",
                     help="default N=1 run: skip the `rccl_1rank` object (the config-5 step through a 1-rank RCCL "
                          "communicator, after the headline measurement)")
@@ -106,6 +114,22 @@ class Workload:
         self.Lbits = 3 if self.dna else 8
         self.m = plen if plen is not None else (args.plen if self.dna else (16 if args.plen == 32 else args.plen))
         self.npat = npat if npat is not None else args.npat
+        # patterns are a function of (seed, GLOBAL pattern index) alone, so any sharding of the same global set
+        # searches the same patterns: weak scaling = world x npat patterns, rank r owns [r npat, (r+1) npat);
+        # strong scaling (--total-patterns T) = T patterns, rank r owns sharding.shard_range(T, r, world)
+        self.total_patterns = self.npat * world
+        self.pat_lo = rank * self.npat
+        self.strong = bool(getattr(args, "total_patterns", None)) and npat is None
+        if self.strong:
+            from fm_index_amd import sharding
+            self.total_patterns = args.total_patterns
+            self.pat_lo, hi = sharding.shard_range(self.total_patterns, rank, world)
+            self.npat = hi - self.pat_lo
+            self.shard_sizes = [sharding.shard_range(self.total_patterns, r, world)[1] -
+                                sharding.shard_range(self.total_patterns, r, world)[0] for r in range(world)]
+        else:
+            self.shard_sizes = [self.npat] * world
+        self.npat_pad = max(self.shard_sizes)        # every rank's slot in the gathered buffer
         t0 = time.time()
         if self.dna:
             self.text = W.dna_text_torch(self.n, 1, dev)
@@ -124,10 +148,11 @@ class Workload:
         self.h = self.index.handle()
         self.build_ms = self.lib.fmx_build_ms(self.h)
         # global pattern set = world * npat substrings of the text; this rank owns a contiguous shard
-        seed = (3 if world == 1 else 7) if self.dna else 6
+        seed = (3 if (world == 1 and not self.strong) else 7) if self.dna else 6
         if args.pattern_seed is not None:
             seed = args.pattern_seed
-        z = W.splitmix64_torch(seed, rank * self.npat, self.npat, dev)
+        self.pattern_seed = seed
+        z = W.splitmix64_torch(seed, self.pat_lo, self.npat, dev)
         self.src_pos = W.umod_torch(z, self.n - 1 - self.m)
         idx2d = self.src_pos[:, None] + torch.arange(self.m, dtype=torch.int64, device=dev)[None, :]
         self.pat = self.text[idx2d].reshape(-1).contiguous()
@@ -182,6 +207,10 @@ class Workload:
 
     def describe(self, world):
         if self.dna:
+            if self.strong:
+                return ("config5: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d substring patterns (seed %d) in "
+                        "contiguous shards over %d GPU(s), index replicated, counts all-gathered every step"
+                        % (self.n.bit_length() - 1, self.total_patterns, self.m, self.pattern_seed, world))
             w = "config2: FMIndex count, n=2^%d sigma=4 DNA text (L=3), %d x len-%d substring patterns per GPU"
         elif self.name.startswith("rep"):
             w = "config4b (" + self.name + "): n=2^%d repetitive byte text (L=8), %d x len-%d substring patterns per GPU"
@@ -191,6 +220,9 @@ class Workload:
         return w % (self.n.bit_length() - 1, self.npat, self.m)
 
     def close(self):
+        if getattr(self, "_oracle", None) is not None:
+            self._oracle[0].close()
+            self._oracle = None
         self.index.close()
 
 
@@ -463,7 +495,7 @@ def pmc_child(args):
         wr.close()
 
 
-def run_pmc_passes(args):
+def run_pmc_passes(args, npat=None, count_only=False):
     """returns {leg: {"bytes", "fetch_kb_raw", "write_kb", "kernel", "source"}} or {} when rocprofv3 is
     missing / fails.  FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), kernel-trace only."""
     exe = shutil.which("rocprofv3")
@@ -476,13 +508,15 @@ def run_pmc_passes(args):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--log2n", str(args.log2n),
-             "--npat", str(args.npat), "--plen", str(args.plen), "--level", str(args.level)]
-    if args.no_rlfm:
+             "--npat", str(npat or args.npat), "--plen", str(args.plen), "--level", str(args.level)]
+    if args.no_rlfm or count_only:
         child.append("--no-rlfm")
-    if args.no_locate:
+    if args.no_locate or count_only:
         child.append("--no-locate")
-    if args.no_3b:
+    if args.no_3b or count_only:
         child.append("--no-3b")
+    if count_only:
+        child += ["--pattern-seed", "7"]
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
@@ -595,13 +629,7 @@ def cpu_baseline(wl, args, kind):
     decomposition that fills them, so their pages are spread over the sockets like the threads that probe them
     at random."""
     import numpy as np
-    from oracle import fm_oracle as O
-    t0 = time.time()
-    bwt = wl.index.export_bwt()
-    cs = wl.index.export_cs()
-    oi = O.OracleIndex.from_bwt(bwt, cs, wl.maxc, native=True, kind=kind)
-    del bwt
-    t_ob = time.time() - t0
+    oi, t_ob = wl_oracle(wl, kind)
     host = host_cpu()
     cores = host["effective_cpus"]
     oi.set_thread_spread(True)
@@ -616,7 +644,7 @@ def cpu_baseline(wl, args, kind):
         so, eo = oi.count_batch(pat_h[:k * m], offk, nthreads=threads)
         return time.perf_counter() - t, so, eo
     budget = args.cpu_seconds
-    k0 = 1 << 14
+    k0 = min(1 << 14, wl.npat)
     t_probe, so, eo = cpu_run(k0, cores)
     k = int(min(wl.npat, max(k0, k0 * budget / 5 / max(t_probe, 1e-6))))
     t_all, so, eo = cpu_run(k, cores)
@@ -647,7 +675,6 @@ def cpu_baseline(wl, args, kind):
     best = max(sweep, key=lambda p: p["value"])
     team = oi.team_size(cores)
     oi.set_thread_spread(False)
-    oi.close()
     return {"value": max(value, best["value"]), "unit": "pattern-chars/s", "cores": cores, "threads_used": team or cores,
             "kind": "port", "cpu_model": host["cpu_model"], "sockets": host["sockets"],
             "physical_cores": host["physical_cores"], "threads_per_core": host["threads_per_core"],
@@ -662,6 +689,58 @@ def cpu_baseline(wl, args, kind):
             "parallel_efficiency_note": "best rate / (single-thread rate x effective CPUs = min(affinity, cgroup quota, "
                                         "physical cores))",
             "thread_sweep": sweep, "oracle_build_s": round(t_ob, 1)}
+
+
+# --------------------------------------------------------------------------------------------
+# config 5: one hash for "multi-GPU output identical to 1-GPU output"
+# --------------------------------------------------------------------------------------------
+def counts_sha256(counts):
+    """sha256 over the per-pattern counts of the whole global pattern set, input order, as little-endian int64"""
+    import hashlib
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(counts).astype("<i8", copy=False))
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def ranges_sha256(s, e):
+    """sha256 over the (s, e) pairs of the whole global pattern set, input order: [s_0, e_0, s_1, e_1, ...] as
+    little-endian int64 -- the search ranges themselves (wrapper.rs:126-129), not only their widths"""
+    import hashlib
+    import numpy as np
+    a = np.empty((len(s), 2), dtype="<i8")
+    a[:, 0] = np.asarray(s).astype("<i8", copy=False)
+    a[:, 1] = np.asarray(e).astype("<i8", copy=False)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def golden_key(workload, log2n, seed, total, m):
+    return "%s:n=2^%d:seed=%d:patterns=%d:len=%d" % (workload, log2n, seed, total, m)
+
+
+def golden_counts_sha(wl, args, total=None, seed=None):
+    """the committed hash of this global pattern set's counts (tests/golden/config5_counts.json: computed by the CPU
+    oracle over ALL patterns, tests/golden/make_config5_golden.py), or None when this set has no entry"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "config5_counts.json")) as f:
+            g = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = g.get("entries", {}).get(golden_key(wl.name, args.log2n, wl.pattern_seed if seed is None else seed,
+                                               wl.total_patterns if total is None else total, wl.m))
+    return (ent["counts_sha256"], ent.get("ranges_sha256")) if ent else None
+
+
+def wl_oracle(wl, kind):
+    """the CPU oracle of this workload's index (built once per workload from the index's exported BWT / C array:
+    test infrastructure, used only by the cpu_baseline leg and the oracle sample of config5_g1) -> (index, build s)"""
+    if getattr(wl, "_oracle", None) is None:
+        from oracle import fm_oracle as O
+        t0 = time.time()
+        bwt = wl.index.export_bwt()
+        cs = wl.index.export_cs()
+        wl._oracle = (O.OracleIndex.from_bwt(bwt, cs, wl.maxc, native=True, kind=kind), time.time() - t0)
+        del bwt
+    return wl._oracle
 
 
 # --------------------------------------------------------------------------------------------
@@ -682,9 +761,17 @@ def main():
     # script.  Started BEFORE this process touches the GPU (no torch import yet): the children are
     # then spawned from a process that holds no device state.
     pmc = None
-    if world == 1 and args.workload == "dna" and not args.no_pmc and not args.force_dist:
+    rank = int(os.environ.get("RANK", "0"))
+    dist_line = world > 1 or args.force_dist or bool(args.total_patterns)
+    if rank == 0 and args.workload == "dna" and not args.no_pmc and args.dist_backend != "gloo":
         try:
-            pmc = run_pmc_passes(args)
+            if not dist_line:
+                pmc = run_pmc_passes(args)
+            else:
+                # the config-5 line: counters of RANK 0's count launch (its shard's shape) on rank 0's GPU, collected
+                # now -- the other ranks build their indexes meanwhile and wait for rank 0 in the rendezvous
+                shard0 = (args.total_patterns + world - 1) // world if args.total_patterns else args.npat
+                pmc = run_pmc_passes(args, npat=shard0, count_only=True)
         except Exception as ex:  # noqa: BLE001 -- never lose the line to the counter passes
             pmc = ({}, repr(ex))
     run(args, world, pmc)
@@ -702,7 +789,10 @@ def run(args, world, pmc=None):
     if rank != 0:            # the ranks share one stdout: only rank 0 may write to it (libraries' banners included)
         os.dup2(2, 1)
     gloo = args.dist_backend == "gloo"
-    use_dist = world > 1 or args.force_dist      # the N>1 step, also on a 1-rank communicator when forced
+    strong = bool(args.total_patterns)
+    # the N>1 step, also on a 1-rank communicator when forced -- and at the G = 1 point of the strong-scaling curve,
+    # so that every point of config 5 includes the gather ("throughput at G = 1,2,4,8 incl. gather")
+    use_dist = world > 1 or args.force_dist or strong
     if use_dist:
         dist = open_process_group(torch, local, rank, world, gloo)
         if gloo:
@@ -716,11 +806,12 @@ def run(args, world, pmc=None):
     F.FMIndex(F.Text.with_max_character(W.dna_text_np(4096, 9), 4), device=local).close()
     wl = Workload(args.workload, args, dev, local, rank, world)
     lib, npat, m, n = wl.lib, wl.npat, wl.m, wl.n
-    total_pat = npat * world
+    total_pat = wl.total_patterns
     stream = wl.stream
 
     # ---- headline: count (+ gather of every rank's counts for N > 1, config 5) ----
-    pipe = sharding.CountGatherPipeline(npat, world, n, dev, backend="gloo" if gloo else "nccl",
+    # every rank's slot in the gathered buffer is npat_pad = the largest shard (ragged shards: T not a multiple of G)
+    pipe = sharding.CountGatherPipeline(wl.npat_pad, world, n, dev, backend="gloo" if gloo else "nccl",
                                         pipelined=not os.environ.get("FMX_BENCH_SYNC_GATHER"),
                                         force_collective=use_dist)
 
@@ -759,18 +850,31 @@ def run(args, world, pmc=None):
     pipe.drain()
     torch.cuda.synchronize()
     if use_dist:
-        # gathered counts: this rank's shard sits at [rank*npat, (rank+1)*npat) and equals its own
-        mine = last[rank * npat:(rank + 1) * npat].to(torch.int64).to(dev)
+        # gathered counts: rank r's shard sits at [r * npat_pad, r * npat_pad + shard_sizes[r]); this rank's
+        # slot must equal its own counts, and the compacted buffer IS the one-GPU output (input order)
+        mine = last[rank * wl.npat_pad:rank * wl.npat_pad + npat].to(torch.int64).to(dev)
         assert bool((mine == wl.d_c).all()), "gathered counts differ from this rank's"
-        if args.dump_counts and rank == 0:
-            np.save(args.dump_counts, last.cpu().numpy().astype(np.int64))
-    elif args.dump_counts:
-        np.save(args.dump_counts, wl.d_c.cpu().numpy())
+        allc = sharding.compact_padded(last, wl.shard_sizes, wl.npat_pad).cpu().numpy().astype(np.int64)
+        # the ranges themselves, gathered ONCE for validation (the timed step gathers the counts only: SURVEY 8e)
+        se = torch.zeros(wl.npat_pad, 2, dtype=torch.int64, device="cpu" if gloo else dev)
+        se[:npat, 0], se[:npat, 1] = wl.d_s, wl.d_e
+        allse = torch.empty(wl.npat_pad * world, 2, dtype=torch.int64, device=se.device)
+        dist.all_gather_into_tensor(allse, se)
+        allse = sharding.compact_padded(allse, wl.shard_sizes, wl.npat_pad).cpu().numpy()
+        alls, alle = allse[:, 0], allse[:, 1]
+        del se, allse
+    else:
+        allc, alls, alle = wl.d_c.cpu().numpy(), wl.d_s.cpu().numpy(), wl.d_e.cpu().numpy()
+    assert allc.shape == (total_pat,) and bool((alle - alls == allc).all())
+    counts_sha, ranges_sha = counts_sha256(allc), ranges_sha256(alls, alle)
+    del alls, alle
+    if args.dump_counts and rank == 0:
+        np.save(args.dump_counts, allc)
     assert steps_exec == npat * m, (steps_exec, npat * m)   # substrings: every step executes
     assert bool((wl.d_c >= 1).all()), "a substring of the text must occur at least once"
 
     chars_per_step_rank = npat * m
-    value = chars_per_step_rank * world * args.steps / dt
+    value = total_pat * m * args.steps / dt
     # dominant kernel's average launch duration: the event bracket of the timed region at N=1
     # (launches back to back on one stream), the library's per-launch events at N>1
     avg_kernel_ms = ev_ms / args.steps if not use_dist else kernel_ms_single
@@ -790,18 +894,31 @@ def run(args, world, pmc=None):
         "metric": "pattern-chars/sec backward search (count) + locate hits/sec, 1 GB text",
         "value": value, "unit": "pattern-chars/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": wl.describe(world), "text_len": n, "patterns_per_gpu": npat, "pattern_len": m,
+                   "total_patterns": total_pat, "pattern_seed": wl.pattern_seed,
                    "parallelism": "patterns sharded x%d, index replicated" % world,
                    "index_bytes": wl.index.heap_size(), "build_ms": round(wl.build_ms, 1),
                    "textgen_s": round(wl.textgen_s, 2)},
         "roofline": roofline,
+        # sha256 over the int64 little-endian counts of ALL patterns of the global set in input order: equal at
+        # every G for the same global set ("multi-GPU output identical to 1-GPU output")
+        "counts_sha256": counts_sha,
+        # ... and over the (s, e) pairs, gathered once outside the timed region
+        "ranges_sha256": ranges_sha,
     }
+    gold = golden_counts_sha(wl, args)
+    if gold is not None:
+        # tests/golden/config5_counts.json: made by the CPU oracle over ALL patterns of this set
+        out["matches_golden"] = {"counts_sha256": gold[0] == counts_sha, "ranges_sha256": gold[1] == ranges_sha,
+                                 "source": "tests/golden/config5_counts.json (CPU oracle over all patterns)"}
+        assert gold[0] == counts_sha and gold[1] in (None, ranges_sha), \
+            "results on the config-5 pattern set differ from tests/golden/config5_counts.json"
     if use_dist:
         dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, gloo, dt_rank, ev_ms,
                     kernel_ms_single, step)
 
-    single = world == 1 and rank == 0 and not use_dist
+    single = world == 1 and rank == 0 and not use_dist          # the default line: every BASELINE config
     # ---- config 2b: uniform random patterns -> the early exit of wrapper.rs:111-113 ----
     rflat = None
     if wl.dna and single and not args.no_early_exit:
@@ -855,11 +972,20 @@ def run(args, world, pmc=None):
             out["value_incl_d2h"] = None
             out["incl_d2h"] = {"error": repr(ex)}
 
-    # ---- CPU baseline of the headline ----
-    if single and not args.no_cpu_baseline:
-        wl.count()
-        torch.cuda.synchronize()
-        out["cpu_baseline"] = cpu_baseline(wl, args, "rlfm" if wl.rlfm else "fm")
+    # ---- CPU baseline of the headline: rank 0 only, after the timed regions.  At N > 1 the other ranks wait in a
+    # gloo barrier (a socket wait): an RCCL barrier would have their host threads spin on a stream and take CPU time
+    # from the very cores the baseline is measured on ----
+    if not args.no_cpu_baseline and (single or use_dist):
+        side = None
+        if use_dist and world > 1:
+            side = dist.group.WORLD if gloo else dist.new_group(backend="gloo")
+            dist.barrier(group=side)
+        if rank == 0:
+            wl.count()
+            torch.cuda.synchronize()
+            out["cpu_baseline"] = cpu_baseline(wl, args, "rlfm" if wl.rlfm else "fm")
+        if side is not None:
+            dist.barrier(group=side)
 
     # ---- config 4 (RLFMIndex, sigma = 255) as its own object ----
     wr = None
@@ -895,6 +1021,11 @@ def run(args, world, pmc=None):
         sys.stdout.flush()
 
 
+# rank 0 reaches the rendezvous after its counter passes (two rocprofv3 runs over a child that builds the index),
+# and is waited for in a gloo barrier while it measures the CPU baseline
+RENDEZVOUS_TIMEOUT = datetime.timedelta(minutes=30)
+
+
 def open_process_group(torch, local, rank, world, gloo):
     """one process per GPU: backend "nccl" IS RCCL on ROCm (communicator bound to this rank's device);
     "gloo" is the rehearsal in which all ranks share cuda:0 and gather through host memory"""
@@ -913,10 +1044,11 @@ def open_process_group(torch, local, rank, world, gloo):
     try:
         if gloo:
             torch.cuda.set_device(0)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=RENDEZVOUS_TIMEOUT)
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=RENDEZVOUS_TIMEOUT)
         flush_c_stdio()
     finally:
         os.dup2(saved, 1)
@@ -988,13 +1120,14 @@ def dist_report(out, torch, dist, sharding, pipe, wl, args, world, rank, local, 
                        for r, v in enumerate(allr)]
     out["gather"] = {"backend": "gloo (rehearsal through host memory)" if gloo else "nccl (RCCL)",
                      "counts_wire_dtype": str(pipe.wire).replace("torch.", ""),
-                     "bytes_per_rank_per_step": npat * (4 if pipe.wire == torch.int32 else 8),
+                     "bytes_per_rank_per_step": wl.npat_pad * (4 if pipe.wire == torch.int32 else 8),
+                     "shard_sizes": wl.shard_sizes if len(set(wl.shard_sizes)) > 1 else wl.shard_sizes[0],
                      "pipelined": pipe.nbuf > 1, "trace": tr}
 
 
 def traced_steps(torch, sharding, wl, world, steps=8):
     """event timeline of a few steps of the count + gather pipeline (sharding.CountGatherPipeline.trace_report)"""
-    tp = sharding.CountGatherPipeline(wl.npat, world, wl.n, wl.dev, backend="nccl", force_collective=True, trace=True)
+    tp = sharding.CountGatherPipeline(wl.npat_pad, world, wl.n, wl.dev, backend="nccl", force_collective=True, trace=True)
     for _ in range(steps):
         tp.step(lambda out64: wl.count(out_cnt=out64))
     tp.drain()
@@ -1043,8 +1176,96 @@ def rccl_1rank_leg(out, wl, args, dev, local):
                 "positions gathered over RCCL differ"
             o["positions_gathered"] = wl.total_hits
         out["rccl_1rank"] = o
+        # ---- BASELINE config 5 at G = 1: the whole 8 M-pattern set on this GPU, through the same communicator ----
+        if wl.dna and not args.no_config5:
+            try:
+                config5_g1_leg(out, wl, args, dev)
+            except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
+                out["config5_g1"] = {"error": repr(ex)}
     finally:
         dist.destroy_process_group()
+
+
+CONFIG5_PATTERNS = 8 << 20          # BASELINE.json configs[4]: 8M length-32 patterns; SURVEY 8d: seed 7
+CONFIG5_SEED = 7
+
+
+def config5_g1_leg(out, wl, args, dev):
+    """BASELINE config 5 at one GPU: ALL 8 388 608 length-32 substring patterns (seed 7; the set `--gpus G
+    --total-patterns 8388608` shards over G ranks, and the set the default `--gpus 8` weak run searches) in one batch
+    on this GPU, the int32 counts all-gathered through the 1-rank RCCL communicator every step.  counts_sha256 is the
+    hash every G must reproduce; (s, e) of a 2^15-pattern sample (every 256th pattern) is compared with the CPU oracle."""
+    import numpy as np
+    import torch
+    from fm_index_amd import sharding
+    from fm_index_amd import workload as W
+    lib, n, m = wl.lib, wl.n, wl.m
+    T = CONFIG5_PATTERNS if args.log2n >= 30 else max(args.npat * 8, 1 << 15)
+    pat = torch.empty(T * m, dtype=torch.uint8, device=dev)
+    ar = torch.arange(m, dtype=torch.int64, device=dev)[None, :]
+    chunk = 1 << 20
+    for lo in range(0, T, chunk):                      # in chunks: the (patterns x m) int64 index tensor is 2 GB at once
+        k = min(chunk, T - lo)
+        src = W.umod_torch(W.splitmix64_torch(CONFIG5_SEED, lo, k, dev), n - 1 - m)
+        pat[lo * m:(lo + k) * m] = wl.text[src[:, None] + ar].reshape(-1)
+    del src
+    off = (torch.arange(T + 1, dtype=torch.int64, device=dev) * m).contiguous()
+    s = torch.empty(T, dtype=torch.int64, device=dev)
+    e = torch.empty(T, dtype=torch.int64, device=dev)
+    pipe = sharding.CountGatherPipeline(T, 1, n, dev, backend="nccl", force_collective=True)
+
+    def launch(out64):
+        rc = lib.fmx_count_batch_dev(wl.h, C.c_void_p(pat.data_ptr()), C.c_void_p(off.data_ptr()), T, None,
+                                     C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()), C.c_void_p(out64.data_ptr()), wl.sp)
+        if rc != 0:
+            raise RuntimeError(lib.fmx_last_error().decode())
+    for _ in range(max(2, args.warmup // 2)):
+        pipe.step(launch)
+    pipe.drain()
+    torch.cuda.synchronize()
+    steps = max(5, args.steps // 2)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(wl.stream)
+    for _ in range(steps):
+        g = pipe.step(launch)
+    pipe.drain()
+    ev1.record(wl.stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert lib.fmx_stream_status(wl.h) == 0
+    lib.fmx_set_timing(wl.h, 1)
+    launch(pipe.local64[0])
+    torch.cuda.synchronize()
+    kms, executed = lib.fmx_last_kernel_ms(wl.h), int(lib.fmx_last_steps(wl.h))
+    lib.fmx_set_timing(wl.h, 0)
+    assert executed == T * m, (executed, T * m)
+    cnt = g.to(torch.int64)
+    assert bool((cnt == e - s).all()) and bool((cnt >= 1).all())
+    sha = counts_sha256(cnt.cpu().numpy())
+    rsha = ranges_sha256(s.cpu().numpy(), e.cpu().numpy())
+    # the weak run's rank-0 shard is the first 2^20 patterns of this set
+    o = {"workload": "config5 at G=1: %d x len-%d substring patterns (seed %d) in one batch, counts all-gathered (int32) "
+                     "through a 1-rank RCCL communicator every step" % (T, m, CONFIG5_SEED),
+         "total_patterns": T, "value": T * m * steps / dt, "unit": "pattern-chars/s", "steps": steps,
+         "ms_per_step": dt / steps * 1e3, "stream_ms_per_step": ev0.elapsed_time(ev1) / steps, "kernel_ms": round(kms, 4),
+         "executed_steps": executed, "vs_headline_value": round(T * m * steps / dt / out["value"], 4),
+         "counts_sha256": sha, "ranges_sha256": rsha, "counts_sum": int(cnt.sum().item())}
+    gold = golden_counts_sha(wl, args, total=T, seed=CONFIG5_SEED)
+    if gold is not None:
+        o["matches_golden"] = {"counts_sha256": gold[0] == sha, "ranges_sha256": gold[1] == rsha,
+                               "source": "tests/golden/config5_counts.json (CPU oracle over all patterns)"}
+        assert gold[0] == sha and gold[1] in (None, rsha), "config-5 results differ from tests/golden/config5_counts.json"
+    if not args.no_cpu_baseline:
+        oi, _ = wl_oracle(wl, "fm")
+        k = 1 << 15
+        idx = torch.arange(0, T, T // k, device=dev)[:k]
+        ph = pat.view(T, m)[idx].reshape(-1).cpu().numpy()
+        so, eo = oi.count_batch(ph, np.arange(k + 1, dtype=np.uint64) * np.uint64(m), nthreads=host_cpu()["effective_cpus"])
+        ok = (so == s[idx].cpu().numpy().view(np.uint64)).all() and (eo == e[idx].cpu().numpy().view(np.uint64)).all()
+        assert ok, "config5_g1: GPU (s, e) != oracle on the sample"
+        o["oracle_sample"] = {"patterns": k, "stride": T // k, "identical_s_e": True}
+    out["config5_g1"] = o
 
 
 def apply_pmc(out, pmc, cal):
@@ -1140,7 +1361,7 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     plan = pipe_pos = None
     if use_dist:
         cnt = (wl.d_e - wl.d_s)
-        plan = sharding.PositionGatherPlan(cnt.cpu() if gloo else cnt, npat * world)
+        plan = sharding.PositionGatherPlan(cnt.cpu() if gloo else cnt, wl.total_patterns)
         pipe_pos = sharding.CountGatherPipeline(plan.mx, world, wl.n, wl.dev, backend="gloo" if gloo else "nccl",
                                                 force_collective=True)
 

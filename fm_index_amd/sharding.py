@@ -82,6 +82,15 @@ class PositionGatherPlan:
         return torch.cat([self.buf[r * self.mx:r * self.mx + self.totals[r]] for r in range(self.world)])
 
 
+def compact_padded(buf, sizes, slot):
+    """rank r's `sizes[r]` valid entries sit at buf[r * slot : r * slot + sizes[r]] (the layout of an
+    all_gather_into_tensor of equal, padded slots); returns them concatenated = input order.  Equal full slots
+    need no copy."""
+    if all(sz == slot for sz in sizes):
+        return buf[:slot * len(sizes)]
+    return torch.cat([buf[r * slot:r * slot + sz] for r, sz in enumerate(sizes)])
+
+
 def gather_positions(local_counts, local_pos, nitems, group=None):
     """Variable-length gather of locate output, one shot.
 
@@ -178,7 +187,8 @@ class CountGatherPipeline:
         # search -- on the one GPU a test box has)
         self.collective = world > 1 or force_collective
         self.nbuf = 2 if (pipelined and self.collective) else 1
-        self.local64 = [torch.empty(npat_local, dtype=torch.int64, device=self.device) for _ in range(self.nbuf)]
+        # zeros: with ragged shards (npat_local = the largest shard) a smaller rank never writes its slot's tail
+        self.local64 = [torch.zeros(npat_local, dtype=torch.int64, device=self.device) for _ in range(self.nbuf)]
         gdev = torch.device("cpu") if self.host else self.device
         self.local_w = [torch.empty(npat_local, dtype=self.wire, device=gdev) for _ in range(self.nbuf)]
         self.gathered = [torch.empty(npat_local * world, dtype=self.wire, device=gdev)

@@ -80,3 +80,58 @@ def test_one_rank_rccl_communicator_carries_the_gathers(tmp_path):
     r1 = plain["rccl_1rank"]
     assert r1.get("backend") == "nccl" and r1["ranks"] == 1 and r1["value"] > 0, r1
     assert r1["positions_gathered"] == plain["locate"]["hits"]
+
+
+def test_strong_scaling_two_ranks_hash_like_one_process(tmp_path):
+    """config 5 (`--total-patterns`): a FIXED global pattern set (seed 7) in contiguous shards.
+    Two ranks (gloo rehearsal on cuda:0, the real HIP search per rank; 8193 patterns -> ragged shards 4097 + 4096)
+    must produce the counts_sha256 of the one-rank run -- which itself goes through a 1-rank RCCL communicator, like
+    every point of the strong-scaling curve -- and the N > 1 line must carry cpu_baseline and say it scales strongly."""
+    strong = ["--total-patterns", "8193", "--cpu-seconds", "1"]
+    common = [a for a in COMMON if a not in ("--no-cpu-baseline", "--pattern-seed", "7")]
+    def run(extra, tag):
+        dump = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + strong + extra +
+                           ["--dump-counts", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+        return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]), np.load(dump)
+    two, c2 = run(["--gpus", "2", "--dist-backend", "gloo"], "two")
+    one, c1 = run(["--gpus", "1"], "one")
+    assert two["scaling"] == one["scaling"] == "strong"
+    assert two["config"]["total_patterns"] == one["config"]["total_patterns"] == 8193
+    assert two["config"]["pattern_seed"] == one["config"]["pattern_seed"] == 7
+    assert two["config"]["patterns_per_gpu"] == 4097 and two["gather"]["shard_sizes"] == [4097, 4096]
+    assert one["dist_backend"] == "nccl" and one["rccl_ranks"] == 1          # the G = 1 point includes the gather
+    assert c1.shape == c2.shape == (8193,) and (c1 == c2).all()
+    assert two["ranges_sha256"] == one["ranges_sha256"]
+    assert two["counts_sha256"] == one["counts_sha256"] and len(one["counts_sha256"]) == 64
+    import hashlib
+    assert one["counts_sha256"] == hashlib.sha256(c1.astype("<i8").tobytes()).hexdigest()
+    for line in (one, two):                                                   # the N > 1 line is complete
+        cb = line["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+        assert line["roofline"]["avg_kernel_ms"] > 0
+    assert two["locate"]["hits"] == one["locate"]["hits"] == int(c1.sum())
+
+
+def test_default_line_carries_config5_at_one_gpu(tmp_path):
+    """the default N = 1 line has a `config5_g1` object: the config-5 pattern set (seed 7; 8 x --npat patterns at
+    test sizes) in ONE batch through the 1-rank RCCL communicator, hashed, and a sample checked against the oracle;
+    its hash equals the hash of a strong-scaling run over the same set"""
+    small = [a for a in COMMON if a not in ("--no-cpu-baseline", "--pattern-seed", "7")] + ["--cpu-seconds", "1"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + ["--gpus", "1", "--npat", "8192"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    c5 = line["config5_g1"]
+    assert "error" not in c5, c5
+    assert c5["total_patterns"] == 65536 and c5["executed_steps"] == 65536 * 32
+    assert c5["oracle_sample"]["identical_s_e"] is True and c5["oracle_sample"]["patterns"] == 1 << 15
+    # tests/golden/config5_counts.json holds this set's hashes from the CPU oracle over all 65 536 patterns
+    assert c5["matches_golden"]["counts_sha256"] is True and c5["matches_golden"]["ranges_sha256"] is True
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small +
+                       ["--gpus", "1", "--total-patterns", "65536", "--no-cpu-baseline", "--no-locate"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert q.returncode == 0, q.stderr.decode(errors="replace")[-2000:]
+    strong = json.loads([ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert strong["counts_sha256"] == c5["counts_sha256"] and strong["ranges_sha256"] == c5["ranges_sha256"]

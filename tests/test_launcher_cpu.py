@@ -184,3 +184,68 @@ def test_distinct_device_check():
     assert launcher.rank_env(1, 2, 1234, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
     assert launcher.rank_env(0, 2, 1234, base={})["GPU_MAX_HW_QUEUES"] == "8"
     assert launcher.rank_env(0, 2, 1234, base={"GPU_MAX_HW_QUEUES": "4"})["GPU_MAX_HW_QUEUES"] == "4"
+
+
+def _strong_worker(rank, world, port, total, q):
+    """strong scaling (bench.py --total-patterns): a FIXED global pattern set in contiguous, possibly ragged shards
+    (sharding.shard_range), every rank's slot padded to the largest shard, the compacted gather hashed"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from fm_index_amd import sharding as S
+    from fm_index_amd import workload as W
+    from oracle import fm_oracle as O
+    text = W.dna_text_np(30000, 1)
+    idx = O.OracleIndex(text, 4)
+    flat, off, _ = W.substring_patterns_np(text, total, 6, 7)
+    fs, fe = idx.count_batch(flat, off)
+    expect = (fe - fs).astype(np.int64)
+    sizes = [S.shard_range(total, r, world)[1] - S.shard_range(total, r, world)[0] for r in range(world)]
+    slot = max(sizes)
+    lo, hi = S.shard_range(total, rank, world)
+    assert hi - lo == sizes[rank] and sum(sizes) == total
+    s, e = idx.count_batch(flat[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo])
+    pipe = S.CountGatherPipeline(slot, world, len(text), "cpu", backend="gloo")
+
+    def launch(out64):                   # a rank writes only its shard's entries of its (padded) slot
+        out64[:hi - lo].copy_(torch.from_numpy((e - s).astype(np.int64)))
+    for _ in range(3):
+        g = pipe.step(launch)
+    pipe.drain()
+    allc = S.compact_padded(g, sizes, slot).numpy().astype(np.int64)
+    ok = allc.shape == (total,) and bool((allc == expect).all())
+    ok = ok and bench.counts_sha256(allc) == bench.counts_sha256(expect)
+    if rank == 0:
+        q.put((ok, bench.counts_sha256(allc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_shards_hash_like_one_rank():
+    """config 5: the hash of the gathered counts is the same at G = 1, 2 (equal shards) and 3 (ragged shards)"""
+    shas = []
+    for world in (1, 2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_strong_worker, args=(r, world, port, 1000, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        ok, sha = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert ok
+        shas.append(sha)
+    assert len(set(shas)) == 1
+
+
+def test_counts_sha256_is_of_the_int64_little_endian_counts():
+    import hashlib
+    import bench
+    c = np.array([1, 2, 70000, 0], dtype=np.int32)
+    assert bench.counts_sha256(c) == hashlib.sha256(c.astype("<i8").tobytes()).hexdigest()
+    assert bench.counts_sha256(c) == bench.counts_sha256(c.astype(np.uint64))
+    assert bench.golden_key("dna", 30, 7, 8 << 20, 32) == "dna:n=2^30:seed=7:patterns=8388608:len=32"

@@ -106,21 +106,22 @@ class Text:
         return self._max
 
 
-def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False):
+def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_records=True):
     """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
     (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
     if sampling not in (None, "text", "row"):
         raise ValueError("sampling must be None, 'text' or 'row'")
     return ((L.FLAG_KEEP_SA if keep_sa else 0) | (L.FLAG_PAIR_INDEX if pair_index else 0) |
             (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
-            (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0))
+            (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0) |
+            (0 if walk_records else L.FLAG_NO_WALK_RECORDS))
 
 
 class _Index:
     _kind = L.KIND_FM
 
     def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False,
-                 sampling=None, force_wide=False):
+                 sampling=None, force_wide=False, walk_records=True):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -130,13 +131,15 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
                                  text.max_character(),
-                                 self._kind, lvl, _flags(keep_sa, pair_index, kmer_table, sampling, force_wide),
+                                 self._kind, lvl,
+                                 _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records),
                                  device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
-                         pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False):
+                         pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False,
+                         walk_records=True):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -144,8 +147,8 @@ class _Index:
         self._dtype = np.dtype(_DTYPES[sym_bytes])
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
-                                       _flags(keep_sa, pair_index, kmer_table, sampling, force_wide), device,
-                                       C.byref(self._h)))
+                                       _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records),
+                                       device, C.byref(self._h)))
         return self
 
     def save(self, path):
@@ -293,6 +296,10 @@ class _Index:
         """served by the 64-bit engine (n >= 2^32 - 16, or FMX_FLAG_FORCE_WIDE)?"""
         return bool(self._lib.fmx_is_wide(self._h))
 
+    def walk_records(self):
+        """does the index carry walk records (text-order DNA index, levels 1..3; FMX_FLAG_NO_WALK_RECORDS)?"""
+        return bool(self._lib.fmx_walk_records(self._h))
+
     def text_order(self):
         """suffix-array samples kept in text order (FMX_FLAG_TEXT_ORDER or the builder's default)?"""
         return bool(self._lib.fmx_text_order(self._h))
@@ -333,8 +340,8 @@ class FMIndexWithLocate(_Index):
     _kind = L.KIND_FM
 
     def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False, sampling=None,
-                 force_wide=False):
-        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling, force_wide)
+                 force_wide=False, walk_records=True):
+        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records)
 
 
 class RLFMIndex(_Index):

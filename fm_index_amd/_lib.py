@@ -27,6 +27,7 @@ FLAG_KMER_TABLE = 4
 FLAG_TEXT_ORDER = 8
 FLAG_ROW_ORDER = 16
 FLAG_FORCE_WIDE = 32
+FLAG_NO_WALK_RECORDS = 64
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
@@ -98,6 +99,7 @@ SYMBOLS = [
     ("fmx_has_pair_index", _I, [_V]),
     ("fmx_is_wide", _I, [_V]),
     ("fmx_text_order", _I, [_V]),
+    ("fmx_walk_records", _I, [_V]),
     ("fmx_kmer_k", _U32, [_V]),
 ]
 

@@ -199,6 +199,7 @@ uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; 
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
 int fmx_text_order(const fmx_index *idx) { return idx && idx->dev.phase ? 1 : 0; }
+int fmx_walk_records(const fmx_index *idx) { return idx && !idx->is_wide && idx->dev.walk ? 1 : 0; }
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
@@ -1096,7 +1097,7 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
   return nullptr;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 8;   // 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
+const uint32_t kFileVersion = 9;   // 9: FmxDev::walk (walk records: a presence flag only, rebuilt by fmx_load); 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
 }  // namespace
 
 // wide indexes (n >= 2^32 - 16): header (dev_struct_bytes carries kWideMark) | FmxWideDev with presence flags for
@@ -1173,6 +1174,9 @@ int fmx_save(const fmx_index *idx, const char *path) {
     const int nf = enumerate_blobs(dfile, idx->nsamples, fb);
     for (int b = 0; b < nf; b++) *fb[b].field = (const void *)(uintptr_t)1;
     dfile.status = nullptr;
+    // walk records are derived from the level-0 records and the phase pieces: the file only says that the index
+    // had them, fmx_load rebuilds them
+    dfile.walk = idx->dev.walk ? (const uint4 *)(uintptr_t)1 : nullptr;
   }
   bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(&dfile, sizeof dfile, 1, f) == 1 &&
             fwrite(idx->h_cs, 8, idx->max_character + 1, f) == idx->max_character + 1;
@@ -1315,6 +1319,8 @@ int fmx_load(const char *path, int device, fmx_index **out) {
       need += blobs[b].bytes;
     }
     idx->dev.status = nullptr;
+    const bool had_walk = idx->dev.walk != nullptr;   // a presence flag, like the blob fields
+    idx->dev.walk = nullptr;
     {
       const long at = ftell(f);
       fseek(f, 0, SEEK_END);
@@ -1341,6 +1347,9 @@ int fmx_load(const char *path, int device, fmx_index **out) {
         if ((e = hipMemcpy((uint8_t *)p + o, &buf[0], m, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
       }
     }
+    // walk records: derived (fmx_make_walk_records checks eligibility itself -- a file cannot ask for them on an
+    // index whose arrays do not support them)
+    if (rc == FMX_OK && had_walk) rc = fmx_make_walk_records(idx);
   } while (0);
   fclose(f);
   if (rc != FMX_OK) { fmx_free(idx); return rc; }

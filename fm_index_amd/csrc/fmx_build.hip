@@ -229,6 +229,56 @@ __global__ __launch_bounds__(BLK) void k_phase_counts(const uint32_t *__restrict
   const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (j < npieces) out[j].x = base[j];
 }
+// walk records (FmxDev::walk, fmx_internal.h): thread = piece g of walk record j = rows [128 j + 16 g, + 16).  Derived
+// from the fmt-3 records (code planes, lf_map2 counters) and the phase pieces (phases, phase-0 rank) alone, so that
+// fmx_load can rebuild them; rows past the end have code 0 / phase 1 like their sources.
+__global__ __launch_bounds__(BLK) void k_walk_records(const uint4 *__restrict__ rec, const uint4 *__restrict__ phase,
+                                                       uint32_t n, uint32_t level, uint32_t nsamples, uint32_t nwalk,
+                                                       uint4 *__restrict__ out) {
+  const uint64_t tid = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (tid >= (uint64_t)nwalk * 8u) return;
+  const uint32_t j = (uint32_t)(tid >> 3), g = (uint32_t)(tid & 7u);
+  const uint4 *R = rec + (size_t)(j >> 1) * 8u;                 // the 256-row record holding these 128 rows
+  const uint32_t half = j & 1u;
+  // code planes of the 16 rows: piece (half * 4 + g / 2) of R, bits [16 (g & 1), + 16)
+  const uint4 src = R[half * 4u + (g >> 1)];
+  const uint32_t sh = (g & 1u) * 16u;
+  const uint32_t p0 = (src.y >> sh) & 0xFFFFu, p1 = (src.z >> sh) & 0xFFFFu, p2 = (src.w >> sh) & 0xFFFFu;
+  // phases of the 16 rows
+  uint32_t q0 = 0, q1 = 0, q2 = 0;
+  const uint64_t row0 = (uint64_t)j * FMX_WALK_ROWS + g * 16u;
+  for (uint32_t t = 0; t < 16u; t++) {
+    const uint64_t row = row0 + t;
+    uint32_t ph = 1u;
+    if (row < n) {
+      uint32_t k, r0;
+      const uint32_t pi = fmx_phase_piece((uint32_t)row, level, k);
+      ph = fmx_phase_decode(phase[pi], k, level, r0);
+    }
+    q0 |= (ph & 1u) << t;
+    q1 |= ((ph >> 1) & 1u) << t;
+    q2 |= ((ph >> 2) & 1u) << t;
+  }
+  // counter: g <= 6 -> lf_map2(g, 128 j) = counter of code g at the start of R (+ its occurrences in R's first half);
+  // g == 7 -> phase-0 rows before row 128 j
+  uint32_t x;
+  if (g < 7u) {
+    x = R[g].x;
+    if (half)
+      for (uint32_t pp = 0; pp < 4u; pp++) x += __popc(fmx_piece_match<3>(R[pp], g));
+  } else {
+    const uint64_t first = (uint64_t)j * FMX_WALK_ROWS;
+    if (first < n) {
+      uint32_t k;
+      const uint32_t pi = fmx_phase_piece((uint32_t)first, level, k);
+      (void)fmx_phase_decode(phase[pi], k, level, x);
+    } else {
+      x = nsamples;
+    }
+  }
+  out[tid] = make_uint4(x, p0 | (p1 << 16), p2 | (q0 << 16), q1 | (q2 << 16));
+}
+
 struct PhaseZero {   // flag of rocprim::select: rows whose suffix-array value is a multiple of 2^level
   uint32_t mask;
   __host__ __device__ bool operator()(uint32_t v) const { return (v & mask) == 0u; }
@@ -1266,6 +1316,21 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   return FMX_OK;
 }
 
+int fmx_make_walk_records(fmx_index *idx) {
+  if (!fmx_walk_eligible(idx)) return FMX_OK;
+  FmxDev &dv = idx->dev;
+  const uint32_t nwalk = dv.n / FMX_WALK_ROWS + 1u;
+  uint4 *d_walk;
+  FMX_HIP(hipMalloc((void **)&d_walk, (size_t)nwalk * 128u));
+  if (int rc = fmx_keep(idx, d_walk, (uint64_t)nwalk * 128u)) { (void)hipFree(d_walk); return rc; }
+  hipLaunchKernelGGL(k_walk_records, dim3((unsigned)(((uint64_t)nwalk * 8u + BLK - 1) / BLK)), dim3(BLK), 0, 0,
+                     dv.bw.lv[0].rec, dv.phase, dv.n, dv.sa_level, dv.nsamples, nwalk, d_walk);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  dv.walk = d_walk;
+  return FMX_OK;
+}
+
 template <typename T>
 static int build_impl_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
@@ -1449,6 +1514,10 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
       FMX_HIP(hipMemcpy(d_c32, c32.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
       dv.cs = d_c32;
     }
+    // text-order sampling on a DNA-like index: the walk records the batched locate kernel reads (fmx_internal.h)
+    dv.walk = nullptr;
+    if (!(idx->flags & FMX_FLAG_NO_WALK_RECORDS))
+      if (int rc = fmx_make_walk_records(idx)) return rc;
   } else {
     if (n < 2) {  // the reference hits unreachable!() (rlfmi.rs:62-65) / has nothing to index
       fmx_set_error(FMX_ERR_UNSUPPORTED, "RLFM index needs a text of at least 2 symbols");

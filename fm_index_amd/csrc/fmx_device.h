@@ -630,6 +630,33 @@ __device__ __forceinline__ uint32_t fmx_phase_decode(const uint4 pc, uint32_t t,
   return (w >> (k * level)) & ((1u << level) - 1u);
 }
 
+// ---- walk records (FmxDev::walk, fmx_internal.h) ----------------------------------------------
+// One LF step of a text-order walk on the walk record holding `row`; p = piece g of that record.  Every lane of the
+// group gets lf_map(row) (fm_index.rs:86-91: cs[L[row]] + rank of L[row], the counters hold cs[] folded in),
+// ph = SA[row] mod 2^level and r0 = the number of phase-0 rows before `row` (the row's index into samples[] when
+// ph == 0).  Two group sums and one broadcast: the row's code and phase and the piece-wise phase-0 counts (<= 128)
+// share the first sum.
+__device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t row, uint32_t g, uint32_t &ph, uint32_t &r0) {
+  const uint32_t off = row & (FMX_WALK_ROWS - 1u), bit = off & 15u;
+  int nb = (int)off - (int)(g * 16u);
+  nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
+  const uint32_t low = (1u << nb) - 1u;
+  const uint32_t zero = ~((p.z >> 16) | p.w | (p.w >> 16)) & 0xFFFFu;       // rows of this piece whose phase is 0
+  uint32_t v = (uint32_t)__popc(zero & low) << 8;
+  if (g == (off >> 4))
+    v |= __builtin_amdgcn_ubfe(p.y, bit, 1u) | (__builtin_amdgcn_ubfe(p.y, bit + 16u, 1u) << 1) |
+         (__builtin_amdgcn_ubfe(p.z, bit, 1u) << 2) | (__builtin_amdgcn_ubfe(p.z, bit + 16u, 1u) << 3) |
+         (__builtin_amdgcn_ubfe(p.w, bit, 1u) << 4) | (__builtin_amdgcn_ubfe(p.w, bit + 16u, 1u) << 5);
+  v = fmx_group_sum(v);
+  const uint32_t sym = v & 7u;
+  ph = (v >> 3) & 7u;
+  r0 = fmx_oct_bcast_c<7>(p.x) + (v >> 8);
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 0u, 1u), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 1u, 1u),
+                 m2 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 2u, 1u);
+  const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & 0xFFFFu;
+  return fmx_group_sum((uint32_t)__popc(match & low) + (g == sym ? p.x : 0u));
+}
+
 // greatest c with cs[c] <= v  (get_f's binary search, fm_index.rs:97-112)
 __device__ __forceinline__ uint32_t fmx_cs_upper(const uint32_t *cs, uint32_t max_character,
                                                  uint32_t v) {

@@ -106,8 +106,22 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   //             phases SA[row] mod 2^level, floor(32 / level) per word } -> 96, 48, 30, 24 rows per piece;
   //   samples[] then holds SA[row] of the phase-0 rows in row order (same ((n-1) >> level) + 1 entries).
   const uint4 *phase;
+  // Walk records (round 4; one 3-bit level, max_character <= 6, text-order sampling at levels 1..3): a second
+  // encoding of the BWT for the batched locate walk, DERIVED from bw.lv[0].rec and phase[] (never stored in a file).
+  // One 128-byte record = 128 rows = 8 pieces of 16 rows; piece g = { x, y, z, w }:
+  //     y = code plane 0 | code plane 1 << 16,  z = code plane 2 | phase plane 0 << 16,  w = phase plane 1 | plane 2 << 16
+  //     x = g <= 6: lf_map2(g, first row of the record) (cs[] folded in, like the fmt-3 counters)
+  //         g == 7: number of phase-0 rows before the record (= index into samples[] of its first phase-0 row)
+  // so ONE line answers everything an LF step of a text-order walk asks of a row: L[row], lf_map(row), the row's phase
+  // SA[row] mod 2^level (= the steps left, known from the walk's first record on) and -- on the final row -- the sample
+  // index.  The two 16-byte phase probes of the text-order walk (start row, final row) disappear: a hit costs
+  // phase + 1 records + 1 sample = 3.5 requests at level 2, against 4 (+ a geometric tail) in row order.
+  const uint4 *walk;
 };
 #define FMX_PHASE_MAX_LEVEL 4u
+#define FMX_WALK_MAX_LEVEL 3u        // three phase planes fit the piece
+#define FMX_WALK_MAX_CHARACTER 6u    // counter slot 7 holds the phase-0 rank
+#define FMX_WALK_ROWS 128u
 
 // ---- wide indexes: n >= 2^32 - 16 (usize rows of the reference, fm_index.rs:86-95) ------------------------
 // FMIndex / FMIndexWithLocate over byte texts, rows and positions 64 bits wide.  One-level alphabets
@@ -192,6 +206,14 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// walk records of an index that has the fmt-3 records and the phase pieces (builder, fmx_load): allocates, fills and
+// registers dev.walk; no-op (FMX_OK, dev.walk stays NULL) when the index is not eligible
+int fmx_make_walk_records(fmx_index *idx);
+static inline bool fmx_walk_eligible(const fmx_index *idx) {
+  const FmxDev &d = idx->dev;
+  return idx->kind == FMX_KIND_FM && !idx->is_wide && idx->sym_bytes == 1 && d.bw.nlevels == 1 && d.bw.lv[0].fmt == 3 &&
+         d.max_character <= FMX_WALK_MAX_CHARACTER && d.phase && d.sa_level >= 1 && d.sa_level <= FMX_WALK_MAX_LEVEL && d.n > 0;
+}
 // wide indexes (fmx_wide.hip / the wide section of fmx_build.hip)
 static inline bool fmx_wide_n(uint64_t n) { return n >= 0xFFFFFFF0ull; }
 static inline bool fmx_wide_build(const fmx_index *idx) { return fmx_wide_n(idx->n) || (idx->flags & FMX_FLAG_FORCE_WIDE); }

@@ -1118,6 +1118,166 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
   if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+// Text-order walk over WALK RECORDS (FmxDev::walk, fmx_internal.h; round 4).  The shape of fmx_locate_f3p_kernel --
+// 8 lanes per record, Q walks per group with walk q's state in lane q of each quad, the block's hit queue, the hand-over
+// at the top of the round, the write-combining ring -- but a record of the walk array tells, next to lf_map(row), the
+// row's phase SA[row] mod 2^level and its rank among the phase-0 rows.  So a walk needs no probe of its own: its FIRST
+// record gives the number of LF steps (the phase of the start row), and the record of the row it ends on gives the index
+// of the sample: phase + 1 records and one sample per hit (3.5 requests at level 2 where the row-order walk issues 4 and
+// the round-3 text-order walk 4.5), and no walk is longer than 2^level - 1 steps -- the geometric tail of row-order
+// sampling (a 2^20-hit batch ends on a chain of ~41 dependent round trips) does not exist.
+// get_sa is unchanged as a function: (sample + steps) % len (fm_index.rs:127-140).
+template <int Q, bool WC>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
+    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
+    uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  static_assert(Q == 1 || Q == 2 || Q == 4 || Q == 8, "walks per group");
+  __shared__ unsigned int lds_q;
+  __shared__ uint32_t wc_ring[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS * 64 : 1];
+  __shared__ uint32_t wc_tag[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS : 1];
+  if (threadIdx.x == 0) lds_q = 0;
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint32_t slot = g & (uint32_t)(Q - 1);        // the walk whose state this lane keeps (8 / Q replicas)
+  const bool owner = g < (uint32_t)Q;                 // the replica that counts, stores and is counted
+  const uint32_t olane = (lane & ~7u) | slot;         // its lane
+  constexpr unsigned long long SLOT0 = Q == 8   ? 0x0101010101010101ull
+                                       : Q == 4 ? 0x1111111111111111ull
+                                       : Q == 2 ? 0x5555555555555555ull
+                                                : 0xFFFFFFFFFFFFFFFFull;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample / no position (n < 2^32 - 16)
+  FmxHitQueue<> hq;
+  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
+  uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
+  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64);
+  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS;
+  [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;   // ring slots of the resident tickets c0 / c1; tickets drawn
+  if (WC) {
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) ring[r * 64u + lane] = NONE;
+    if (lane < FMX_WC_SLOTS) ring_tag[lane] = lane == 0 ? hq.c0 : (lane == 1 ? hq.c1 : FMX_NOCHUNK);
+  }
+  uint32_t hx, row;                                   // hit (index into the slice) and current row of the walk
+  [[maybe_unused]] uint32_t myslot = 0;               // WC: ring slot of the ticket the hit came from
+  bool active = hq.take32((slot << 3) | grp, hx, row);   // first 8 hits -> walk 0 of the 8 groups, ... (all of c0)
+  {
+    const bool slid = hq.advance(8u * (uint32_t)Q, lds_q);
+    if (WC && slid) {                                 // Q = 8 hands out a whole ticket at once
+      const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+      if (lane == 0) ring_tag[ns] = hq.c1;            // slot ns is still empty (all NONE)
+      rseq++; rs0 = rs1; rs1 = ns;
+    }
+  }
+  if (!active) row = 0u;
+  // ctl = LF steps still to do | the steps of the whole walk (= the phase of the start row) << 8; FRESH until the
+  // walk's first record has told its phase.  fin: index of the sample once the walk stands on its phase-0 row
+  constexpr uint32_t FRESH = 0xFFu;
+  uint32_t ctl = FRESH, fin = NONE, nsteps = 0;
+  for (;;) {
+    if (!__any(active)) break;
+    // walks that found their sampled row in the previous round: the slot goes to the next hit, the walk is completed
+    // in this round (its sample travels with the new walk's first record)
+    const bool done = active && fin != NONE;
+    const unsigned long long fm = __ballot(done && owner);     // one bit per finishing walk
+    uint32_t fin_si = NONE, fin_steps = 0, fin_x = 0;
+    [[maybe_unused]] uint32_t fin_slot = 0;
+    if (fm) {                                         // wave-uniform
+      uint32_t x_new, r_new;
+      bool first;
+      const bool ok = hq.take32((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), x_new, r_new, first);
+      if (done) {
+        fin_si = fin;
+        fin_steps = ctl >> 8;
+        fin_x = hx;
+        fin_slot = myslot;
+        nsteps += ctl >> 8;
+        hx = x_new;
+        myslot = first ? rs0 : rs1;
+        active = ok;
+        row = ok ? r_new : 0u;
+        ctl = FRESH;
+        fin = NONE;
+      }
+      const bool slid = hq.advance((uint32_t)__popcll(fm), lds_q);
+      if (WC && slid) {
+        const uint32_t ns = rseq & (FMX_WC_SLOTS - 1u);
+        const uint32_t old_tag = ring_tag[ns];
+        const uint32_t v = ring[ns * 64u + lane];
+        FMX_CHECK(old_tag == FMX_NOCHUNK || v == NONE || old_tag * 64u + lane < bn);
+        if (old_tag != FMX_NOCHUNK && v != NONE) out[old_tag * 64u + lane] = (uint64_t)v;
+        ring[ns * 64u + lane] = NONE;
+        if (lane == 0) ring_tag[ns] = hq.c1;
+        rseq++; rs0 = rs1; rs1 = ns;
+      }
+    }
+    uint32_t sa = 0;
+    if (fin_si != NONE) {                             // sample.rs:46-60 Some(sa)
+      FMX_CHECK(fin_si < nsamples);
+      if (owner) FMX_TOUCH(&samples[fin_si]);
+      sa = samples[fin_si];
+    }
+    // one record per live walk (a live walk has no sample index yet): its first record, or an LF step
+    const uint32_t rowx = active ? row : NONE;
+    const unsigned long long wm = __ballot(active);
+    uint4 p[Q];
+    uint32_t rq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      rq[q] = NONE;
+      if (!(wm & (SLOT0 << q))) continue;             // walk q idle in every group of the wave
+      rq[q] = Q == 1 ? rowx : Q == 8 ? fmx_oct_bcast(rowx, q) : fmx_quad_bcast(rowx, q);
+      if (rq[q] != NONE) {                            // group-uniform
+        FMX_CHECK(rq[q] < n && (rq[q] >> 7) < n / FMX_WALK_ROWS + 1u);
+        const uint4 *addr = walk + ((size_t)(rq[q] >> 7) * 8u + g);
+        FMX_TOUCH_G0(g, addr - g);
+        p[q] = *addr;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (!(wm & (SLOT0 << q))) continue;
+      if (rq[q] != NONE) {
+        uint32_t ph, r0;
+        const uint32_t nr = fmx_walk_step(p[q], rq[q], g, ph, r0);
+        if (slot == (uint32_t)q) {
+          if (ctl == FRESH) ctl = ph * 0x101u;        // the walk is exactly SA[row] mod 2^level steps long
+          if ((ctl & 0xFFu) == 0u) {                  // Some(sa): this row carries a sample (sample.rs:46-60)
+            FMX_CHECK(ph == 0u);
+            fin = r0;
+          } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+            row = nr;
+            ctl--;
+          }
+        }
+      }
+    }
+    if (fin_si != NONE && owner) {
+      // fm_index.rs:131-133: (sa + steps) % len; sa < n and steps < 8, one subtraction is exact
+      uint32_t v = sa + fin_steps;
+      if (v < sa || v >= n) v -= n;
+      FMX_CHECK(fin_x < bn && fin_slot < FMX_WC_SLOTS);
+      if (WC && ring_tag[fin_slot] == (fin_x >> 6)) ring[fin_slot * 64u + (fin_x & 63u)] = v;   // its ticket is resident
+      else out[fin_x] = (uint64_t)v;
+    }
+  }
+  if (WC) {                                           // what is still in the ring
+#pragma unroll
+    for (uint32_t r = 0; r < FMX_WC_SLOTS; r++) {
+      const uint32_t tag = ring_tag[r];
+      const uint32_t v = ring[r * 64u + lane];
+      FMX_CHECK(tag == FMX_NOCHUNK || v == NONE || tag * 64u + lane < bn);
+      if (tag != FMX_NOCHUNK && v != NONE) out[tag * 64u + lane] = (uint64_t)v;
+    }
+  }
+  if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
 // probe -> access+rank rounds over the levels of S -> lane-wise B' / B selects; FM over several wavelet
 // levels: one access+rank round per level (eight records in flight per lane).  Lanes take
@@ -1612,6 +1772,7 @@ struct FmxTune {
   bool use_kmer = true;          // honour the k-mer start table when the index has one
   bool use_pair = true;          // honour the pair index when the index has one
   bool wc = true;                // locate: positions through the write-combining ring
+  bool walk_records = true;      // DNA locate: the walk-record kernel when the index has walk records
   int alt = 0;                   // measurement-only kernel (fmx_measure.inc), 0 = none
   int walks = 0;                 // DNA locate: walks per group, 0 = by batch size
   long ep_blocks = 1024;         // count, endpoint per lane: grid cap (4 waves per SIMD saturate the memory system)
@@ -1708,6 +1869,10 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
   hipLaunchKernelGGL((fmx_locate_f3p_kernel<Q, WCF>), dim3(gr), dim3(thr), 0, (c).st,                  \
                      (c).dv.bw.lv[0].rec, (c).dv.samples, (c).dv.n, (c).dv.sa_level, (c).total, hpb,   \
                      chunk, (c).rows, (c).pos, (c).steps)
+#define FMX_LOCT_LAUNCH(c, gr, thr, hpb, chunk, Q, WCF)                                              \
+  hipLaunchKernelGGL((fmx_locate_f3t_kernel<Q, WCF>), dim3(gr), dim3(thr), 0, (c).st,                  \
+                     (c).dv.walk, (c).dv.samples, (c).dv.n, (c).dv.nsamples, (c).total, hpb, chunk,    \
+                     (c).rows, (c).pos, (c).steps)
 // group per walk (any kind / any number of levels)
 #define FMX_LOCATE_LAUNCH(c, grid, hpw, KIND, NL, SM)                                                \
   hipLaunchKernelGGL((fmx_locate_kernel<KIND, NL, SM>), dim3(grid), dim3(FMX_BLOCK), 0, (c).st,        \
@@ -1871,7 +2036,17 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     uint32_t hpb;
     unsigned gr;
     c.slice(nb, chunk, hpb, gr);
-    if (dv.phase) {         // text-order sampling (FMX_FLAG_TEXT_ORDER, or a file written that way)
+    if (dv.phase && dv.walk && tn.walk_records) {   // text-order sampling with walk records: no phase probes
+      if (chunk == FMX_LCHUNK && tn.wc) {
+        if (q == 4) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 4, true);
+        else if (q == 2) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 2, true);
+        else FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 1, true);
+      } else {
+        if (q == 4) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 4, false);
+        else if (q == 2) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 2, false);
+        else FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 1, false);
+      }
+    } else if (dv.phase) {  // text-order sampling (FMX_FLAG_TEXT_ORDER, or a file written that way)
       if (q == 4) FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 4, true);
       else if (q == 2) FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 2, true);
       else FMX_LOCQ_LAUNCH(c, gr, lthreads, hpb, chunk, 1, true);

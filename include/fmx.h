@@ -99,6 +99,12 @@ typedef struct fmx_index fmx_index;
  * override the default either way; both set, or a level outside 1..4, means row order. */
 #define FMX_FLAG_TEXT_ORDER 8u
 #define FMX_FLAG_ROW_ORDER 16u
+/* A text-order FM index over one 3-bit wavelet level with max_character <= 6 (DNA) and level 1..3 also gets WALK
+ * RECORDS (fmx_walk_records() == 1): a second 128-byte-record encoding of the BWT, 128 rows per record, that
+ * carries every row's phase and the phase-0 rank next to its symbol, so that the batched locate walk needs no
+ * phase probe: phase + 1 records and one sample per hit.  +1 byte per text symbol of HBM; derived from the other
+ * arrays (not stored in index files).  This flag builds the index without them (the round-3 text-order walk). */
+#define FMX_FLAG_NO_WALK_RECORDS 64u
 /* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
  * superblocks of 2^12 rows instead of 2^31, so that a small text exercises every part of it.  Same eligibility
  * (FMX_KIND_FM, n >= 2); same results. */
@@ -281,6 +287,7 @@ uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol w
 uint32_t fmx_kmer_k(const fmx_index *idx);   /* k of the FMX_FLAG_KMER_TABLE table, 0 = none */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
 int fmx_is_wide(const fmx_index *idx);        /* 1: served by the wide (64-bit rows) engine */
+int fmx_walk_records(const fmx_index *idx);   /* 1: the index has walk records (FMX_FLAG_NO_WALK_RECORDS) */
 int fmx_text_order(const fmx_index *idx);     /* 1: suffix-array samples in text order (FMX_FLAG_TEXT_ORDER) */
 
 #ifdef __cplusplus

@@ -400,9 +400,12 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
 # --------------------------------------------------------------------------------------------
 # live PMC passes: rocprofv3 runs a child of this script; separate --pmc passes, no trace domains
 # --------------------------------------------------------------------------------------------
-WALK_KERNEL = "fmx_locate_f3p_kernel"
+WALK_KERNEL = "fmx_locate_f3t_kernel"    # the default DNA index: text order + walk records (round 4)
 PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
-    "dna_count": ["fmx_count_f3_kernel"],
+    "dna_count": ["fmx_count_f3_kernel<1, false, false>", "fmx_count_f3_kernel"],
+    "dna_count_pair": ["fmx_count_pair_kernel<false>"],          # opt-in accelerators (accel_legs)
+    "dna_count_kmer": ["fmx_count_f3_kernel<1, false, true>"],
+    "dna_count_both": ["fmx_count_pair_kernel<true>"],
     "dna_locate": [WALK_KERNEL],
     "dna_locate_3b": [WALK_KERNEL],
     "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
@@ -479,6 +482,17 @@ def pmc_child(args):
             for _ in range(2):
                 lstep3b()
             del lstep3b
+    if not args.no_accel:            # the opt-in count accelerators on the same patterns
+        import fm_index_amd as F
+        for kw in (dict(pair_index=True), dict(kmer_table=True), dict(auto=True)):
+            pidx = F.FMIndex.from_device_text(wl.text.data_ptr(), wl.n, wl.maxc, device=local, **kw)
+            for _ in range(reps):
+                rc = wl.lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(wl.pat.data_ptr()), C.c_void_p(wl.off.data_ptr()),
+                                                wl.npat, None, C.c_void_p(wl.d_s.data_ptr()), C.c_void_p(wl.d_e.data_ptr()),
+                                                None, wl.sp)
+                assert rc == 0
+            torch.cuda.synchronize()
+            pidx.close()
     torch.cuda.synchronize()
     wl.close()
     del wl
@@ -515,6 +529,8 @@ def run_pmc_passes(args, npat=None, count_only=False):
         child.append("--no-locate")
     if args.no_3b or count_only:
         child.append("--no-3b")
+    if args.no_accel or count_only:
+        child.append("--no-accel")
     if count_only:
         child += ["--pattern-seed", "7"]
     try:
@@ -943,12 +959,12 @@ def run(args, world, pmc=None):
     if wl.level is not None:
         locate_leg(out, wl, args, world, rank, dist, gloo, key)
 
-    # ---- opt-in text-order sampling on the one-level index (FMX_FLAG_TEXT_ORDER): same positions ----
+    # ---- the reference's own row-order sampling on the same index (FMX_FLAG_ROW_ORDER): same positions ----
     if single and wl.dna and wl.level is not None and not args.no_accel:
         try:
-            locate_text_order_leg(out, wl, args)
+            locate_row_order_leg(out, wl, args)
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
-            out["locate_text_order"] = {"error": repr(ex)}
+            out["locate_row_order"] = {"error": repr(ex)}
 
     # ---- the config-5 step through a 1-rank RCCL communicator on this GPU (default N=1 run) ----
     if single and not args.no_rccl_check:
@@ -1280,6 +1296,8 @@ def apply_pmc(out, pmc, cal):
     else:
         out["pmc"] = {"status": "no counters collected"}
     redo(out.get("roofline"), pmc.get("dna_count"))
+    for leg, key in (("pair_index", "dna_count_pair"), ("kmer_table", "dna_count_kmer"), ("kmer_table+pair_index", "dna_count_both")):
+        redo((out.get(leg) or {}).get("roofline"), pmc.get(key))
     redo(out.get("locate", {}).get("roofline"), pmc.get("dna_locate"))
     redo(out.get("locate_3b", {}).get("roofline"), pmc.get("dna_locate_3b"))
     redo(out.get("rlfm", {}).get("roofline"), pmc.get("rlfm_count"))
@@ -1287,16 +1305,23 @@ def apply_pmc(out, pmc, cal):
 
 
 def accel_legs(out, wl, args, rflat):
+    """the opt-in count accelerators on the config-2 patterns: pair index, k-mer start table, and both -- the last one
+    built with FMX_FLAG_AUTO (the builder adds both when the index qualifies and the device has room) and reported as
+    `value_auto`.  (s, e) asserted identical to the plain index on all patterns; each leg gets the roofline object of
+    the headline (census of its own launch, counters of its own kernel from the live PMC passes)."""
     torch, F, lib = wl.torch, wl.F, wl.lib
     legs = []
     if wl.dna:
-        legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX"))
-    legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE"))
+        legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX", "fmx_count_pair_kernel<false>"))
+    legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE",
+                 "fmx_count_f3_kernel<1,false,true>" if wl.dna else "fmx_count_ep_kernel<..., true>"))
     if wl.dna:
-        legs.append(("kmer_table+pair_index", dict(kmer_table=True, pair_index=True),
-                     "FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX"))
+        legs.append(("kmer_table+pair_index", dict(auto=True),
+                     "FMX_FLAG_AUTO: the builder added FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX (DNA-like FM index, "
+                     "n >= 2^24, four times the index free on the device)", "fmx_count_pair_kernel<true>"))
     npat, m = wl.npat, wl.m
-    for leg_name, leg_kw, leg_note in legs:
+    stream_bytes = npat * m + (npat + 1) * 8 + 2 * npat * 8
+    for leg_name, leg_kw, leg_note, kname in legs:
         try:
             pidx = (F.RLFMIndex if wl.rlfm else F.FMIndex).from_device_text(wl.text.data_ptr(), wl.n, wl.maxc,
                                                                             device=wl.local, **leg_kw)
@@ -1304,11 +1329,15 @@ def accel_legs(out, wl, args, rflat):
                 out[leg_name] = {"skipped": "FMX_FLAG_KMER_TABLE is ignored for this kind / alphabet"}
                 pidx.close()
                 continue
+            if leg_kw.get("auto") and not (pidx.kmer_k() and pidx.has_pair_index()):
+                out[leg_name] = {"skipped": "FMX_FLAG_AUTO left the index plain (n < 2^24, or not enough free HBM)"}
+                pidx.close()
+                continue
             ps = torch.empty(npat, dtype=torch.int64, device=wl.dev)
             pe = torch.empty(npat, dtype=torch.int64, device=wl.dev)
 
-            def pstep(p):
-                rc = lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(p.data_ptr()), C.c_void_p(wl.off.data_ptr()),
+            def pstep(p, use=lib):
+                rc = use.fmx_count_batch_dev(pidx.handle(), C.c_void_p(p.data_ptr()), C.c_void_p(wl.off.data_ptr()),
                                              npat, None, C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()),
                                              None, wl.sp)
                 assert rc == 0
@@ -1317,10 +1346,18 @@ def accel_legs(out, wl, args, rflat):
             torch.cuda.synchronize()
             pms = event_time_ms(torch, wl.stream, lambda: pstep(wl.pat), args.steps)
             assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != plain index"
+            cen = None
+            if not args.no_census:
+                cen = run_census(wl, lambda cl: pstep(wl.pat, cl), npat * m * 3 + (1 << 20))
             out[leg_name] = {"value": npat * m / (pms / 1e3), "unit": "pattern-chars/s", "ms_per_step": pms,
                              "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
+                             "pair_index": pidx.has_pair_index(),
                              "build_ms": round(float(lib.fmx_build_ms(pidx.handle())), 1),
-                             "note": leg_note + "; (s,e) identical to the plain-index run"}
+                             "note": leg_note + "; (s,e) identical to the plain-index run",
+                             "roofline": make_roofline(kname, pms, npat * m, wl.ref_bytes_per_char(), stream_bytes, cen,
+                                                       None)}
+            if leg_kw.get("auto"):
+                out["value_auto"] = out[leg_name]["value"]
             if rflat is not None:
                 # config 2b patterns (uniform random, mostly absent) through the same index
                 wl.count(pat=rflat)
@@ -1336,6 +1373,10 @@ def accel_legs(out, wl, args, rflat):
             pidx.close()
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
             out[leg_name] = {"error": repr(ex)}
+
+
+def dna_walk_kernel(wl):
+    return "fmx_locate_f3t_kernel<4>" if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
 
 
 def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="locate"):
@@ -1416,8 +1457,7 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     if not args.no_census and rank == 0:
         cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
     ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
-    kname = "fmx_locate_f3p_kernel<4>" if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else
-                                                        "fmx_locate_kernel<FMX_KIND_FM>")
+    kname = dna_walk_kernel(wl) if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else "fmx_locate_kernel<FMX_KIND_FM>")
     roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
                          stored_traffic(key, "locate"))
     two = None
@@ -1428,6 +1468,8 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
             two = {"error": repr(ex)}
     dest[legname] = {"hits_per_s": all_hits * lsteps / ldt, "hits": all_hits, "hits_per_gpu": total_hits,
                      "lf_steps": lf_steps, "level": wl.level, "ms_per_batch": ldt / lsteps * 1e3,
+                     "sampling": "text order" + (" + walk records" if wl.index.walk_records() else "")
+                     if wl.index.text_order() else "row order",
                      "includes": "row expansion + walk" + (" + gather of counts and positions over the ranks"
                                                            if use_dist else ""),
                      "roofline": roof}
@@ -1435,15 +1477,15 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
         dest[legname]["two_streams"] = two
 
 
-def locate_text_order_leg(out, wl, args):
-    """config 3 on an index built with FMX_FLAG_TEXT_ORDER (opt-in for one-level indexes): the rows whose SA
-    value is a multiple of 2^level carry the samples and every walk is exactly SA[row] mod 2^level steps.
-    Positions must equal the row-order index's (the reference's answers) on every hit."""
+def locate_row_order_leg(out, wl, args):
+    """config 3 on an index built with FMX_FLAG_ROW_ORDER: the reference's own sampling (the rows i with i mod 2^level
+    == 0, sample.rs:21-44) and its geometric walks (fmx_locate_f3p_kernel) -- the default until round 3.  Positions must
+    equal the default index's (text order + walk records) on every hit."""
     torch, F, lib = wl.torch, wl.F, wl.lib
     tix = F.FMIndexWithLocate.from_device_text(wl.text.data_ptr(), wl.n, wl.maxc, level=wl.level, device=wl.local,
-                                               sampling="text")
+                                               sampling="row")
     try:
-        assert tix.text_order()
+        assert not tix.text_order() and not tix.walk_records()
         total, npat = wl.total_hits, wl.npat
         pos = torch.empty(max(total, 1), dtype=torch.int64, device=wl.dev)
 
@@ -1465,13 +1507,13 @@ def locate_text_order_leg(out, wl, args):
         torch.cuda.synchronize()
         kms, steps = lib.fmx_last_kernel_ms(tix.handle()), int(lib.fmx_last_steps(tix.handle()))
         lib.fmx_set_timing(tix.handle(), 0)
-        assert bool((pos[:total] == wl.d_pos[:total]).all()), "text-order index locates differently"
-        out["locate_text_order"] = {"hits_per_s": total / dt, "ms_per_batch": dt * 1e3, "walk_kernel_ms": round(kms, 4),
-                                    "hits": total, "lf_steps": steps, "index_bytes": tix.heap_size(),
-                                    "row_order_index_bytes": wl.index.heap_size(),
-                                    "build_ms": round(float(lib.fmx_build_ms(tix.handle())), 1),
-                                    "note": "opt-in FMX_FLAG_TEXT_ORDER on the config-3 index; positions identical "
-                                            "to the row-order index on every hit"}
+        assert bool((pos[:total] == wl.d_pos[:total]).all()), "row-order index locates differently"
+        out["locate_row_order"] = {"hits_per_s": total / dt, "ms_per_batch": dt * 1e3, "walk_kernel_ms": round(kms, 4),
+                                   "hits": total, "lf_steps": steps, "index_bytes": tix.heap_size(),
+                                   "default_index_bytes": wl.index.heap_size(),
+                                   "build_ms": round(float(lib.fmx_build_ms(tix.handle())), 1),
+                                   "note": "FMX_FLAG_ROW_ORDER on the config-3 index (SOSampledSuffixArray's own rows, "
+                                           "sample.rs:21-44); positions identical to the default index on every hit"}
     finally:
         tix.close()
 
@@ -1598,9 +1640,14 @@ def locate_3b(out, wl, args, key):
                         "count_max": int(cnts.max().item())}
     # HBM-side traffic of this launch (told from the config-3 launches of the same kernel by its grid)
     # request widths by construction (what the census counts for config 3): one record per LF step, one sample per hit
-    widths = {"requested_lines": lf_steps + total, "requested_records": lf_steps, "requested_probes": total,
+    # (walk records: max(phase, 1) records per hit, phase = position mod 2^level -- one more than the LF steps for the
+    # hits that sit on a sampled position)
+    nrec = lf_steps + (int(((pos[:total] & ((1 << wl.level) - 1)) == 0).sum().item()) if wl.index.walk_records() else 0)
+    widths = {"requested_lines": nrec + total, "requested_records": nrec, "requested_probes": total,
               "distinct_lines": None}
-    out["locate_3b"]["roofline"] = make_roofline("fmx_locate_f3p_kernel<4>", kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
+    out["locate_3b"]["requested_lines"] = nrec + total
+    out["locate_3b"]["requested_lines_per_s"] = (nrec + total) / (kms / 1e3)
+    out["locate_3b"]["roofline"] = make_roofline(dna_walk_kernel(wl), kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
                                                  total * 4 + total * 8, widths, stored_traffic(key, "locate_3b"))
 
 

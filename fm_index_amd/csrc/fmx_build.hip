@@ -229,45 +229,60 @@ __global__ __launch_bounds__(BLK) void k_phase_counts(const uint32_t *__restrict
   const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (j < npieces) out[j].x = base[j];
 }
-// walk records (FmxDev::walk, fmx_internal.h): thread = piece g of walk record j = rows [128 j + 16 g, + 16).  Derived
-// from the fmt-3 records (code planes, lf_map2 counters) and the phase pieces (phases, phase-0 rank) alone, so that
-// fmx_load can rebuild them; rows past the end have code 0 / phase 1 like their sources.
+// ---- walk records (FmxDev::walk, fmx_internal.h) ----------------------------------------------------------------
+// Derived from the fmt-3 records (code planes, lf_map2 counters) and the phase pieces (phases, phase-0 rank) alone,
+// so that fmx_load can rebuild them; rows past the end have code 0 / phase 1 like their sources.
+__device__ __forceinline__ uint32_t kw_code_of(const uint4 *__restrict__ rec, uint64_t row) {
+  const uint4 p = rec[(size_t)(row >> 8) * 8u + ((row & 255u) >> 5)];
+  return fmx_piece_code<3>(p, (uint32_t)(row & 31u));
+}
+__device__ __forceinline__ uint32_t kw_phase_of(const uint4 *__restrict__ phase, uint32_t row, uint32_t level) {
+  uint32_t t, r0;
+  const uint32_t pi = fmx_phase_piece(row, level, t);
+  return fmx_phase_decode(phase[pi], t, level, r0);
+}
+// cnt[(c - 1) * nwalk + j] = rows of walk record j with phase 1 and BWT code c, c = 1..FMX_WALK_MAX_CHARACTER
+__global__ __launch_bounds__(BLK) void k_walk_counts(const uint4 *__restrict__ rec, const uint4 *__restrict__ phase,
+                                                      uint32_t n, uint32_t level, uint32_t nwalk,
+                                                      uint32_t *__restrict__ cnt) {
+  const uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j >= nwalk) return;
+  uint32_t c[FMX_WALK_MAX_CHARACTER + 1u];
+  for (uint32_t k = 0; k <= FMX_WALK_MAX_CHARACTER; k++) c[k] = 0;
+  for (uint32_t t = 0; t < FMX_WALK_ROWS; t++) {
+    const uint64_t row = j * FMX_WALK_ROWS + t;
+    if (row >= n) break;
+    if (kw_phase_of(phase, (uint32_t)row, level) != 1u) continue;
+    const uint32_t code = kw_code_of(rec, row);
+    // (register array indexed by a loop-invariant compare chain, not by `code`: no scratch)
+    for (uint32_t k = 1; k <= FMX_WALK_MAX_CHARACTER; k++) c[k] += code == k;
+  }
+  for (uint32_t k = 1; k <= FMX_WALK_MAX_CHARACTER; k++) cnt[(size_t)(k - 1u) * nwalk + j] = c[k];
+}
+// thread = piece g of walk record j.  base[(c - 1) * nwalk + j] = exclusive scan of the counts over the [code][record]
+// layout = (phase-1 rows with a smaller code) + (phase-1 rows with code c before record j); `edge` = 1 when row 0
+// (SA = n - 1) is a phase-0 row: it is the one phase-0 row that is not the LF image of a phase-1 row.
 __global__ __launch_bounds__(BLK) void k_walk_records(const uint4 *__restrict__ rec, const uint4 *__restrict__ phase,
-                                                       uint32_t n, uint32_t level, uint32_t nsamples, uint32_t nwalk,
+                                                       const uint32_t *__restrict__ base, uint32_t n, uint32_t level,
+                                                       uint32_t nsamples, uint32_t nwalk, uint32_t edge,
                                                        uint4 *__restrict__ out) {
   const uint64_t tid = (uint64_t)blockIdx.x * BLK + threadIdx.x;
   if (tid >= (uint64_t)nwalk * 8u) return;
   const uint32_t j = (uint32_t)(tid >> 3), g = (uint32_t)(tid & 7u);
-  const uint4 *R = rec + (size_t)(j >> 1) * 8u;                 // the 256-row record holding these 128 rows
-  const uint32_t half = j & 1u;
-  // code planes of the 16 rows: piece (half * 4 + g / 2) of R, bits [16 (g & 1), + 16)
-  const uint4 src = R[half * 4u + (g >> 1)];
-  const uint32_t sh = (g & 1u) * 16u;
-  const uint32_t p0 = (src.y >> sh) & 0xFFFFu, p1 = (src.z >> sh) & 0xFFFFu, p2 = (src.w >> sh) & 0xFFFFu;
-  // phases of the 16 rows
-  uint32_t q0 = 0, q1 = 0, q2 = 0;
-  const uint64_t row0 = (uint64_t)j * FMX_WALK_ROWS + g * 16u;
-  for (uint32_t t = 0; t < 16u; t++) {
-    const uint64_t row = row0 + t;
-    uint32_t ph = 1u;
-    if (row < n) {
-      uint32_t k, r0;
-      const uint32_t pi = fmx_phase_piece((uint32_t)row, level, k);
-      ph = fmx_phase_decode(phase[pi], k, level, r0);
-    }
-    q0 |= (ph & 1u) << t;
-    q1 |= ((ph >> 1) & 1u) << t;
-    q2 |= ((ph >> 2) & 1u) << t;
+  const uint64_t first = (uint64_t)j * FMX_WALK_ROWS;                // first row of the record
+  auto rank1 = [&](uint32_t c) { return base[(size_t)(c - 1u) * nwalk + j] + edge; };
+  if (g == 7u) {                                                     // the counter piece
+    out[tid] = make_uint4(rank1(2), rank1(3), rank1(4), rank1(5));
+    return;
   }
-  // counter: g <= 6 -> lf_map2(g, 128 j) = counter of code g at the start of R (+ its occurrences in R's first half);
-  // g == 7 -> phase-0 rows before row 128 j
   uint32_t x;
-  if (g < 7u) {
-    x = R[g].x;
-    if (half)
-      for (uint32_t pp = 0; pp < 4u; pp++) x += __popc(fmx_piece_match<3>(R[pp], g));
-  } else {
-    const uint64_t first = (uint64_t)j * FMX_WALK_ROWS;
+  if (g < 5u) {
+    // lf_map2(g + 1, first): the fmt-3 record holding `first`, its counter of the code + the occurrences before `first`
+    const uint64_t fr = first <= n ? first : n;                      // (row n is addressable; beyond it nothing is read)
+    const uint4 *R = rec + (size_t)(fr >> 8) * 8u;
+    x = 0;
+    for (uint32_t pp = 0; pp < 8u; pp++) x += fmx_piece_rank<3>(R[pp], (uint32_t)(fr & 255u), g + 1u, pp);
+  } else if (g == 5u) {
     if (first < n) {
       uint32_t k;
       const uint32_t pi = fmx_phase_piece((uint32_t)first, level, k);
@@ -275,6 +290,23 @@ __global__ __launch_bounds__(BLK) void k_walk_records(const uint4 *__restrict__ 
     } else {
       x = nsamples;
     }
+  } else {
+    x = rank1(1);
+  }
+  // code planes and phase planes of the 16 rows [first + 16 g, + 16): one half of an fmt-3 piece (16 | first)
+  const uint64_t row0 = first + g * 16u;
+  uint32_t p0 = 0, p1 = 0, p2 = 0, q0 = 0, q1 = 0, q2 = 0;
+  if (row0 < n) {
+    const uint4 src = rec[(size_t)(row0 >> 8) * 8u + ((row0 & 255u) >> 5)];
+    const uint32_t sh = (uint32_t)(row0 & 16u);
+    p0 = (src.y >> sh) & 0xFFFFu; p1 = (src.z >> sh) & 0xFFFFu; p2 = (src.w >> sh) & 0xFFFFu;
+  }
+  for (uint32_t t = 0; t < 16u; t++) {
+    const uint64_t row = row0 + t;
+    const uint32_t ph = row < n ? kw_phase_of(phase, (uint32_t)row, level) : 1u;
+    q0 |= (ph & 1u) << t;
+    q1 |= ((ph >> 1) & 1u) << t;
+    q2 |= ((ph >> 2) & 1u) << t;
   }
   out[tid] = make_uint4(x, p0 | (p1 << 16), p2 | (q0 << 16), q1 | (q2 << 16));
 }
@@ -1320,13 +1352,37 @@ int fmx_make_walk_records(fmx_index *idx) {
   if (!fmx_walk_eligible(idx)) return FMX_OK;
   FmxDev &dv = idx->dev;
   const uint32_t nwalk = dv.n / FMX_WALK_ROWS + 1u;
-  uint4 *d_walk;
-  FMX_HIP(hipMalloc((void **)&d_walk, (size_t)nwalk * 128u));
+  const size_t ncnt = (size_t)FMX_WALK_MAX_CHARACTER * nwalk;
+  uint4 *d_walk = nullptr;
+  uint32_t *d_cnt = nullptr, *d_base = nullptr;
+  void *d_tmp = nullptr;
+  size_t tb = 0;
+  hipError_t e = hipMalloc((void **)&d_walk, (size_t)nwalk * 128u);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, ncnt * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_base, ncnt * 4);
+  if (e == hipSuccess) e = exclusive_sum(nullptr, tb, d_cnt, d_base, ncnt);
+  if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 8);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_walk_counts, dim3(nblocks(nwalk)), dim3(BLK), 0, 0, dv.bw.lv[0].rec, dv.phase, dv.n, dv.sa_level,
+                       nwalk, d_cnt);
+    e = exclusive_sum(d_tmp, tb, d_cnt, d_base, ncnt);
+  }
+  if (e == hipSuccess) {
+    // row 0 holds SA = n - 1: when that is a multiple of 2^level it is a phase-0 row with no phase-1 row in front of it
+    const uint32_t edge = ((dv.n - 1u) & ((1u << dv.sa_level) - 1u)) == 0u ? 1u : 0u;
+    hipLaunchKernelGGL(k_walk_records, dim3((unsigned)(((uint64_t)nwalk * 8u + BLK - 1) / BLK)), dim3(BLK), 0, 0,
+                       dv.bw.lv[0].rec, dv.phase, d_base, dv.n, dv.sa_level, dv.nsamples, nwalk, edge, d_walk);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (d_base) (void)hipFree(d_base);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (e != hipSuccess) {
+    if (d_walk) (void)hipFree(d_walk);
+    return fmx_hip_fail(e, "walk records", __LINE__);
+  }
   if (int rc = fmx_keep(idx, d_walk, (uint64_t)nwalk * 128u)) { (void)hipFree(d_walk); return rc; }
-  hipLaunchKernelGGL(k_walk_records, dim3((unsigned)(((uint64_t)nwalk * 8u + BLK - 1) / BLK)), dim3(BLK), 0, 0,
-                     dv.bw.lv[0].rec, dv.phase, dv.n, dv.sa_level, dv.nsamples, nwalk, d_walk);
-  FMX_HIP(hipGetLastError());
-  FMX_HIP(hipDeviceSynchronize());
   dv.walk = d_walk;
   return FMX_OK;
 }
@@ -1405,11 +1461,21 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     // text-order sampling where one LF step costs several dependent requests (RLFM; FM / multi-pieces
     // over two or more wavelet levels): a walk is then SA[row] mod 2^level steps -- half the mean of
     // row-order sampling and no geometric tail -- at the price of two phase-piece reads.  One-level
-    // indexes (DNA) keep row-order sampling: their LF step is ONE request, so the two extra reads cost
-    // more than the saved steps (2^20 hits 0.255 ms against 0.158 ms, profiles/r02/sweeps.md).
-    // FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER override that choice (include/fmx.h).
+    // indexes: the two extra reads cost more than the saved steps (an LF step is ONE request there) unless the
+    // index also gets WALK RECORDS (fmx_internal.h; FM kind, u8 symbols, max_character <= 5, levels 1..3), which
+    // carry the phases inside the records the walk reads anyway: 2.75 requests per hit at level 2 against 4 and a
+    // geometric tail (config 3: 0.085 against 0.125 ms per 2^20 hits).  Round 4: that is the default for
+    // such an index when the device has room (the two arrays add ~1.5 bytes per text symbol: they must fit four times
+    // over in what is free now); FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER override the choice either way,
+    // FMX_FLAG_NO_WALK_RECORDS keeps the walk records off (include/fmx.h).
     const bool can_text = level >= 1 && level <= FMX_PHASE_MAX_LEVEL;
     bool text_order = can_text && (idx->kind == FMX_KIND_RLFM || L > 4);
+    if (can_text && !text_order && idx->kind == FMX_KIND_FM && sizeof(T) == 1 && L <= 3 && maxc <= FMX_WALK_MAX_CHARACTER &&
+        level <= FMX_WALK_MAX_LEVEL && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
+      size_t free_b = 0, total_b = 0;
+      const uint64_t extra = ((uint64_t)n / FMX_WALK_ROWS + 1u) * 128u + ((uint64_t)n / (3u * (32u / level)) + 1u) * 16u;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra) text_order = true;
+    }
     if (idx->flags & FMX_FLAG_TEXT_ORDER) text_order = can_text;
     if (idx->flags & FMX_FLAG_ROW_ORDER) text_order = false;
     if (text_order) {

@@ -631,30 +631,45 @@ __device__ __forceinline__ uint32_t fmx_phase_decode(const uint4 pc, uint32_t t,
 }
 
 // ---- walk records (FmxDev::walk, fmx_internal.h) ----------------------------------------------
-// One LF step of a text-order walk on the walk record holding `row`; p = piece g of that record.  Every lane of the
-// group gets lf_map(row) (fm_index.rs:86-91: cs[L[row]] + rank of L[row], the counters hold cs[] folded in),
-// ph = SA[row] mod 2^level and r0 = the number of phase-0 rows before `row` (the row's index into samples[] when
-// ph == 0).  Two group sums and one broadcast: the row's code and phase and the piece-wise phase-0 counts (<= 128)
-// share the first sum.
-__device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t row, uint32_t g, uint32_t &ph, uint32_t &r0) {
-  const uint32_t off = row & (FMX_WALK_ROWS - 1u), bit = off & 15u;
+// record holding `row` and the row's index inside it (112 rows per record): row / 112 = (row >> 4) / 7, and
+// mulhi(x, ceil(2^32 / 7)) is x / 7 exactly for x < 2^28
+__device__ __forceinline__ uint32_t fmx_walk_record(uint32_t row, uint32_t &off) {
+  const uint32_t rec = __umulhi(row >> 4, 613566757u);
+  off = row - rec * FMX_WALK_ROWS;
+  return rec;
+}
+// One LF step of a text-order walk on the walk record holding `row` (off = the row's index in it); p = piece g of that
+// record.  Every lane of the group gets lf_map(row) (fm_index.rs:86-91: cs[L[row]] + rank of L[row]; the counters hold
+// cs[] folded in), ph = SA[row] mod 2^level, and si = an index into samples[]:
+//     ph == 0: of the row itself (the phase-0 rows before it);
+//     ph == 1: of the row LF(row) -- rank1[L[row]] + the phase-1 rows with the same symbol before it (fmx_internal.h);
+//     else unspecified.
+// Three group sums: the row's code and phase (lane that holds it), the rank, the sample index.
+__device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t off, uint32_t g, uint32_t &ph, uint32_t &si) {
+  const uint32_t bit = off & 15u;
   int nb = (int)off - (int)(g * 16u);
   nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
-  const uint32_t low = (1u << nb) - 1u;
-  const uint32_t zero = ~((p.z >> 16) | p.w | (p.w >> 16)) & 0xFFFFu;       // rows of this piece whose phase is 0
-  uint32_t v = (uint32_t)__popc(zero & low) << 8;
+  const uint32_t low = g < 7u ? (1u << nb) - 1u : 0u;                        // piece 7 holds counters, not rows
+  uint32_t v = 0;
   if (g == (off >> 4))
-    v |= __builtin_amdgcn_ubfe(p.y, bit, 1u) | (__builtin_amdgcn_ubfe(p.y, bit + 16u, 1u) << 1) |
-         (__builtin_amdgcn_ubfe(p.z, bit, 1u) << 2) | (__builtin_amdgcn_ubfe(p.z, bit + 16u, 1u) << 3) |
-         (__builtin_amdgcn_ubfe(p.w, bit, 1u) << 4) | (__builtin_amdgcn_ubfe(p.w, bit + 16u, 1u) << 5);
+    v = __builtin_amdgcn_ubfe(p.y, bit, 1u) | (__builtin_amdgcn_ubfe(p.y, bit + 16u, 1u) << 1) |
+        (__builtin_amdgcn_ubfe(p.z, bit, 1u) << 2) | (__builtin_amdgcn_ubfe(p.z, bit + 16u, 1u) << 3) |
+        (__builtin_amdgcn_ubfe(p.w, bit, 1u) << 4) | (__builtin_amdgcn_ubfe(p.w, bit + 16u, 1u) << 5);
   v = fmx_group_sum(v);
   const uint32_t sym = v & 7u;
-  ph = (v >> 3) & 7u;
-  r0 = fmx_oct_bcast_c<7>(p.x) + (v >> 8);
+  ph = v >> 3;
   const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 0u, 1u), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 1u, 1u),
                  m2 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 2u, 1u);
-  const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & 0xFFFFu;
-  return fmx_group_sum((uint32_t)__popc(match & low) + (g == sym ? p.x : 0u));
+  const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;   // rows before `row` with its symbol
+  const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                         // phase planes (high halves: masked by `low`)
+  // sample index: phase-0 rows before the row (ph == 0), or phase-1 rows with the row's symbol before it (+ rank1[sym])
+  const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (q0 & ~(q1 | q2)) & match;
+  // the counter word of this lane that the index needs: rank0 in lane 5; rank1[1] in lane 6, rank1[2..5] in lane 7
+  const uint32_t c7 = sym == 2u ? p.x : (sym == 3u ? p.y : (sym == 4u ? p.z : p.w));
+  const uint32_t cw = ph == 0u ? (g == 5u ? p.x : 0u)
+                               : (sym == 1u ? (g == 6u ? p.x : 0u) : (g == 7u ? c7 : 0u));
+  si = fmx_group_sum((uint32_t)__popc(sel) + cw);
+  return fmx_group_sum((uint32_t)__popc(match) + (g + 1u == sym ? p.x : 0u));     // lanes 0..4: lf_map2(g + 1, .)
 }
 
 // greatest c with cs[c] <= v  (get_f's binary search, fm_index.rs:97-112)

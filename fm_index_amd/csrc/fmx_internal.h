@@ -106,22 +106,30 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   //             phases SA[row] mod 2^level, floor(32 / level) per word } -> 96, 48, 30, 24 rows per piece;
   //   samples[] then holds SA[row] of the phase-0 rows in row order (same ((n-1) >> level) + 1 entries).
   const uint4 *phase;
-  // Walk records (round 4; one 3-bit level, max_character <= 6, text-order sampling at levels 1..3): a second
+  // Walk records (round 4; one 3-bit level, max_character <= 5, text-order sampling at levels 1..3): a second
   // encoding of the BWT for the batched locate walk, DERIVED from bw.lv[0].rec and phase[] (never stored in a file).
-  // One 128-byte record = 128 rows = 8 pieces of 16 rows; piece g = { x, y, z, w }:
+  // One 128-byte record = 112 rows: pieces 0..6 hold 16 rows each, piece 7 holds counters only.  Piece g <= 6 = { x, y, z, w }:
   //     y = code plane 0 | code plane 1 << 16,  z = code plane 2 | phase plane 0 << 16,  w = phase plane 1 | plane 2 << 16
-  //     x = g <= 6: lf_map2(g, first row of the record) (cs[] folded in, like the fmt-3 counters)
-  //         g == 7: number of phase-0 rows before the record (= index into samples[] of its first phase-0 row)
+  //     x = g <= 4: lf_map2(g + 1, first row of the record)   (cs[] folded in, like the fmt-3 counters)
+  //         g == 5: rank0 = number of phase-0 rows before the record
+  //         g == 6: rank1[1];   piece 7 = { rank1[2], rank1[3], rank1[4], rank1[5] }
+  //     rank1[c] = (row 0 is a phase-0 row) + (phase-1 rows of the index whose BWT symbol is < c)
+  //              + (phase-1 rows before the record whose BWT symbol is c)
   // so ONE line answers everything an LF step of a text-order walk asks of a row: L[row], lf_map(row), the row's phase
-  // SA[row] mod 2^level (= the steps left, known from the walk's first record on) and -- on the final row -- the sample
-  // index.  The two 16-byte phase probes of the text-order walk (start row, final row) disappear: a hit costs
-  // phase + 1 records + 1 sample = 3.5 requests at level 2, against 4 (+ a geometric tail) in row order.
+  // SA[row] mod 2^level (= the steps left, known from the walk's first record on), the index into samples[] of a
+  // phase-0 row (rank0 + the phase-0 rows before it in the record) -- and, for a phase-1 row r with symbol c, the index
+  // of the sample of the row AFTER it, LF(r): LF keeps the order of rows with the same symbol and sends the phase-1
+  // rows onto the phase-0 rows, so rank0(LF(r)) = rank1[c] + (phase-1 rows with symbol c before r in the record).  The
+  // walk never reads the record of its final row, and the two 16-byte phase probes of the round-3 text-order walk are
+  // gone: a hit costs max(phase, 1) records + 1 sample = 2.75 requests at level 2, where the row-order walk issues 4
+  // (+ a geometric tail) and the round-3 text-order walk 4.5.  (Symbol 0 needs no counter: the one row that has it
+  // -- SA = 0 -- maps to row 0, and no walk steps from it: its phase is 0.)
   const uint4 *walk;
 };
 #define FMX_PHASE_MAX_LEVEL 4u
 #define FMX_WALK_MAX_LEVEL 3u        // three phase planes fit the piece
-#define FMX_WALK_MAX_CHARACTER 6u    // counter slot 7 holds the phase-0 rank
-#define FMX_WALK_ROWS 128u
+#define FMX_WALK_MAX_CHARACTER 5u    // 5 lf_map2 counters + rank0 + 5 rank1 counters = the 11 counter words of a record
+#define FMX_WALK_ROWS 112u
 
 // ---- wide indexes: n >= 2^32 - 16 (usize rows of the reference, fm_index.rs:86-95) ------------------------
 // FMIndex / FMIndexWithLocate over byte texts, rows and positions 64 bits wide.  One-level alphabets

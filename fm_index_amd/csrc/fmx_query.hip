@@ -1121,11 +1121,12 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
 // Text-order walk over WALK RECORDS (FmxDev::walk, fmx_internal.h; round 4).  The shape of fmx_locate_f3p_kernel --
 // 8 lanes per record, Q walks per group with walk q's state in lane q of each quad, the block's hit queue, the hand-over
 // at the top of the round, the write-combining ring -- but a record of the walk array tells, next to lf_map(row), the
-// row's phase SA[row] mod 2^level and its rank among the phase-0 rows.  So a walk needs no probe of its own: its FIRST
-// record gives the number of LF steps (the phase of the start row), and the record of the row it ends on gives the index
-// of the sample: phase + 1 records and one sample per hit (3.5 requests at level 2 where the row-order walk issues 4 and
-// the round-3 text-order walk 4.5), and no walk is longer than 2^level - 1 steps -- the geometric tail of row-order
-// sampling (a 2^20-hit batch ends on a chain of ~41 dependent round trips) does not exist.
+// row's phase SA[row] mod 2^level, its rank among the phase-0 rows and, for a phase-1 row, the rank of the row AFTER it
+// among the phase-0 rows.  So a walk needs no probe of its own: its FIRST record gives the number of LF steps (the phase
+// of the start row), and the record of its LAST BUT ONE row (phase 1) gives the index of the sample of its last row,
+// whose record is never read: max(phase, 1) records and one sample per hit -- 2.75 requests at level 2 where the
+// row-order walk issues 4 and the round-3 text-order walk 4.5 -- and no walk is longer than 2^level - 1 steps: the
+// geometric tail of row-order sampling (a 2^20-hit batch ends on a chain of ~41 dependent round trips) does not exist.
 // get_sa is unchanged as a function: (sample + steps) % len (fm_index.rs:127-140).
 template <int Q, bool WC>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
@@ -1175,13 +1176,13 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
     }
   }
   if (!active) row = 0u;
-  // ctl = LF steps still to do | the steps of the whole walk (= the phase of the start row) << 8; FRESH until the
-  // walk's first record has told its phase.  fin: index of the sample once the walk stands on its phase-0 row
+  // ctl = phase of the current row (= LF steps still to do) | the steps of the whole walk (= the phase of the start
+  // row) << 8; FRESH until the walk's first record has told its phase.  fin: index of the walk's sample once known
   constexpr uint32_t FRESH = 0xFFu;
   uint32_t ctl = FRESH, fin = NONE, nsteps = 0;
   for (;;) {
     if (!__any(active)) break;
-    // walks that found their sampled row in the previous round: the slot goes to the next hit, the walk is completed
+    // walks that learnt their sample index in the previous round: the slot goes to the next hit, the walk is completed
     // in this round (its sample travels with the new walk's first record)
     const bool done = active && fin != NONE;
     const unsigned long long fm = __ballot(done && owner);     // one bit per finishing walk
@@ -1233,8 +1234,10 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
       if (!(wm & (SLOT0 << q))) continue;             // walk q idle in every group of the wave
       rq[q] = Q == 1 ? rowx : Q == 8 ? fmx_oct_bcast(rowx, q) : fmx_quad_bcast(rowx, q);
       if (rq[q] != NONE) {                            // group-uniform
-        FMX_CHECK(rq[q] < n && (rq[q] >> 7) < n / FMX_WALK_ROWS + 1u);
-        const uint4 *addr = walk + ((size_t)(rq[q] >> 7) * 8u + g);
+        FMX_CHECK(rq[q] < n);
+        const uint32_t wr = fmx_walk_record(rq[q], rq[q]);   // rq[q] becomes the row's index inside the record
+        FMX_CHECK(wr < n / FMX_WALK_ROWS + 1u && rq[q] < FMX_WALK_ROWS);
+        const uint4 *addr = walk + ((size_t)wr * 8u + g);
         FMX_TOUCH_G0(g, addr - g);
         p[q] = *addr;
       }
@@ -1243,13 +1246,16 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
     for (int q = 0; q < Q; q++) {
       if (!(wm & (SLOT0 << q))) continue;
       if (rq[q] != NONE) {
-        uint32_t ph, r0;
-        const uint32_t nr = fmx_walk_step(p[q], rq[q], g, ph, r0);
+        uint32_t ph, si;
+        const uint32_t nr = fmx_walk_step(p[q], rq[q], g, ph, si);
         if (slot == (uint32_t)q) {
           if (ctl == FRESH) ctl = ph * 0x101u;        // the walk is exactly SA[row] mod 2^level steps long
-          if ((ctl & 0xFFu) == 0u) {                  // Some(sa): this row carries a sample (sample.rs:46-60)
-            FMX_CHECK(ph == 0u);
-            fin = r0;
+          FMX_CHECK(ph == (ctl & 0xFFu));             // an LF step takes the phase down by one
+          if (ph <= 1u) {
+            // ph == 0 (only a start row): Some(sa), this row carries a sample (sample.rs:46-60).  ph == 1: the row
+            // after this one does, and this record knows which -- the walk's last step (fm_index.rs:134-137) needs
+            // no record of its own
+            fin = si;
           } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
             row = nr;
             ctl--;

@@ -94,17 +94,26 @@ typedef struct fmx_index fmx_index;
  *     geometric tail; costs two 16-byte reads per hit and 128 / rows-per-piece bits per row of HBM;
  *   row order: the rows i with i mod 2^level == 0, exactly as SOSampledSuffixArray (sample.rs:21-44).
  * Default: text order for RLFM indexes and FM / multi-pieces indexes over two or more wavelet levels
- * (an LF step there is several dependent requests), row order for one-level indexes (DNA: an LF step is
- * ONE request, the two extra reads cost more than the steps they save on large batches).  These flags
- * override the default either way; both set, or a level outside 1..4, means row order. */
+ * (an LF step there is several dependent requests) and for FM indexes that qualify for walk records (below; the
+ * walk records carry the phases, so the two extra reads disappear) when the device has room for them; row order
+ * for every other one-level index (an LF step is ONE request, the two extra reads cost more than the steps they
+ * save on large batches).  These flags override the default either way; both set, or a level outside 1..4, means
+ * row order. */
 #define FMX_FLAG_TEXT_ORDER 8u
 #define FMX_FLAG_ROW_ORDER 16u
-/* A text-order FM index over one 3-bit wavelet level with max_character <= 6 (DNA) and level 1..3 also gets WALK
- * RECORDS (fmx_walk_records() == 1): a second 128-byte-record encoding of the BWT, 128 rows per record, that
- * carries every row's phase and the phase-0 rank next to its symbol, so that the batched locate walk needs no
- * phase probe: phase + 1 records and one sample per hit.  +1 byte per text symbol of HBM; derived from the other
- * arrays (not stored in index files).  This flag builds the index without them (the round-3 text-order walk). */
+/* A text-order FM index over one 3-bit wavelet level with max_character <= 5 (DNA) and level 1..3 also gets WALK
+ * RECORDS (fmx_walk_records() == 1): a second 128-byte-record encoding of the BWT, 112 rows per record, that
+ * carries every row's phase, the phase-0 rank and per-symbol phase-1 ranks next to its symbol, so that the batched
+ * locate walk needs no phase probe and never reads the record of its last row: max(phase, 1) records and one
+ * sample per hit.  +1.14 bytes per text symbol of HBM; derived from the other arrays (not stored in index files).
+ * This flag builds the index without them (the round-3 text-order walk). */
 #define FMX_FLAG_NO_WALK_RECORDS 64u
+/* Let the builder add the two count accelerators -- FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE -- when they pay and
+ * the device has room: FMX_KIND_FM over u8 symbols with max_character <= 4, n >= 2^24, and at least four times the
+ * finished index free on the device at build time (2.2 x the count rate on a 1 GiB DNA text for 2.1 x the count
+ * structures).  Results are bit-identical either way (see the two flags); fmx_has_pair_index() / fmx_kmer_k() tell
+ * what the index got. */
+#define FMX_FLAG_AUTO 128u
 /* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
  * superblocks of 2^12 rows instead of 2^31, so that a small text exercises every part of it.  Same eligibility
  * (FMX_KIND_FM, n >= 2); same results. */

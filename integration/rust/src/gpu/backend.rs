@@ -3,10 +3,11 @@ use std::ffi::CStr;
 use std::marker::PhantomData;
 
 use super::ffi;
-use crate::backend::{HasPosition, SearchIndexBackend};
+use crate::backend::{HasMultiPieces, HasPosition, SearchIndexBackend};
 use crate::character::Character;
 use crate::error::Error;
 use crate::heap_size::HeapSize;
+use crate::piece::PieceId;
 use crate::text::Text;
 
 /// which of the reference's index types the handle stands for (`frontend.rs:110-193`)
@@ -16,6 +17,8 @@ pub enum GpuIndexKind {
     Fm = ffi::FMX_KIND_FM as isize,
     /// `RLFMIndex` / `RLFMIndexWithLocate` (`src/rlfmi.rs`)
     Rlfm = ffi::FMX_KIND_RLFM as isize,
+    /// `FMIndexMultiPieces` / `FMIndexMultiPiecesWithLocate` (`src/multi_pieces.rs`)
+    Multi = ffi::FMX_KIND_MULTI as isize,
 }
 
 /// Symbol widths libfmx takes natively (`Character`, `character.rs:38-42`).
@@ -130,8 +133,19 @@ impl<C: GpuCharacter> SearchIndexBackend for GpuBackend<C> {
         C::from_u64_lossy(checked(unsafe { ffi::fmx_get_f(self.h, i as u64) }))
     }
     fn fl_map(&self, i: usize) -> Option<usize> {
-        // always Some for FM / RLFM (fm_index.rs:114-120, rlfmi.rs:160-169)
-        Some(checked(unsafe { ffi::fmx_fl_map(self.h, i as u64) }) as usize)
+        // Some for FM / RLFM (fm_index.rs:114-120, rlfmi.rs:160-169); None on a multi-pieces index when
+        // F[i] is the piece separator (multi_pieces.rs:176-187).  The batch form tells the two apart: its
+        // return code is the error, the all-ones value is None
+        let (row, mut out) = (i as u64, u64::MAX);
+        let rc = unsafe { ffi::fmx_fl_map_batch(self.h, &row, 1, &mut out) };
+        if rc != ffi::FMX_OK {
+            panic!("libfmx: {}", last_error());
+        }
+        if out == u64::MAX {
+            None
+        } else {
+            Some(out as usize)
+        }
     }
     fn len(&self) -> usize {
         unsafe { ffi::fmx_len(self.h) as usize }
@@ -160,6 +174,48 @@ impl<C: GpuCharacter> SearchIndexBackend for GpuBackend<C> {
             panic!("libfmx: {}", last_error());
         }
         (os as usize, oe as usize)
+    }
+
+    /// the rows `iter_matches` visits (`wrapper.rs:203-217`): `s..e`, or for a prefix-only search
+    /// (`search_prefix` / `search_exact`, `wrapper.rs:57-82`) the rows of the range whose L symbol is 0 --
+    /// counted and listed on the device (`fmx_match_counts` + `fmx_match_rows`) instead of one `get_l`
+    /// call per row.  See gpu-backend.patch for the provided method this overrides.
+    fn match_rows<'a>(
+        &'a self,
+        s: usize,
+        e: usize,
+        match_prefix_only: bool,
+    ) -> Box<dyn Iterator<Item = usize> + 'a> {
+        if !match_prefix_only {
+            return Box::new(s..e);
+        }
+        let (ss, ee) = (s as u64, e as u64);
+        let mut count = 0u64;
+        let rc = unsafe { ffi::fmx_match_counts(self.h, &ss, &ee, 1, 1, &mut count) };
+        if rc != ffi::FMX_OK {
+            panic!("libfmx: {}", last_error());
+        }
+        let mut rows = vec![0u64; count as usize];
+        if count > 0 {
+            let off = [0u64, count];
+            let rc = unsafe {
+                ffi::fmx_match_rows(self.h, &ss, &ee, 1, 1, off.as_ptr(), rows.as_mut_ptr())
+            };
+            if rc != ffi::FMX_OK {
+                panic!("libfmx: {}", last_error());
+            }
+        }
+        Box::new(rows.into_iter().map(|r| r as usize))
+    }
+}
+
+/// `FMIndexMultiPieces*` (`multi_pieces.rs:201-224`): built with `GpuIndexKind::Multi`
+impl<C: GpuCharacter> HasMultiPieces for GpuBackend<C> {
+    fn piece_id(&self, i: usize) -> PieceId {
+        PieceId::from(checked(unsafe { ffi::fmx_piece_id(self.h, i as u64) }) as usize)
+    }
+    fn pieces_count(&self) -> usize {
+        unsafe { ffi::fmx_pieces_count(self.h) as usize }
     }
 }
 

@@ -1,9 +1,10 @@
 //! MI355X backend for the count / locate path (feature `gpu`).
 //!
 //! * [`ffi`]     -- raw binding of `include/fmx.h`, generated from the header.
-//! * [`backend`] -- `GpuBackend`: `impl SearchIndexBackend + HasPosition + HeapSize`
-//!                  (`src/backend.rs:5-31`), so `SearchIndexWrapper<GpuBackend<_>>` -- and with it the
-//!                  public `Search` / `Match` / `MatchWithLocate` traits -- run unchanged.
+//! * [`backend`] -- `GpuBackend`: `impl SearchIndexBackend + HasPosition + HasMultiPieces + HeapSize`
+//!                  (`src/backend.rs:5-40`), so `SearchIndexWrapper<GpuBackend<_>>` -- and with it the
+//!                  public `Search` / `Match` / `MatchWithLocate` / `MatchWithPieceId` traits and the
+//!                  multi-pieces searches (`search_prefix` / `search_suffix` / `search_exact`) -- run unchanged.
 //! * [`batch`]   -- what the GPU is for: many patterns per call (`search_many`, `locate_many`).
 pub mod backend;
 pub mod batch;

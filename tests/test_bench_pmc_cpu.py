@@ -14,7 +14,7 @@ def row(name, grid, counter, value):
     return {"Kernel_Name": name, "Grid_Size": str(grid), "Counter_Name": counter, "Counter_Value": str(value)}
 
 
-WALK = "void fmx_locate_f3p_kernel<4, true>(HIP_vector_type<unsigned int, 4u> const*, ...)"
+WALK = "void fmx_locate_f3t_kernel<4, true>(HIP_vector_type<unsigned int, 4u> const*, ...)"
 COUNT = "void fmx_count_f3_kernel<1, false, false>(HIP_vector_type<unsigned int, 4u> const*, ...)"
 EPC = "void fmx_count_ep_kernel<1, 2, 2, false>(FmxDev, ...)"
 

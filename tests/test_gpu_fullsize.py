@@ -34,6 +34,51 @@ def _count_dev(index, pat, off, npat):
     return s, e, c
 
 
+def _suffix_less(text, a, b, step=64):
+    """suffix text[a:] < suffix text[b:] for arrays of start positions, on the host: windows of `step` symbols until
+    the first differing symbol.  The text ends with its unique smallest symbol, so two different suffixes differ at or
+    before the end of the shorter one (reads past the end are clamped onto the terminator, which decides)."""
+    n = len(text)
+    less = np.zeros(len(a), dtype=bool)
+    undecided = np.ones(len(a), dtype=bool)
+    win = np.arange(step, dtype=np.int64)
+    o = 0
+    while undecided.any():
+        ii = np.nonzero(undecided)[0]
+        ta = text[np.minimum(a[ii, None] + o + win, n - 1)]
+        tb = text[np.minimum(b[ii, None] + o + win, n - 1)]
+        ne = ta != tb
+        has = ne.any(axis=1)
+        first = ne.argmax(axis=1)
+        r = np.nonzero(has)[0]
+        less[ii[r]] = ta[r, first[r]] < tb[r, first[r]]
+        undecided[ii[r]] = False
+        o += step
+        assert o < n
+    return less
+
+
+def _independent_sa_spot_check(index, text, level, pairs=1 << 16, seed=91):
+    """The suffix array the GPU builder made, checked WITHOUT any kernel of the builder or the index:
+    random adjacent pairs (SA[i], SA[i+1]) are compared on the host against the TEXT itself (numpy, first differing
+    symbol), the exported L column against text[SA[i] - 1] on those rows (fm_index.rs:44-58), and EVERY exported
+    suffix-array sample against SA[k << level] (sample.rs:33-37: with text-order sampling each of them is a get_sa walk
+    through the index)."""
+    n = index.len()
+    sa = index.export_sa()
+    th = text.cpu().numpy()
+    assert sa.shape == (n,) and sa[0] == n - 1                  # the terminator suffix sorts first
+    i = (W.splitmix64_np(seed, 0, pairs) % np.uint64(n - 1)).astype(np.int64)
+    a, b = sa[i].astype(np.int64), sa[i + 1].astype(np.int64)
+    assert _suffix_less(th, a, b).all(), "adjacent suffixes out of order"
+    bwt = index.export_bwt()
+    want = np.where(a > 0, th[np.maximum(a - 1, 0)], 0)
+    assert (bwt[i] == want).all(), "L column differs from text[SA - 1]"
+    smp = index.export_sa_samples()
+    assert smp.shape == (((n - 1) >> level) + 1,) and (smp == sa[::1 << level]).all(), "samples differ from SA[k << level]"
+    del sa, th, bwt, smp
+
+
 def test_config2_config3_dna_1gb():
     import torch
     from oracle import fm_oracle as O
@@ -42,7 +87,9 @@ def test_config2_config3_dna_1gb():
     text = W.dna_text_torch(N, 1, dev)
     index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=2, keep_sa=True)
     assert index.len() == N and index.level() == 2
-    assert index.verify_sa() == 0                      # the array IS the suffix array
+    assert index.verify_sa() == 0                      # the array IS the suffix array (device-side check)
+    _independent_sa_spot_check(index, text, 2)         # ... and says the host, from the text alone
+    assert index.text_order() and index.walk_records()  # the default DNA index of round 4
     npat, m = 1 << 20, 32
     pat, off, pos = W.substring_patterns_torch(text, npat, m, 3)
     s, e, c = _count_dev(index, pat, off, npat)
@@ -106,7 +153,8 @@ def test_config4_rlfm_byte_text_1gb():
     npat, m = 1 << 20, 16
     pat, off, pos = W.substring_patterns_torch(text, npat, m, 6)
     lib = L.lib()
-    rl = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), N, 255, level=3)
+    rl = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), N, 255, level=3, keep_sa=True)
+    _independent_sa_spot_check(rl, text, 3, seed=92)
     s, e, c = _count_dev(rl, pat, off, npat)
     assert bool((c >= 1).all())
     runs = int(lib.fmx_num_runs(rl.handle()))

@@ -62,9 +62,10 @@ def test_every_row_and_step_bound(kind, maxc, alpha, level):
 
 
 @pytest.mark.parametrize("kind,maxc,alpha", [("rlfm", 4, 4), ("fm", 255, 90)])
-def test_one_level_dna_keeps_row_order_and_text_order_steps_halve(kind, maxc, alpha):
-    """One-level FM indexes keep row-order sampling (their LF step is one request); the others walk
-    SA[row] mod 2^level steps, half the row-order mean."""
+def test_row_order_dna_walks_are_geometric_and_text_order_steps_halve(kind, maxc, alpha):
+    """Row-order sampling (the reference's; FMX_FLAG_ROW_ORDER on a DNA index, whose default became text order with
+    walk records in round 4) walks a geometric number of steps, mean 2^level - 1; text order walks SA[row] mod
+    2^level steps, half that mean."""
     n, level = 1 << 16, 2
     t = _text(77, n, alpha)
     cls = {"rlfm": F.RLFMIndexWithLocate, "fm": F.FMIndexWithLocate}[kind]
@@ -72,9 +73,15 @@ def test_one_level_dna_keeps_row_order_and_text_order_steps_halve(kind, maxc, al
     _, steps = _locate_steps(gi, np.array([0], np.uint64), np.array([n], np.uint64))
     assert steps <= 3 * n                                          # at most 2^level - 1 per row
     assert abs(steps / n - 1.5) < 0.05                             # uniform phases: mean 1.5
-    dna = F.FMIndexWithLocate(F.Text.with_max_character(_text(78, n, 4), 4), level)
+    dna = F.FMIndexWithLocate(F.Text.with_max_character(_text(78, n, 4), 4), level, sampling="row")
+    assert not dna.text_order()
     _, steps_dna = _locate_steps(dna, np.array([0], np.uint64), np.array([n], np.uint64))
     assert steps_dna > 2 * n                                       # geometric, mean 3 (row-order sampling)
+    # the default DNA index: text order + walk records (2.75 requests per hit at level 2)
+    dflt = F.FMIndexWithLocate(F.Text.with_max_character(_text(78, n, 4), 4), level)
+    assert dflt.text_order() and dflt.walk_records()
+    _, steps_dflt = _locate_steps(dflt, np.array([0], np.uint64), np.array([n], np.uint64))
+    assert abs(steps_dflt / n - 1.5) < 0.05
 
 
 @pytest.mark.parametrize("kind", ["rlfm", "fm"])

@@ -35,6 +35,7 @@ _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
 SYMBOLS = [
     ("fmx_last_error", C.c_char_p, []),
     ("fmx_error_message", C.c_char_p, [_I]),
+    ("fmx_release_scratch", None, []),
     ("fmx_build", _I, [_V, _U64, _U32, _U64, _U32, _U32, _U32, _I, C.POINTER(_V)]),
     ("fmx_build_dev", _I, [_V, _U64, _U32, _U64, _U32, _U32, _U32, _I, C.POINTER(_V)]),
     ("fmx_free", None, [_V]),

@@ -77,11 +77,14 @@ static int select_device(int device) {
   return FMX_OK;
 }
 
+void fmx_release_scratch(void) { fmx_release_build_scratch(); }
+
 void fmx_free(fmx_index *idx) {
   if (!idx) return;
   DeviceGuard dg;
   (void)dg.set(idx->device);
   for (int i = 0; i < idx->nalloc; i++) (void)hipFree(idx->d_alloc[i]);
+  free(idx->d_alloc);
   if (idx->dev.status) (void)hipFree(idx->dev.status);
   if (idx->d_steps) (void)hipFree(idx->d_steps);
   if (idx->ev0) (void)hipEventDestroy(idx->ev0);
@@ -508,6 +511,16 @@ static void *device_view(const void *p) {
   }
   return d;
 }
+// ... of a whole array [p, p + bytes): the LAST byte must be page-locked too and map where the first byte's mapping
+// says it should (a caller may have registered only part of an array -- hipHostRegister on a sub-range, a pinned
+// allocation shorter than the array: the copy kernels and the DMA engine must not run into the unregistered tail,
+// which is a fatal GPU memory fault without XNACK).  Called with the index's device current (CHECK_IDX).
+static void *device_view(const void *p, size_t bytes) {
+  void *d = device_view(p);
+  if (!d || bytes <= 1) return d;
+  void *dl = device_view((const uint8_t *)p + (bytes - 1));
+  return dl == (uint8_t *)d + (bytes - 1) ? d : nullptr;
+}
 // dst[0, n) = src[0, n); both sides aligned alike modulo 16 (the callers see to that): bytes up to the first
 // 16-byte boundary, 16-byte vectors, bytes again
 __global__ __launch_bounds__(256) void fmx_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
@@ -591,11 +604,13 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   // Built from hipMemcpyAsync alone it was slower than no pipeline at all: every hand-over between a DMA copy and
   // a kernel of the same stream costs tens of microseconds on this runtime (4.0 ms per 2^20 x 32 call with eight
   // chunks, 2.0 ms with two; benchmarks/gpu/pcie_probe.hip, hostpipe_sweep.sh).
-  const bool all_pinned = idx->sym_bytes_abi != 8 && !idx->timing && npat >= (1u << 16) &&
-                          device_view(pat) && device_view(pat_off) && (!s0e0 || device_view(s0e0)) &&
-                          (!out_s || device_view(out_s)) && (!out_e || device_view(out_e)) &&
-                          (!out_count || device_view(out_count));
   const size_t b_pat = (size_t)total * sb, b_out = (size_t)npat * 8;
+  // (every array checked over its whole length, with the index's device current; one that is only partly
+  // page-locked sends the call down the pageable path)
+  const bool all_pinned = idx->sym_bytes_abi != 8 && !idx->timing && npat >= (1u << 16) &&
+                          device_view(pat, b_pat) && device_view(pat_off, (size_t)(npat + 1) * 8) &&
+                          (!s0e0 || device_view(s0e0, 2 * b_out)) && (!out_s || device_view(out_s, b_out)) &&
+                          (!out_e || device_view(out_e, b_out)) && (!out_count || device_view(out_count, b_out));
   const uint64_t max_ch = 8;
   const size_t b_off = (size_t)(npat + 1 + max_ch) * 8;      // every chunk gets its own slice of the offsets
   HostCall hc;
@@ -634,8 +649,16 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     if (const char *v = getenv("FMX_PIPE_H2D")) h2d_dma = atoi(v) != 0;
     if (const char *v = getenv("FMX_PIPE_OFF_STREAM")) off_stream = atoi(v) != 0;
 #endif
+    // a HIP call that fails in the middle of the pipeline must not leave earlier chunks in flight: their copy
+    // kernels would keep writing the caller's arrays, and the thread's retained scratch -- which the next call on
+    // this thread overwrites -- would still be read by their searches
+#define FMX_HIP_DRAIN(x)                                             \
+    do {                                                             \
+      hipError_t _e = (x);                                           \
+      if (_e != hipSuccess) { drain(); return fmx_hip_fail(_e, #x, __LINE__); } \
+    } while (0)
     auto cut = [&](uint64_t k) { return npat * k / nch; };
-    FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, s_k));   // ahead of every search in the search stream
+    FMX_HIP_DRAIN(hipMemsetAsync(status_dev(sx), 0, 4, s_k));   // ahead of every search in the search stream
     // the device copy of the symbols keeps the caller's alignment modulo 16, so that both sides of every
     // chunk's copy are aligned alike whatever pa is
     uint8_t *d_pat_al = d_pat + ((uintptr_t)src & 15u);
@@ -659,22 +682,22 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       // the concurrent search five-fold (benchmarks/gpu/hostpipe_trace.sh)
       uint64_t *off_k = d_off + a + k;               // entries a..b of the caller's offsets, this chunk's own copy
       if (h2d_dma) {
-        FMX_HIP(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice,
+        FMX_HIP_DRAIN(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice,
                                off_stream ? s_off : s_in));
         if (off_stream) {
-          FMX_HIP(hipEventRecord(sx->ev_off[k], s_off));
-          FMX_HIP(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
+          FMX_HIP_DRAIN(hipEventRecord(sx->ev_off[k], s_off));
+          FMX_HIP_DRAIN(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
         }
         if (pb > pa)
-          FMX_HIP(hipMemcpyAsync(d_pat_al + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, s_in));
-        if (s0e0) FMX_HIP(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, s_in));
+          FMX_HIP_DRAIN(hipMemcpyAsync(d_pat_al + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, s_in));
+        if (s0e0) FMX_HIP_DRAIN(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, s_in));
       } else {
         launch_copy(off_k, v_off + a, (size_t)(b - a + 1) * 8, s_in);
         if (pb > pa) launch_copy(d_pat_al + pa * sb, v_pat + pa * sb, (size_t)(pb - pa) * sb, s_in);
         if (s0e0) launch_copy(d_se + 2 * a, v_se + 2 * a, (size_t)(b - a) * 16, s_in);
       }
-      FMX_HIP(hipEventRecord(sx->ev_in[k], s_in));
-      FMX_HIP(hipStreamWaitEvent(s_k, sx->ev_in[k], 0));
+      FMX_HIP_DRAIN(hipEventRecord(sx->ev_in[k], s_in));
+      FMX_HIP_DRAIN(hipStreamWaitEvent(s_k, sx->ev_in[k], 0));
       // the kernel bounds every pattern's offsets by the last entry it is given: pb <= total.  Fewer blocks than
       // the CUs have slots for: the download kernels of the chunk before need somewhere to run WHILE this
       // search runs (a persistent 2048-block grid holds every slot until its last pattern)
@@ -683,17 +706,18 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
         drain();
         return rc;
       }
-      FMX_HIP(hipEventRecord(sx->ev_k[k], s_k));
-      FMX_HIP(hipStreamWaitEvent(s_out, sx->ev_k[k], 0));
+      FMX_HIP_DRAIN(hipEventRecord(sx->ev_k[k], s_k));
+      FMX_HIP_DRAIN(hipStreamWaitEvent(s_out, sx->ev_k[k], 0));
       // download by copy kernels: kernel after kernel, no hand-over to a DMA engine
       if (v_os) launch_copy(v_os + a, d_s + a, (size_t)(b - a) * 8, s_out);
       if (v_oe) launch_copy(v_oe + a, d_e + a, (size_t)(b - a) * 8, s_out);
       if (v_oc) launch_copy(v_oc + a, d_c + a, (size_t)(b - a) * 8, s_out);
     }
-    FMX_HIP(hipGetLastError());
-    FMX_HIP(hipStreamSynchronize(s_in));
-    FMX_HIP(hipStreamSynchronize(s_off));
-    FMX_HIP(hipStreamSynchronize(s_out));            // s_k == sx->st is waited for below
+    FMX_HIP_DRAIN(hipGetLastError());
+    FMX_HIP_DRAIN(hipStreamSynchronize(s_in));
+    FMX_HIP_DRAIN(hipStreamSynchronize(s_off));
+    FMX_HIP_DRAIN(hipStreamSynchronize(s_out));            // s_k == sx->st is waited for below
+#undef FMX_HIP_DRAIN
     return finish_host_call(sx);
   }
   // pageable arrays: the runtime's copies (pin, copy, unpin), each chunk chained in one of two streams.  Two

@@ -15,6 +15,7 @@
 #include <iterator>
 #include <rocprim/rocprim.hpp>
 #include <vector>
+#include <mutex>
 #include <chrono>
 #include "fmx_device.h"
 
@@ -22,27 +23,66 @@
 
 namespace {
 
-// Scratch of SMALL builds: every temporary of a text of up to kArenaMaxN symbols is carved from one buffer the
-// calling thread keeps per device, instead of ~30 hipMalloc / hipFree pairs (a hipFree waits for the device; at
-// n = 1000 they were most of the build).  Released when the thread exits.
+// Scratch of SMALL builds: every temporary of a text of up to kArenaMaxN symbols is carved from one leased buffer
+// instead of ~30 hipMalloc / hipFree pairs (a hipFree waits for the device; at n = 1000 they were most of the build).
+// The buffers belong to a process-wide pool per device, behind a mutex: a build leases one for its duration -- sized
+// from n (4 MiB up to 8192 symbols, else 48 MiB: 384 bytes per symbol) -- and hands it back; at most kArenaKeep idle
+// buffers per device and size class are retained, whatever the number of threads that build (a thread-pool service
+// used to pin 48 MiB per worker thread and device until the thread exited), fmx_release_scratch() frees the idle ones,
+// and nothing is freed at process exit (the pool is never destroyed: no hipFree can race the runtime's teardown).
+// A failed allocation is not retried for the next kArenaBackoff small builds on that device.
 const uint64_t kArenaMaxN = 1ull << 17;
-const size_t kArenaBytes = 48u << 20;
-struct SmallArenaSet {
-  uint8_t *p[16] = {};
-  ~SmallArenaSet() {
-    for (int d = 0; d < 16; d++)
-      if (p[d] && hipSetDevice(d) == hipSuccess) (void)hipFree(p[d]);
+const size_t kArenaBytes = 48u << 20, kArenaSmallBytes = 4u << 20;
+const uint64_t kArenaSmallN = 8192;
+const int kArenaKeep = 2, kArenaBackoff = 64, kArenaDevices = 16;
+struct ArenaPool {
+  std::mutex mu;
+  std::vector<uint8_t *> idle[kArenaDevices][2];
+  int backoff[kArenaDevices] = {};
+};
+inline ArenaPool &arena_pool() {
+  static ArenaPool *pool = new ArenaPool;     // leaked on purpose
+  return *pool;
+}
+struct ArenaLease {   // RAII: the buffer goes back to the pool (or is freed when the pool is full) when the build returns
+  uint8_t *p = nullptr;
+  size_t bytes = 0;
+  int device = -1, cls = 0;
+  void take(int dev, uint64_t n) {
+    if (dev < 0 || dev >= kArenaDevices) return;
+    device = dev;
+    cls = n <= kArenaSmallN ? 0 : 1;
+    bytes = cls ? kArenaBytes : kArenaSmallBytes;
+    ArenaPool &ap = arena_pool();
+    {
+      std::lock_guard<std::mutex> lk(ap.mu);
+      if (!ap.idle[dev][cls].empty()) {
+        p = ap.idle[dev][cls].back();
+        ap.idle[dev][cls].pop_back();
+        return;
+      }
+      if (ap.backoff[dev] > 0) { ap.backoff[dev]--; return; }
+    }
+    if (hipMalloc((void **)&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      std::lock_guard<std::mutex> lk(ap.mu);
+      ap.backoff[dev] = kArenaBackoff;
+    }
+  }
+  ~ArenaLease() {
+    if (!p) return;
+    ArenaPool &ap = arena_pool();
+    {
+      std::lock_guard<std::mutex> lk(ap.mu);
+      if ((int)ap.idle[device][cls].size() < kArenaKeep) {
+        ap.idle[device][cls].push_back(p);
+        return;
+      }
+    }
+    (void)hipFree(p);      // the calling thread's current device is the build's device
   }
 };
-inline uint8_t *small_arena(int device) {
-  static thread_local SmallArenaSet set;
-  if (device < 0 || device >= 16) return nullptr;
-  if (!set.p[device] && hipMalloc((void **)&set.p[device], kArenaBytes) != hipSuccess) {
-    (void)hipGetLastError();
-    set.p[device] = nullptr;
-  }
-  return set.p[device];
-}
 
 struct DevPool {  // temporaries freed when the builder returns
   std::vector<void *> v;
@@ -1348,6 +1388,25 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   return FMX_OK;
 }
 
+// idle small-build buffers of every device (include/fmx.h: fmx_release_scratch)
+void fmx_release_build_scratch(void) {
+  ArenaPool &ap = arena_pool();
+  std::vector<std::pair<int, uint8_t *>> drop;
+  {
+    std::lock_guard<std::mutex> lk(ap.mu);
+    for (int d = 0; d < kArenaDevices; d++)
+      for (int c = 0; c < 2; c++) {
+        for (uint8_t *p : ap.idle[d][c]) drop.push_back({d, p});
+        ap.idle[d][c].clear();
+      }
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (auto &dp : drop)
+    if (hipSetDevice(dp.first) == hipSuccess) (void)hipFree(dp.second);
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
 int fmx_make_walk_records(fmx_index *idx) {
   if (!fmx_walk_eligible(idx)) return FMX_OK;
   FmxDev &dv = idx->dev;
@@ -1403,7 +1462,11 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
   const uint32_t maxc = (uint32_t)idx->max_character;
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);  // text.rs:61-63
   // (FMX_FLAG_KEEP_SA hands the suffix array over to the index: it must be an allocation of its own)
-  if (n <= kArenaMaxN && !(idx->flags & FMX_FLAG_KEEP_SA)) pool.use_arena(small_arena(idx->device), kArenaBytes);
+  ArenaLease lease;     // declared after the pool: returned before the pool's own frees run
+  if (n <= kArenaMaxN && !(idx->flags & FMX_FLAG_KEEP_SA)) {
+    lease.take(idx->device, n);
+    pool.use_arena(lease.p, lease.bytes);
+  }
 
   // -- statistics + validation (sais.rs:115-139) --
   std::vector<uint64_t> hist;

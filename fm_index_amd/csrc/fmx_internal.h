@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstddef>
 #include "fmx.h"
 
@@ -192,8 +193,8 @@ struct fmx_index {
   uint64_t runs;
   double build_ms;
   // owned device allocations
-  void *d_alloc[96];
-  int nalloc;
+  void **d_alloc;        // grows by doubling (fmx_keep); freed by fmx_free
+  int nalloc, cap_alloc;
   uint64_t *h_cs;        // character-based C array (sais.rs:9-32), host copy
   uint8_t *d_text;       // FMX_FLAG_KEEP_SA
   uint32_t *d_sa;        // FMX_FLAG_KEEP_SA
@@ -214,6 +215,7 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+void fmx_release_build_scratch(void);   // the idle small-build buffers of every device (fmx_release_scratch)
 // walk records of an index that has the fmt-3 records and the phase pieces (builder, fmx_load): allocates, fills and
 // registers dev.walk; no-op (FMX_OK, dev.walk stays NULL) when the index is not eligible
 int fmx_make_walk_records(fmx_index *idx);
@@ -252,7 +254,16 @@ static inline FmxDev fmx_launch_dev(const fmx_index *idx) {
 }
 // registers a device allocation owned by the index (freed by fmx_free, counted in index bytes)
 static inline int fmx_keep(fmx_index *idx, void *p, uint64_t bytes) {
-  if (idx->nalloc >= 96) return FMX_ERR_ARG;
+  if (idx->nalloc >= idx->cap_alloc) {
+    const int cap = idx->cap_alloc ? idx->cap_alloc * 2 : 64;
+    void **grown = (void **)realloc(idx->d_alloc, (size_t)cap * sizeof(void *));
+    if (!grown) {
+      fmx_set_error(FMX_ERR_ARG, "out of host memory");
+      return FMX_ERR_ARG;
+    }
+    idx->d_alloc = grown;
+    idx->cap_alloc = cap;
+  }
   idx->d_alloc[idx->nalloc++] = p;
   idx->bytes += bytes;
   return FMX_OK;

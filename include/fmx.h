@@ -122,6 +122,10 @@ typedef struct fmx_index fmx_index;
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
 const char *fmx_last_error(void);
+/* Frees the device scratch the library keeps between calls and that no call is using: the pool of small-build
+ * buffers (at most two per device and size class: 4 MiB / 48 MiB, leased by fmx_build* of texts up to 2^17
+ * symbols).  A long-lived service calls it after a burst of small builds; nothing else ever needs to. */
+void fmx_release_scratch(void);
 const char *fmx_error_message(int code);
 
 /* ---- construction ------------------------------------------------------- */

@@ -39,8 +39,8 @@ int orc_max_threads(void) {
 
 /* Thread placement for the batch drivers (bench.py's cpu_baseline): when switched on, the threads of a batch
  * pin themselves one per CPU, spread evenly over the CPUs this process is allowed to use (so over both sockets
- * and, while there are fewer threads than cores, one per core); the calling thread gets its own mask back when
- * the batch is done.  Done here rather than with OMP_PROC_BIND because that also narrows the mask of the calling
+ * and, while there are fewer threads than cores, one per core); every thread of the team gets the calling thread's
+ * mask back when the batch is done.  Done here rather than with OMP_PROC_BIND because that also narrows the mask of the calling
  * (Python) thread for good -- and with it the mask every thread created later inherits. */
 static int g_spread = 0;
 void orc_set_thread_spread(int on) { g_spread = on; }
@@ -863,6 +863,10 @@ int orc_count_batch(const orc_backend *b, const uint8_t *pat, const uint64_t *of
       out_s[k] = s; out_e[k] = e;
       if (out_steps) out_steps[k] = st;
     }
+    /* EVERY thread of the team gets the caller's mask back, not only the calling thread: libgomp keeps its workers
+     * between regions, and a worker left on one CPU would run later batches -- a smaller team of the thread sweep,
+     * orc_locate_batch -- on that stale one-CPU mask */
+    orc_place_end(&pl);
   }
   orc_place_end(&pl);
   return err;

@@ -106,7 +106,8 @@ class Text:
         return self._max
 
 
-def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_records=True, auto=False):
+def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_records=True, auto=False,
+           keep_scratch=False):
     """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
     (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
     if sampling not in (None, "text", "row"):
@@ -114,7 +115,8 @@ def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_rec
     return ((L.FLAG_KEEP_SA if keep_sa else 0) | (L.FLAG_PAIR_INDEX if pair_index else 0) |
             (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
             (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0) |
-            (0 if walk_records else L.FLAG_NO_WALK_RECORDS) | (L.FLAG_AUTO if auto else 0))
+            (0 if walk_records else L.FLAG_NO_WALK_RECORDS) | (L.FLAG_AUTO if auto else 0) |
+            (L.FLAG_KEEP_SCRATCH if keep_scratch else 0))
 
 
 class _Index:
@@ -139,7 +141,7 @@ class _Index:
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
                          pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False,
-                         walk_records=True, auto=False):
+                         walk_records=True, auto=False, keep_scratch=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -147,7 +149,8 @@ class _Index:
         self._dtype = np.dtype(_DTYPES[sym_bytes])
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
-                                       _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto),
+                                       _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
+                                              keep_scratch),
                                        device, C.byref(self._h)))
         return self
 

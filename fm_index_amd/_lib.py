@@ -29,6 +29,7 @@ FLAG_ROW_ORDER = 16
 FLAG_FORCE_WIDE = 32
 FLAG_NO_WALK_RECORDS = 64
 FLAG_AUTO = 128
+FLAG_KEEP_SCRATCH = 256
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
@@ -79,6 +80,7 @@ SYMBOLS = [
     ("fmx_offsets_ws_dev", _I, [_V, _V, _V, _U64, _V, _V, _U64, _V]),
     ("fmx_set_timing", None, [_V, _I]),
     ("fmx_last_kernel_ms", _D, [_V]),
+    ("fmx_series_kernel_ms", _D, [_V]),
     ("fmx_last_steps", _U64, [_V]),
     ("fmx_build_ms", _D, [_V]),
     ("fmx_export_bwt", _I, [_V, _V]),

@@ -89,6 +89,10 @@ void fmx_free(fmx_index *idx) {
   if (idx->d_steps) (void)hipFree(idx->d_steps);
   if (idx->ev0) (void)hipEventDestroy(idx->ev0);
   if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+  if (idx->ev_series) {
+    for (int i = 0; i < 2 * FMX_SERIES_CAP; i++) (void)hipEventDestroy(idx->ev_series[i]);
+    free(idx->ev_series);
+  }
   free(idx->h_cs);
   free(idx);
 }
@@ -220,7 +224,32 @@ uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->d
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
 void fmx_set_timing(fmx_index *idx, int enabled) {
-  if (idx) { idx->timing = enabled; idx->ev_valid = 0; }
+  if (!idx) return;
+  idx->ev_valid = 0;
+  idx->series_n = 0;
+  if (enabled == 2 && !idx->ev_series) {          // a series of launches: FMX_SERIES_CAP event pairs, created once
+    DeviceGuard dg;
+    if (dg.set(idx->device) != hipSuccess) return;
+    hipEvent_t *ev = (hipEvent_t *)calloc(2 * FMX_SERIES_CAP, sizeof(hipEvent_t));
+    bool ok = ev != nullptr;
+    for (int i = 0; ok && i < 2 * FMX_SERIES_CAP; i++) ok = hipEventCreate(&ev[i]) == hipSuccess;
+    if (!ok) { free(ev); enabled = 0; } else idx->ev_series = ev;
+  }
+  idx->timing = enabled;
+}
+double fmx_series_kernel_ms(fmx_index *idx) {
+  if (!idx || !idx->ev_series || idx->series_n == 0) return -1.0;
+  double sum = 0;
+  for (int i = 0; i < idx->series_n; i++) {
+    float ms = 0;
+    if (hipEventSynchronize(idx->ev_series[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, idx->ev_series[2 * i], idx->ev_series[2 * i + 1]) != hipSuccess)
+      return -1.0;
+    sum += ms;
+  }
+  const double mean = sum / idx->series_n;
+  idx->series_n = 0;
+  return mean;
 }
 double fmx_last_kernel_ms(const fmx_index *idx) {
   if (!idx || !idx->ev_valid) return -1.0;
@@ -541,6 +570,24 @@ __global__ __launch_bounds__(256) void fmx_copy8_kernel(uint64_t *__restrict__ d
   const size_t nth = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += nth) dst[i] = src[i];
 }
+// off[j] = first + j * stride, j = 0..count (a chunk of equally long patterns: the offsets are made here, not uploaded)
+__global__ __launch_bounds__(256) void fmx_fill_offsets_kernel(uint64_t *__restrict__ off, uint64_t first, uint64_t stride,
+                                                               uint64_t count) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= count; j += nth) off[j] = first + j * stride;
+}
+// are the offsets off[0..count] an arithmetic progression (equally long patterns)?  The common shape of a batch --
+// and then the 8 bytes per pattern need not cross the host link at all.  Runs on the calling thread while the DMA
+// engine uploads the chunk's symbols; the chunk's slice (2 MB of a 2^20-pattern batch's four) is read once.
+static bool uniform_offsets(const uint64_t *off, uint64_t count, uint64_t *stride) {
+  if (count == 0) { *stride = 0; return true; }
+  const uint64_t m = off[1] - off[0], first = off[0];
+  if (off[1] < off[0]) return false;
+  uint64_t bad = 0;
+  for (uint64_t j = 2; j <= count; j++) bad |= off[j] ^ (first + j * m);     // branch-free: vectorises
+  *stride = m;
+  return bad == 0;
+}
 // 256 blocks move 56 GB/s over the host link and leave the CUs to the search kernels (pcie_probe: 64 blocks the
 // same rate alone, 1024 slower)
 static unsigned g_copy_blocks = 32;   // 32 x 256 lanes x 16 B in flight carry 56 GB/s over the host link
@@ -642,12 +689,17 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     unsigned search_blocks = kPipeSearchBlocks;
     bool h2d_dma = true;
     bool off_stream = false;   // offsets on a copy stream of their own: measured slower (see above)
+    bool synth_off = true;     // equally long patterns: offsets made on the device instead of uploaded
+    int direct_out = 2;        // the search writes its results straight into the caller's page-locked arrays: 0 never
+                               // (copy kernels per chunk), 1 the last chunk only, 2 every chunk
 #ifdef FMX_TUNE_HOSTPIPE   // benchmarks/gpu/hostpipe_sweep.sh only: never defined for the shipped library
     if (const char *v = getenv("FMX_PIPE_CHUNKS")) { const uint64_t u = (uint64_t)atoi(v); if (u >= 1 && u <= max_ch) nch = u; }
     if (const char *v = getenv("FMX_PIPE_BLOCKS")) search_blocks = (unsigned)atoi(v);
     if (const char *v = getenv("FMX_PIPE_COPY_BLOCKS")) g_copy_blocks = (unsigned)atoi(v);
     if (const char *v = getenv("FMX_PIPE_H2D")) h2d_dma = atoi(v) != 0;
     if (const char *v = getenv("FMX_PIPE_OFF_STREAM")) off_stream = atoi(v) != 0;
+    if (const char *v = getenv("FMX_PIPE_SYNTH_OFF")) synth_off = atoi(v) != 0;
+    if (const char *v = getenv("FMX_PIPE_DIRECT_OUT")) direct_out = atoi(v);
 #endif
     // a HIP call that fails in the middle of the pipeline must not leave earlier chunks in flight: their copy
     // kernels would keep writing the caller's arrays, and the thread's retained scratch -- which the next call on
@@ -682,14 +734,26 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       // the concurrent search five-fold (benchmarks/gpu/hostpipe_trace.sh)
       uint64_t *off_k = d_off + a + k;               // entries a..b of the caller's offsets, this chunk's own copy
       if (h2d_dma) {
-        FMX_HIP_DRAIN(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice,
-                               off_stream ? s_off : s_in));
-        if (off_stream) {
-          FMX_HIP_DRAIN(hipEventRecord(sx->ev_off[k], s_off));
-          FMX_HIP_DRAIN(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
-        }
+        // the symbols first: while the DMA engine moves them, this thread looks at the chunk's offsets.  Equally long
+        // patterns (the usual batch) -> the offsets are generated on the device by a tiny kernel ahead of the search
+        // and never cross the link: one DMA copy per chunk instead of two, and 8 bytes per pattern less to upload
+        // (2^20 x 32: 32 MB instead of 40, 1.36 -> ~1.0 ms per call)
         if (pb > pa)
           FMX_HIP_DRAIN(hipMemcpyAsync(d_pat_al + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, s_in));
+        uint64_t stride = 0;
+        if (synth_off && uniform_offsets(pat_off + a, b - a, &stride)) {
+          // on the fourth stream, long before the search needs them: no kernel of its own between two searches
+          hipLaunchKernelGGL(fmx_fill_offsets_kernel, dim3(64), dim3(256), 0, s_off, off_k, pa, stride, b - a);
+          FMX_HIP_DRAIN(hipEventRecord(sx->ev_off[k], s_off));
+          FMX_HIP_DRAIN(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
+        } else {
+          FMX_HIP_DRAIN(hipMemcpyAsync(off_k, pat_off + a, (size_t)(b - a + 1) * 8, hipMemcpyHostToDevice,
+                                 off_stream ? s_off : s_in));
+          if (off_stream) {
+            FMX_HIP_DRAIN(hipEventRecord(sx->ev_off[k], s_off));
+            FMX_HIP_DRAIN(hipStreamWaitEvent(s_k, sx->ev_off[k], 0));
+          }
+        }
         if (s0e0) FMX_HIP_DRAIN(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, s_in));
       } else {
         launch_copy(off_k, v_off + a, (size_t)(b - a + 1) * 8, s_in);
@@ -701,17 +765,27 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       // the kernel bounds every pattern's offsets by the last entry it is given: pb <= total.  Fewer blocks than
       // the CUs have slots for: the download kernels of the chunk before need somewhere to run WHILE this
       // search runs (a persistent 2048-block grid holds every slot until its last pattern)
-      if (int rc = fmx_launch_count(idx, d_pat_al, off_k, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a, d_e + a,
-                                    d_c + a, s_k, search_blocks)) {
+      // results: written by the search itself into the caller's page-locked arrays (posted writes over the link,
+      // 24 bytes per pattern: far below what it carries) -- no download stage, no copy kernels sharing the CUs with
+      // the searches, the whole grid for every search (round 3 downloaded every chunk with three copy kernels and
+      // kept an eighth of the workgroup slots free for them: the last chunk's copies, ~135 us, ended every call)
+      const bool direct = direct_out == 2 || (direct_out == 1 && b == npat);
+      if (int rc = direct ? fmx_launch_count(idx, d_pat_al, off_k, b - a, s0e0 ? d_se + 2 * a : nullptr,
+                                             v_os ? v_os + a : nullptr, v_oe ? v_oe + a : nullptr,
+                                             v_oc ? v_oc + a : nullptr, s_k, direct_out == 2 ? 0u : search_blocks)
+                          : fmx_launch_count(idx, d_pat_al, off_k, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a, d_e + a,
+                                             d_c + a, s_k, search_blocks)) {
         drain();
         return rc;
       }
-      FMX_HIP_DRAIN(hipEventRecord(sx->ev_k[k], s_k));
-      FMX_HIP_DRAIN(hipStreamWaitEvent(s_out, sx->ev_k[k], 0));
-      // download by copy kernels: kernel after kernel, no hand-over to a DMA engine
-      if (v_os) launch_copy(v_os + a, d_s + a, (size_t)(b - a) * 8, s_out);
-      if (v_oe) launch_copy(v_oe + a, d_e + a, (size_t)(b - a) * 8, s_out);
-      if (v_oc) launch_copy(v_oc + a, d_c + a, (size_t)(b - a) * 8, s_out);
+      if (!direct) {
+        FMX_HIP_DRAIN(hipEventRecord(sx->ev_k[k], s_k));
+        FMX_HIP_DRAIN(hipStreamWaitEvent(s_out, sx->ev_k[k], 0));
+        // download by copy kernels: kernel after kernel, no hand-over to a DMA engine
+        if (v_os) launch_copy(v_os + a, d_s + a, (size_t)(b - a) * 8, s_out);
+        if (v_oe) launch_copy(v_oe + a, d_e + a, (size_t)(b - a) * 8, s_out);
+        if (v_oc) launch_copy(v_oc + a, d_c + a, (size_t)(b - a) * 8, s_out);
+      }
     }
     FMX_HIP_DRAIN(hipGetLastError());
     FMX_HIP_DRAIN(hipStreamSynchronize(s_in));

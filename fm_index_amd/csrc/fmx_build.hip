@@ -84,12 +84,93 @@ struct ArenaLease {   // RAII: the buffer goes back to the pool (or is freed whe
   }
 };
 
-struct DevPool {  // temporaries freed when the builder returns
-  std::vector<void *> v;
-  uint8_t *arena = nullptr;   // small builds: bump allocation from the thread's retained buffer
+// Scratch of LARGE builds.  On this runtime hipMalloc / hipFree cost 0.2-0.5 ms whatever the size only while the
+// process is handed device memory it has not used before; once it has cycled through about the device's memory --
+// which a few 2^30-symbol builds (24-30 GB of scratch each) do -- every further hipMalloc pays ~30 ms per GiB
+// (benchmarks/gpu/alloc_probe.hip, r04_wide_dirty.sh: the second n = 2^32 build of a process spends 4.9 s in its first
+// allocations, the first one 0.7 ms).  So temporaries of at least kScratchMin bytes go back to a process-wide cache per
+// device instead of to the driver, and the next build takes them from there (smallest cached block that fits with at
+// most a quarter of it wasted): after its first large build a process allocates little that is new.  The cache holds
+// at most kScratchKeep bytes or an eighth of the device, whichever is less; what does not fit is freed, a failing
+// hipMalloc empties the cache and tries again, and fmx_release_scratch() gives everything back.
+const size_t kScratchMin = 1u << 20;
+const size_t kScratchKeep = 32ull << 30;
+struct ScratchCache {
+  struct Blk { void *p; size_t bytes; };
+  std::mutex mu;
+  std::vector<Blk> idle[kArenaDevices];
+  size_t held[kArenaDevices] = {}, cap[kArenaDevices] = {}, total[kArenaDevices] = {};
+};
+inline ScratchCache &scratch_cache() {
+  static ScratchCache *c = new ScratchCache;      // leaked on purpose: nothing is freed at process exit
+  return *c;
+}
+inline void scratch_drop(int dev, std::vector<ScratchCache::Blk> &out) {   // caller holds the lock
+  ScratchCache &sc = scratch_cache();
+  out.insert(out.end(), sc.idle[dev].begin(), sc.idle[dev].end());
+  sc.idle[dev].clear();
+  sc.held[dev] = 0;
+}
+inline hipError_t scratch_get(int dev, size_t bytes, void **out, size_t *got) {
+  ScratchCache &sc = scratch_cache();
+  const bool cached = dev >= 0 && dev < kArenaDevices && bytes >= kScratchMin;
+  if (cached) {
+    std::lock_guard<std::mutex> lk(sc.mu);
+    auto &v = sc.idle[dev];
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].bytes >= bytes && v[i].bytes - bytes <= bytes / 4 && (best == v.size() || v[i].bytes < v[best].bytes)) best = i;
+    if (best != v.size()) {
+      *out = v[best].p;
+      *got = v[best].bytes;
+      sc.held[dev] -= v[best].bytes;
+      v.erase(v.begin() + best);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && cached) {                 // out of memory: give the cached blocks back and try once more
+    (void)hipGetLastError();
+    std::vector<ScratchCache::Blk> drop;
+    { std::lock_guard<std::mutex> lk(sc.mu); scratch_drop(dev, drop); }
+    for (auto &b : drop) (void)hipFree(b.p);
+    e = hipMalloc(out, bytes);
+  }
+  *got = bytes;
+  return e;
+}
+// keep_all (FMX_FLAG_KEEP_SCRATCH): the caller asked for this build's temporaries to stay whatever their size -- up to
+// three quarters of the device
+inline void scratch_put(int dev, void *p, size_t bytes, bool keep_all = false) {
+  ScratchCache &sc = scratch_cache();
+  if (dev >= 0 && dev < kArenaDevices && bytes >= kScratchMin) {
+    std::lock_guard<std::mutex> lk(sc.mu);
+    if (!sc.cap[dev]) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+      sc.total[dev] = total_b;
+      sc.cap[dev] = total_b && total_b / 8 < kScratchKeep ? total_b / 8 : kScratchKeep;
+    }
+    const size_t cap = keep_all && sc.total[dev] ? sc.total[dev] / 4 * 3 : sc.cap[dev];
+    if (sc.held[dev] + bytes <= cap) {
+      sc.idle[dev].push_back({p, bytes});
+      sc.held[dev] += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+struct DevPool {  // temporaries given back when the builder returns (large ones to the scratch cache)
+  struct Ent { void *p; size_t bytes; };
+  std::vector<Ent> v;
+  int device = -1;
+  bool keep_all = false;      // FMX_FLAG_KEEP_SCRATCH
+  uint8_t *arena = nullptr;   // small builds: bump allocation from the leased buffer
   size_t arena_cap = 0, arena_off = 0;
+  explicit DevPool(int dev, bool keep = false) : device(dev), keep_all(keep) {}
   ~DevPool() {
-    for (void *p : v) (void)hipFree(p);
+    for (const Ent &e : v) scratch_put(device, e.p, e.bytes, keep_all);
   }
   void use_arena(uint8_t *base, size_t cap) { arena = base; arena_cap = base ? cap : 0; arena_off = 0; }
   template <typename T>
@@ -101,19 +182,25 @@ struct DevPool {  // temporaries freed when the builder returns
       return hipSuccess;
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) v.push_back(p);
+    size_t got = bytes;
+    hipError_t e = scratch_get(device, bytes, &p, &got);
+    if (e == hipSuccess) v.push_back({p, got});
     *out = (T *)p;
     return e;
   }
   void release(void *p) {
     if (arena && (uint8_t *)p >= arena && (uint8_t *)p < arena + arena_cap) return;   // goes with the arena
     for (size_t i = 0; i < v.size(); i++)
-      if (v[i] == p) {
-        (void)hipFree(p);
+      if (v[i].p == p) {
+        scratch_put(device, p, v[i].bytes, keep_all);
         v.erase(v.begin() + i);
         return;
       }
+  }
+  // the buffer leaves the pool for good (handed over to the index)
+  void disown(void *p) {
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].p == p) { v.erase(v.begin() + i); return; }
   }
 };
 
@@ -1400,6 +1487,15 @@ void fmx_release_build_scratch(void) {
         ap.idle[d][c].clear();
       }
   }
+  ScratchCache &sc = scratch_cache();
+  {
+    std::lock_guard<std::mutex> lk(sc.mu);
+    for (int d = 0; d < kArenaDevices; d++) {
+      std::vector<ScratchCache::Blk> blks;
+      scratch_drop(d, blks);
+      for (auto &b : blks) drop.push_back({d, (uint8_t *)b.p});
+    }
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
   for (auto &dp : drop)
@@ -1457,7 +1553,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     fprintf(stderr, "[fmx build] %-18s %8.1f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
-  DevPool pool;
+  DevPool pool(idx->device, (idx->flags & FMX_FLAG_KEEP_SCRATCH) != 0);
   const uint32_t n = (uint32_t)idx->n;
   const uint32_t maxc = (uint32_t)idx->max_character;
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);  // text.rs:61-63
@@ -1721,8 +1817,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (int rc = keep(idx, kt, (uint64_t)n * sizeof(T))) return rc;
     idx->d_text = (uint8_t *)kt;
     // hand the SA over to the index instead of freeing it
-    for (size_t i = 0; i < pool.v.size(); i++)
-      if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
+    pool.disown(d_sa);
     if (int rc = keep(idx, d_sa, (uint64_t)n * 4)) return rc;
     idx->d_sa = d_sa;
   }
@@ -1976,7 +2071,11 @@ __global__ __launch_bounds__(BLK) void kw_count_not_one(const uint8_t *mark, uin
 
 template <typename T>
 int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
-  uint64_t *keys_a, *keys_b, *vals_b, *rank;
+  // scratch: the (key, suffix) double buffers of the radix sort -- 32 bytes per symbol with d_sa -- and, ONLY when some
+  // suffixes are still tied after the text round (or the text has too many ties for it), 8 more for the ranks: random
+  // DNA / byte texts never allocate them (round 3 held 40 bytes per symbol from the start: 172 GB at n = 2^32 + 2^20)
+  uint64_t *keys_a, *keys_b, *vals_b, *rank = nullptr;
+  auto need_rank = [&]() -> hipError_t { return rank ? hipSuccess : pool.get(&rank, n); };
   unsigned int *d_ng;
   static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
   auto ts0 = std::chrono::steady_clock::now();
@@ -1989,7 +2088,6 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
   FMX_HIP(pool.get(&keys_a, n));
   FMX_HIP(pool.get(&keys_b, n));
   FMX_HIP(pool.get(&vals_b, n));
-  FMX_HIP(pool.get(&rank, n));
   FMX_HIP(pool.get(&d_ng, 1));
   uint32_t k = 63 / sym_bits;
   if (k > 32) k = 32;
@@ -2163,6 +2261,7 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
     if (m2) {   // tied beyond 2h symbols: ranks for every suffix (position; a tied one its group's first position)
       FMX_HIP(pool.get(&apos2, m2));
       if (int rc = compact(apos, fl, m, apos2, m2)) return rc;
+      FMX_HIP(need_rank());                                   // (the 16 n bytes of key buffers are gone by now)
       hipLaunchKernelGGL(kwt_rank_identity, dim3(nb), dim3(BLK), 0, 0, sa, n, rank);
       hipLaunchKernelGGL(kwr_rank, dim3(mb), dim3(BLK), 0, 0, suf, grp, m, rank);
       FMX_HIP(hipGetLastError());
@@ -2204,6 +2303,7 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
     }
     size_t tb = tmp_bytes;
     FMX_HIP(rocprim::inclusive_scan(tmp, tb, head, head, (size_t)n, MaxOp64(), (hipStream_t)0));
+    FMX_HIP(need_rank());
     hipLaunchKernelGGL(kw_scatter_rank, dim3(nb), dim3(BLK), 0, 0, sa_cur, head, n, rank);
     {
       // how many suffixes are still tied?  (the keys are spent: their buffer takes the flags)
@@ -2237,7 +2337,8 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
   FMX_HIP(hipDeviceSynchronize());
   if (keys_a) pool.release(keys_a);
   if (keys_b) pool.release(keys_b);
-  pool.release(vals_b); pool.release(rank);
+  pool.release(vals_b);
+  if (rank) pool.release(rank);
   pool.release(tmp); pool.release(d_ng); pool.release(d_cnt);
   return FMX_OK;
 }
@@ -2253,7 +2354,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     fprintf(stderr, "[fmx build wide] %-14s %8.1f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   };
-  DevPool pool;
+  DevPool pool(idx->device, (idx->flags & FMX_FLAG_KEEP_SCRATCH) != 0);
   const uint64_t n = idx->n;
   const uint32_t maxc = (uint32_t)idx->max_character;
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);   // text.rs:61-63
@@ -2321,8 +2422,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     FMX_HIP(hipMemcpy(kt, d_text, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice));
     if (int rc = keep(idx, kt, n * sizeof(T))) return rc;
     idx->d_text = (uint8_t *)kt;
-    for (size_t i = 0; i < pool.v.size(); i++)
-      if (pool.v[i] == d_sa) { pool.v.erase(pool.v.begin() + i); break; }
+    pool.disown(d_sa);
     if (int rc = keep(idx, d_sa, n * 8)) return rc;
     idx->d_sa64 = d_sa;
   } else {

@@ -26,6 +26,7 @@
 #include "fmx.h"
 
 #define FMX_MAX_LEVELS 8
+#define FMX_SERIES_CAP 64
 
 struct FmxLevel {
   const uint4 *rec;   // nrec records x 8 pieces
@@ -199,9 +200,11 @@ struct fmx_index {
   uint8_t *d_text;       // FMX_FLAG_KEEP_SA
   uint32_t *d_sa;        // FMX_FLAG_KEEP_SA
   // instrumentation
-  int timing;
+  int timing;            // 0 off; 1 the last launch (events + executed-step counter); 2 a series of launches (events only)
   hipEvent_t ev0, ev1;
   int ev_valid;
+  hipEvent_t *ev_series; // timing == 2: FMX_SERIES_CAP pairs, created on first use
+  int series_n;
   uint64_t *d_steps;     // device counter
 };
 

@@ -1752,17 +1752,22 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_compute_K_kernel(FmxMwm w, cons
 // launchers
 // ---------------------------------------------------------------------------
 static void fmx_time_begin(const fmx_index *idx, hipStream_t st) {
-  if (idx->timing) {
-    fmx_index *m = const_cast<fmx_index *>(idx);
+  fmx_index *m = const_cast<fmx_index *>(idx);
+  if (idx->timing == 1) {
     (void)hipMemsetAsync(m->d_steps, 0, sizeof(uint64_t), st);
     (void)hipEventRecord(m->ev0, st);
+  } else if (idx->timing == 2 && m->ev_series && m->series_n < FMX_SERIES_CAP) {
+    (void)hipEventRecord(m->ev_series[2 * m->series_n], st);      // a series: launches back to back, events only
   }
 }
 static void fmx_time_end(const fmx_index *idx, hipStream_t st) {
-  if (idx->timing) {
-    fmx_index *m = const_cast<fmx_index *>(idx);
+  fmx_index *m = const_cast<fmx_index *>(idx);
+  if (idx->timing == 1) {
     (void)hipEventRecord(m->ev1, st);
     m->ev_valid = 1;
+  } else if (idx->timing == 2 && m->ev_series && m->series_n < FMX_SERIES_CAP) {
+    (void)hipEventRecord(m->ev_series[2 * m->series_n + 1], st);
+    m->series_n++;
   }
 }
 
@@ -1938,7 +1943,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   }
   fmx_time_begin(idx, st);
   const FmxTune tn = fmx_tune();
-  const FmxCountCall c{idx, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr,
+  const FmxCountCall c{idx, dv, d_pat, d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr,
                        st, dv.kmer != nullptr && tn.use_kmer, fmx_grid_capped(npat, max_blocks)};
   const FmxMwm &w = dv.bw;
   const int sm = fmx_select_mode(idx, dv);
@@ -2017,7 +2022,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   }
   fmx_time_begin(idx, st);
   const FmxTune tn = fmx_tune();
-  const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing ? idx->d_steps : nullptr, st};
+  const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};
   const int sm = fmx_select_mode(idx, dv);
   bool done = false;
 #ifdef FMX_MEASURE

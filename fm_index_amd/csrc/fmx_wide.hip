@@ -670,17 +670,22 @@ static int fmxw_unsupported(const char *what) {
   return FMX_ERR_UNSUPPORTED;
 }
 static void fmxw_time_begin(const fmx_index *idx, hipStream_t st) {
-  if (idx->timing) {
-    fmx_index *m = const_cast<fmx_index *>(idx);
+  fmx_index *m = const_cast<fmx_index *>(idx);
+  if (idx->timing == 1) {
     (void)hipMemsetAsync(m->d_steps, 0, sizeof(uint64_t), st);
     (void)hipEventRecord(m->ev0, st);
+  } else if (idx->timing == 2 && m->ev_series && m->series_n < FMX_SERIES_CAP) {
+    (void)hipEventRecord(m->ev_series[2 * m->series_n], st);
   }
 }
 static void fmxw_time_end(const fmx_index *idx, hipStream_t st) {
-  if (idx->timing) {
-    fmx_index *m = const_cast<fmx_index *>(idx);
+  fmx_index *m = const_cast<fmx_index *>(idx);
+  if (idx->timing == 1) {
     (void)hipEventRecord(m->ev1, st);
     m->ev_valid = 1;
+  } else if (idx->timing == 2 && m->ev_series && m->series_n < FMX_SERIES_CAP) {
+    (void)hipEventRecord(m->ev_series[2 * m->series_n + 1], st);
+    m->series_n++;
   }
 }
 
@@ -692,7 +697,7 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   if (w.generic) {
 #define FMXW_GCNT(GLDS)                                                                                            \
   hipLaunchKernelGGL(fmxw_g_count_kernel<GLDS>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,             \
-                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr)
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
     if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true); else FMXW_GCNT(false);
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
@@ -702,7 +707,7 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   // both ends of a narrow interval, measured slower (0.75-0.80 ms against 0.70 ms, benchmarks/gpu/wide_tune.sh)
 #define FMXW_CNT(LDSB)                                                                                             \
   hipLaunchKernelGGL(fmxw_count_kernel<LDSB>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, (const uint8_t *)d_pat, \
-                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing ? idx->d_steps : nullptr)
+                     d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
   if (w.nsb <= FMXW_LDS_SB) FMXW_CNT(true); else FMXW_CNT(false);
   fmxw_time_end(idx, st);
   FMX_HIP(hipGetLastError());
@@ -719,10 +724,10 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
   if (w.generic) {
     if (w.nsb <= FMXW_GLDS_SB)
       hipLaunchKernelGGL(fmxw_g_walk_kernel<true>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
-                         idx->timing ? idx->d_steps : nullptr);
+                         idx->timing == 1 ? idx->d_steps : nullptr);
     else
       hipLaunchKernelGGL(fmxw_g_walk_kernel<false>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
-                         idx->timing ? idx->d_steps : nullptr);
+                         idx->timing == 1 ? idx->d_steps : nullptr);
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     return FMX_OK;
@@ -731,7 +736,7 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
   // of a wave and is issue-bound (0.196 / 0.204 / 0.226 ms against 0.181 ms per 2^20 hits, wide_tune.sh)
 #define FMXW_WALK(LDSB)                                                                                            \
   hipLaunchKernelGGL((fmxw_walk_kernel<1, LDSB>), dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,  \
-                     idx->timing ? idx->d_steps : nullptr)
+                     idx->timing == 1 ? idx->d_steps : nullptr)
   if (w.nsb <= FMXW_LDS_SB) FMXW_WALK(true); else FMXW_WALK(false);
   fmxw_time_end(idx, st);
   FMX_HIP(hipGetLastError());

@@ -114,6 +114,12 @@ typedef struct fmx_index fmx_index;
  * structures).  Results are bit-identical either way (see the two flags); fmx_has_pair_index() / fmx_kmer_k() tell
  * what the index got. */
 #define FMX_FLAG_AUTO 128u
+/* Keep ALL of this build's temporaries in the library's scratch cache (see fmx_release_scratch) whatever their size,
+ * up to three quarters of the device -- for a process that builds several very large indexes in a row (a text of
+ * 2^32 symbols needs 137 GB of scratch: above the cache's default cap, so the second such build would pay the
+ * runtime ~30 ms per GiB for memory the process has already cycled through: 5 s instead of 0.6).  The default cap
+ * (32 GiB or an eighth of the device) covers texts up to ~2^30 symbols without the flag. */
+#define FMX_FLAG_KEEP_SCRATCH 256u
 /* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
  * superblocks of 2^12 rows instead of 2^31, so that a small text exercises every part of it.  Same eligibility
  * (FMX_KIND_FM, n >= 2); same results. */
@@ -122,9 +128,13 @@ typedef struct fmx_index fmx_index;
 /* Message of the last failing call on this thread.  For the two InvalidText codes it
  * is "invalid text: <reference message>" exactly as error.rs:9-15 formats it. */
 const char *fmx_last_error(void);
-/* Frees the device scratch the library keeps between calls and that no call is using: the pool of small-build
- * buffers (at most two per device and size class: 4 MiB / 48 MiB, leased by fmx_build* of texts up to 2^17
- * symbols).  A long-lived service calls it after a burst of small builds; nothing else ever needs to. */
+/* Frees the device scratch the library keeps between builds and that no build is using: the cache of large-build
+ * temporaries (at most 32 GiB or an eighth of the device per device: on this runtime a hipMalloc of memory the process
+ * has already cycled through costs ~30 ms per GiB, so a process that builds several large indexes keeps their
+ * temporaries instead of returning them to the driver every time) and the pool of small-build buffers (at most two
+ * per device and size class: 4 MiB / 48 MiB, leased by fmx_build* of texts up to 2^17 symbols).  A long-lived
+ * service calls it when it is done building; nothing else ever needs to (a failing allocation inside a build empties
+ * the cache and retries by itself). */
 void fmx_release_scratch(void);
 const char *fmx_error_message(int code);
 
@@ -283,6 +293,11 @@ int fmx_match_rows(const fmx_index *idx, const uint64_t *s, const uint64_t *e, u
  * events on the launch stream when timing is enabled */
 void fmx_set_timing(fmx_index *idx, int enabled);
 double fmx_last_kernel_ms(const fmx_index *idx);
+/* enabled == 2: a SERIES -- every following count / locate launch of the index (up to 64) gets its own pair of events
+ * around its dominant kernel, nothing else changes (no step counter, no synchronisation), so that launches issued back
+ * to back are timed as they run back to back.  fmx_series_kernel_ms waits for them, returns their mean duration in
+ * milliseconds (-1 when there is none) and starts a new series. */
+double fmx_series_kernel_ms(fmx_index *idx);
 /* LF steps executed by the last count / locate call when timing is enabled (else 0) */
 uint64_t fmx_last_steps(const fmx_index *idx);
 double fmx_build_ms(const fmx_index *idx);

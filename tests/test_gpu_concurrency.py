@@ -1,6 +1,7 @@
 """Thread-safety promise of the ABI (include/fmx.h): a handle is immutable after build, so any
 number of host threads may query it concurrently; *_dev calls honour the caller's stream."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -365,3 +366,69 @@ def test_pinned_host_batch_agrees_with_pageable():
     rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), npat, None,
                              C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
     assert rc == F._lib.ERR_ARG
+
+
+def test_pinned_batch_with_equal_length_chunks_and_ragged_chunks():
+    """page-locked batches (round 4): a chunk of equally long patterns gets its offsets from a kernel on the device
+    instead of an upload; a ragged chunk still uploads them.  One batch whose first half is fixed-length and whose
+    second half is ragged (so both kinds of chunk occur in one call), one that is fixed-length throughout, one with a
+    constant stride but a non-zero first offset -- all against the pageable call."""
+    import ctypes as C
+    import torch
+    t = W.dna_text_np(400000, 31)
+    idx = F.FMIndex(F.Text.with_max_character(t, 4))
+    lib = idx._lib
+    npat = (1 << 18) + 40
+    fixed_flat, fixed_off, _ = W.substring_patterns_np(t, npat // 2, 7, 3)
+    rag_flat, rag_off = W.ragged_patterns_np(npat - npat // 2, 12, 4, 5)
+    flat = np.concatenate([fixed_flat, rag_flat])
+    off = np.concatenate([fixed_off, rag_off[1:] + fixed_off[-1]]).astype(np.uint64)
+    cases = [(flat, off), (fixed_flat, fixed_off.astype(np.uint64))]
+    lead = np.concatenate([np.full(5, 2, np.uint8), fixed_flat])           # offsets start at 5, stride 7
+    cases.append((lead, (fixed_off + 5).astype(np.uint64)))
+    for f, o in cases:
+        k = len(o) - 1
+        want = idx.search_many(flat=f, off=o) if int(o[0]) == 0 else None      # (the mirror wants offsets from 0)
+        hp = torch.from_numpy(f.copy()).pin_memory()
+        ho = torch.from_numpy(o.astype(np.int64)).pin_memory()
+        hs, he, hc = (torch.zeros(k, dtype=torch.int64).pin_memory() for _ in range(3))
+        rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), k, None,
+                                 C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+        assert rc == 0, lib.fmx_last_error()
+        if want is None:                                                    # same patterns as the fixed-length case
+            want = idx.search_many(flat=fixed_flat, off=fixed_off.astype(np.uint64))
+        assert (hs.numpy().view(np.uint64) == want.s).all() and (he.numpy().view(np.uint64) == want.e).all()
+        assert (hc.numpy().view(np.uint64) == want.counts).all()
+    idx.close()
+
+
+def test_partly_page_locked_array_takes_the_pageable_path():
+    """an array of which only a part is page-locked (hipHostRegister on a sub-range) must not send the copy
+    kernels / the DMA engine into its unregistered tail: the call falls back to the pageable path and answers."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    t = W.dna_text_np(200000, 9)
+    idx = F.FMIndex(F.Text.with_max_character(t, 4))
+    lib = idx._lib
+    npat = (1 << 17)
+    flat, off, _ = W.substring_patterns_np(t, npat, 8, 3)
+    want = idx.search_many(flat=flat, off=off)
+    page = 4096
+    buf = np.zeros(len(flat) + 2 * page, dtype=np.uint8)
+    start = (-buf.ctypes.data) % page                                      # a page-aligned window inside the buffer
+    pat = buf[start:start + len(flat)]
+    pat[:] = flat
+    half = (len(flat) // 2) // page * page
+    assert hip.hipHostRegister(C.c_void_p(pat.ctypes.data), C.c_size_t(half), C.c_uint(0)) == 0   # first half only
+    try:
+        offs = off.astype(np.uint64)
+        o_s, o_e, o_c = (np.zeros(npat, dtype=np.uint64) for _ in range(3))
+        rc = lib.fmx_count_batch(idx.handle(), C.c_void_p(pat.ctypes.data), offs.ctypes.data_as(C.c_void_p), npat, None,
+                                 o_s.ctypes.data_as(C.c_void_p), o_e.ctypes.data_as(C.c_void_p),
+                                 o_c.ctypes.data_as(C.c_void_p))
+        assert rc == 0, lib.fmx_last_error()
+        assert (o_s == want.s).all() and (o_e == want.e).all() and (o_c == want.counts).all()
+    finally:
+        hip.hipHostUnregister(C.c_void_p(pat.ctypes.data))
+    idx.close()

@@ -67,3 +67,33 @@ def test_big_index_memory_is_returned():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+def test_release_scratch_gives_the_builder_cache_back():
+    """Large builds keep their temporaries in a process-wide cache (a hipMalloc of memory the process has cycled through
+    costs ~30 ms per GiB on this runtime) -- at most 32 GiB or an eighth of the device -- and fmx_release_scratch()
+    returns all of it (and the idle small-build buffers) to the driver."""
+    from fm_index_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    lib.fmx_release_scratch()
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info(dev)
+    n = 1 << 26
+    d_text = W.dna_text_torch(n, 5, dev)
+    torch.cuda.synchronize()
+    free_text, _ = torch.cuda.mem_get_info(dev)
+    F.FMIndex.from_device_text(d_text.data_ptr(), n, 4).close()
+    F.FMIndex(F.Text.with_max_character(W.dna_text_np(3000, 1), 4)).close()        # a small build: leased buffer
+    torch.cuda.synchronize()
+    held, _ = torch.cuda.mem_get_info(dev)
+    assert free_text - held > 8 * n                      # the suffix sort's buffers are still ours ...
+    assert free_text - held <= min(32 << 30, total // 8) + (64 << 20)
+    lib.fmx_release_scratch()
+    torch.cuda.synchronize()
+    after, _ = torch.cuda.mem_get_info(dev)
+    assert free_text - after < (8 << 20), (free_text, after)   # ... until the hook is called
+    # and the next build simply allocates again
+    F.FMIndex.from_device_text(d_text.data_ptr(), n, 4).close()
+    lib.fmx_release_scratch()
+    del d_text

@@ -218,8 +218,8 @@ uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
 uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
-int fmx_text_order(const fmx_index *idx) { return idx && idx->dev.phase ? 1 : 0; }
-int fmx_walk_records(const fmx_index *idx) { return idx && !idx->is_wide && idx->dev.walk ? 1 : 0; }
+int fmx_text_order(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.phase != nullptr) ? 1 : 0; }
+int fmx_walk_records(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.walk != nullptr) ? 1 : 0; }
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
@@ -1060,9 +1060,32 @@ int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {
 int fmx_export_sa_samples64(const fmx_index *idx, uint64_t *host_out) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
-  if (idx->is_wide) {
+  if (idx->is_wide && !idx->wide.walk) {
     FMX_HIP(hipMemcpy(host_out, idx->wide.samples, idx->nsamples * 8, hipMemcpyDeviceToHost));
     return FMX_OK;
+  }
+  if (idx->is_wide) {
+    // text-order samples (walk records): the reference's samples SA[k << level] are computed, get_sa of those rows,
+    // in chunks of 2^22 rows through the device entry point
+    const uint64_t k = idx->nsamples, step = 1ull << idx->wide.sa_level, chunk = 1ull << 22;
+    const uint64_t cap = k < chunk ? k : chunk;
+    uint64_t *d_rows = nullptr, *d_vals = nullptr;
+    uint64_t *h_buf = (uint64_t *)malloc((size_t)(cap ? cap : 1) * 8);
+    if (!h_buf) return fail(FMX_ERR_ARG, "out of host memory");
+    hipError_t e = hipMalloc((void **)&d_rows, (size_t)(cap ? cap : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_vals, (size_t)(cap ? cap : 1) * 8);
+    int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "hipMalloc(export scratch)", __LINE__);
+    for (uint64_t a = 0; a < k && rc == FMX_OK; a += chunk) {
+      const uint64_t m = k - a < chunk ? k - a : chunk;
+      for (uint64_t j = 0; j < m; j++) h_buf[j] = (a + j) * step;
+      if ((e = hipMemcpy(d_rows, h_buf, (size_t)m * 8, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
+      if ((rc = fmx_launch_scalar(idx, 3, nullptr, d_rows, m, d_vals, 0)) != FMX_OK) break;
+      if ((e = hipMemcpy(host_out + a, d_vals, (size_t)m * 8, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy", __LINE__); break; }
+    }
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_vals) (void)hipFree(d_vals);
+    free(h_buf);
+    return rc;
   }
   uint32_t *tmp = (uint32_t *)malloc((size_t)(idx->nsamples ? idx->nsamples : 1) * 4);
   if (!tmp) return fail(FMX_ERR_ARG, "out of host memory");
@@ -1215,7 +1238,7 @@ const uint32_t kFileVersion = 9;   // 9: FmxDev::walk (walk records: a presence 
 // pointers | cs[] | records | bases | samples
 namespace {
 const uint32_t kWideMark = 0x80000000u;
-struct WideBlobs { const void **field[4 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[4 + 2 * FMXW_MAX_LEVELS]; int n; };
+struct WideBlobs { const void **field[6 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[6 + 2 * FMXW_MAX_LEVELS]; int n; };
 WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
   WideBlobs b;
   b.n = 0;
@@ -1231,6 +1254,10 @@ WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
     b.field[b.n] = (const void **)&w.base; b.bytes[b.n++] = (uint64_t)w.nsb * 64ull;
   }
   if (w.sa_level != FMX_NO_LOCATE) { b.field[b.n] = (const void **)&w.samples; b.bytes[b.n++] = nsamples * 8ull; }
+  if (w.walk) {   // text-order samples: the walk records hold the phases (this engine has no phase pieces to derive them from)
+    b.field[b.n] = (const void **)&w.walk;  b.bytes[b.n++] = (w.n / FMX_WALK_ROWS + 1u) * 128ull;
+    b.field[b.n] = (const void **)&w.wbase; b.bytes[b.n++] = (uint64_t)w.nwsb * 128ull;
+  }
   return b;
 }
 }  // namespace
@@ -1323,6 +1350,12 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";
   else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";
   else if (!w.generic && (!w.rec || !w.base || (locate && !w.samples))) bad = "array presence";
+  else if ((w.walk != nullptr) != (w.wbase != nullptr)) bad = "walk records";
+  else if (w.walk && (w.generic || !locate || w.sa_level < 1 || w.sa_level > FMX_WALK_MAX_LEVEL || h.sym_bytes != 1 ||
+                      h.max_character > FMX_WALK_MAX_CHARACTER ||
+                      (w.wsb_shift != FMXW_WALK_SB_SHIFT && w.wsb_shift != FMXW_WALK_SB_SHIFT_TEST) ||
+                      w.nwsb != (uint32_t)((h.n / FMX_WALK_ROWS) >> w.wsb_shift) + 1u))
+    bad = "walk records";
   else if (w.generic) {
     // the levels must be the builder's split of max_bits (text.rs:61-63) -- the kernels index records, bases and K[]
     // by what these fields say
@@ -1350,10 +1383,12 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   idx->level_requested = h.level_requested;
   idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
   if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) return fail(FMX_ERR_ARG, "truncated index file");
+  const bool has_walk = w.walk != nullptr;          // presence flags of the file, like every blob field
   WideBlobs bs = wide_blobs(w, idx->nsamples);
   uint64_t need = sizeof(FileHeader) + sizeof(FmxWideDev) + (h.max_character + 1) * 8;
   for (int b = 0; b < bs.n; b++) { *bs.field[b] = nullptr; need += bs.bytes[b]; }
   w.samples = nullptr; w.status = nullptr;
+  if (!has_walk) { w.walk = nullptr; w.wbase = nullptr; w.nwsb = 0; w.wsb_shift = 0; }
   {
     const long at = ftell(f);
     fseek(f, 0, SEEK_END);

@@ -2069,6 +2069,72 @@ __global__ __launch_bounds__(BLK) void kw_count_not_one(const uint8_t *mark, uin
   KW_FOR(p, n) if (mark[p] != 1u) atomicAdd(bad, 1ull);
 }
 
+
+// ---- walk records of a one-level wide index (FmxWideDev::walk, fmx_internal.h) ---------------------------------
+// Built straight from the L column and the 64-bit suffix array (this engine has no phase pieces).  Counter arrays of a
+// record, k = 0..10: rows with code k + 1 (k < 5); phase-0 rows (5); phase-1 rows with code k - 5 (6..10).
+struct PhaseZero64 {
+  uint64_t mask;
+  __host__ __device__ bool operator()(uint64_t v) const { return (v & mask) == 0ull; }
+};
+#define KWW_COUNTERS 11u
+__global__ __launch_bounds__(BLK) void kww_counts(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ sa, uint64_t n,
+                                                   uint32_t level, uint32_t nwalk, uint32_t *__restrict__ cnt) {
+  const uint64_t mask = (1ull << level) - 1ull;
+  KW_FOR(j, nwalk) {
+    uint32_t c[KWW_COUNTERS];
+    for (uint32_t k = 0; k < KWW_COUNTERS; k++) c[k] = 0;
+    for (uint32_t t = 0; t < FMX_WALK_ROWS; t++) {
+      const uint64_t row = j * FMX_WALK_ROWS + t;
+      if (row >= n) break;
+      const uint32_t code = bwt[row];
+      const uint64_t ph = sa[row] & mask;
+      for (uint32_t k = 0; k < 5u; k++) {
+        c[k] += code == k + 1u;
+        c[6u + k] += (code == k + 1u) & (ph == 1ull);
+      }
+      c[5] += ph == 0ull;
+    }
+    for (uint32_t k = 0; k < KWW_COUNTERS; k++) cnt[(size_t)k * nwalk + j] = c[k];
+  }
+}
+// wbase[superblock][k] = the absolute value of counter k at the superblock's first record (adj[k] turns the scan of
+// array k into it: cs[] / the smaller symbols' phase-1 rows / the row-0 edge folded in, the array's own start taken out)
+__global__ __launch_bounds__(64) void kww_bases(const uint64_t *__restrict__ scan, const uint64_t *__restrict__ adj,
+                                                 uint32_t nwalk, uint32_t nwsb, uint32_t shift, uint64_t *__restrict__ wbase) {
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= nwsb * 16u) return;
+  const uint32_t sb = t >> 4, k = t & 15u;
+  const uint64_t j = (uint64_t)sb << shift;
+  wbase[t] = (k < KWW_COUNTERS && j < nwalk) ? scan[(size_t)k * nwalk + j] + adj[k] : 0ull;
+}
+// thread = piece g of walk record j (layout: fmx_internal.h, FmxDev::walk), counters relative to the walk superblock
+__global__ __launch_bounds__(BLK) void kww_records(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ sa, uint64_t n,
+                                                    uint32_t level, const uint64_t *__restrict__ scan,
+                                                    const uint64_t *__restrict__ adj, const uint64_t *__restrict__ wbase,
+                                                    uint32_t nwalk, uint32_t shift, uint4 *__restrict__ out) {
+  const uint64_t mask = (1ull << level) - 1ull;
+  KW_FOR(tid, (uint64_t)nwalk * 8u) {
+    const uint32_t j = (uint32_t)(tid >> 3), g = (uint32_t)(tid & 7u);
+    const uint64_t *wb = wbase + (size_t)(j >> shift) * 16u;
+    auto rel = [&](uint32_t k) { return (uint32_t)(scan[(size_t)k * nwalk + j] + adj[k] - wb[k]); };
+    if (g == 7u) {
+      out[tid] = make_uint4(rel(7), rel(8), rel(9), rel(10));
+      continue;
+    }
+    uint32_t p0 = 0, p1 = 0, p2 = 0, q0 = 0, q1 = 0, q2 = 0;
+    const uint64_t row0 = (uint64_t)j * FMX_WALK_ROWS + g * 16u;
+    for (uint32_t t = 0; t < 16u; t++) {
+      const uint64_t row = row0 + t;
+      const uint32_t code = row < n ? bwt[row] : 0u;
+      const uint32_t ph = row < n ? (uint32_t)(sa[row] & mask) : 1u;
+      p0 |= (code & 1u) << t; p1 |= ((code >> 1) & 1u) << t; p2 |= ((code >> 2) & 1u) << t;
+      q0 |= (ph & 1u) << t;   q1 |= ((ph >> 1) & 1u) << t;   q2 |= ((ph >> 2) & 1u) << t;
+    }
+    out[tid] = make_uint4(rel(g), p0 | (p1 << 16), p2 | (q0 << 16), q1 | (q2 << 16));
+  }
+}
+
 template <typename T>
 int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
   // scratch: the (key, suffix) double buffers of the radix sort -- 32 bytes per symbol with d_sa -- and, ONLY when some
@@ -2397,6 +2463,11 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   idx->dev.kind = idx->kind;
   idx->dev.sym_bytes = (uint32_t)sizeof(T);
   // -- SA samples (sample.rs:21-44) --
+  // One-level indexes (max_character <= 5, levels 1..3) sample in TEXT order and get walk records, like the 32-bit
+  // engine's DNA indexes (fmx_internal.h): the batched walk is max(phase, 1) records + 1 sample per hit and never longer
+  // than 2^level - 1 steps.  FMX_FLAG_ROW_ORDER / FMX_FLAG_NO_WALK_RECORDS keep the reference's rows (the round-3 shape).
+  bool walk_records = false;
+  w.walk = nullptr; w.wbase = nullptr; w.nwsb = 0; w.wsb_shift = 0;
   if (idx->level_requested != FMX_NO_LOCATE) {
     uint32_t level = idx->level_requested;
     if (level >= 63 || n <= (1ull << level)) level = 0;            // sample.rs:28-31
@@ -2404,7 +2475,33 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     uint64_t *d_samp;
     FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
     if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
-    hipLaunchKernelGGL(kw_samples, dim3(wblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    walk_records = sizeof(T) == 1 && maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
+                   !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
+    if (walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {     // by default only when the device has room
+      size_t free_b = 0, total_b = 0;
+      const uint64_t extra = (n / FMX_WALK_ROWS + 1u) * 128u;
+      walk_records = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
+    }
+    if (walk_records) {
+      // the rows whose SA value is a multiple of 2^level (as many as the reference samples), in row order
+      unsigned long long *d_got;
+      FMX_HIP(pool.get(&d_got, 1));
+      auto flags = rocprim::make_transform_iterator(d_sa, PhaseZero64{(1ull << level) - 1ull});
+      size_t sb = 0;
+      FMX_HIP(rocprim::select(nullptr, sb, d_sa, flags, d_samp, d_got, (size_t)n, (hipStream_t)0));
+      uint8_t *stmp;
+      FMX_HIP(pool.get(&stmp, sb));
+      FMX_HIP(rocprim::select(stmp, sb, d_sa, flags, d_samp, d_got, (size_t)n, (hipStream_t)0));
+      unsigned long long got = 0;
+      FMX_HIP(hipMemcpy(&got, d_got, sizeof got, hipMemcpyDeviceToHost));
+      pool.release(stmp); pool.release(d_got);
+      if (got != nsamp) {
+        fmx_set_error(FMX_ERR_HIP, "text-order sampling: unexpected number of samples");
+        return FMX_ERR_HIP;
+      }
+    } else {
+      hipLaunchKernelGGL(kw_samples, dim3(wblocks(nsamp)), dim3(BLK), 0, 0, d_sa, nsamp, level, d_samp);
+    }
     w.samples = d_samp;
     w.sa_level = level;
     idx->dev.sa_level = level;
@@ -2416,6 +2513,56 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   FMX_HIP(pool.get(&d_bwt, n));
   hipLaunchKernelGGL(kw_bwt<T>, dim3(wblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
   FMX_HIP(hipGetLastError());
+  if (walk_records) {
+    if constexpr (sizeof(T) == 1) {
+      const uint32_t level = w.sa_level;
+      const uint32_t nwalk = (uint32_t)(n / FMX_WALK_ROWS + 1u);
+      const uint32_t shift = fmx_wide_n(n) ? FMXW_WALK_SB_SHIFT : FMXW_WALK_SB_SHIFT_TEST;
+      const uint32_t nwsb = ((nwalk - 1u) >> shift) + 1u;
+      const size_t ncnt = (size_t)KWW_COUNTERS * nwalk + 1;          // one more: the scan's last entry = the grand total
+      uint32_t *d_cnt;
+      uint64_t *d_scan, *d_adj, *d_wbase;
+      uint4 *d_walk;
+      FMX_HIP(pool.get(&d_cnt, ncnt));
+      FMX_HIP(pool.get(&d_scan, ncnt));
+      FMX_HIP(pool.get(&d_adj, 16));
+      FMX_HIP(hipMalloc((void **)&d_walk, (size_t)nwalk * 128));
+      if (int rc = keep(idx, d_walk, (uint64_t)nwalk * 128)) return rc;
+      FMX_HIP(hipMalloc((void **)&d_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
+      if (int rc = keep(idx, d_wbase, (uint64_t)nwsb * 128)) return rc;
+      FMX_HIP(hipMemsetAsync(d_cnt + (ncnt - 1), 0, sizeof(uint32_t), 0));
+      hipLaunchKernelGGL(kww_counts, dim3(wblocks(nwalk)), dim3(BLK), 0, 0, (const uint8_t *)d_bwt, d_sa, n, level, nwalk, d_cnt);
+      size_t tb = 0;
+      FMX_HIP(exclusive_sum(nullptr, tb, d_cnt, d_scan, ncnt));
+      uint8_t *tmp;
+      FMX_HIP(pool.get(&tmp, tb));
+      FMX_HIP(exclusive_sum(tmp, tb, d_cnt, d_scan, ncnt));
+      // the scan at the start of every counter array (and its end): what each array's own prefix sums start from
+      uint64_t start[KWW_COUNTERS + 1], adj[16] = {};
+      for (uint32_t k = 0; k <= KWW_COUNTERS; k++)
+        FMX_HIP(hipMemcpy(&start[k], d_scan + (size_t)k * nwalk, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      const uint64_t edge = ((n - 1) & ((1ull << level) - 1ull)) == 0 ? 1 : 0;   // row 0 (SA = n - 1) is a phase-0 row
+      uint64_t smaller = 0;                                          // phase-1 rows with a smaller symbol
+      for (uint32_t k = 0; k < KWW_COUNTERS; k++) {
+        uint64_t abs0 = 0;
+        if (k < 5u) abs0 = k + 1u <= maxc ? idx->h_cs[k + 1u] : 0;   // lf_map2: cs[] folded in (sais.rs:9-32)
+        else if (k > 5u) { abs0 = edge + smaller; smaller += start[k + 1] - start[k]; }
+        adj[k] = abs0 - start[k];
+      }
+      FMX_HIP(hipMemcpy(d_adj, adj, sizeof adj, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(kww_bases, dim3((nwsb * 16u + 63u) / 64u), dim3(64), 0, 0, d_scan, d_adj, nwalk, nwsb, shift, d_wbase);
+      hipLaunchKernelGGL(kww_records, dim3(wblocks((uint64_t)nwalk * 8u)), dim3(BLK), 0, 0, (const uint8_t *)d_bwt, d_sa, n,
+                         level, d_scan, d_adj, d_wbase, nwalk, shift, d_walk);
+      FMX_HIP(hipGetLastError());
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(tmp); pool.release(d_adj); pool.release(d_scan); pool.release(d_cnt);
+      w.walk = d_walk;
+      w.wbase = d_wbase;
+      w.nwsb = nwsb;
+      w.wsb_shift = shift;
+      mark("walk records");
+    }
+  }
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
     FMX_HIP(hipMalloc((void **)&kt, n * sizeof(T)));

@@ -639,13 +639,15 @@ __device__ __forceinline__ uint32_t fmx_walk_record(uint32_t row, uint32_t &off)
   return rec;
 }
 // One LF step of a text-order walk on the walk record holding `row` (off = the row's index in it); p = piece g of that
-// record.  Every lane of the group gets lf_map(row) (fm_index.rs:86-91: cs[L[row]] + rank of L[row]; the counters hold
-// cs[] folded in), ph = SA[row] mod 2^level, and si = an index into samples[]:
-//     ph == 0: of the row itself (the phase-0 rows before it);
-//     ph == 1: of the row LF(row) -- rank1[L[row]] + the phase-1 rows with the same symbol before it (fmx_internal.h);
-//     else unspecified.
+// record.  Every lane of the group gets the row's symbol and phase SA[row] mod 2^level, the return value r_lf and si:
+//     lf_map(row) = r_lf  [+ the superblock's base of counter sym - 1 on a wide index]     (fm_index.rs:86-91)
+//     ph == 0: si [+ base of counter 5] = index into samples[] of the row itself (the phase-0 rows before it);
+//     ph == 1: si [+ base of counter 5 + sym] = index of the sample of the row LF(row) -- rank1[L[row]] + the phase-1
+//              rows with the same symbol before it (fmx_internal.h);   else si is unspecified.
+// On the 32-bit engine the record counters are absolute (cs[] folded in) and the bases are zero.
 // Three group sums: the row's code and phase (lane that holds it), the rank, the sample index.
-__device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t off, uint32_t g, uint32_t &ph, uint32_t &si) {
+__device__ __forceinline__ uint32_t fmx_walk_step_rel(const uint4 &p, uint32_t off, uint32_t g, uint32_t &sym, uint32_t &ph,
+                                                      uint32_t &si) {
   const uint32_t bit = off & 15u;
   int nb = (int)off - (int)(g * 16u);
   nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
@@ -656,7 +658,7 @@ __device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t off, 
         (__builtin_amdgcn_ubfe(p.z, bit, 1u) << 2) | (__builtin_amdgcn_ubfe(p.z, bit + 16u, 1u) << 3) |
         (__builtin_amdgcn_ubfe(p.w, bit, 1u) << 4) | (__builtin_amdgcn_ubfe(p.w, bit + 16u, 1u) << 5);
   v = fmx_group_sum(v);
-  const uint32_t sym = v & 7u;
+  sym = v & 7u;
   ph = v >> 3;
   const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 0u, 1u), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 1u, 1u),
                  m2 = (uint32_t)__builtin_amdgcn_sbfe((int)sym, 2u, 1u);
@@ -670,6 +672,16 @@ __device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t off, 
                                : (sym == 1u ? (g == 6u ? p.x : 0u) : (g == 7u ? c7 : 0u));
   si = fmx_group_sum((uint32_t)__popc(sel) + cw);
   return fmx_group_sum((uint32_t)__popc(match) + (g + 1u == sym ? p.x : 0u));     // lanes 0..4: lf_map2(g + 1, .)
+}
+__device__ __forceinline__ uint32_t fmx_walk_step(const uint4 &p, uint32_t off, uint32_t g, uint32_t &ph, uint32_t &si) {
+  uint32_t sym;
+  return fmx_walk_step_rel(p, off, g, sym, ph, si);
+}
+// record holding a 64-bit row (wide engine): row / 112 = (row >> 4) / 7 with mulhi(x, ceil(2^64 / 7)), exact for x < 2^61
+__device__ __forceinline__ uint64_t fmx_walk_record64(uint64_t row, uint32_t &off) {
+  const uint64_t rec = __umul64hi(row >> 4, 0x2492492492492493ull);
+  off = (uint32_t)(row - rec * FMX_WALK_ROWS);
+  return rec;
 }
 
 // greatest c with cs[c] <= v  (get_f's binary search, fm_index.rs:97-112)

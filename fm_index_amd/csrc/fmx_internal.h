@@ -174,7 +174,17 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   const uint64_t *cs;        // [max_character + 1] C array on the device (get_f / fl_map)
   uint32_t sym_bytes;        // width of text / pattern symbols (1, 2 or 4; generic indexes only when > 1)
   uint32_t pad;
+  // Walk records of a one-level wide index (round 4; FmxDev::walk above is the 32-bit engine's): the same 112-row
+  // records, their 11 counters RELATIVE to a walk superblock (2^wsb_shift records), wbase[superblock][16] = the 64-bit
+  // values at the superblock's first record in the order { lf_map2(1..5, .), rank0, rank1[1..5] }.  When `walk` is set
+  // the index samples in text order: samples[] = SA of the phase-0 rows in row order, and every get_sa -- batched
+  // walk, trait call, sample export -- goes through the walk records (there are no phase pieces on this engine).
+  const uint4 *walk;
+  const uint64_t *wbase;
+  uint32_t nwsb, wsb_shift;
 };
+#define FMXW_WALK_SB_SHIFT 24u      // records per walk superblock: 2^24 x 112 rows < 2^31, so relative counters fit 32 bits
+#define FMXW_WALK_SB_SHIFT_TEST 5u  // FMX_FLAG_FORCE_WIDE: 32 records, so that a small text has many superblocks
 
 struct fmx_index {
   FmxDev dev;

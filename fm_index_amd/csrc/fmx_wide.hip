@@ -79,6 +79,35 @@ __device__ __forceinline__ uint64_t fmxw_fl_map(const FmxWideDev &w, uint64_t i,
   return (uint64_t)lo * 256u + fmx_group_sum(pos);
 }
 
+// counter of the superblock table a step needs: lf_map2 of the row's symbol while the walk goes on (phase >= 2), the
+// phase-0 rank on a phase-0 row, rank1[symbol] on a phase-1 row (fmx_walk_step_rel)
+__device__ __forceinline__ uint32_t fmxw_walk_counter(uint32_t sym, uint32_t ph) {
+  return ph >= 2u ? sym - 1u : (ph == 0u ? 5u : 5u + sym);
+}
+
+// get_sa(row) through the walk records, for a group that holds one row (trait call, sample export): at most
+// 2^level - 1 LF steps, the last of them without a record of its own                         fm_index.rs:127-140
+__device__ __forceinline__ uint64_t fmxw_get_sa_walk(const FmxWideDev &w, uint64_t row, uint32_t g) {
+  uint32_t steps = 0;
+  for (;;) {
+    uint32_t off, sym, ph, si;
+    const uint64_t rec = fmx_walk_record64(row, off);
+    FMX_CHECK(rec < w.n / FMX_WALK_ROWS + 1u);
+    const uint4 p = w.walk[(size_t)rec * 8u + g];
+    const uint32_t nr = fmx_walk_step_rel(p, off, g, sym, ph, si);
+    if (ph >= 2u && sym == 0u) return ~0ull;          // (cannot happen: the one row with symbol 0 -- SA = 0 -- has phase 0)
+    const uint64_t b = w.wbase[(size_t)(rec >> w.wsb_shift) * 16u + fmxw_walk_counter(sym, ph)];
+    if (ph <= 1u) {                                   // the sample of this row (phase 0) or of the next one (phase 1)
+      steps += ph;
+      uint64_t v = w.samples[b + si] + steps;         // (sa + steps) % len
+      if (v >= w.n) v -= w.n;
+      return v;
+    }
+    row = b + nr;                                     // i = lf_map(i); steps += 1
+    steps++;
+  }
+}
+
 // The superblock bases are read with a data-dependent symbol in every step.  Up to FMXW_LDS_SB superblocks
 // (n < 2^37) every block keeps them in LDS (kernels instantiated with LDSB = true: ds_read, 32-bit address); beyond
 // that -- and for the many tiny superblocks of FMX_FLAG_FORCE_WIDE test indexes -- the LDSB = false instantiation
@@ -257,6 +286,8 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_scalar_kernel(FmxWideDev w, i
       uint32_t sym;
       const uint64_t r = fmxw_fl_map(w, i, g, sym);
       res = op == 4 ? (uint64_t)sym : r;
+    } else if (w.walk) {                            // get_sa, text-order samples: through the walk records
+      res = fmxw_get_sa_walk(w, i, g);
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
@@ -309,6 +340,222 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_export_l_kernel(FmxWideDev w,
     const uint4 p = w.rec[(size_t)(i >> 8) * 8u + (off >> 5)];
     out[i] = (uint8_t)fmx_piece_code<3>(p, off & 31u);
   }
+}
+
+// ===========================================================================
+// Walk records on the wide engine (round 4; FmxWideDev::walk): the text-order walk of fmx_locate_f3t_kernel
+// (fmx_query.hip) with 64-bit rows, positions and sample indices.  A record's counters are relative to its walk
+// superblock; the 64-bit bases sit in LDS (LDSW, up to FMXW_LDS_WSB superblocks) or in global memory.
+// ===========================================================================
+#define FMXW_LDS_WSB 32u
+#define FMXW_WBASES(w, LDSW)                                                                          \
+  __shared__ uint64_t lds_wb[(LDSW) ? FMXW_LDS_WSB * 16u : 1u];                                        \
+  if (LDSW) {                                                                                         \
+    for (uint32_t t_ = threadIdx.x; t_ < (w).nwsb * 16u; t_ += blockDim.x) lds_wb[t_] = (w).wbase[t_]; \
+    __syncthreads();                                                                                  \
+  }                                                                                                   \
+  auto wbase_at = [&](uint64_t rec_, uint32_t k_) -> uint64_t {                                       \
+    const uint32_t sb_ = (uint32_t)(rec_ >> (w).wsb_shift);                                           \
+    if constexpr (LDSW) return lds_wb[sb_ * 16u + k_]; else return (w).wbase[(size_t)sb_ * 16u + k_]; \
+  }
+// hit queue of a block over 64-bit rows that stand where their positions will be written (fmx_launch_expand64): the
+// FmxHitQueue of fmx_query.hip with two registers per resident row
+struct FmxwHitQueue {
+  const uint64_t *rows;
+  uint32_t nhits, chunk, lane, c0, c1, used;
+  uint32_t w0lo, w0hi, w1lo, w1hi;
+  static constexpr uint32_t NOCHUNK = 0xFFFFFFFFu;
+  __device__ __forceinline__ void load_win(uint32_t c, uint32_t &lo, uint32_t &hi) const {
+    const uint32_t x = c * chunk + lane;
+    const uint64_t v = (c != NOCHUNK && lane < chunk && x < nhits) ? rows[x] : 0ull;
+    lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+  }
+  __device__ __forceinline__ uint32_t valid(uint32_t c) const { return (c != NOCHUNK && c * chunk < nhits) ? c : NOCHUNK; }
+  __device__ __forceinline__ uint32_t draw(unsigned int &counter) const {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&counter, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  }
+  __device__ __forceinline__ void init(const uint64_t *r, uint32_t count, uint32_t rows_per_ticket, uint32_t ln,
+                                       unsigned int &counter) {
+    rows = r; nhits = count; chunk = rows_per_ticket; lane = ln;
+    c0 = valid(draw(counter));
+    load_win(c0, w0lo, w0hi);
+    __syncthreads();                                  // every wave of the block draws its first ticket before any draws a second
+    c1 = valid(draw(counter));
+    load_win(c1, w1lo, w1hi);
+    used = 0;
+  }
+  __device__ __forceinline__ bool take(uint32_t rank, uint32_t &x, uint64_t &row, bool &first) const {
+    const uint32_t idx = used + rank;
+    first = idx < chunk;
+    const uint32_t c = first ? c0 : c1, within = first ? idx : idx - chunk;
+    const int src = (int)(within & 63u);
+    const uint32_t a0 = (uint32_t)__shfl((int)w0lo, src), a1 = (uint32_t)__shfl((int)w0hi, src);
+    const uint32_t b0 = (uint32_t)__shfl((int)w1lo, src), b1 = (uint32_t)__shfl((int)w1hi, src);
+    row = first ? ((uint64_t)a1 << 32 | a0) : ((uint64_t)b1 << 32 | b0);
+    x = c * chunk + within;
+    return idx < 2u * chunk && c != NOCHUNK && x < nhits;
+  }
+  __device__ __forceinline__ bool advance(uint32_t count, unsigned int &counter) {
+    used += count;
+    if (used >= chunk) {                              // wave-uniform: slide
+      used -= chunk;
+      c0 = c1;
+      c1 = c1 != NOCHUNK ? valid(draw(counter)) : NOCHUNK;
+      w0lo = w1lo; w0hi = w1hi;
+      load_win(c1, w1lo, w1hi);
+      return true;
+    }
+    return false;
+  }
+};
+
+#define FMXW_LOC_BLOCK 1024
+#define FMXW_WC_SLOTS 4
+template <int Q, bool WC, bool LDSW>
+__global__ __launch_bounds__(FMXW_LOC_BLOCK) void fmxw_walk_t_kernel(FmxWideDev w, uint64_t total, uint32_t hits_per_block,
+                                                                      uint32_t chunk, uint64_t *__restrict__ io,
+                                                                      uint64_t *__restrict__ steps_out) {
+  static_assert(Q == 1 || Q == 4, "walks per group");
+  __shared__ unsigned int lds_q;
+  __shared__ uint64_t wc_ring[WC ? (FMXW_LOC_BLOCK / 64) * FMXW_WC_SLOTS * 64 : 1];
+  __shared__ uint32_t wc_tag[WC ? (FMXW_LOC_BLOCK / 64) * FMXW_WC_SLOTS : 1];
+  if (threadIdx.x == 0) lds_q = 0;
+  FMXW_WBASES(w, LDSW);
+  __syncthreads();
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane & (FMX_GROUP - 1);
+  const uint32_t grp = lane >> 3;
+  const uint32_t slot = g & (uint32_t)(Q - 1);        // the walk whose state this lane keeps (8 / Q replicas)
+  const bool owner = g < (uint32_t)Q;
+  const uint32_t olane = (lane & ~7u) | slot;
+  constexpr unsigned long long SLOT0 = Q == 4 ? 0x1111111111111111ull : 0xFFFFFFFFFFFFFFFFull;
+  constexpr uint64_t NONE = ~0ull;
+  constexpr uint32_t NOCH = FmxwHitQueue::NOCHUNK;
+  uint64_t *const out = io + blo;                     // the block's slice: rows on entry, positions on exit
+  FmxwHitQueue hq;
+  hq.init(out, bn, chunk, lane, lds_q);
+  [[maybe_unused]] volatile uint64_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMXW_WC_SLOTS * 64);
+  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMXW_WC_SLOTS;
+  [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;
+  if (WC) {
+#pragma unroll
+    for (uint32_t r = 0; r < FMXW_WC_SLOTS; r++) ring[r * 64u + lane] = NONE;
+    if (lane < FMXW_WC_SLOTS) ring_tag[lane] = lane == 0 ? hq.c0 : (lane == 1 ? hq.c1 : NOCH);
+  }
+  uint32_t hx;
+  uint64_t row;
+  [[maybe_unused]] uint32_t myslot = 0;
+  bool first0;
+  bool active = hq.take((slot << 3) | grp, hx, row, first0);
+  {
+    const bool slid = hq.advance(8u * (uint32_t)Q, lds_q);
+    if (WC && slid) {
+      const uint32_t ns = rseq & (FMXW_WC_SLOTS - 1u);
+      if (lane == 0) ring_tag[ns] = hq.c1;
+      rseq++; rs0 = rs1; rs1 = ns;
+    }
+  }
+  if (!active) row = 0;
+  constexpr uint32_t FRESH = 0xFFu;
+  uint32_t ctl = FRESH;                               // phase of the current row | steps of the whole walk << 8
+  uint64_t fin = NONE, nsteps = 0;                    // index of the walk's sample once known
+  for (;;) {
+    if (!__any(active)) break;
+    const bool done = active && fin != NONE;
+    const unsigned long long fm = __ballot(done && owner);
+    uint64_t fin_si = NONE;
+    uint32_t fin_steps = 0, fin_x = 0;
+    [[maybe_unused]] uint32_t fin_slot = 0;
+    if (fm) {                                         // wave-uniform
+      uint32_t x_new;
+      uint64_t r_new;
+      bool first;
+      const bool ok = hq.take((uint32_t)__popcll(fm & ((1ull << olane) - 1ull)), x_new, r_new, first);
+      if (done) {
+        fin_si = fin;
+        fin_steps = ctl >> 8;
+        fin_x = hx;
+        fin_slot = myslot;
+        nsteps += ctl >> 8;
+        hx = x_new;
+        myslot = first ? rs0 : rs1;
+        active = ok;
+        row = ok ? r_new : 0;
+        ctl = FRESH;
+        fin = NONE;
+      }
+      const bool slid = hq.advance((uint32_t)__popcll(fm), lds_q);
+      if (WC && slid) {
+        const uint32_t ns = rseq & (FMXW_WC_SLOTS - 1u);
+        const uint32_t old_tag = ring_tag[ns];
+        const uint64_t v = ring[ns * 64u + lane];
+        if (old_tag != NOCH && v != NONE) out[old_tag * 64u + lane] = v;
+        ring[ns * 64u + lane] = NONE;
+        if (lane == 0) ring_tag[ns] = hq.c1;
+        rseq++; rs0 = rs1; rs1 = ns;
+      }
+    }
+    uint64_t sa = 0;
+    if (fin_si != NONE) sa = w.samples[fin_si];       // sample.rs:46-60 Some(sa)
+    // (every row fmx_launch_expand64 wrote is a row of this index: refused ranges were replaced by row 0)
+    FMX_CHECK(!active || row < w.n);
+    const uint32_t rlo = active ? (uint32_t)row : 0xFFFFFFFFu, rhi = active ? (uint32_t)(row >> 32) : 0xFFFFFFFFu;
+    const unsigned long long wm = __ballot(active);
+    uint4 p[Q];
+    uint32_t offq[Q];
+    uint64_t recq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      offq[q] = 0xFFFFFFFFu;
+      recq[q] = 0;
+      if (!(wm & (SLOT0 << q))) continue;
+      const uint32_t lo = Q == 1 ? rlo : fmx_quad_bcast(rlo, q), hi = Q == 1 ? rhi : fmx_quad_bcast(rhi, q);
+      if ((lo & hi) != 0xFFFFFFFFu) {                 // group-uniform (rows are below 2^38)
+        recq[q] = fmx_walk_record64((uint64_t)hi << 32 | lo, offq[q]);
+        FMX_CHECK(recq[q] < w.n / FMX_WALK_ROWS + 1u);
+        p[q] = w.walk[(size_t)recq[q] * 8u + g];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (!(wm & (SLOT0 << q))) continue;
+      if (offq[q] != 0xFFFFFFFFu) {
+        uint32_t sym, ph, si;
+        const uint32_t nr = fmx_walk_step_rel(p[q], offq[q], g, sym, ph, si);
+        const uint64_t b = (ph >= 2u && sym == 0u) ? 0ull : wbase_at(recq[q], fmxw_walk_counter(sym, ph));
+        if (slot == (uint32_t)q) {
+          if (ctl == FRESH) ctl = ph * 0x101u;
+          FMX_CHECK(ph == (ctl & 0xFFu));
+          if (ph <= 1u) {
+            fin = b + si;                             // this row's sample (phase 0) or the next row's (phase 1)
+          } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+            row = b + nr;
+            ctl--;
+          }
+        }
+      }
+    }
+    if (fin_si != NONE && owner) {
+      uint64_t v = sa + fin_steps;                    // fm_index.rs:131-133: (sa + steps) % len
+      if (v >= w.n) v -= w.n;
+      if (WC && ring_tag[fin_slot] == (fin_x >> 6)) ring[fin_slot * 64u + (fin_x & 63u)] = v;
+      else out[fin_x] = v;
+    }
+  }
+  if (WC) {
+#pragma unroll
+    for (uint32_t r = 0; r < FMXW_WC_SLOTS; r++) {
+      const uint32_t tag = ring_tag[r];
+      const uint64_t v = ring[r * 64u + lane];
+      if (tag != NOCH && v != NONE) out[tag * 64u + lane] = v;
+    }
+  }
+  if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
 // ===========================================================================
@@ -570,6 +817,8 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
       uint32_t sym;
       const uint64_t r = fmxw_g_fl(w, gbase, i, g, sym);
       res = op == 4 ? (uint64_t)sym : r;
+    } else if (w.walk) {                            // get_sa, text-order samples: through the walk records
+      res = fmxw_get_sa_walk(w, i, g);
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
@@ -728,6 +977,38 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
     else
       hipLaunchKernelGGL(fmxw_g_walk_kernel<false>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
                          idx->timing == 1 ? idx->d_steps : nullptr);
+    fmxw_time_end(idx, st);
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
+  if (w.walk) {
+    // text-order samples + walk records: the shape of the 32-bit engine's fmx_locate_f3t_kernel (block-wide hit queue,
+    // four walks per group with distributed state, write-combining ring)
+    const int q = total >= (1u << 16) ? 4 : 1;
+    const uint64_t nb0 = total >= (4u << 20) ? 512 : 256;
+    const uint64_t per_wave = (total + nb0 * (FMXW_LOC_BLOCK / 64) - 1) / (nb0 * (FMXW_LOC_BLOCK / 64));
+    uint32_t chunk = (uint32_t)((per_wave + 7) / 8 * 8);
+    if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;
+    if (chunk > 64u) chunk = 64u;
+    uint64_t nb = nb0;
+    const uint64_t min_nb = (total >> 31) + 1;
+    if (nb < min_nb) nb = min_nb;
+    uint64_t per = (total + nb - 1) / nb;
+    per = (per + chunk - 1) / chunk * chunk;
+    const uint32_t hpb = (uint32_t)per;
+    const unsigned gr = (unsigned)((total + per - 1) / per);
+    uint64_t *steps = idx->timing == 1 ? idx->d_steps : nullptr;
+#define FMXW_WALKT(QQ, WCF, LDSW)                                                                                   \
+    hipLaunchKernelGGL((fmxw_walk_t_kernel<QQ, WCF, LDSW>), dim3(gr), dim3(FMXW_LOC_BLOCK), 0, st, w, total, hpb, chunk, \
+                       d_pos, steps)
+    const bool lds = w.nwsb <= FMXW_LDS_WSB, wc = chunk == 64u;
+    if (q == 4) {
+      if (wc) { if (lds) FMXW_WALKT(4, true, true); else FMXW_WALKT(4, true, false); }
+      else { if (lds) FMXW_WALKT(4, false, true); else FMXW_WALKT(4, false, false); }
+    } else {
+      if (wc) { if (lds) FMXW_WALKT(1, true, true); else FMXW_WALKT(1, true, false); }
+      else { if (lds) FMXW_WALKT(1, false, true); else FMXW_WALKT(1, false, false); }
+    }
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     return FMX_OK;

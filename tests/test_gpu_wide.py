@@ -43,6 +43,8 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, dtype, tm
     t = _dna(n, 100 + n % 97, sigma, dtype)
     gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True)
     assert gi.is_wide() and gi.len() == n and gi.level() == level
+    # one-level byte indexes with max_character <= 5 at levels 1..3 sample in text order and carry walk records (round 4)
+    assert gi.walk_records() == (dtype == np.uint8 and sigma <= 5 and 1 <= level <= 3) and gi.text_order() == gi.walk_records()
     oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level)
     assert gi.verify_sa() == 0                                    # the 64-bit suffix sort
     # backward search: ragged patterns (empty ones included), substrings, early exit
@@ -107,6 +109,47 @@ def test_wide_engine_equals_the_oracle_on_small_texts(n, sigma, level, dtype, tm
     with pytest.raises(F.Error):
         type(gi).load(path)
     gi.close()
+
+
+@pytest.mark.parametrize("n,sigma,level", [(70001, 4, 2), (3000, 5, 1), ((1 << 18) + 9, 4, 3), (113, 4, 1), (5000, 1, 2)])
+def test_wide_walk_records_against_row_order_and_the_oracle(n, sigma, level, tmp_path):
+    """the wide engine's walk records (text-order samples; counters relative to walk superblocks of 32 records here)
+    against the same engine in row order (FMX_FLAG_ROW_ORDER: the round-3 walk) and the oracle: every row through the
+    batched walk (four walks per group + ring from 2^16 hits, one per group below), step counts, trait get_sa, the
+    exported reference samples, save / load."""
+    t = _dna(n, 7 + n % 13, sigma)
+    tx = F.Text.with_max_character(t, sigma)
+    gw = F.FMIndexWithLocate(tx, level, force_wide=True)
+    gr = F.FMIndexWithLocate(tx, level, force_wide=True, sampling="row")
+    gn = F.FMIndexWithLocate(tx, level, force_wide=True, walk_records=False)
+    assert gw.is_wide() and gw.walk_records() and gw.text_order()
+    assert gr.is_wide() and not gr.walk_records() and not gn.walk_records()
+    oi = O.OracleIndex(t, sigma, level=level)
+    rows = np.arange(n, dtype=np.uint64)
+    want = oi.get_sa(rows).astype(np.uint64)
+    lib = gw._lib
+    for gi in (gw, gr, gn):
+        lib.fmx_set_timing(gi.handle(), 1)
+        _, pos = gi.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))
+        steps = int(lib.fmx_last_steps(gi.handle()))
+        lib.fmx_set_timing(gi.handle(), 0)
+        assert (pos == want).all()
+        if gi is gw:
+            assert steps == int((want & np.uint64((1 << level) - 1)).sum())      # a walk is SA[row] mod 2^level steps
+        s = np.array([0, min(5, n), n // 2, max(n - 9, 0)], np.uint64)
+        e = np.array([min(3, n), min(40, n), min(n // 2 + 70, n), n], np.uint64)
+        _, pos = gi.locate_many(s, e)
+        assert (pos == np.concatenate([want[int(a):int(b)] for a, b in zip(s, e)])).all()
+        assert (gi.get_sa(rows[:3000]) == want[:3000]).all()
+        assert (gi.export_sa_samples() == want[::1 << level]).all()
+    path = str(tmp_path / "ww.fmx")
+    gw.save(path)
+    lw = F.FMIndexWithLocate.load(path)
+    assert lw.is_wide() and lw.walk_records() and lw.heap_size() == gw.heap_size()
+    _, pos = lw.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))
+    assert (pos == want).all()
+    for gi in (gw, gr, gn, lw):
+        gi.close()
 
 
 def test_wide_engine_errors_and_refusals(tmp_path):

@@ -9,7 +9,7 @@ import fm_index_amd as F
 from fm_index_amd import workload as W, _lib as L
 lib = L.lib()
 dev = torch.device("cuda", 0)
-tag = "v" + os.environ.get("FMX_VARIANT", "1")
+tag = "v" + os.environ.get("FMX_VARIANT", "1") + ("-" + os.environ["SAMPLING"] if os.environ.get("SAMPLING") else "")
 only = sys.argv[1:]            # e.g. `dna`: only that index
 for log2n in (16, 20, 24, 27):
     n = 1 << log2n
@@ -17,7 +17,8 @@ for log2n in (16, 20, 24, 27):
         if only and name not in only:
             continue
         text = W.dna_text_torch(n, 1, dev) if name == "dna" else W.byte_text_torch(n, 4, dev)
-        idx = cls.from_device_text(text.data_ptr(), n, 4 if name == "dna" else 255, level=2, device=0)
+        kw = {"sampling": os.environ["SAMPLING"]} if os.environ.get("SAMPLING") else {}     # "row" / "text": override the default
+        idx = cls.from_device_text(text.data_ptr(), n, 4 if name == "dna" else 255, level=2, device=0, **kw)
         h = idx.handle()
         for log2p in (8, 12, 16, 20):
             npat, m = 1 << log2p, 8 if log2n <= 20 else 12

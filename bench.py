@@ -290,6 +290,11 @@ def run_census(wl, launch, cap_entries):
     try:
         launch(lib)
         torch.cuda.synchronize()
+    except (RuntimeError, AssertionError) as ex:
+        # e.g. a census library built from other sources than libfmx.so refuses the handle (FMX_LAYOUT): no census,
+        # the line goes on without the request counts
+        lib.fmx_census_end()
+        return {"requested_lines": None, "distinct_lines": None, "note": "census launch failed: %r" % (ex,)}
     finally:
         lib.fmx_census_end()
     requested = int(cnt.item())
@@ -758,6 +763,25 @@ def golden_counts_sha(wl, args, total=None, seed=None):
     ent = g.get("entries", {}).get(golden_key(wl.name, args.log2n, wl.pattern_seed if seed is None else seed,
                                                wl.total_patterns if total is None else total, wl.m))
     return (ent["counts_sha256"], ent.get("ranges_sha256")) if ent else None
+
+
+def golden_locate(wl, args):
+    """{"level", "hits", "positions_sha256"} of this global pattern set in tests/golden/config5_counts.json (the ORDERED
+    positions of every pattern, from the CPU oracle), or None"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "config5_counts.json")) as f:
+            g = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = g.get("entries", {}).get(golden_key(wl.name, args.log2n, wl.pattern_seed, wl.total_patterns, wl.m))
+    loc = (ent or {}).get("locate")
+    return loc if loc and loc.get("level") == wl.level else None
+
+
+def positions_sha256(pos):
+    import hashlib
+    import numpy as np
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(pos).astype("<i8", copy=False)).tobytes()).hexdigest()
 
 
 def wl_oracle(wl, kind):
@@ -1447,9 +1471,18 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
         torch.cuda.synchronize()
         mine = g[rank * plan.mx:rank * plan.mx + total_hits].to(wl.dev).to(torch.int64)
         assert bool((mine == wl.d_pos[:total_hits]).all()), "gathered positions differ from this rank's"
+        allp = torch.cat([g[r * plan.mx:r * plan.mx + plan.totals[r]] for r in range(world)]).cpu().numpy().astype(np.int64)
         if args.dump_counts and rank == 0:                # tests: every rank's positions, compacted
-            allp = torch.cat([g[r * plan.mx:r * plan.mx + plan.totals[r]] for r in range(world)])
-            np.save(args.dump_counts.replace(".npy", "_pos.npy"), allp.cpu().numpy().astype(np.int64))
+            np.save(args.dump_counts.replace(".npy", "_pos.npy"), allp)
+    else:
+        allp = wl.d_pos[:total_hits].cpu().numpy()
+    # the ORDERED positions of the whole global pattern set, hashed (input order; suffix-array order within a pattern)
+    pos_sha = positions_sha256(allp)
+    gold = golden_locate(wl, args)
+    del allp
+    if gold is not None:
+        assert gold["hits"] == all_hits and gold["positions_sha256"] == pos_sha, \
+            "located positions differ from tests/golden/config5_counts.json (the oracle's ordered positions)"
     # the walk kernel alone, one launch at a time, HIP events on the launch stream
     kms, lf_steps = [], 0
     for _ in range(lsteps):
@@ -1489,6 +1522,9 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
                      "includes": "row expansion + walk" + (" + gather of counts and positions over the ranks"
                                                            if use_dist else ""),
                      "walk_kernel_ms": round(kavg_ms, 4), "walk_kernel_ms_launched_alone": round(kalone_ms, 4),
+                     "positions_sha256": pos_sha,
+                     "matches_golden": ({"positions_sha256": True, "source": "tests/golden/config5_counts.json (the CPU oracle's "
+                                         "ordered positions of every pattern)"} if gold is not None else None),
                      "roofline": roof}
     if two is not None:
         dest[legname]["two_streams"] = two

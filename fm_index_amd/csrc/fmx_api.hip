@@ -139,6 +139,7 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   }
 
   fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
+  idx->layout = FMX_LAYOUT;
   idx->device = device;
   idx->n = n;
   idx->sym_bytes = sym_bytes;
@@ -290,6 +291,8 @@ int fmx_stream_status(const fmx_index *idx) {
 // ---------------------------------------------------------------------------
 #define CHECK_IDX(idx)                                   \
   if (!(idx)) return fail(FMX_ERR_ARG, "index is NULL"); \
+  if ((idx)->layout != FMX_LAYOUT)                       \
+    return fail(FMX_ERR_ARG, "the index was made by another build of the library (rebuild libfmx*.so together)"); \
   DeviceGuard _dg;                                       \
   FMX_HIP(_dg.set((idx)->device))
 
@@ -1432,6 +1435,7 @@ int fmx_load(const char *path, int device, fmx_index **out) {
   if (!f) return fail(FMX_ERR_ARG, "cannot open index file");
   FileHeader h;
   fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
+  idx->layout = FMX_LAYOUT;
   int rc = FMX_OK;
   do {
     if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "FMXIDX01", 8) != 0 || h.version != kFileVersion) {

@@ -187,6 +187,7 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
 #define FMXW_WALK_SB_SHIFT_TEST 5u  // FMX_FLAG_FORCE_WIDE: 32 records, so that a small text has many superblocks
 
 struct fmx_index {
+  uint64_t layout;       // FMX_LAYOUT of the library that made the handle (first member: checked before anything else is read)
   FmxDev dev;
   FmxWideDev wide;       // valid when is_wide
   int is_wide;
@@ -217,6 +218,13 @@ struct fmx_index {
   int series_n;
   uint64_t *d_steps;     // device counter
 };
+
+// The measurement libraries (libfmx_census.so, libfmx_measure.so, libfmx_debug.so) take handles made by libfmx.so: same
+// ABI, same structs -- IF they were built from the same sources.  A handle carries the sizes of the structs of the
+// library that made it; a library with another layout refuses it (FMX_ERR_ARG) instead of reading pointers at the
+// wrong offsets (a stale census library did exactly that in round 4: a GPU memory fault in the middle of bench.py).
+#define FMX_LAYOUT (0x464D5800ull << 32 | (uint64_t)sizeof(fmx_index) << 20 | (uint64_t)sizeof(FmxDev) << 10 | \
+                    ((uint64_t)sizeof(FmxWideDev) & 0x3FFu))
 
 // ---- internal entry points --------------------------------------------------
 void fmx_set_error(int code, const char *detail);

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--plen", type=int, default=32)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--locate-level", type=int, default=2,
+                    help="also hash the ORDERED locate positions of every pattern (iter_matches().map(locate), "
+                         "wrapper.rs:203-242) at this sampling level; -1 = counts only")
     a = ap.parse_args()
     import torch
     import bench
@@ -38,11 +41,16 @@ def main():
     dev = torch.device("cuda", 0)
     n, T, m = 1 << a.log2n, a.total, a.plen
     text = W.dna_text_torch(n, 1, dev)
-    index = F.FMIndex.from_device_text(text.data_ptr(), n, 4, device=0)
+    lvl = a.locate_level if a.locate_level >= 0 else None
+    index = (F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=lvl, device=0) if lvl is not None else
+             F.FMIndex.from_device_text(text.data_ptr(), n, 4, device=0))
     t0 = time.time()
-    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4, native=True, kind="fm")
+    # (export_sa_samples yields the reference's samples SA[k << level] whatever the index samples inside)
+    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), 4, native=True, kind="fm",
+                                samples=index.export_sa_samples() if lvl is not None else None, level=lvl)
     threads = a.threads or bench.host_cpu()["effective_cpus"]
-    h, hr = hashlib.sha256(), hashlib.sha256()
+    h, hr, hp = hashlib.sha256(), hashlib.sha256(), hashlib.sha256()
+    hits = 0
     total_count = 0
     ar = torch.arange(m, dtype=torch.int64, device=dev)[None, :]
     chunk = 1 << 20
@@ -58,6 +66,10 @@ def main():
         se = np.empty((k, 2), dtype="<i8")                 # bench.ranges_sha256: [s_0, e_0, s_1, e_1, ...]
         se[:, 0], se[:, 1] = so.astype("<i8"), eo.astype("<i8")
         hr.update(se.tobytes())
+        if lvl is not None:                                # the ordered positions, pattern after pattern
+            _, pos = oi.locate_batch(so, eo, nthreads=threads)
+            hp.update(pos.astype("<i8").tobytes())
+            hits += len(pos)
         print("patterns %d..%d done (%.0f s)" % (lo, lo + k, time.time() - t0), file=sys.stderr)
     path = os.path.join(ROOT, "tests", "golden", "config5_counts.json")
     try:
@@ -67,10 +79,16 @@ def main():
                      "same over the (s, e) pairs [s_0, e_0, s_1, e_1, ...], of a global pattern set: "
                      "substrings text[p : p + len] with p = splitmix64(seed, k) mod (n - 1 - len) of the sigma=4 DNA text "
                      "(seed 1) -- computed by the CPU oracle over ALL patterns (tests/golden/make_config5_golden.py)",
+             "locate": "positions_sha256 = sha256 over the int64 little-endian text positions of every pattern's matches in "
+                       "the reference's iteration order (ascending suffix-array row within a pattern, wrapper.rs:203-217), "
+                       "patterns in input order, from the oracle's get_sa walk over the reference's own samples",
              "entries": {}}
-    g["entries"][bench.golden_key("dna", a.log2n, a.seed, T, m)] = {
-        "counts_sha256": h.hexdigest(), "ranges_sha256": hr.hexdigest(), "counts_sum": total_count, "oracle_threads": threads,
-        "oracle_seconds": round(time.time() - t0, 1)}
+    ent = {"counts_sha256": h.hexdigest(), "ranges_sha256": hr.hexdigest(), "counts_sum": total_count,
+           "oracle_threads": threads}
+    if lvl is not None:
+        ent["locate"] = {"level": lvl, "hits": hits, "positions_sha256": hp.hexdigest()}
+    ent["oracle_seconds"] = round(time.time() - t0, 1)
+    g["entries"][bench.golden_key("dna", a.log2n, a.seed, T, m)] = ent
     with open(path, "w") as f:
         json.dump(g, f, indent=1, sort_keys=True)
         f.write("\n")

@@ -36,6 +36,12 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert two["gather"]["counts_wire_dtype"] == "int32"
     assert c2.shape == c1.shape == (8192,)
     assert (c2 == c1).all()
+    # the weak-scaling lines carry the hashes of the whole set too, and this set (n = 2^16, seed 7, 8192 patterns) has a
+    # golden entry made by the CPU oracle: counts, ranges and ordered positions
+    assert two["counts_sha256"] == one["counts_sha256"] and two["ranges_sha256"] == one["ranges_sha256"]
+    assert two["matches_golden"]["counts_sha256"] is True and one["matches_golden"]["ranges_sha256"] is True
+    assert two["locate"]["positions_sha256"] == one["locate"]["positions_sha256"]
+    assert two["locate"]["matches_golden"]["positions_sha256"] is True
     # aggregate value = all ranks' characters over the max-over-ranks time
     assert two["config"]["patterns_per_gpu"] == 4096 and two["value"] > 0
     # the locate leg gathered every rank's positions
@@ -112,6 +118,12 @@ def test_strong_scaling_two_ranks_hash_like_one_process(tmp_path):
         assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
         assert line["roofline"]["avg_kernel_ms"] > 0
     assert two["locate"]["hits"] == one["locate"]["hits"] == int(c1.sum())
+    # both lines agree with the hashes the CPU oracle computed over ALL patterns of this set (tests/golden/): counts,
+    # (s, e) ranges and the ordered locate positions
+    for line in (one, two):
+        assert line["matches_golden"]["counts_sha256"] is True and line["matches_golden"]["ranges_sha256"] is True
+        assert line["locate"]["matches_golden"]["positions_sha256"] is True
+    assert two["locate"]["positions_sha256"] == one["locate"]["positions_sha256"]
 
 
 def test_default_line_carries_config5_at_one_gpu(tmp_path):

@@ -1004,6 +1004,16 @@ def run(args, world, pmc=None):
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
             out["locate_row_order"] = {"error": repr(ex)}
 
+    # ---- beyond 2^32 rows: the 64-bit engine on the config-2 / config-3 shapes.  EARLY in the run: its builder needs
+    # 137 GB of scratch beyond what the scratch cache holds, and on this runtime a process that has cycled through about
+    # the device's memory pays ~30 ms per GiB for every further hipMalloc -- the legs below
+    # allocate and free tens of GB between them (round 3 ran this leg last: build_ms 0.57 s in some runs, 3-8 s in others)
+    if single and wl.dna and not args.no_wide and args.log2n >= 30:      # only next to the full-size configs
+        try:
+            wide_leg(out, args, dev)
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
+            out["wide"] = {"error": repr(ex)}
+
     # ---- the config-5 step through a 1-rank RCCL communicator on this GPU (default N=1 run) ----
     if single and not args.no_rccl_check:
         try:
@@ -1051,14 +1061,6 @@ def run(args, world, pmc=None):
         if wr is not None:
             wr.close()
             del wr
-
-    # ---- beyond 2^32 rows: the 64-bit engine on the config-2 / config-3 shapes.  LAST: its builder holds ~172 GB of
-    # scratch, and a process that has cycled through the device's memory pays for every later hipMalloc / hipFree ----
-    if single and wl.dna and not args.no_wide and args.log2n >= 30:      # only next to the full-size configs
-        try:
-            wide_leg(out, args, dev)
-        except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
-            out["wide"] = {"error": repr(ex)}
 
     # ---- HBM-side traffic measured by the counter passes at the start of this run ----
     if pmc is not None and rank == 0:
@@ -1846,8 +1848,9 @@ def wide_leg(out, args, dev):
                    "checked": "every located position holds its pattern; every source position is among the hits"},
         "index_bytes": index.heap_size(), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
         "build_wall_s": round(build_wall_s, 2), "textgen_s": round(textgen_s, 2),
-        "note": "build_ms includes the driver's hipMalloc / hipFree of ~172 GB of scratch: 0.6 s on fresh device memory, "
-                "seconds once the process has cycled through it (DESIGN.md section 4.3)"}
+        "walk_records": index.walk_records(),
+        "note": "build_ms includes the driver's hipMalloc of ~137 GB of scratch: 0.6 s while the process is handed memory it "
+                "has not used before, ~30 ms per GiB once it has cycled through the device's memory (DESIGN.md section 4.3)"}
     index.close()
     del text, pat, pat2, pos
     torch.cuda.empty_cache()

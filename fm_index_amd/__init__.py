@@ -359,8 +359,8 @@ class RLFMIndexWithLocate(_Index):
     """RLFMIndexWithLocate::new(&text, level) (frontend.rs:233-243)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None):
-        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, walk_records=True):
+        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, walk_records=walk_records)
 
 
 class FMIndexMultiPieces(_Index):

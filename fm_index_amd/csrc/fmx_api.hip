@@ -220,7 +220,9 @@ uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; 
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
 int fmx_text_order(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.phase != nullptr) ? 1 : 0; }
-int fmx_walk_records(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.walk != nullptr) ? 1 : 0; }
+int fmx_walk_records(const fmx_index *idx) {
+  return idx && (idx->is_wide ? idx->wide.walk != nullptr : (idx->dev.walk != nullptr || idx->dev.lfrun != nullptr)) ? 1 : 0;
+}
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
 
@@ -1186,6 +1188,7 @@ int enumerate_blobs(FmxDev &d, uint64_t nsamples, Blob *out) {
     if (d.bp.dsel) out[k++] = {(const void **)&d.bp.dsel, (((uint64_t)d.bp.ones + (1ull << d.bp.dsel_shift) - 1) >> d.bp.dsel_shift) * 16};
     if (d.b.pos) out[k++] = {(const void **)&d.b.pos, (uint64_t)d.b.ones * 4};
     if (d.bp.pos) out[k++] = {(const void **)&d.bp.pos, (uint64_t)d.bp.ones * 4};
+    if (d.lfrun) out[k++] = {(const void **)&d.lfrun, (uint64_t)d.b.ones * 4};       // one entry per run
   }
   if (d.pair_rec) out[k++] = {(const void **)&d.pair_rec, ((uint64_t)d.n / 128 + 1) * 128};
   if (d.kmer) out[k++] = {(const void **)&d.kmer, (1ull << (d.kmer_bits * d.kmer_k)) * 8};
@@ -1231,6 +1234,7 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
     }
   }
   if (d.pair_rec && (d.pair_row0 > h.n || d.pair_row1 > h.n)) return "pair index";
+  if (d.lfrun && (d.kind != FMX_KIND_RLFM || d.sa_level == FMX_NO_LOCATE)) return "run LF table";
   return nullptr;
 }
 const size_t kChunk = 64u << 20;

@@ -621,6 +621,12 @@ __global__ __launch_bounds__(BLK) void k_sorted_run_lens(const uint32_t *__restr
   uint32_t end = k + 1 < r ? starts[k + 1] : n;
   lens[q] = end - starts[k];
 }
+// lfrun[run] = F position of the run (FmxDev::lfrun): order[t] = the run that comes t-th in (head, row) order
+__global__ __launch_bounds__(BLK) void k_scatter_lfrun(const uint32_t *__restrict__ order, const uint32_t *__restrict__ fpos,
+                                                        uint32_t r, uint32_t *__restrict__ lfrun) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t < r) lfrun[order[t]] = fpos[t];
+}
 __global__ __launch_bounds__(BLK) void k_scatter_ones(const uint32_t *__restrict__ pos, uint32_t r,
                                                        uint8_t *__restrict__ flags) {
   uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
@@ -1412,6 +1418,19 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   uint8_t *etmp;
   FMX_HIP(pool.get(&etmp, eb));
   FMX_HIP(exclusive_sum(etmp, eb, lens, fpos, (size_t)r));
+  // lf_map of every run start (FmxDev::lfrun), for indexes that locate -- when the device has room for 4 bytes per run
+  // four times over; FMX_FLAG_NO_WALK_RECORDS keeps it off
+  dv.lfrun = nullptr;
+  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 16ull * r) {
+      uint32_t *d_lfrun;
+      FMX_HIP(hipMalloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 4));
+      if (int rc = keep(idx, d_lfrun, (uint64_t)r * 4)) return rc;
+      hipLaunchKernelGGL(k_scatter_lfrun, dim3(nblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
+      dv.lfrun = d_lfrun;
+    }
+  }
   FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
   hipLaunchKernelGGL(k_scatter_ones, dim3(nblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
   FMX_HIP(hipDeviceSynchronize());

@@ -299,6 +299,41 @@ __device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_map(const FmxDev &ix, const u
   return f + i - st;                                         // rlfmi.rs:132
 }
 
+// ---- the same lf_map through the run table (FmxDev::lfrun; round 4) ----------------------------------
+// Rows of one run map to consecutive rows, and lfrun[j] is lf_map of run j's first row, so
+//     lf_map(i) = lfrun[lo] + (i - start of run lo),   lo = b.rank1(i + 1) - 1            (rlfmi.rs:122-133)
+// Two lane-wise requests -- the B piece of row i, then the table entry (and, only when the run starts before the piece,
+// one select on B: stored position / select block, the rare block that does not hold its ones through the group's
+// cooperative search) -- and no wavelet record at all.
+template <int SM>
+__device__ __forceinline__ uint32_t fmx_rlfm_ep_lf_run(const FmxDev &ix, uint32_t i, bool live, uint32_t base, uint32_t g) {
+  const FmxProbe pr = fmx_bits_probe_issue<false>(ix.b, i, live);
+  uint32_t bit, nx;
+  const uint32_t j = fmx_bits_probe_rank(pr, bit, nx);       // b.rank1(i)
+  const uint32_t lo = j - 1u + bit;                          // the run holding row i
+  // its start = the last one at or before i: in the piece unless the run began before it
+  uint32_t st = FMX_NONE;
+  {
+    const uint32_t b1 = pr.bit + 1u;                         // bits [0, pr.bit] of the 96-bit window
+    const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+    const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+    const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+    const uint32_t y = pr.pc.y & m0, z = pr.pc.z & m1, w = pr.pc.w & m2;
+    uint32_t cand = FMX_NONE;
+    if (w) cand = 95u - (uint32_t)__builtin_clz(w);
+    else if (z) cand = 63u - (uint32_t)__builtin_clz(z);
+    else if (y) cand = 31u - (uint32_t)__builtin_clz(y);
+    if (cand != FMX_NONE) st = cand + pr.pidx * FMX_BITS_PER_PIECE;
+  }
+  FMX_CHECK(!live || lo < ix.b.ones);
+  FMX_TOUCH_LANE(false, &ix.lfrun[live ? lo : 0u], live);
+  const uint32_t f = ix.lfrun[live ? lo : 0u];               // lf_map(start of the run)
+  const FmxSel ss = fmx_ep_select_issue<SM, false>(ix.b, lo, live && st == FMX_NONE, live);   // b.select1(lo)
+  if (st == FMX_NONE) st = fmx_ep_select_finish<SM>(ix.b, ss);
+  if (SM == 2) fmx_ep_select_slow(ix.b, lo, live && st == FMX_NONE, base, g, st);
+  return f + i - st;
+}
+
 // ---- FMIndexBackend::get_l + lf_map for 8 walks per group (fm_index.rs:82-91) -------------------
 // access + rank along the same positions, one round per wavelet level
 template <int NL>

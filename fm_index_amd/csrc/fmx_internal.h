@@ -127,6 +127,12 @@ struct FmxDev {  // passed BY VALUE to every query kernel
   // (+ a geometric tail) and the round-3 text-order walk 4.5.  (Symbol 0 needs no counter: the one row that has it
   // -- SA = 0 -- maps to row 0, and no walk steps from it: its phase is 0.)
   const uint4 *walk;
+  // RLFM with locate (round 4): lfrun[j] = lf_map(first row of run j) = the F position of run j (rlfmi.rs:127-133 at a
+  // run start).  Rows of a run map to consecutive rows, so lf_map(i) = lfrun[run of i] + (i - start of that run): the
+  // batched locate walk takes an LF step with TWO lane-wise requests -- the B piece of row i (run index, run start) and
+  // this entry -- instead of B piece + one S record per wavelet level + B' select (4.25 requests on a byte alphabet).
+  // 4 bytes per run (a repetitive text has few); built from the builder's F order, stored in index files.
+  const uint32_t *lfrun;
 };
 #define FMX_PHASE_MAX_LEVEL 4u
 #define FMX_WALK_MAX_LEVEL 3u        // three phase planes fit the piece

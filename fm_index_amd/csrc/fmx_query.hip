@@ -1299,7 +1299,9 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
 // contiguous 64 x 8-byte store.  Round 2 stored every position on its own: an 8-byte store in
 // completion order is one 32-byte sector and one request at the memory side (config 4: 22.5 MB written
 // for 8.4 MB of positions).
-template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC>
+// LFR (RLFM with the run table FmxDev::lfrun, round 4): an LF step is two lane-wise requests (fmx_rlfm_ep_lf_run) and the
+// cooperative rank rounds are not run at all.
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR = false>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_kernel(
     FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
@@ -1435,9 +1437,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     const bool walking = active && (TEXT ? (ctl >> 8) == 1u : (row & lmask) != 0u);
     if (__any(walking)) {
       uint32_t sym;
-      const uint32_t nrow = KIND == FMX_KIND_RLFM
-                                ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
-                                : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
+      uint32_t nrow;
+      if constexpr (LFR) nrow = fmx_rlfm_ep_lf_run<(SM > 0 ? SM : 1)>(ix, walking ? row : 0u, walking, base, g);
+      else nrow = KIND == FMX_KIND_RLFM
+                      ? fmx_rlfm_ep_lf_map<NL, (SM > 0 ? SM : 1)>(ix, kt, walking ? row : 0u, walking, base, g, sym)
+                      : fmx_fm_ep_lf_map<NL>(ix, kt, walking ? row : 0u, walking, base, g, sym);
       if (walking) {
         row = nrow;
         if (TEXT) {
@@ -1914,6 +1918,16 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
     else { if (text_) FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, false, true);              \
            else FMX_EPL_LAUNCH2(c, gr, thr, hpb, wcf, KIND, NL, SM, false, false); }                 \
   } while (0)
+// RLFM with the run table: no wavelet level is read (NL, KLDS irrelevant: one instantiation per select structure)
+#define FMX_EPL_LFR(c, gr, thr, hpb, SM)                                                             \
+  do {                                                                                               \
+    if ((c).dv.phase != nullptr)                                                                     \
+      hipLaunchKernelGGL((fmx_locate_ep_kernel<FMX_KIND_RLFM, 1, SM, false, true, true, true>), dim3(gr), dim3(thr), 0, \
+                         (c).st, (c).dv, (c).total, hpb, (c).rows, (c).pos, (c).steps);              \
+    else                                                                                             \
+      hipLaunchKernelGGL((fmx_locate_ep_kernel<FMX_KIND_RLFM, 1, SM, false, false, true, true>), dim3(gr), dim3(thr), 0, \
+                         (c).st, (c).dv, (c).total, hpb, (c).rows, (c).pos, (c).steps);              \
+  } while (0)
 #define FMX_EPL_SM(c, gr, thr, hpb, wcf, KIND, SM)                                                   \
   do {                                                                                               \
     if ((c).dv.bw.nlevels == 1) FMX_EPL_LAUNCH(c, gr, thr, hpb, wcf, KIND, 1, SM);                   \
@@ -2088,6 +2102,9 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
+      else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
+        if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);
+      }
       else if (sm == 1) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_RLFM, 1);
       else FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_RLFM, 2);
     } else {

@@ -315,7 +315,11 @@ uint32_t fmx_sym_bytes(const fmx_index *idx);                        /* symbol w
 uint32_t fmx_kmer_k(const fmx_index *idx);   /* k of the FMX_FLAG_KMER_TABLE table, 0 = none */
 int fmx_has_pair_index(const fmx_index *idx);                        /* FMX_FLAG_PAIR_INDEX honoured? */
 int fmx_is_wide(const fmx_index *idx);        /* 1: served by the wide (64-bit rows) engine */
-int fmx_walk_records(const fmx_index *idx);   /* 1: the index has walk records (FMX_FLAG_NO_WALK_RECORDS) */
+/* 1: the index carries the derived structure that speeds up its batched locate walk -- walk records (FM, DNA-like),
+ * or the run table of an RLFM index: lf_map of every run's first row, 4 bytes per run, so that an LF step of the walk
+ * is the B piece of the row + one table entry instead of B piece + S records + B' select (rlfmi.rs:127-133).
+ * FMX_FLAG_NO_WALK_RECORDS builds without either. */
+int fmx_walk_records(const fmx_index *idx);
 int fmx_text_order(const fmx_index *idx);     /* 1: suffix-array samples in text order (FMX_FLAG_TEXT_ORDER) */
 
 #ifdef __cplusplus

@@ -12,7 +12,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --no-accel --no-early-exit: only config-2/3/4 launches of the headline kernels in the trace
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-3b --no-wide ${2:---no-accel}"
+# --no-config5 / --no-rccl-check: the 8 M-pattern batch runs the same count kernel on another shape (5 ms per launch)
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-3b --no-wide --no-config5 --no-rccl-check ${2:---no-accel}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_write.out 2> $OUT/pmc_write.err
@@ -26,7 +27,8 @@ for tag in ("pmc_fetch", "pmc_write"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(tag + "/**/*counter_collection*.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            k = (row.get("Kernel_Name", "?").split("(")[0][:90], row.get("Counter_Name", "?"))
+            kn = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "")
+            k = (kn.split("(")[0][:90], row.get("Counter_Name", "?"))
             agg[k][0] += 1
             agg[k][1] += float(row.get("Counter_Value", 0) or 0)
     out[tag] = {"%s|%s" % k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)}

@@ -202,6 +202,40 @@ def test_every_run_density_gets_a_one_load_select(gen):
     assert (gi.fl_map(r2) == oi.fl_map(r2)).all()
 
 
+@pytest.mark.parametrize("gen,level,sampling", [("sigma255", 1, None), ("sigma255", 3, None), ("sigma4", 2, "row"), ("rep60", 3, None),
+                                                ("rep5", 1, "row"), ("sigma255", 4, None), ("rep5", 0, None)])
+def test_run_table_walk_equals_the_wavelet_walk_and_the_oracle(gen, level, sampling, tmp_path):
+    """RLFM indexes that locate carry lf_map of every run's first row (round 4, FmxDev::lfrun): an LF step of the batched
+    walk (>= 2^18 hits: fmx_locate_ep_kernel<..., LFR>) is the B piece of the row + one table entry.  Same ordered
+    positions as the walk through S and B' (FMX_FLAG_NO_WALK_RECORDS) and as the oracle -- text and row order, levels
+    0..4, select blocks and stored positions, runs that start before their B piece -- and through save / load."""
+    n = 1 << 17
+    if gen.startswith("sigma"):
+        sig = int(gen[5:])
+        t = (W.splitmix64_np(94, 0, n) % np.uint64(sig)).astype(np.uint8) + 1
+        t[-1] = 0
+    else:
+        t = W.repetitive_text_np(n, 5, base_len=1 << 9, mut_per_1024=int(gen[3:]))
+    with_t = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)
+    without = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling, walk_records=False)
+    assert with_t.walk_records() and not without.walk_records()
+    runs = int(with_t._lib.fmx_num_runs(with_t.handle()))
+    assert with_t.heap_size() - without.heap_size() == 4 * runs
+    oi = O.OracleIndex(t, 255, level=level, kind="rlfm")
+    want = oi.get_sa(np.arange(n)).astype(np.uint64)
+    s = np.array([0, 0, n // 3], np.uint64)                  # 2 n + ... hits: the one-walk-per-lane kernel
+    e = np.array([n, n, n], np.uint64)
+    expect = np.concatenate([want, want, want[n // 3:]])
+    path = str(tmp_path / "rl.fmx")
+    with_t.save(path)
+    loaded = F.RLFMIndexWithLocate.load(path)
+    assert loaded.walk_records() and loaded.heap_size() == with_t.heap_size()
+    for gi in (with_t, without, loaded):
+        _, pos = gi.locate_many(s, e)
+        assert (pos == expect).all(), gen
+        gi.close()
+
+
 @pytest.mark.parametrize("gen", ["sigma4", "sigma255", "rep60", "rep5"])
 def test_large_hit_batches_take_the_walk_per_lane_kernel(gen):
     """locate batches of >= 2^18 hits run fmx_locate_ep_kernel (one walk per lane, LDS hit queue);

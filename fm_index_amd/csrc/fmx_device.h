@@ -422,6 +422,37 @@ __device__ __forceinline__ uint32_t fmx_bits_rank_next(const FmxBits &bv, uint32
   next = fmx_group_min(cand);
   return fmx_group_sum(mine * (pc.x + c));
 }
+// rank1(i + 1) - 1 = the index of the last one at or before i (the run holding row i of an RLFM index), and `prev` =
+// that one's position when it lies in the record just loaded (0xFFFFFFFF otherwise: the run began before the record)
+__device__ __forceinline__ uint32_t fmx_bits_rank_prev(const FmxBits &bv, uint32_t i, uint32_t g, uint32_t &prev) {
+  if (i >= bv.len) i = bv.len ? bv.len - 1u : 0u;
+  const uint32_t rec = fmx_div3(i >> 8);            // i / 768
+  const uint32_t within = i - rec * FMX_BITS_PER_REC;
+  const uint32_t p = fmx_div3(within >> 5);         // within / 96
+  const uint32_t b1 = within - p * FMX_BITS_PER_PIECE + 1u;   // bits [0, bit] of piece p
+  FMX_CHECK(rec < bv.nrec);
+  FMX_TOUCH_G0(g, &bv.rec[(size_t)rec * 8u]);
+  const uint4 pc = bv.rec[(size_t)rec * 8u + g];
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  const uint32_t c = __popc(pc.y & m0) + __popc(pc.z & m1) + __popc(pc.w & m2);
+  // last one at or before the row: in piece p below the mask, or the last one of an earlier piece
+  uint32_t y = pc.y, z = pc.z, w = pc.w;
+  if (g == p) { y &= m0; z &= m1; w &= m2; }
+  else if (g > p) { y = 0u; z = 0u; w = 0u; }
+  uint32_t cand = 0u;                               // position + 1; 0 = none (max over the group)
+  if (w) cand = 96u - (uint32_t)__builtin_clz(w);
+  else if (z) cand = 64u - (uint32_t)__builtin_clz(z);
+  else if (y) cand = 32u - (uint32_t)__builtin_clz(y);
+  if (cand) cand += rec * FMX_BITS_PER_REC + g * FMX_BITS_PER_PIECE;
+  uint32_t mx = cand;
+  mx = max(mx, fmx_dpp_xor1(mx));
+  mx = max(mx, fmx_dpp_xor2(mx));
+  mx = max(mx, fmx_dpp_half_mirror(mx));
+  prev = mx ? mx - 1u : 0xFFFFFFFFu;
+  return fmx_group_sum((g == p) ? pc.x + c : 0u) - 1u;
+}
 // dense-vector select block: position of one number (k & 63) inside the block's 96-bit window
 __device__ __forceinline__ uint32_t fmx_dsel_pos(const uint4 blk, uint32_t k, uint32_t shift) {
   const uint32_t r = k & ((1u << shift) - 1u), c0 = __popc(blk.y), c1 = __popc(blk.z);
@@ -737,7 +768,26 @@ __device__ __forceinline__ void fmx_lf_map2_pair(const FmxDev &ix, uint32_t c, u
     fmx_rlfm_lf_map2_pair<NL, SM>(ix, c, s, e, g);
   }
 }
+// lf_map(i) for a walk that has no use for the symbol (get_sa: fm_index.rs:134-137, rlfmi.rs:183-186): an RLFM index
+// with the run table (FmxDev::lfrun) answers with the B record of the row + one table entry -- lf_map(i) = lfrun[run] +
+// (i - start of the run) -- and only a run that began before the record costs a select on B
 template <int KIND, int NL = 0, int SM = -1>
+__device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g, uint32_t &sym);
+template <int KIND, int NL = 0, int SM = -1>
+__device__ __forceinline__ uint32_t fmx_lf_step_any(const FmxDev &ix, uint32_t i, uint32_t g) {
+  if (KIND == FMX_KIND_RLFM && ix.lfrun) {
+    uint32_t st;
+    const uint32_t lo = fmx_bits_rank_prev(ix.b, i, g, st);
+    FMX_CHECK(lo < ix.b.ones);
+    FMX_TOUCH_G0N(g, &ix.lfrun[lo]);
+    const uint32_t f = ix.lfrun[lo];
+    if (st == 0xFFFFFFFFu) st = fmx_bits_select(ix.b, lo, g);   // group-uniform
+    return f + i - st;
+  }
+  uint32_t sym;
+  return fmx_lf_map_any<KIND, NL, SM>(ix, i, g, sym);
+}
+template <int KIND, int NL, int SM>
 __device__ __forceinline__ uint32_t fmx_lf_map_any(const FmxDev &ix, uint32_t i, uint32_t g,
                                                    uint32_t &sym) {
   if (KIND == FMX_KIND_FM || KIND == FMX_KIND_MULTI) {

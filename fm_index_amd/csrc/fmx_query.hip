@@ -632,8 +632,7 @@ __device__ __forceinline__ uint64_t fmx_get_sa_text(const FmxDev &ix, uint32_t r
   FMX_TOUCH_G0N(g, &ix.phase[p]);
   const uint32_t phi = fmx_phase_decode(ix.phase[p], t, ix.sa_level, rank0);
   for (uint32_t k = 0; k < phi; k++) {               // i = lf_map(i); steps += 1     fm_index.rs:134-137
-    uint32_t sym;
-    row = fmx_lf_map_any<KIND, NL, SM>(ix, row, g, sym);
+    row = fmx_lf_step_any<KIND, NL, SM>(ix, row, g);
   }
   nsteps += phi;
   if (phi) {
@@ -692,8 +691,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
         fin = true;
       } else {
         // None: i = lf_map(i); steps += 1      fm_index.rs:134-137
-        uint32_t sym;
-        row = fmx_lf_map_any<KIND, NL, SM>(ix, row, g, sym);
+        row = fmx_lf_step_any<KIND, NL, SM>(ix, row, g);
         steps++;
         nsteps++;
       }
@@ -1599,8 +1597,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_scalar_kernel(FmxDev ix, int op
       uint32_t row = (uint32_t)i64, steps = 0;
       const uint32_t lmask = (1u << ix.sa_level) - 1u;
       while ((row & lmask) != 0) {
-        uint32_t sym;
-        row = fmx_lf_map_any<KIND>(ix, row, g, sym);
+        row = fmx_lf_step_any<KIND>(ix, row, g);
         steps++;
       }
       FMX_CHECK((row >> ix.sa_level) < ix.nsamples);

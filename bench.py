@@ -302,7 +302,12 @@ def run_census(wl, launch, cap_entries):
         return {"requested_lines": requested, "distinct_lines": None, "note": "log capacity exceeded"}
     ent = log[:requested]
     narrow = int((ent < 0).sum().item())          # bit 63: a lane-wise probe of <= 16 bytes (fmx_device.h)
-    distinct = int(torch.unique(ent & 0x7FFFFFFFFFFFFFFF).numel())
+    distinct = None
+    if requested < (1 << 31):                     # (torch.unique sorts through a 32-bit-indexed primitive)
+        try:
+            distinct = int(torch.unique(ent & 0x7FFFFFFFFFFFFFFF).numel())
+        except RuntimeError:
+            distinct = None
     del log, ent
     return {"requested_lines": requested, "distinct_lines": distinct, "requested_records": requested - narrow,
             "requested_probes": narrow}

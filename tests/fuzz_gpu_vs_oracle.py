@@ -65,23 +65,26 @@ def main():
         # eligible indexes sometimes the 64-bit engine (FMX_FLAG_FORCE_WIDE)
         sampling = [None, "text", "row"][int(rng.integers(0, 3))] if level is not None else None
         engine64 = kind == "fm" and n >= 2 and rng.random() < (0.4 if (maxc <= 7 and dtype == np.uint8) else 0.25)
-        if engine64:
-            pair, kmer, sampling = False, False, None
+        if engine64:                     # (the 64-bit engine: row order or its default -- walk records where eligible)
+            pair, kmer, sampling = False, False, (sampling if sampling != "text" else None)
+        # the derived locate structures (walk records / run table: FMX_FLAG_NO_WALK_RECORDS) on or off
+        walk = bool(rng.random() < 0.7)
         if kind == "fm":
             gi = F.FMIndexWithLocate(text, level, pair_index=pair, kmer_table=kmer, sampling=sampling,
-                                     force_wide=engine64) if level is not None else \
+                                     force_wide=engine64, walk_records=walk) if level is not None else \
                 F.FMIndex(text, pair_index=pair, kmer_table=kmer, force_wide=engine64)
             assert gi.is_wide() == engine64
         elif kind == "rlfm":
             if n < 2:
                 continue
-            gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer, sampling=sampling) if level is not None else \
-                F.RLFMIndex(text, kmer_table=kmer)
+            gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer, sampling=sampling, walk_records=walk) \
+                if level is not None else F.RLFMIndex(text, kmer_table=kmer)
         else:
             gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer, sampling=sampling) if level is not None else \
                 F.FMIndexMultiPieces(text, kmer_table=kmer)
         stats["engine64"] = stats.get("engine64", 0) + int(engine64)
         stats["text_order"] = stats.get("text_order", 0) + int(gi.text_order())
+        stats["walk_records"] = stats.get("walk_records", 0) + int(gi.walk_records())
         stats[kind] += 1
         stats["pair"] += int(pair)
         stats["kmer"] = stats.get("kmer", 0) + int(gi.kmer_k() > 0)

@@ -351,16 +351,17 @@ class RLFMIndex(_Index):
     """RLFMIndex::new(&text) (frontend.rs:223-231)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, device=0, keep_sa=False, kmer_table=False):
-        super().__init__(text, None, device, keep_sa, False, kmer_table)
+    def __init__(self, text, device=0, keep_sa=False, kmer_table=False, force_wide=False):
+        super().__init__(text, None, device, keep_sa, False, kmer_table, None, force_wide)
 
 
 class RLFMIndexWithLocate(_Index):
     """RLFMIndexWithLocate::new(&text, level) (frontend.rs:233-243)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, walk_records=True):
-        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, walk_records=walk_records)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, walk_records=True,
+                 force_wide=False):
+        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, force_wide, walk_records)
 
 
 class FMIndexMultiPieces(_Index):

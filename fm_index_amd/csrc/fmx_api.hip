@@ -115,9 +115,9 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
-  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate
-  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) && !(kind == FMX_KIND_FM && n >= 2))
-    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM only");
+  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate and RLFMIndex / RLFMIndexWithLocate
+  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) && !((kind == FMX_KIND_FM || kind == FMX_KIND_RLFM) && n >= 2))
+    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM and FMX_KIND_RLFM only");
   // the wide engine's record and superblock indices are 32 bits wide: n / 128 + 1 records, (superblock + 1) << 24
   if (n >= (1ull << 38)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^38 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
@@ -221,7 +221,8 @@ int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ?
 int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
 int fmx_text_order(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.phase != nullptr) ? 1 : 0; }
 int fmx_walk_records(const fmx_index *idx) {
-  return idx && (idx->is_wide ? idx->wide.walk != nullptr : (idx->dev.walk != nullptr || idx->dev.lfrun != nullptr)) ? 1 : 0;
+  return idx && (idx->is_wide ? (idx->wide.walk != nullptr || idx->wide.lfrun != nullptr)
+                              : (idx->dev.walk != nullptr || idx->dev.lfrun != nullptr)) ? 1 : 0;
 }
 uint32_t fmx_kmer_k(const fmx_index *idx) { return idx && idx->dev.kmer ? idx->dev.kmer_k : 0; }
 double fmx_build_ms(const fmx_index *idx) { return idx ? idx->build_ms : 0.0; }
@@ -1238,14 +1239,14 @@ const char *validate_loaded(const FileHeader &h, const FmxDev &d) {
   return nullptr;
 }
 const size_t kChunk = 64u << 20;
-const uint32_t kFileVersion = 9;   // 9: FmxDev::walk (walk records: a presence flag only, rebuilt by fmx_load); 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
+const uint32_t kFileVersion = 10;   // 10: wide RLFM indexes (FmxWideDev::b / bp / lfrun); 9: FmxDev::walk (walk records: a presence flag only, rebuilt by fmx_load); 2: select hints every 64 ones (was 512); 3: positions of sparse vectors; 4: wavelet select hints; 5: dense select blocks; 6: pointer fields written as presence flags, fields validated on load; 7: select blocks of 8 / 16 / 32 / 64 ones by density; 8: text-order sampling (phase pieces)
 }  // namespace
 
 // wide indexes (n >= 2^32 - 16): header (dev_struct_bytes carries kWideMark) | FmxWideDev with presence flags for
 // pointers | cs[] | records | bases | samples
 namespace {
 const uint32_t kWideMark = 0x80000000u;
-struct WideBlobs { const void **field[6 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[6 + 2 * FMXW_MAX_LEVELS]; int n; };
+struct WideBlobs { const void **field[16 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[16 + 2 * FMXW_MAX_LEVELS]; int n; };
 WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
   WideBlobs b;
   b.n = 0;
@@ -1264,6 +1265,16 @@ WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
   if (w.walk) {   // text-order samples: the walk records hold the phases (this engine has no phase pieces to derive them from)
     b.field[b.n] = (const void **)&w.walk;  b.bytes[b.n++] = (w.n / FMX_WALK_ROWS + 1u) * 128ull;
     b.field[b.n] = (const void **)&w.wbase; b.bytes[b.n++] = (uint64_t)w.nwsb * 128ull;
+  }
+  if (w.kind == FMX_KIND_RLFM) {
+    FmxWideBits *v[2] = {&w.b, &w.bp};
+    for (int t = 0; t < 2; t++) {
+      b.field[b.n] = (const void **)&v[t]->rec;  b.bytes[b.n++] = (uint64_t)v[t]->nrec * 128ull;
+      b.field[b.n] = (const void **)&v[t]->base; b.bytes[b.n++] = (uint64_t)v[t]->nsb * 8ull;
+      b.field[b.n] = (const void **)&v[t]->sel;  b.bytes[b.n++] = v[t]->nsel * 4ull;
+      if (v[t]->pos) { b.field[b.n] = (const void **)&v[t]->pos; b.bytes[b.n++] = v[t]->ones * 8ull; }
+    }
+    if (w.lfrun) { b.field[b.n] = (const void **)&w.lfrun; b.bytes[b.n++] = w.slen * 8ull; }
   }
   return b;
 }
@@ -1345,19 +1356,23 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   if (fread(&w, sizeof w, 1, f) != 1) return fail(FMX_ERR_ARG, "truncated index file");
   const bool locate = w.sa_level != FMX_NO_LOCATE;
   const char *bad = nullptr;
-  if (h.kind != FMX_KIND_FM || (h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) ||
+  const bool rl = h.kind == FMX_KIND_RLFM;
+  const uint64_t slen = rl ? h.runs : h.n;          // entries of the wavelet levels: run heads (RLFM) or the BWT
+  if ((h.kind != FMX_KIND_FM && !rl) || w.kind != h.kind || (h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) ||
       (h.sym_bytes_abi != h.sym_bytes && !(h.sym_bytes_abi == 8 && h.sym_bytes == 4)))
     bad = "kind / symbol width";
   else if (h.n < 2 || h.n >= (1ull << 38) || w.n != h.n) bad = "n";
   else if (h.max_character == 0 || h.max_character >= (1ull << 26) || w.max_character != h.max_character ||
            (h.sym_bytes < 4 && h.max_character >= (1ull << (8 * h.sym_bytes))))
     bad = "max_character";
-  else if (w.generic != ((h.max_character > 7 || h.sym_bytes != 1) ? 1u : 0u) || (w.generic && w.sym_bytes != h.sym_bytes))
+  else if (w.generic != ((h.max_character > 7 || h.sym_bytes != 1 || rl) ? 1u : 0u) || (w.generic && w.sym_bytes != h.sym_bytes))
     bad = "engine";
-  else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(h.n >> w.sb_shift) + 1u) bad = "superblocks";
+  else if (rl ? (h.runs == 0 || h.runs > h.n || w.slen != h.runs) : (h.runs != 0 || w.slen != 0 || w.lfrun)) bad = "runs";
+  else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(slen >> w.sb_shift) + 1u) bad = "superblocks";
   else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";
   else if (!w.generic && (!w.rec || !w.base || (locate && !w.samples))) bad = "array presence";
   else if ((w.walk != nullptr) != (w.wbase != nullptr)) bad = "walk records";
+  else if (rl && (w.lfrun != nullptr) && !locate) bad = "run table";
   else if (w.walk && (w.generic || !locate || w.sa_level < 1 || w.sa_level > FMX_WALK_MAX_LEVEL || h.sym_bytes != 1 ||
                       h.max_character > FMX_WALK_MAX_CHARACTER ||
                       (w.wsb_shift != FMXW_WALK_SB_SHIFT && w.wsb_shift != FMXW_WALK_SB_SHIFT_TEST) ||
@@ -1375,8 +1390,19 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
       shift -= bits;
       const FmxWideLevel &v = w.lv[l];
       if (v.fmt != fmt || v.shift != shift || v.mask != (1u << bits) - 1u || !v.rec || !v.base ||
-          v.nrec != (uint32_t)((h.n >> (fmt == 3 ? 8 : 7)) + 1u) || w.sb_shift < (fmt == 3 ? 8u : 7u))
+          v.nrec != (uint32_t)((slen >> (fmt == 3 ? 8 : 7)) + 1u) || w.sb_shift < (fmt == 3 ? 8u : 7u))
         bad = "level fields";
+    }
+  }
+  if (!bad && rl) {
+    const FmxWideBits *v[2] = {&w.b, &w.bp};
+    for (int t = 0; t < 2 && !bad; t++) {
+      if (v[t]->len != h.n || v[t]->ones != h.runs) bad = "bit vector length";
+      else if (v[t]->nrec != (uint32_t)(h.n / FMX_BITS_PER_REC + 1u)) bad = "bit vector records";
+      else if ((v[t]->sb_shift != FMXW_BITS_SB_SHIFT && v[t]->sb_shift != FMXW_BITS_SB_SHIFT_TEST) ||
+               v[t]->nsb != ((v[t]->nrec - 1u) >> v[t]->sb_shift) + 1u) bad = "bit vector superblocks";
+      else if (v[t]->nsel != v[t]->ones / FMX_SEL_STEP + 2u) bad = "select hints";
+      else if (!v[t]->rec || !v[t]->base || !v[t]->sel) bad = "bit vector arrays";
     }
   }
   if (bad) {
@@ -1385,8 +1411,8 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
     return fail(FMX_ERR_ARG, msg);
   }
   idx->device = device;
-  idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = locate ? h.nsamples : 0; idx->runs = 0;
-  idx->sym_bytes = h.sym_bytes; idx->sym_bytes_abi = h.sym_bytes_abi; idx->kind = FMX_KIND_FM;
+  idx->n = h.n; idx->max_character = h.max_character; idx->nsamples = locate ? h.nsamples : 0; idx->runs = rl ? h.runs : 0;
+  idx->sym_bytes = h.sym_bytes; idx->sym_bytes_abi = h.sym_bytes_abi; idx->kind = h.kind;
   idx->level_requested = h.level_requested;
   idx->h_cs = (uint64_t *)calloc(h.max_character + 1, 8);
   if (fread(idx->h_cs, 8, h.max_character + 1, f) != h.max_character + 1) return fail(FMX_ERR_ARG, "truncated index file");
@@ -1424,7 +1450,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   idx->wide = w;
   idx->is_wide = 1;
   idx->dev.sa_level = w.sa_level;
-  idx->dev.kind = FMX_KIND_FM;
+  idx->dev.kind = h.kind;
   idx->dev.sym_bytes = h.sym_bytes;
   return FMX_OK;
 }

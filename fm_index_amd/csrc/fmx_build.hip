@@ -2154,6 +2154,71 @@ __global__ __launch_bounds__(BLK) void kww_records(const uint8_t *__restrict__ b
   }
 }
 
+// ---- RLFM on the wide engine (rlfmi.rs:30-96; FmxWideBits, FmxWideDev::lfrun) ----
+template <typename T>
+__global__ __launch_bounds__(BLK) void kwb_run_flags(const T *__restrict__ L, uint64_t n, uint8_t *__restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const T prev = i ? L[i - 1] : (T)0;               // c0 starts at 0: a run begins wherever c != c0   rlfmi.rs:41, 56-59
+  flags[i] = L[i] != prev ? 1 : 0;
+}
+__global__ __launch_bounds__(BLK) void kwb_iota(uint64_t *out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+// length of the q-th run in (head, row) order
+__global__ __launch_bounds__(BLK) void kwb_sorted_run_lens(const uint64_t *__restrict__ starts, const uint64_t *__restrict__ order,
+                                                            uint64_t r, uint64_t n, uint64_t *__restrict__ lens) {
+  const uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (q >= r) return;
+  const uint64_t k = order[q];
+  lens[q] = (k + 1 < r ? starts[k + 1] : n) - starts[k];
+}
+__global__ __launch_bounds__(BLK) void kwb_scatter_lfrun(const uint64_t *__restrict__ order, const uint64_t *__restrict__ fpos,
+                                                          uint64_t r, uint64_t *__restrict__ lfrun) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t < r) lfrun[order[t]] = fpos[t];
+}
+__global__ __launch_bounds__(BLK) void kwb_scatter_ones(const uint64_t *__restrict__ pos, uint64_t r, uint8_t *__restrict__ flags) {
+  const uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (q < r) flags[pos[q]] = 1;
+}
+// bit-vector records: one thread per 96-bit piece (payload + its popcount)
+__global__ __launch_bounds__(BLK) void kwb_pieces(const uint8_t *__restrict__ flags, uint64_t n, uint64_t npieces,
+                                                   uint4 *__restrict__ rec, uint32_t *__restrict__ cnt) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t >= npieces) return;
+  const uint64_t base = t * FMX_BITS_PER_PIECE;
+  uint32_t w[3] = {0, 0, 0};
+  for (uint32_t j = 0; j < FMX_BITS_PER_PIECE; j++) {
+    const uint64_t p = base + j;
+    if (p < n && flags[p]) w[j >> 5] |= 1u << (j & 31u);
+  }
+  rec[t] = make_uint4(0u, w[0], w[1], w[2]);
+  cnt[t] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]);
+}
+// counts relative to the record's superblock; scan[] = exclusive 64-bit sums of the piece popcounts
+__global__ __launch_bounds__(BLK) void kwb_counters(const uint64_t *__restrict__ scan, uint64_t npieces, uint32_t sb_shift,
+                                                     uint4 *__restrict__ rec) {
+  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (t >= npieces) return;
+  const uint64_t first = (((t >> 3) >> sb_shift) << sb_shift) * 8u;      // first piece of the superblock
+  rec[t].x = (uint32_t)(scan[t] - scan[first]);
+}
+__global__ __launch_bounds__(64) void kwb_bases(const uint64_t *__restrict__ scan, uint32_t nsb, uint32_t sb_shift,
+                                                uint64_t *__restrict__ base) {
+  const uint32_t sb = blockIdx.x * 64u + threadIdx.x;
+  if (sb < nsb) base[sb] = scan[((uint64_t)sb << sb_shift) * 8u];
+}
+// sel[m / STEP] = record holding the m-th one, for every multiple m of STEP
+__global__ __launch_bounds__(BLK) void kwb_select_hints(const uint64_t *__restrict__ scan, uint32_t nrec, uint64_t ones,
+                                                         uint32_t *__restrict__ sel) {
+  const uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  if (r >= nrec) return;
+  const uint64_t b0 = scan[r * 8u], b1 = r + 1 < nrec ? scan[(r + 1) * 8u] : ones;
+  for (uint64_t m = (b0 + FMX_SEL_STEP - 1) / FMX_SEL_STEP * FMX_SEL_STEP; m < b1; m += FMX_SEL_STEP) sel[m / FMX_SEL_STEP] = (uint32_t)r;
+}
+
 template <typename T>
 int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
   // scratch: the (key, suffix) double buffers of the radix sort -- 32 bytes per symbol with d_sa -- and, ONLY when some
@@ -2429,6 +2494,249 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
 }
 }  // namespace
 
+// the levels of a generic wide index (FmxWideDev::lv / nsb / sb_shift) over a sequence of `len` symbols of L bits --
+// the BWT of an FM index, the run heads of an RLFM index -- which is consumed (sorted level by level)
+template <typename T>
+static int build_wide_levels(fmx_index *idx, T *d_seq, uint64_t len, uint32_t L, DevPool &pool) {
+  FmxWideDev &w = idx->wide;
+  const uint64_t n = len;
+  const uint32_t sb_shift = fmx_wide_n(idx->n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST;
+  const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
+  {
+    uint32_t nlv, bits[FMX_MAX_LEVELS];
+    split_levels(L, &nlv, bits);
+    if (nlv > FMXW_MAX_LEVELS) {
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "wide index: more wavelet levels than FMXW_MAX_LEVELS");
+      return FMX_ERR_UNSUPPORTED;
+    }
+    T *cur = d_seq, *alt = nullptr;
+    if (nlv > 1) FMX_HIP(pool.get(&alt, n ? n : 1));
+    uint32_t shift = L;
+    w.generic = 1;
+    w.nlevels = nlv;
+    w.nsb = nsb;
+    w.sb_shift = sb_shift;
+    for (uint32_t l = 0; l < nlv; l++) {
+      shift -= bits[l];
+      FmxWideLevel &lv = w.lv[l];
+      lv.fmt = bits[l] == 4 ? 4u : 3u;
+      lv.shift = shift;
+      lv.mask = (1u << bits[l]) - 1u;
+      const uint32_t rec_shift = lv.fmt == 3 ? 8u : 7u, ncode = lv.fmt == 3 ? 8u : 16u;
+      lv.nrec = (uint32_t)((n >> rec_shift) + 1u);           // +1: position n itself must be addressable
+      uint4 *rec;
+      uint64_t *base, *scan;
+      uint32_t *hist;
+      FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
+      if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
+      FMX_HIP(hipMalloc((void **)&base, (size_t)nsb * 16 * sizeof(uint64_t)));
+      if (int rc = keep(idx, base, (uint64_t)nsb * 128)) return rc;
+      const size_t nh = (size_t)ncode * lv.nrec;
+      FMX_HIP(pool.get(&hist, nh));
+      FMX_HIP(pool.get(&scan, nh));
+      const unsigned grid = nblocks((uint64_t)lv.nrec * 8);
+      if (lv.fmt == 3)
+        hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+      else
+        hipLaunchKernelGGL((k_mwm_pieces<4, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
+      size_t tb = 0;
+      FMX_HIP(exclusive_sum(nullptr, tb, hist, scan, nh));
+      uint8_t *tmp;
+      FMX_HIP(pool.get(&tmp, tb));
+      FMX_HIP(exclusive_sum(tmp, tb, hist, scan, nh));
+      if (lv.fmt == 3)
+        hipLaunchKernelGGL(kw_counters_g<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
+      else
+        hipLaunchKernelGGL(kw_counters_g<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
+      hipLaunchKernelGGL(kw_bases_g, dim3((nsb * 16 + 63) / 64), dim3(64), 0, 0, scan, lv.nrec, nsb, sb_shift - rec_shift,
+                         ncode, l + 1 < nlv ? 1 : 0, base);
+      FMX_HIP(hipGetLastError());
+      lv.rec = rec;
+      lv.base = base;
+      if (l + 1 < nlv) {   // stable sort of the whole sequence by this level's code -> order of the next level
+        size_t sb = 0;
+        FMX_HIP(rocprim::radix_sort_keys(nullptr, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
+        uint8_t *stmp;
+        FMX_HIP(pool.get(&stmp, sb));
+        FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
+        FMX_HIP(hipDeviceSynchronize());
+        pool.release(stmp);
+        T *x = cur; cur = alt; alt = x;
+      }
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(hist); pool.release(scan); pool.release(tmp);
+    }
+    if (alt) pool.release(cur == d_seq ? alt : cur);   // the buffer that is not the caller's
+  }
+  return FMX_OK;
+}
+
+// FmxWideBits from one flag byte per bit; d_pos = the positions of its ones in order (kept when the vector is sparse)
+static int build_bits_wide(fmx_index *idx, FmxWideBits *bv, const uint8_t *d_flags, uint64_t n, const uint64_t *d_pos,
+                           DevPool &pool) {
+  memset(bv, 0, sizeof *bv);
+  bv->len = n;
+  bv->nrec = (uint32_t)(n / FMX_BITS_PER_REC + 1);  // position `len` itself must be addressable
+  bv->sb_shift = fmx_wide_n(idx->n) ? FMXW_BITS_SB_SHIFT : FMXW_BITS_SB_SHIFT_TEST;
+  bv->nsb = ((bv->nrec - 1u) >> bv->sb_shift) + 1u;
+  const uint64_t npieces = (uint64_t)bv->nrec * 8;
+  uint4 *rec;
+  uint32_t *cnt;
+  uint64_t *scan, *base;
+  FMX_HIP(hipMalloc((void **)&rec, (size_t)bv->nrec * 128));
+  if (int rc = keep(idx, rec, (uint64_t)bv->nrec * 128)) return rc;
+  FMX_HIP(hipMalloc((void **)&base, (size_t)bv->nsb * 8));
+  if (int rc = keep(idx, base, (uint64_t)bv->nsb * 8)) return rc;
+  FMX_HIP(pool.get(&cnt, (size_t)npieces + 1));
+  FMX_HIP(pool.get(&scan, (size_t)npieces + 1));
+  FMX_HIP(hipMemsetAsync(cnt + npieces, 0, 4, 0));
+  hipLaunchKernelGGL(kwb_pieces, dim3(wblocks(npieces)), dim3(BLK), 0, 0, d_flags, n, npieces, rec, cnt);
+  size_t tb = 0;
+  FMX_HIP(exclusive_sum(nullptr, tb, cnt, scan, (size_t)npieces + 1));
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tb));
+  FMX_HIP(exclusive_sum(tmp, tb, cnt, scan, (size_t)npieces + 1));
+  hipLaunchKernelGGL(kwb_counters, dim3(wblocks(npieces)), dim3(BLK), 0, 0, scan, npieces, bv->sb_shift, rec);
+  hipLaunchKernelGGL(kwb_bases, dim3((bv->nsb + 63u) / 64u), dim3(64), 0, 0, scan, bv->nsb, bv->sb_shift, base);
+  uint64_t ones = 0;
+  FMX_HIP(hipMemcpy(&ones, scan + npieces, 8, hipMemcpyDeviceToHost));
+  bv->ones = ones;
+  bv->nsel = ones / FMX_SEL_STEP + 2;
+  uint32_t *sel;
+  FMX_HIP(hipMalloc((void **)&sel, (size_t)bv->nsel * 4));
+  if (int rc = keep(idx, sel, bv->nsel * 4)) return rc;
+  hipLaunchKernelGGL(k_fill_u32, dim3(wblocks(bv->nsel)), dim3(BLK), 0, 0, sel, (uint32_t)bv->nsel, bv->nrec - 1);
+  hipLaunchKernelGGL(kwb_select_hints, dim3(wblocks(bv->nrec)), dim3(BLK), 0, 0, scan, bv->nrec, ones, sel);
+  FMX_HIP(hipGetLastError());
+  bv->rec = rec;
+  bv->base = base;
+  bv->sel = sel;
+  // fewer than 0.11 ones per bit (runs of 9+ on average; the 32-bit engine's rule): keep the positions, select1 is one load
+  if (ones && n && ones * 256u / n < 28u && d_pos) {
+    uint64_t *p;
+    FMX_HIP(hipMalloc((void **)&p, (size_t)ones * 8));
+    if (int rc = keep(idx, p, ones * 8)) return rc;
+    FMX_HIP(hipMemcpy(p, d_pos, (size_t)ones * 8, hipMemcpyDeviceToDevice));
+    bv->pos = p;
+  }
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(cnt); pool.release(scan); pool.release(tmp);
+  return FMX_OK;
+}
+
+// RLFMIndexBackend::new (rlfmi.rs:30-96) on the wide engine, from the L column (d_L is consumed)
+template <typename T>
+static int build_rlfm_wide(fmx_index *idx, T *d_L, uint64_t n, uint32_t L, DevPool &pool) {
+  FmxWideDev &w = idx->wide;
+  const uint32_t maxc = (uint32_t)idx->max_character;
+  uint8_t *flags;
+  T *heads;
+  uint64_t *starts;
+  unsigned long long *d_num;
+  FMX_HIP(pool.get(&flags, n));
+  FMX_HIP(pool.get(&d_num, 1));
+  hipLaunchKernelGGL(kwb_run_flags<T>, dim3(wblocks(n)), dim3(BLK), 0, 0, d_L, n, flags);
+  // S = run heads (rlfmi.rs:57), starts = first row of every run: count first, so that the arrays are r long, not n
+  size_t t1 = 0, t2 = 0;
+  rocprim::counting_iterator<uint64_t> rows(0);
+  FMX_HIP(rocprim::select(nullptr, t1, d_L, flags, d_L, d_num, (size_t)n, (hipStream_t)0));
+  FMX_HIP(rocprim::select(nullptr, t2, rows, flags, (uint64_t *)nullptr, d_num, (size_t)n, (hipStream_t)0));
+  uint64_t r = 0;
+  {
+    uint64_t *d_r;
+    size_t rb = 0;
+    FMX_HIP(pool.get(&d_r, 1));
+    auto ones = rocprim::make_transform_iterator(flags, AsU64());
+    FMX_HIP(rocprim::reduce(nullptr, rb, ones, (unsigned long long *)d_r, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), (hipStream_t)0));
+    uint8_t *rtmp;
+    FMX_HIP(pool.get(&rtmp, rb));
+    FMX_HIP(rocprim::reduce(rtmp, rb, ones, (unsigned long long *)d_r, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), (hipStream_t)0));
+    FMX_HIP(hipMemcpy(&r, d_r, 8, hipMemcpyDeviceToHost));
+    pool.release(rtmp); pool.release(d_r);
+  }
+  idx->runs = r;
+  w.slen = r;
+  FMX_HIP(pool.get(&heads, r ? r : 1));
+  FMX_HIP(pool.get(&starts, r ? r : 1));
+  const size_t tb = t1 > t2 ? t1 : t2;
+  uint8_t *tmp;
+  FMX_HIP(pool.get(&tmp, tb));
+  size_t tt = tb;
+  FMX_HIP(rocprim::select(tmp, tt, d_L, flags, heads, d_num, (size_t)n, (hipStream_t)0));
+  tt = tb;
+  FMX_HIP(rocprim::select(tmp, tt, rows, flags, starts, d_num, (size_t)n, (hipStream_t)0));
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(tmp);
+  // B (rlfmi.rs:46, 58, 61, 85)
+  if (int rc = build_bits_wide(idx, &w.b, flags, n, starts, pool)) return rc;
+  // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
+  std::vector<uint64_t> rcs;
+  if (int rc = symbol_histogram<T>(heads, r, maxc, rcs, nullptr, pool)) return rc;
+  {
+    uint64_t acc = 0;
+    for (uint32_t c = 0; c <= maxc; c++) { const uint64_t v = rcs[c]; rcs[c] = acc; acc += v; }
+  }
+  // B' (rlfmi.rs:71-83): runs in (head, row) order, each 1 0^{len-1}
+  uint64_t *order, *order2, *lens, *fpos;
+  T *hk2;
+  FMX_HIP(pool.get(&order, r ? r : 1));
+  FMX_HIP(pool.get(&order2, r ? r : 1));
+  FMX_HIP(pool.get(&hk2, r ? r : 1));
+  hipLaunchKernelGGL(kwb_iota, dim3(wblocks(r)), dim3(BLK), 0, 0, order, r);
+  size_t sb = 0;
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, sb, heads, hk2, order, order2, (size_t)r, 0u, (unsigned)L, (hipStream_t)0));
+  uint8_t *stmp;
+  FMX_HIP(pool.get(&stmp, sb));
+  FMX_HIP(rocprim::radix_sort_pairs(stmp, sb, heads, hk2, order, order2, (size_t)r, 0u, (unsigned)L, (hipStream_t)0));
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(stmp); pool.release(order); pool.release(hk2);
+  FMX_HIP(pool.get(&lens, r ? r : 1));
+  FMX_HIP(pool.get(&fpos, r ? r : 1));
+  hipLaunchKernelGGL(kwb_sorted_run_lens, dim3(wblocks(r)), dim3(BLK), 0, 0, starts, order2, r, n, lens);
+  size_t eb = 0;
+  FMX_HIP(exclusive_sum(nullptr, eb, lens, fpos, (size_t)r));
+  uint8_t *etmp;
+  FMX_HIP(pool.get(&etmp, eb));
+  FMX_HIP(exclusive_sum(etmp, eb, lens, fpos, (size_t)r));
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(etmp); pool.release(lens); pool.release(starts);
+  // lf_map of every run start (FmxWideDev::lfrun) for indexes that locate, when the device has room for 8 bytes per run
+  // four times over; FMX_FLAG_NO_WALK_RECORDS keeps it off
+  w.lfrun = nullptr;
+  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 32ull * r) {
+      uint64_t *d_lfrun;
+      FMX_HIP(hipMalloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 8));
+      if (int rc = keep(idx, d_lfrun, r * 8)) return rc;
+      hipLaunchKernelGGL(kwb_scatter_lfrun, dim3(wblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
+      w.lfrun = d_lfrun;
+    }
+  }
+  FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
+  hipLaunchKernelGGL(kwb_scatter_ones, dim3(wblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  if (int rc = build_bits_wide(idx, &w.bp, flags, n, fpos, pool)) return rc;
+  pool.release(order2); pool.release(fpos); pool.release(flags); pool.release(d_num);
+  // S over the r run heads (rlfmi.rs:69-70): the generic levels; cs[] / K[] count runs
+  if (int rc = build_wide_levels<T>(idx, heads, r, L, pool)) return rc;
+  uint64_t *d_cs, *d_K;
+  FMX_HIP(hipMalloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
+  if (int rc = keep(idx, d_cs, ((uint64_t)maxc + 1) * 8)) return rc;
+  FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * 8));
+  if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 8)) return rc;
+  FMX_HIP(hipMemcpy(d_cs, rcs.data(), ((size_t)maxc + 1) * 8, hipMemcpyHostToDevice));
+  w.cs = d_cs;
+  w.K = d_K;
+  w.kind = FMX_KIND_RLFM;
+  if (int rc = fmxw_launch_compute_K(w, d_K)) return rc;
+  FMX_HIP(hipDeviceSynchronize());
+  pool.release(heads);
+  (void)d_L;
+  return FMX_OK;
+}
+
 template <typename T>
 static int build_wide_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
@@ -2494,7 +2802,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     uint64_t *d_samp;
     FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
     if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
-    walk_records = sizeof(T) == 1 && maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
+    walk_records = idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
                    !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
     if (walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {     // by default only when the device has room
       size_t free_b = 0, total_b = 0;
@@ -2595,73 +2903,21 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     FMX_HIP(hipDeviceSynchronize());
     pool.release(d_sa);
   }
+  w.kind = idx->kind;
+  w.slen = 0;
+  w.lfrun = nullptr;
+  if (idx->kind == FMX_KIND_RLFM) {
+    if (int rc = build_rlfm_wide<T>(idx, d_bwt, n, L, pool)) return rc;
+    idx->is_wide = 1;
+    mark("rlfm");
+    idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FMX_OK;
+  }
   const uint32_t sb_shift = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST, sb_recs = sb_shift - 8u;
   const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
   if (maxc > 7 || sizeof(T) != 1) {
     // -- generic wide index: the levels of the multi-ary wavelet matrix (as build_mwm, 64-bit scans) --
-    uint32_t nlv, bits[FMX_MAX_LEVELS];
-    split_levels(L, &nlv, bits);
-    if (nlv > FMXW_MAX_LEVELS) {
-      fmx_set_error(FMX_ERR_UNSUPPORTED, "wide index: more wavelet levels than FMXW_MAX_LEVELS");
-      return FMX_ERR_UNSUPPORTED;
-    }
-    T *cur = d_bwt, *alt = nullptr;
-    if (nlv > 1) FMX_HIP(pool.get(&alt, n));
-    uint32_t shift = L;
-    w.generic = 1;
-    w.nlevels = nlv;
-    w.nsb = nsb;
-    w.sb_shift = sb_shift;
-    for (uint32_t l = 0; l < nlv; l++) {
-      shift -= bits[l];
-      FmxWideLevel &lv = w.lv[l];
-      lv.fmt = bits[l] == 4 ? 4u : 3u;
-      lv.shift = shift;
-      lv.mask = (1u << bits[l]) - 1u;
-      const uint32_t rec_shift = lv.fmt == 3 ? 8u : 7u, ncode = lv.fmt == 3 ? 8u : 16u;
-      lv.nrec = (uint32_t)((n >> rec_shift) + 1u);           // +1: position n itself must be addressable
-      uint4 *rec;
-      uint64_t *base, *scan;
-      uint32_t *hist;
-      FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
-      if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
-      FMX_HIP(hipMalloc((void **)&base, (size_t)nsb * 16 * sizeof(uint64_t)));
-      if (int rc = keep(idx, base, (uint64_t)nsb * 128)) return rc;
-      const size_t nh = (size_t)ncode * lv.nrec;
-      FMX_HIP(pool.get(&hist, nh));
-      FMX_HIP(pool.get(&scan, nh));
-      const unsigned grid = nblocks((uint64_t)lv.nrec * 8);
-      if (lv.fmt == 3)
-        hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
-      else
-        hipLaunchKernelGGL((k_mwm_pieces<4, T>), dim3(grid), dim3(BLK), 0, 0, cur, n, lv.shift, lv.mask, lv.nrec, rec, hist);
-      size_t tb = 0;
-      FMX_HIP(exclusive_sum(nullptr, tb, hist, scan, nh));
-      uint8_t *tmp;
-      FMX_HIP(pool.get(&tmp, tb));
-      FMX_HIP(exclusive_sum(tmp, tb, hist, scan, nh));
-      if (lv.fmt == 3)
-        hipLaunchKernelGGL(kw_counters_g<3>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
-      else
-        hipLaunchKernelGGL(kw_counters_g<4>, dim3(grid), dim3(BLK), 0, 0, scan, lv.nrec, sb_shift - rec_shift, rec);
-      hipLaunchKernelGGL(kw_bases_g, dim3((nsb * 16 + 63) / 64), dim3(64), 0, 0, scan, lv.nrec, nsb, sb_shift - rec_shift,
-                         ncode, l + 1 < nlv ? 1 : 0, base);
-      FMX_HIP(hipGetLastError());
-      lv.rec = rec;
-      lv.base = base;
-      if (l + 1 < nlv) {   // stable sort of the whole sequence by this level's code -> order of the next level
-        size_t sb = 0;
-        FMX_HIP(rocprim::radix_sort_keys(nullptr, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
-        uint8_t *stmp;
-        FMX_HIP(pool.get(&stmp, sb));
-        FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)n, lv.shift, lv.shift + bits[l], (hipStream_t)0));
-        FMX_HIP(hipDeviceSynchronize());
-        pool.release(stmp);
-        T *x = cur; cur = alt; alt = x;
-      }
-      FMX_HIP(hipDeviceSynchronize());
-      pool.release(hist); pool.release(scan); pool.release(tmp);
-    }
+    if (int rc = build_wide_levels<T>(idx, d_bwt, n, L, pool)) return rc;
     uint64_t *d_cs, *d_K;
     FMX_HIP(hipMalloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
     if (int rc = keep(idx, d_cs, ((uint64_t)maxc + 1) * 8)) return rc;

@@ -163,6 +163,21 @@ struct FmxWideLevel {
   uint32_t mask;
   uint32_t nrec;
 };
+// bit vector of a wide RLFM index (B and B', rlfmi.rs:19-20): the 128-byte records of FmxBits -- 8 pieces of { ones before
+// the piece, 96 payload bits } -- with the count RELATIVE to the record's superblock (2^sb_shift records: at most
+// 2^22 x 768 bits < 2^32 ones) and base[superblock] = the 64-bit count at its start.  select1: the stored positions of
+// the ones (sparse vectors: fewer than one bit in nine set, as on the 32-bit engine; 8 bytes per one), else a hint per
+// FMX_SEL_STEP ones (the record that holds it) + a search over the record counts between two hints.
+struct FmxWideBits {
+  const uint4 *rec;
+  const uint64_t *base;  // [nsb]
+  const uint64_t *pos;   // NULL: hints + records
+  const uint32_t *sel;   // [nsel] record indices
+  uint64_t len, ones, nsel;
+  uint32_t nrec, sb_shift, nsb, pad;
+};
+#define FMXW_BITS_SB_SHIFT 22u      // records per superblock
+#define FMXW_BITS_SB_SHIFT_TEST 1u  // FMX_FLAG_FORCE_WIDE
 struct FmxWideDev {  // passed BY VALUE to the wide kernels
   const uint4 *rec;          // one 3-bit level (max_character <= 7): n / 256 + 1 records (row n is addressable)
   const uint64_t *base;      // ... [nsb][8], cs[] folded in
@@ -188,6 +203,14 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   const uint4 *walk;
   const uint64_t *wbase;
   uint32_t nwsb, wsb_shift;
+  // RLFMIndex (round 4; kind == FMX_KIND_RLFM): always `generic` -- lv[] / K / nsb describe S, the run heads (slen of
+  // them, rlfmi.rs:17), cs[] counts RUNS with a smaller head (rlfmi.rs:72-76) -- plus B, B' and, on indexes that locate,
+  // the run table lfrun[j] = lf_map(first row of run j) of FmxDev::lfrun, 64 bits per run.  Samples are the reference's
+  // rows (sample.rs:33-37).
+  uint32_t kind, pad2;
+  uint64_t slen;
+  FmxWideBits b, bp;
+  const uint64_t *lfrun;
 };
 #define FMXW_WALK_SB_SHIFT 24u      // records per walk superblock: 2^24 x 112 rows < 2^31, so relative counters fit 32 bits
 #define FMXW_WALK_SB_SHIFT_TEST 5u  // FMX_FLAG_FORCE_WIDE: 32 records, so that a small text has many superblocks

@@ -8,9 +8,10 @@
 // First half of the file: one-level alphabets (max_character <= 7, DNA); second half: the generic kernels for
 // larger byte alphabets (the multi-ary wavelet levels of the 32-bit engine with per-level bases and a 64-bit K[]).
 //
-// Shapes: a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel) / a walk from
-// start to end (locate: one memory round trip per iteration); the distributed walk state, the hit queue and the
-// write-combining ring of the 32-bit locate kernels are not repeated here.
+// Shapes: a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel); locate: the text-order
+// walk over walk records with the hit queue, distributed walk state and write-combining ring of the 32-bit engine's
+// fmx_locate_f3t_kernel (one-level indexes), a group per walk (row-order samples, generic indexes), a lane per walk
+// (RLFM with the run table).  Third part: RLFMIndex (B / B' with 64-bit superblock bases, S on the generic levels).
 #include "fmx_device.h"
 
 #define FMXW_BLOCK 256
@@ -687,6 +688,184 @@ __device__ __forceinline__ uint64_t fmxw_g_fl(const FmxWideDev &w, const GB &gba
   return target;
 }
 
+// ===========================================================================
+// RLFMIndex on the wide engine (FmxWideDev::kind == FMX_KIND_RLFM; rlfmi.rs:15-24, 122-190): S = the generic levels
+// above over the run heads, B / B' = FmxWideBits, rows and run indices 64 bits wide.  Group-uniform code, like the
+// generic kernels: every lane of a group holds the same row.
+// ===========================================================================
+#define FMXW_NONE (~0ull)
+__device__ __forceinline__ uint64_t fmxw_div3(uint64_t x) { return __umul64hi(x, 0xAAAAAAAAAAAAAAABull) >> 1; }
+
+// the record that holds bit i: this lane's piece, the superblock's base, and where i sits in the record
+struct FmxwBitsRec { uint4 pc; uint64_t rec, base; uint32_t p, bit; };
+__device__ __forceinline__ FmxwBitsRec fmxw_bits_load(const FmxWideBits &bv, uint64_t i, uint32_t g) {
+  FmxwBitsRec r;
+  r.rec = fmxw_div3(i >> 8);                                  // i / 768
+  const uint32_t within = (uint32_t)(i - r.rec * FMX_BITS_PER_REC);
+  r.p = fmx_div3(within >> 5);                                // within / 96
+  r.bit = within - r.p * FMX_BITS_PER_PIECE;
+  FMX_CHECK(r.rec < bv.nrec && (r.rec >> bv.sb_shift) < bv.nsb);
+  r.pc = bv.rec[(size_t)r.rec * 8u + g];
+  r.base = bv.base[r.rec >> bv.sb_shift];
+  return r;
+}
+// rank1(i) (clamped like vers-vecs RsVec::rank1), the bit B[i] (0 past the end) and `next` = the position of the first
+// one at or after i when it lies in the record just loaded (FMXW_NONE otherwise) -- that position is select1(rank1(i)),
+// the run start the RLFM formulas subtract (rlfmi.rs:132, 141)
+__device__ __forceinline__ uint64_t fmxw_bits_rank_next(const FmxWideBits &bv, uint64_t i, uint32_t g, uint32_t &bit_i,
+                                                        uint64_t &next) {
+  if (i > bv.len) i = bv.len;
+  const FmxwBitsRec r = fmxw_bits_load(bv, i, g);
+  const uint32_t bit = r.bit;
+  const uint32_t m0 = fmx_lowmask(bit < 32u ? bit : 32u);
+  const uint32_t m1 = bit > 32u ? fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u) : 0u;
+  const uint32_t m2 = bit > 64u ? fmx_lowmask(bit - 64u) : 0u;
+  const uint32_t c = __popc(r.pc.y & m0) + __popc(r.pc.z & m1) + __popc(r.pc.w & m2);
+  const uint32_t word = bit < 32u ? r.pc.y : (bit < 64u ? r.pc.z : r.pc.w);
+  const uint32_t mine = (g == r.p) ? 1u : 0u;
+  bit_i = fmx_group_sum(mine * ((word >> (bit & 31u)) & 1u));
+  uint32_t y = r.pc.y, z = r.pc.z, ww = r.pc.w;
+  if (g == r.p) { y &= ~m0; z &= ~m1; ww &= ~m2; }
+  else if (g < r.p) { y = 0u; z = 0u; ww = 0u; }
+  uint32_t cand = 0xFFFFFFFFu;
+  if (y) cand = (uint32_t)__builtin_ctz(y);
+  else if (z) cand = 32u + (uint32_t)__builtin_ctz(z);
+  else if (ww) cand = 64u + (uint32_t)__builtin_ctz(ww);
+  if (cand != 0xFFFFFFFFu) cand += g * FMX_BITS_PER_PIECE;
+  cand = fmx_group_min(cand);
+  next = cand != 0xFFFFFFFFu ? r.rec * FMX_BITS_PER_REC + cand : FMXW_NONE;
+  return r.base + fmx_group_sum(mine * (r.pc.x + c));
+}
+// rank1(i + 1) - 1 = the index of the last one at or before i (the run that holds row i), and `prev` = that one's
+// position when it lies in the record just loaded (FMXW_NONE otherwise: the run began before the record)
+__device__ __forceinline__ uint64_t fmxw_bits_rank_prev(const FmxWideBits &bv, uint64_t i, uint32_t g, uint64_t &prev) {
+  if (i >= bv.len) i = bv.len ? bv.len - 1u : 0u;
+  const FmxwBitsRec r = fmxw_bits_load(bv, i, g);
+  const uint32_t b1 = r.bit + 1u;                             // bits [0, bit] of piece p
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  const uint32_t c = __popc(r.pc.y & m0) + __popc(r.pc.z & m1) + __popc(r.pc.w & m2);
+  uint32_t y = r.pc.y, z = r.pc.z, ww = r.pc.w;
+  if (g == r.p) { y &= m0; z &= m1; ww &= m2; }
+  else if (g > r.p) { y = 0u; z = 0u; ww = 0u; }
+  uint32_t cand = 0u;                                         // position in the record + 1; 0 = none (max over the group)
+  if (ww) cand = 96u - (uint32_t)__builtin_clz(ww);
+  else if (z) cand = 64u - (uint32_t)__builtin_clz(z);
+  else if (y) cand = 32u - (uint32_t)__builtin_clz(y);
+  if (cand) cand += g * FMX_BITS_PER_PIECE;
+  uint32_t mx = cand;
+  mx = max(mx, fmx_dpp_xor1(mx));
+  mx = max(mx, fmx_dpp_xor2(mx));
+  mx = max(mx, fmx_dpp_half_mirror(mx));
+  prev = mx ? r.rec * FMX_BITS_PER_REC + (mx - 1u) : FMXW_NONE;
+  return r.base + fmx_group_sum((g == r.p) ? r.pc.x + c : 0u) - 1u;
+}
+// select1(k): position of the k-th one (0-based); len when k >= #ones (vers-vecs RsVec::select1)
+__device__ __forceinline__ uint64_t fmxw_bits_select(const FmxWideBits &bv, uint64_t k, uint32_t g) {
+  if (k >= bv.ones) return bv.len;
+  if (bv.pos) return bv.pos[k];                               // sparse vector: the positions are stored
+  const uint64_t h = k / FMX_SEL_STEP;
+  FMX_CHECK(h + 1 < bv.nsel);
+  uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
+  FMX_CHECK(lo < bv.nrec && hi < bv.nrec);
+  while (lo < hi) {                                           // last record whose count <= k (group-uniform)
+    const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+    if (bv.base[mid >> bv.sb_shift] + bv.rec[(size_t)mid * 8u].x <= k) lo = mid; else hi = mid - 1u;
+  }
+  const uint4 pc = bv.rec[(size_t)lo * 8u + g];
+  const uint64_t ab = bv.base[lo >> bv.sb_shift] + pc.x;      // ones before this lane's piece
+  const uint32_t p = fmx_group_sum(ab <= k ? 1u : 0u) - 1u;   // last piece whose count <= k
+  const uint32_t rem = (uint32_t)(k - ab);                    // meaningful on lane p only
+  const uint32_t c0 = __popc(pc.y), c1 = __popc(pc.z);
+  uint32_t pos;
+  if (rem < c0) pos = fmx_select32(pc.y, rem);
+  else if (rem < c0 + c1) pos = 32u + fmx_select32(pc.z, rem - c0);
+  else pos = 64u + fmx_select32(pc.w, rem - c0 - c1);
+  pos = fmx_group_sum((g == p) ? pos : 0u);
+  return (uint64_t)lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
+}
+
+// RLFMIndexBackend::lf_map2 for both ends of an interval (rlfmi.rs:135-143), staged: B ranks, then one rank chain per
+// end at lo = b.rank1(i + 1) - 1 (the run holding row i) that yields s.rank(lo, c) and m = [s[lo] == c] from the same
+// records -- s.rank(j, c) with j = b.rank1(i) in {lo, lo + 1} is s.rank(lo, c) + (j > lo ? m : 0), and get_l(i) == c is m
+// (rlfmi.rs:137-138) -- then the B' selects (rlfmi.rs:139) and, when the row's symbol is c, the run start (rlfmi.rs:141).
+template <class GB, class GK>
+__device__ __forceinline__ void fmxw_r_lf_map2_pair(const FmxWideDev &w, const GB &gbase, const GK &gk, uint32_t c,
+                                                    uint64_t &s, uint64_t &e, uint32_t g) {
+  uint32_t bs, be;
+  uint64_t nxs, nxe;
+  const uint64_t js = fmxw_bits_rank_next(w.b, s, g, bs, nxs);    // b.rank1(i)            rlfmi.rs:136
+  const uint64_t je = fmxw_bits_rank_next(w.b, e, g, be, nxe);
+  uint64_t ps = js - 1u + bs, pe = je - 1u + be;                  // b.rank1(i + 1) - 1    rlfmi.rs:124
+  uint32_t ms = 1u, me = 1u;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    const uint32_t code = (c >> L.shift) & L.mask;
+    const uint4 pa = fmxw_g_piece(L, ps, g), pb = fmxw_g_piece(L, pe, g);
+    const uint64_t ba = gbase(l, ps, code), bb = gbase(l, pe, code);
+    ms &= fmxw_g_code(L, pa, ps, g) == code ? 1u : 0u;
+    me &= fmxw_g_code(L, pb, pe, g) == code ? 1u : 0u;
+    ps = ba + fmxw_g_rank32(L, pa, ps, code, g);
+    pe = bb + fmxw_g_rank32(L, pb, pe, code, g);
+  }
+  const uint64_t kc = gk(c);
+  const uint64_t nrs = kc + ps + (bs ? 0u : ms), nre = kc + pe + (be ? 0u : me);   // cs[c] + s.rank(j, c)   rlfmi.rs:137,139
+  uint64_t fs = fmxw_bits_select(w.bp, nrs, g), fe = fmxw_bits_select(w.bp, nre, g);
+  if (ms) fs = fs + s - (nxs != FMXW_NONE ? nxs : fmxw_bits_select(w.b, js, g));   // + i - b.select1(j)   rlfmi.rs:141
+  if (me) fe = fe + e - (nxe != FMXW_NONE ? nxe : fmxw_bits_select(w.b, je, g));
+  s = fs;
+  e = fe;
+}
+// RLFMIndexBackend::get_l + lf_map (rlfmi.rs:122-133): one access + rank chain at lo = b.rank1(i + 1) - 1 gives
+// c = s[lo] and s.rank(lo, c); s.rank(j, c) = that + (j - lo)
+template <class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_r_lf(const FmxWideDev &w, const GB &gbase, const GK &gk, uint64_t i, uint32_t g,
+                                              uint32_t &sym) {
+  uint32_t bit;
+  uint64_t nx;
+  const uint64_t j = fmxw_bits_rank_next(w.b, i, g, bit, nx);     // b.rank1(i)
+  const uint64_t r = fmxw_g_lf(w, gbase, j - 1u + bit, g, sym);   // s[lo], rank chain of it at lo
+  const uint64_t nr = gk(sym) + r + (bit ? 0u : 1u);              // cs[c] + s.rank(j, c)     rlfmi.rs:129-130
+  const uint64_t f = fmxw_bits_select(w.bp, nr, g);
+  const uint64_t st = nx != FMXW_NONE ? nx : fmxw_bits_select(w.b, j, g);
+  return f + i - st;                                              // rlfmi.rs:132
+}
+// lf_map(i) for a walk that has no use for the symbol (get_sa, rlfmi.rs:183-186): through the run table when the index
+// has one -- lf_map(i) = lfrun[run of i] + (i - start of that run) -- the B record of the row + one table entry
+template <class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_r_lf_step(const FmxWideDev &w, const GB &gbase, const GK &gk, uint64_t i, uint32_t g) {
+  if (w.lfrun) {
+    uint64_t st;
+    const uint64_t lo = fmxw_bits_rank_prev(w.b, i, g, st);
+    FMX_CHECK(lo < w.b.ones);
+    const uint64_t f = w.lfrun[lo];
+    if (st == FMXW_NONE) st = fmxw_bits_select(w.b, lo, g);       // group-uniform
+    return f + i - st;
+  }
+  uint32_t sym;
+  return fmxw_r_lf(w, gbase, gk, i, g, sym);
+}
+// RLFMIndexBackend::get_f + fl_map (rlfmi.rs:145-169)
+template <class GB>
+__device__ __forceinline__ uint64_t fmxw_r_fl(const FmxWideDev &w, const GB &gbase, uint64_t i, uint32_t g, uint32_t &sym) {
+  uint64_t p;
+  const uint64_t j = fmxw_bits_rank_prev(w.bp, i, g, p);          // bp.rank1(i + 1) - 1
+  uint32_t s = 0, e = w.max_character + 1u;
+  while (e - s > 1u) {                                            // the greatest c with cs[c] <= j
+    const uint32_t m = s + (e - s) / 2u;
+    if (w.cs[m] <= j) s = m; else e = m;
+  }
+  sym = s;
+  if (p == FMXW_NONE) p = fmxw_bits_select(w.bp, j, g);           // bp.select1(j)
+  uint64_t target = fmxw_g_chain(w, gbase, s, 0, g) + (j - w.cs[s]);   // s.select(j - cs[c], c)
+  for (uint32_t l = w.nlevels; l-- > 0;) {
+    const FmxWideLevel &L = w.lv[l];
+    target = fmxw_g_select(w, L, (s >> L.shift) & L.mask, target, g);
+  }
+  return fmxw_bits_select(w.b, target, g) + i - p;                // b.select1(m) + i - bp.select1(j)
+}
+
 __global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint64_t *__restrict__ K) {
   FMXW_GBASES(w, false);
   (void)gk;
@@ -699,7 +878,7 @@ __global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint
 
 // SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern; per level the records of both
 // interval ends are requested together, the next pattern symbol with the first level's
-template <bool GLDS>
+template <bool GLDS, bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
     FmxWideDev w, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
@@ -732,6 +911,15 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
         break;
       }
       uint32_t cn = 0;
+      if constexpr (RL) {                           // RLFMIndexBackend::lf_map2             rlfmi.rs:135-143
+        if (j > 1) cn = fmx_load_sym(pat, w.sym_bytes, pbeg + j - 2);
+        fmxw_r_lf_map2_pair(w, gbase, gk, c, s, e, g);                     // wrapper.rs:109-110
+        c = cn;
+        j--;
+        nsteps++;
+        if (s == e) break;                          // wrapper.rs:111-113
+        continue;
+      }
       uint64_t ps = s, pe = e;
       for (uint32_t l = 0; l < w.nlevels; l++) {
         const FmxWideLevel &L = w.lv[l];
@@ -760,7 +948,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
 }
 
 // get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60): a group per walk, rows in, positions out
-template <bool GLDS>
+template <bool GLDS, bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
                                                                   uint64_t *__restrict__ steps_out) {
   FMXW_GBASES(w, GLDS);
@@ -774,10 +962,14 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
     if (row >= w.n) {                               // refuse, do not read
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
     } else {
-      while (row & lmask) {                         // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
-        uint32_t sym;
-        const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
-        row = gk(sym) + r;
+      while (row & lmask) {                         // None: i = lf_map(i); steps += 1        fm_index.rs:134-137, rlfmi.rs:183-186
+        if constexpr (RL) {
+          row = fmxw_r_lf_step(w, gbase, gk, row, g);
+        } else {
+          uint32_t sym;
+          const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
+          row = gk(sym) + r;
+        }
         steps++;
       }
       v = w.samples[row >> w.sa_level] + steps;     // Some(sa): (sa + steps) % len           fm_index.rs:131-133
@@ -789,7 +981,80 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
+// select1(k) by ONE lane (k < ones): the stored position, or hint + search over the record counts + the pieces of the record
+__device__ __forceinline__ uint64_t fmxw_bits_lane_select(const FmxWideBits &bv, uint64_t k) {
+  if (bv.pos) return bv.pos[k];
+  const uint64_t h = k / FMX_SEL_STEP;
+  uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
+  while (lo < hi) {                                 // last record whose count <= k
+    const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+    if (bv.base[mid >> bv.sb_shift] + bv.rec[(size_t)mid * 8u].x <= k) lo = mid; else hi = mid - 1u;
+  }
+  const uint32_t rel = (uint32_t)(k - bv.base[lo >> bv.sb_shift]);
+  uint32_t p = 0;
+  for (uint32_t q = 1; q < 8u; q++)                 // last piece of it whose count <= k (the record is one line)
+    if (bv.rec[(size_t)lo * 8u + q].x <= rel) p = q;
+  const uint4 pc = bv.rec[(size_t)lo * 8u + p];
+  const uint32_t rem = rel - pc.x, c0 = __popc(pc.y), c1 = __popc(pc.z);
+  uint32_t pos;
+  if (rem < c0) pos = fmx_select32(pc.y, rem);
+  else if (rem < c0 + c1) pos = 32u + fmx_select32(pc.z, rem - c0);
+  else pos = 64u + fmx_select32(pc.w, rem - c0 - c1);
+  return (uint64_t)lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
+}
+// get_sa for a batch of rows on an RLFM index that has the run table (rlfmi.rs:172-190): a LANE per walk -- every
+// probe of a step is a lane-wise request (the 16-byte B piece of the row: run index and, unless the run began before the
+// piece, its start; then the table entry), 64 independent walks per wave instruction and no cross-lane traffic.  A lane
+// whose walk ends writes its position and takes its next hit (hits tid, tid + threads, ...) while its neighbours walk on.
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                  uint64_t *__restrict__ steps_out) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t lmask = (1ull << w.sa_level) - 1ull;
+  uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool have = h < total;
+  uint64_t row = have ? io[h] : 0, steps = 0, nsteps = 0;
+  while (__any(have)) {
+    if (have && (row >= w.n || (row & lmask) == 0)) {   // Some(sa): (sa + steps) % len            rlfmi.rs:178-182
+      uint64_t v = ~0ull;
+      if (row >= w.n) {                             // refuse, do not read
+        atomicOr(w.status, 1u << FMX_ERR_ARG);
+      } else {
+        v = w.samples[row >> w.sa_level] + steps;
+        if (v >= w.n) v -= w.n;
+      }
+      io[h] = v;
+      nsteps += steps;
+      h += nth;
+      have = h < total;
+      row = have ? io[h] : 0;
+      steps = 0;
+    } else if (have) {                              // None: i = lf_map(i); steps += 1          rlfmi.rs:183-186
+      const FmxWideBits &bv = w.b;
+      const uint64_t pidx = fmxw_div3(row >> 5);    // row / 96
+      const uint32_t b1 = (uint32_t)(row - pidx * FMX_BITS_PER_PIECE) + 1u;     // bits [0, bit] of the piece
+      FMX_CHECK((pidx >> 3) < bv.nrec);
+      const uint4 pc = bv.rec[pidx];
+      const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+      const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+      const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+      const uint32_t y = pc.y & m0, z = pc.z & m1, ww = pc.w & m2;
+      const uint64_t lo = bv.base[(pidx >> 3) >> bv.sb_shift] + pc.x + __popc(y) + __popc(z) + __popc(ww) - 1u;   // run of the row
+      FMX_CHECK(lo < bv.ones);
+      const uint64_t f = w.lfrun[lo];               // lf_map(first row of the run)
+      uint64_t st;                                  // its first row: the last one at or before the row
+      if (ww) st = pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(ww);
+      else if (z) st = pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
+      else if (y) st = pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
+      else st = fmxw_bits_lane_select(bv, lo);
+      row = f + row - st;
+      steps++;
+    }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // the trait methods, batched (backend.rs:9-19, 29-31).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
+template <bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w, int op, const uint64_t *__restrict__ cc,
                                                                     const uint64_t *__restrict__ ii, uint64_t k,
                                                                     uint64_t *__restrict__ out) {
@@ -804,6 +1069,10 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
       const uint64_t c = cc[q];
       if (c > w.max_character || i > w.n) {
         if (g == 0) atomicOr(w.status, 1u << (c > w.max_character ? FMX_ERR_SYMBOL_RANGE : FMX_ERR_ARG));
+      } else if constexpr (RL) {
+        uint64_t a = i, b = i;
+        fmxw_r_lf_map2_pair(w, gbase, gk, (uint32_t)c, a, b, g);
+        res = a;
       } else {
         res = gk((uint32_t)c) + fmxw_g_chain(w, gbase, (uint32_t)c, i, g);
       }
@@ -811,21 +1080,31 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
     } else if (op == 0 || op == 1) {
       uint32_t sym;
-      const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
-      res = op == 0 ? (uint64_t)sym : gk(sym) + r;
+      if constexpr (RL) {
+        const uint64_t r = fmxw_r_lf(w, gbase, gk, i, g, sym);
+        res = op == 0 ? (uint64_t)sym : r;
+      } else {
+        const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
+        res = op == 0 ? (uint64_t)sym : gk(sym) + r;
+      }
     } else if (op == 4 || op == 5) {                // get_f / fl_map
       uint32_t sym;
-      const uint64_t r = fmxw_g_fl(w, gbase, i, g, sym);
+      uint64_t r;
+      if constexpr (RL) r = fmxw_r_fl(w, gbase, i, g, sym); else r = fmxw_g_fl(w, gbase, i, g, sym);
       res = op == 4 ? (uint64_t)sym : r;
-    } else if (w.walk) {                            // get_sa, text-order samples: through the walk records
+    } else if (!RL && w.walk) {                     // get_sa, text-order samples: through the walk records
       res = fmxw_get_sa_walk(w, i, g);
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
       while (row & lmask) {
-        uint32_t sym;
-        const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
-        row = gk(sym) + r;
+        if constexpr (RL) {
+          row = fmxw_r_lf_step(w, gbase, gk, row, g);
+        } else {
+          uint32_t sym;
+          const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
+          row = gk(sym) + r;
+        }
         steps++;
       }
       uint64_t v = w.samples[row >> w.sa_level] + steps;
@@ -842,6 +1121,7 @@ __device__ __forceinline__ void fmxw_store_sym(void *p, uint32_t sb, uint64_t i,
   else if (sb == 2) ((uint16_t *)p)[i] = (uint16_t)v;
   else ((uint32_t *)p)[i] = v;
 }
+template <bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w, const uint64_t *__restrict__ rows,
                                                                      uint64_t nrows, uint32_t len, int forward,
                                                                      void *__restrict__ out, uint64_t *__restrict__ out_len,
@@ -858,7 +1138,9 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w
     } else {
       for (; t < len; t++) {
         uint32_t sym;
-        if (forward) {
+        if constexpr (RL) {
+          i = forward ? fmxw_r_fl(w, gbase, i, g, sym) : fmxw_r_lf(w, gbase, gk, i, g, sym);
+        } else if (forward) {
           i = fmxw_g_fl(w, gbase, i, g, sym);
         } else {
           const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
@@ -890,10 +1172,21 @@ __device__ __forceinline__ uint32_t fmxw_g_lane_rank(const FmxWideLevel &L, uint
   for (uint32_t q = 0; q < pi; q++) cnt += __popc(fmx_piece_match<FMT>(L.rec[(size_t)r * 8u + q], code));
   return cnt + __popc(fmx_piece_match<FMT>(piece, code) & ((1u << bit) - 1u));
 }
+// run that holds row i = b.rank1(i + 1) - 1, by one lane from the row's piece alone (rlfmi.rs:122-125)
+__device__ __forceinline__ uint64_t fmxw_bits_lane_run(const FmxWideBits &bv, uint64_t i) {
+  const uint64_t pidx = fmxw_div3(i >> 5);          // i / 96: records are 8 consecutive pieces
+  const uint32_t b1 = (uint32_t)(i - pidx * FMX_BITS_PER_PIECE) + 1u;
+  const uint4 pc = bv.rec[pidx];
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  return bv.base[(pidx >> 3) >> bv.sb_shift] + pc.x + __popc(pc.y & m0) + __popc(pc.z & m1) + __popc(pc.w & m2) - 1u;
+}
+template <bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, void *__restrict__ out) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < w.n; i += stride) {
-    uint64_t pos = i;
+    uint64_t pos = RL ? fmxw_bits_lane_run(w.b, i) : i;   // RLFM: get_l(i) = s[b.rank1(i + 1) - 1]
     uint32_t sym = 0;
     for (uint32_t l = 0; l < w.nlevels; l++) {
       const FmxWideLevel &L = w.lv[l];
@@ -944,10 +1237,11 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
   const FmxWideDev w = fmxw_dev(idx);
   fmxw_time_begin(idx, st);
   if (w.generic) {
-#define FMXW_GCNT(GLDS)                                                                                            \
-  hipLaunchKernelGGL(fmxw_g_count_kernel<GLDS>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,             \
+#define FMXW_GCNT(GLDS, RL)                                                                                        \
+  hipLaunchKernelGGL((fmxw_g_count_kernel<GLDS, RL>), dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,       \
                      d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
-    if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true); else FMXW_GCNT(false);
+    if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, true); else FMXW_GCNT(false, true); }
+    else if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, false); else FMXW_GCNT(false, false);
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     return FMX_OK;
@@ -971,12 +1265,20 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
   if (int rc = fmx_launch_expand64(d_s, d_e, d_off, npat, d_pos, total, w.n, w.status, st)) return rc;
   fmxw_time_begin(idx, st);
   if (w.generic) {
-    if (w.nsb <= FMXW_GLDS_SB)
-      hipLaunchKernelGGL(fmxw_g_walk_kernel<true>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
-                         idx->timing == 1 ? idx->d_steps : nullptr);
-    else
-      hipLaunchKernelGGL(fmxw_g_walk_kernel<false>, dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos,
-                         idx->timing == 1 ? idx->d_steps : nullptr);
+    uint64_t *steps = idx->timing == 1 ? idx->d_steps : nullptr;
+#define FMXW_GWALK(GLDS, RL)                                                                                        \
+    hipLaunchKernelGGL((fmxw_g_walk_kernel<GLDS, RL>), dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps)
+    if (w.kind == FMX_KIND_RLFM && w.lfrun) {       // run table: a lane per walk
+      uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
+      if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
+      hipLaunchKernelGGL(fmxw_r_walk_kernel, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
+    } else if (w.kind == FMX_KIND_RLFM) {
+      if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, true); else FMXW_GWALK(false, true);
+    } else if (w.nsb <= FMXW_GLDS_SB) {
+      FMXW_GWALK(true, false);
+    } else {
+      FMXW_GWALK(false, false);
+    }
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     return FMX_OK;
@@ -1029,7 +1331,8 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
   if (op > 5) return fmxw_unsupported("piece_id needs a multi-pieces index");
   if (k == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.generic) hipLaunchKernelGGL(fmxw_g_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  if (w.kind == FMX_KIND_RLFM) hipLaunchKernelGGL(fmxw_g_scalar_kernel<true>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  else if (w.generic) hipLaunchKernelGGL(fmxw_g_scalar_kernel<false>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
   else hipLaunchKernelGGL(fmxw_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1037,7 +1340,8 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st) {
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, d_out);
+  if (w.kind == FMX_KIND_RLFM) hipLaunchKernelGGL(fmxw_g_export_l_kernel<true>, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, d_out);
+  else if (w.generic) hipLaunchKernelGGL(fmxw_g_export_l_kernel<false>, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, d_out);
   else hipLaunchKernelGGL(fmxw_export_l_kernel, dim3(FMXW_MAX_BLOCKS * 4), dim3(FMXW_BLOCK), 0, st, w, (uint8_t *)d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1047,8 +1351,11 @@ int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t n
                         void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st) {
   if (nrows == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.generic)
-    hipLaunchKernelGGL(fmxw_g_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+  if (w.kind == FMX_KIND_RLFM)
+    hipLaunchKernelGGL(fmxw_g_extract_kernel<true>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+                       d_out, d_out_len, d_out_next);
+  else if (w.generic)
+    hipLaunchKernelGGL(fmxw_g_extract_kernel<false>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
                        d_out, d_out_len, d_out_next);
   else
     hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,

@@ -189,3 +189,112 @@ def gi_count(t, pat):
     for j, c in enumerate(pat):
         hits &= t[j:len(t) - m + 1 + j] == c
     return int(hits.sum())
+
+
+def _runs_text(n, sigma, seed, mean_run, dtype=np.uint8):
+    """symbols drawn like _dna, each repeated 1 .. 2 * mean_run - 1 times (mean_run == 1: plain random text)"""
+    if mean_run <= 1:
+        return _dna(n, seed, sigma, dtype)
+    sym = ((W.splitmix64_np(seed, 0, n) % np.uint64(sigma)) + np.uint64(1)).astype(dtype)
+    rep = (W.splitmix64_np(seed + 1, 0, n) % np.uint64(2 * mean_run - 1)).astype(np.int64) + 1
+    t = np.repeat(sym, rep)[:n].copy()
+    t[-1] = 0
+    return t
+
+
+# RLFMIndex on the wide engine (round 4): S on the generic levels (one 3-bit level for sigma <= 7), B / B' in
+# superblocks of 2 records here, the run table; texts of runs (sparse vectors: stored positions) and random texts
+# (dense vectors: hints + record search); the repetitive text RLFM exists for
+@pytest.mark.parametrize("n,sigma,level,mean_run,dtype,run_table", [
+    (5000, 4, 2, 1, np.uint8, True), (70001, 4, 2, 12, np.uint8, True), ((1 << 17) + 5, 4, 3, 3, np.uint8, True),
+    (40000, 7, 1, 20, np.uint8, False), (9000, 2, 0, 1, np.uint8, True), (30000, 12, 2, 15, np.uint8, True),
+    (50001, 20, 2, 1, np.uint8, False), (60001, 100, 1, 30, np.uint8, True), (45000, 255, 2, 2, np.uint8, True),
+    (7000, 8, 0, 40, np.uint8, True), (30000, 1000, 2, 11, np.uint16, True), (40001, 70000, 1, 1, np.uint32, True),
+    (20000, 300, 2, 25, np.uint32, False), (777, 3, 5, 200, np.uint8, True), (100000, 0, 3, 0, np.uint8, True)])
+def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, dtype, run_table, tmp_path):
+    if sigma == 0:                                                  # 256-symbol block repeated with mutations
+        t = W.repetitive_text_np(n, 5, base_len=256, mut_per_1024=1)
+        sigma = 255
+    else:
+        t = _runs_text(n, sigma, 300 + n % 89, mean_run, dtype)
+    gi = F.RLFMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True,
+                               walk_records=run_table)
+    assert gi.is_wide() and gi.len() == n and gi.level() == (level if n > (1 << level) else 0)
+    assert gi.walk_records() == run_table and not gi.text_order()
+    oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level, kind="rlfm")
+    assert gi.verify_sa() == 0
+    rows = np.arange(n, dtype=np.uint64)
+    want_l = oi.get_l(rows)
+    assert int(gi._lib.fmx_num_runs(gi.handle())) == 1 + int((want_l[1:] != want_l[:-1]).sum())     # rlfmi.rs:56-59
+    # the trait methods: every (c, i) with i == n included; every row
+    for c in (range(0, sigma + 1) if sigma <= 20 else [0, 1, 2, 3, sigma // 2, sigma - 1, sigma]):
+        i = np.arange(n + 1, dtype=np.uint64)
+        cc = np.full(n + 1, c, dtype=np.uint64)
+        assert (gi.lf_map2(cc, i) == oi.lf_map2(cc, i)).all(), c
+    assert (gi.get_l(rows) == want_l).all() and (gi.lf_map(rows) == oi.lf_map(rows)).all()
+    assert (gi.export_bwt() == want_l.astype(dtype)).all()
+    # backward search: ragged patterns (empty ones included), substrings, refinement
+    flat, off = _ragged(3000, 14, sigma, 7, dtype)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts == oe - os_).all()
+    flat2, off2, _ = W.substring_patterns_np(t, 2000, 9, 3)
+    gb2 = gi.search_many(flat=flat2, off=off2)
+    os2, oe2 = oi.count_batch(flat2, off2)
+    assert (gb2.s == os2).all() and (gb2.e == oe2).all()
+    se = np.stack([os2, oe2], axis=1).reshape(-1).copy()
+    one = np.full(len(os2), 2, dtype=dtype)
+    off1 = np.arange(len(os2) + 1, dtype=np.uint64)
+    ref = gi.search_many(flat=one, off=off1, s0e0=se)
+    rs, re_ = oi.count_batch(one, off1, s0e0=se)
+    assert (ref.s == rs).all() and (ref.e == re_).all()
+    # locate: exact sequences in suffix-array order; every row; the trait get_sa; the exported samples
+    keep = slice(0, 600)
+    goff, gpos = gi.locate_many(os2[keep], oe2[keep])
+    ooff, opos = oi.locate_batch(os2[keep], oe2[keep], nthreads=4)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    want = oi.get_sa(rows).astype(np.uint64)
+    _, gpos = gi.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))
+    assert (gpos == want).all()
+    assert (gi.get_sa(rows[:4000]) == want[:4000]).all()
+    samp = gi.export_sa_samples()
+    assert samp.dtype == np.uint64 and (samp == want[::1 << gi.level()]).all()
+    # the extract path (rlfmi.rs:145-169; wrapper.rs:154-183)
+    assert (gi.get_f(rows) == oi.get_f(rows)).all() and (gi.fl_map(rows) == oi.fl_map(rows)).all()
+    some = rows[::97][:300]
+    for forward in (False, True):
+        syms, lens, nxt = gi.extract_many(some, 9, forward=forward)
+        i = some.copy()
+        for t_ in range(9):
+            want_sym = oi.get_f(i) if forward else oi.get_l(i)
+            assert (syms[:, t_] == want_sym).all(), (forward, t_)
+            i = (oi.fl_map(i) if forward else oi.lf_map(i)).astype(np.uint64)
+        assert (lens == 9).all() and (nxt == i).all()
+    # the 32-bit engine's RLFM index gives the same ranges and positions
+    ni = F.RLFMIndexWithLocate(F.Text.with_max_character(t, sigma), level)
+    nb = ni.search_many(flat=flat2, off=off2)
+    assert (nb.s == os2).all() and (nb.e == oe2).all()
+    ni.close()
+    # the index file
+    path = str(tmp_path / "wide_rlfm.fmx")
+    gi.save(path)
+    li = type(gi).load(path)
+    assert li.is_wide() and li.len() == n and li.level() == gi.level() and li.heap_size() == gi.heap_size()
+    assert li.walk_records() == run_table and int(li._lib.fmx_num_runs(li.handle())) == int(gi._lib.fmx_num_runs(gi.handle()))
+    lb = li.search_many(flat=flat2, off=off2)
+    assert (lb.s == os2).all() and (lb.e == oe2).all()
+    _, lpos = li.locate_many(os2[keep], oe2[keep])
+    assert (lpos == opos).all()
+    assert (li.fl_map(rows[:2000]) == oi.fl_map(rows[:2000])).all()
+    li.close()
+    blob = bytearray(open(path, "rb").read())
+    with open(path, "wb") as fh:
+        fh.write(blob[:-16])
+    with pytest.raises(F.Error):
+        type(gi).load(path)
+    gi.close()
+    # count-only
+    ci = F.RLFMIndex(F.Text.with_max_character(t, sigma), force_wide=True)
+    cb = ci.search_many(flat=flat2, off=off2)
+    assert (cb.s == os2).all() and (cb.e == oe2).all() and not ci.walk_records()
+    ci.close()

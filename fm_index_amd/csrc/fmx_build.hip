@@ -2157,53 +2157,50 @@ __global__ __launch_bounds__(BLK) void kww_records(const uint8_t *__restrict__ b
 // ---- RLFM on the wide engine (rlfmi.rs:30-96; FmxWideBits, FmxWideDev::lfrun) ----
 template <typename T>
 __global__ __launch_bounds__(BLK) void kwb_run_flags(const T *__restrict__ L, uint64_t n, uint8_t *__restrict__ flags) {
-  const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const T prev = i ? L[i - 1] : (T)0;               // c0 starts at 0: a run begins wherever c != c0   rlfmi.rs:41, 56-59
-  flags[i] = L[i] != prev ? 1 : 0;
+  KW_FOR(i, n) {
+    const T prev = i ? L[i - 1] : (T)0;             // c0 starts at 0: a run begins wherever c != c0   rlfmi.rs:41, 56-59
+    flags[i] = L[i] != prev ? 1 : 0;
+  }
 }
 __global__ __launch_bounds__(BLK) void kwb_iota(uint64_t *out, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (i < n) out[i] = i;
+  KW_FOR(i, n) out[i] = i;
 }
 // length of the q-th run in (head, row) order
 __global__ __launch_bounds__(BLK) void kwb_sorted_run_lens(const uint64_t *__restrict__ starts, const uint64_t *__restrict__ order,
                                                             uint64_t r, uint64_t n, uint64_t *__restrict__ lens) {
-  const uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (q >= r) return;
-  const uint64_t k = order[q];
-  lens[q] = (k + 1 < r ? starts[k + 1] : n) - starts[k];
+  KW_FOR(q, r) {
+    const uint64_t k = order[q];
+    lens[q] = (k + 1 < r ? starts[k + 1] : n) - starts[k];
+  }
 }
 __global__ __launch_bounds__(BLK) void kwb_scatter_lfrun(const uint64_t *__restrict__ order, const uint64_t *__restrict__ fpos,
                                                           uint64_t r, uint64_t *__restrict__ lfrun) {
-  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (t < r) lfrun[order[t]] = fpos[t];
+  KW_FOR(t, r) lfrun[order[t]] = fpos[t];
 }
 __global__ __launch_bounds__(BLK) void kwb_scatter_ones(const uint64_t *__restrict__ pos, uint64_t r, uint8_t *__restrict__ flags) {
-  const uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (q < r) flags[pos[q]] = 1;
+  KW_FOR(q, r) flags[pos[q]] = 1;
 }
 // bit-vector records: one thread per 96-bit piece (payload + its popcount)
 __global__ __launch_bounds__(BLK) void kwb_pieces(const uint8_t *__restrict__ flags, uint64_t n, uint64_t npieces,
                                                    uint4 *__restrict__ rec, uint32_t *__restrict__ cnt) {
-  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (t >= npieces) return;
-  const uint64_t base = t * FMX_BITS_PER_PIECE;
-  uint32_t w[3] = {0, 0, 0};
-  for (uint32_t j = 0; j < FMX_BITS_PER_PIECE; j++) {
-    const uint64_t p = base + j;
-    if (p < n && flags[p]) w[j >> 5] |= 1u << (j & 31u);
+  KW_FOR(t, npieces) {
+    const uint64_t base = t * FMX_BITS_PER_PIECE;
+    uint32_t w[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < FMX_BITS_PER_PIECE; j++) {
+      const uint64_t p = base + j;
+      if (p < n && flags[p]) w[j >> 5] |= 1u << (j & 31u);
+    }
+    rec[t] = make_uint4(0u, w[0], w[1], w[2]);
+    cnt[t] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]);
   }
-  rec[t] = make_uint4(0u, w[0], w[1], w[2]);
-  cnt[t] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]);
 }
 // counts relative to the record's superblock; scan[] = exclusive 64-bit sums of the piece popcounts
 __global__ __launch_bounds__(BLK) void kwb_counters(const uint64_t *__restrict__ scan, uint64_t npieces, uint32_t sb_shift,
                                                      uint4 *__restrict__ rec) {
-  const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (t >= npieces) return;
-  const uint64_t first = (((t >> 3) >> sb_shift) << sb_shift) * 8u;      // first piece of the superblock
-  rec[t].x = (uint32_t)(scan[t] - scan[first]);
+  KW_FOR(t, npieces) {
+    const uint64_t first = (((t >> 3) >> sb_shift) << sb_shift) * 8u;    // first piece of the superblock
+    rec[t].x = (uint32_t)(scan[t] - scan[first]);
+  }
 }
 __global__ __launch_bounds__(64) void kwb_bases(const uint64_t *__restrict__ scan, uint32_t nsb, uint32_t sb_shift,
                                                 uint64_t *__restrict__ base) {
@@ -2213,10 +2210,13 @@ __global__ __launch_bounds__(64) void kwb_bases(const uint64_t *__restrict__ sca
 // sel[m / STEP] = record holding the m-th one, for every multiple m of STEP
 __global__ __launch_bounds__(BLK) void kwb_select_hints(const uint64_t *__restrict__ scan, uint32_t nrec, uint64_t ones,
                                                          uint32_t *__restrict__ sel) {
-  const uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-  if (r >= nrec) return;
-  const uint64_t b0 = scan[r * 8u], b1 = r + 1 < nrec ? scan[(r + 1) * 8u] : ones;
-  for (uint64_t m = (b0 + FMX_SEL_STEP - 1) / FMX_SEL_STEP * FMX_SEL_STEP; m < b1; m += FMX_SEL_STEP) sel[m / FMX_SEL_STEP] = (uint32_t)r;
+  KW_FOR(r, nrec) {
+    const uint64_t b0 = scan[r * 8u], b1 = r + 1 < nrec ? scan[(r + 1) * 8u] : ones;
+    for (uint64_t m = (b0 + FMX_SEL_STEP - 1) / FMX_SEL_STEP * FMX_SEL_STEP; m < b1; m += FMX_SEL_STEP) sel[m / FMX_SEL_STEP] = (uint32_t)r;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwb_fill_u32(uint32_t *out, uint64_t n, uint32_t v) {
+  KW_FOR(i, n) out[i] = v;
 }
 
 template <typename T>
@@ -2605,7 +2605,7 @@ static int build_bits_wide(fmx_index *idx, FmxWideBits *bv, const uint8_t *d_fla
   uint32_t *sel;
   FMX_HIP(hipMalloc((void **)&sel, (size_t)bv->nsel * 4));
   if (int rc = keep(idx, sel, bv->nsel * 4)) return rc;
-  hipLaunchKernelGGL(k_fill_u32, dim3(wblocks(bv->nsel)), dim3(BLK), 0, 0, sel, (uint32_t)bv->nsel, bv->nrec - 1);
+  hipLaunchKernelGGL(kwb_fill_u32, dim3(wblocks(bv->nsel)), dim3(BLK), 0, 0, sel, bv->nsel, bv->nrec - 1);
   hipLaunchKernelGGL(kwb_select_hints, dim3(wblocks(bv->nrec)), dim3(BLK), 0, 0, scan, bv->nrec, ones, sel);
   FMX_HIP(hipGetLastError());
   bv->rec = rec;

@@ -1006,6 +1006,11 @@ __device__ __forceinline__ uint64_t fmxw_bits_lane_select(const FmxWideBits &bv,
 // probe of a step is a lane-wise request (the 16-byte B piece of the row: run index and, unless the run began before the
 // piece, its start; then the table entry), 64 independent walks per wave instruction and no cross-lane traffic.  A lane
 // whose walk ends writes its position and takes its next hit (hits tid, tid + threads, ...) while its neighbours walk on.
+// LOCKSTEP (intervals of many rows -- a repetitive text's patterns): a wave takes 64 CONSECUTIVE hits and walks them to
+// the end together before it takes the next 64.  Neighbouring rows of an interval sit in the same runs and stay
+// neighbours under LF, so the wave's 64 requests fall into a few lines -- where the refilling shape scatters them
+// over the index after its first iterations and runs at the memory system's request ceiling (2 per step).
+template <bool LOCKSTEP>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
                                                                   uint64_t *__restrict__ steps_out) {
   const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
@@ -1013,8 +1018,18 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, u
   uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool have = h < total;
   uint64_t row = have ? io[h] : 0, steps = 0, nsteps = 0;
+  [[maybe_unused]] bool done = false;               // LOCKSTEP: this lane's walk is over, its neighbours' are not
   while (__any(have)) {
-    if (have && (row >= w.n || (row & lmask) == 0)) {   // Some(sa): (sa + steps) % len            rlfmi.rs:178-182
+    if (LOCKSTEP && !__any(have && !done)) {        // wave-uniform: the next 64 hits
+      h += nth;
+      have = h < total;
+      row = have ? io[h] : 0;
+      steps = 0;
+      done = false;
+      continue;
+    }
+    if (LOCKSTEP && done) {
+    } else if (have && (row >= w.n || (row & lmask) == 0)) {   // Some(sa): (sa + steps) % len            rlfmi.rs:178-182
       uint64_t v = ~0ull;
       if (row >= w.n) {                             // refuse, do not read
         atomicOr(w.status, 1u << FMX_ERR_ARG);
@@ -1024,10 +1039,14 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, u
       }
       io[h] = v;
       nsteps += steps;
-      h += nth;
-      have = h < total;
-      row = have ? io[h] : 0;
-      steps = 0;
+      if (LOCKSTEP) {
+        done = true;
+      } else {
+        h += nth;
+        have = h < total;
+        row = have ? io[h] : 0;
+        steps = 0;
+      }
     } else if (have) {                              // None: i = lf_map(i); steps += 1          rlfmi.rs:183-186
       const FmxWideBits &bv = w.b;
       const uint64_t pidx = fmxw_div3(row >> 5);    // row / 96
@@ -1271,7 +1290,10 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
     if (w.kind == FMX_KIND_RLFM && w.lfrun) {       // run table: a lane per walk
       uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
       if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
-      hipLaunchKernelGGL(fmxw_r_walk_kernel, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
+      static const int force = getenv("FMXW_RL_LOCKSTEP") ? atoi(getenv("FMXW_RL_LOCKSTEP")) : -1;   // measurement switch
+      const bool lockstep = force >= 0 ? force != 0 : total / npat >= 64;
+      if (lockstep) hipLaunchKernelGGL(fmxw_r_walk_kernel<true>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
+      else hipLaunchKernelGGL(fmxw_r_walk_kernel<false>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
     } else if (w.kind == FMX_KIND_RLFM) {
       if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, true); else FMXW_GWALK(false, true);
     } else if (w.nsb <= FMXW_GLDS_SB) {

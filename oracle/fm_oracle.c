@@ -650,8 +650,8 @@ int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_c
  * the symbol the loop reads for row i, T[SA[i]-1] (T[n-1] = 0 when SA[i] = 0), IS bwt[i]
  * (fm_index.rs:50-55).  Used by bench.py's cpu_baseline at n = 2^30, where the CPU suffix sort
  * would take longer than the whole benchmark; `samples` (may be NULL) are the SA samples of `level`. */
-int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
-                      const uint32_t *samples, int level) {
+static int rlfm_from_bwt_any(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                             const uint32_t *samples32, const uint64_t *samples64, int level) {
   *out = NULL;
   if (max_character == 0 || max_character > 255) return ORC_ERR_ARG;
   orc_rlfm *f = (orc_rlfm *)calloc(1, sizeof(orc_rlfm));
@@ -660,10 +660,15 @@ int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t m
   f->max_character = max_character;
   uint64_t nw = (n + 63) / 64 + BLK_WORDS;
   uint64_t *bw = (uint64_t *)calloc(nw, 8), *bpw = (uint64_t *)calloc(nw, 8);
-  uint8_t *heads = (uint8_t *)malloc(n ? n : 1);
-  uint32_t *run_len = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-  uint64_t *runs_of = (uint64_t *)calloc(m, sizeof(uint64_t));
   uint64_t r = 0, c0 = 0;                                       /* rlfmi.rs:41 */
+  for (uint64_t i = 0; i < n; i++) {                            /* the runs are counted first: the arrays below are r long */
+    if (c0 != bwt[i]) r++;
+    c0 = bwt[i];
+  }
+  uint8_t *heads = (uint8_t *)malloc(r ? r : 1);
+  uint64_t *run_len = (uint64_t *)malloc((r ? r : 1) * sizeof(uint64_t));
+  uint64_t *runs_of = (uint64_t *)calloc(m, sizeof(uint64_t));
+  r = 0; c0 = 0;
   for (uint64_t i = 0; i < n; i++) {                            /* rlfmi.rs:48-68 */
     uint64_t c = bwt[i];
     if (c0 != c) {
@@ -697,13 +702,23 @@ int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t m
   }
   orc_rsvec_build(&f->b, bw, n);                                /* rlfmi.rs:85 */
   orc_rsvec_build(&f->bp, bpw, n);                              /* rlfmi.rs:86 */
-  if (level >= 0 && samples) {
-    orc_ssa_from_samples(&f->ssa, samples, n, (uint64_t)level);
+  if (level >= 0 && (samples32 || samples64)) {
+    if (samples64) orc_ssa_from_samples64(&f->ssa, samples64, n, (uint64_t)level);
+    else orc_ssa_from_samples(&f->ssa, samples32, n, (uint64_t)level);
     f->has_locate = 1;
   }
   free(start_of); free(runs_of); free(run_len); free(heads);
   *out = f;
   return ORC_OK;
+}
+int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                      const uint32_t *samples, int level) {
+  return rlfm_from_bwt_any(out, bwt, n, max_character, samples, NULL, level);
+}
+/* the same with 64-bit sample values: texts of 2^32 symbols and more (the reference is usize throughout) */
+int orc_rlfm_from_bwt64(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                        const uint64_t *samples, int level) {
+  return rlfm_from_bwt_any(out, bwt, n, max_character, NULL, samples, level);
 }
 void orc_rlfm_free(orc_rlfm *f) {
   if (!f) return;

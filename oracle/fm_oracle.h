@@ -150,6 +150,8 @@ int orc_rlfm_new(orc_rlfm **out, const uint8_t *text, uint64_t n, uint64_t max_c
                  int level);
 int orc_rlfm_from_bwt(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
                       const uint32_t *samples, int level);
+int orc_rlfm_from_bwt64(orc_rlfm **out, const uint8_t *bwt, uint64_t n, uint64_t max_character,
+                        const uint64_t *samples, int level);   /* n >= 2^32: 64-bit sample values */
 void orc_rlfm_free(orc_rlfm *f);
 orc_backend orc_rlfm_backend(orc_rlfm *f);
 

@@ -58,6 +58,7 @@ def _bind(lib):
     lib.orc_rlfm_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     lib.orc_rlfm_from_bwt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_int]
+    lib.orc_rlfm_from_bwt64.argtypes = lib.orc_rlfm_from_bwt.argtypes
     lib.orc_rlfm_free.argtypes = [C.c_void_p]
     lib.orc_rlfm_backend.restype = _Backend
     lib.orc_rlfm_backend.argtypes = [C.c_void_p]
@@ -213,9 +214,8 @@ class OracleIndex:
             sarr = np.ascontiguousarray(samples, dtype=sdt) if samples is not None else None
             sp = _p(sarr) if sarr is not None else None
             if kind == "rlfm":   # run-length structure of the same L column (rlfmi.rs:41-96)
-                if big:
-                    raise ValueError("the oracle's RLFM import takes 32-bit samples: n < 2^32")
-                rc = self._l.orc_rlfm_from_bwt(C.byref(h), _p(b), len(b), self.max_character, sp, lvl)
+                fn = self._l.orc_rlfm_from_bwt64 if big else self._l.orc_rlfm_from_bwt
+                rc = fn(C.byref(h), _p(b), len(b), self.max_character, sp, lvl)
             else:
                 fn = self._l.orc_fm_from_bwt64 if big else self._l.orc_fm_from_bwt
                 rc = fn(C.byref(h), _p(b), len(b), self.max_character, _p(cs), sp, lvl)

@@ -33,27 +33,34 @@ def _run(alphabet="dna"):
     torch.cuda.empty_cache()
     dev = torch.device("cuda", 0)
     lib = L.lib()
-    dna, u16 = alphabet == "dna", alphabet == "u16"
+    dna, u16, rl = alphabet == "dna", alphabet == "u16", alphabet == "rlfm"
     # DNA: the one-level engine; bytes: the generic wide engine (two 4-bit wavelet levels); u16: 2-byte symbols,
     # sigma = 1000 (4 + 3 + 3 bits), without the
     # oracle -- its u32 copy of the 2^32 symbols plus the exports would need ~50 GB of host memory
-    m, level, sigma = (30, 2, 4) if dna else (6, 3, 1000) if u16 else (10, 3, 255)
+    # rlfm: RLFMIndexWithLocate (round 4) over the repetitive byte text of config 4b at this size -- a 1 MiB block
+    # repeated 4097 times with 1 % of the symbols mutated, runs of ~20 -- so a pattern of 12 symbols has ~3600 hits
+    m, level, sigma = (30, 2, 4) if dna else (6, 3, 1000) if u16 else (12, 3, 255) if rl else (10, 3, 255)
     if u16:
         text = torch.empty(N, dtype=torch.int16, device=dev)       # values 1..1000: the bit patterns of u16
         for a in range(0, N, 1 << 26):
             k_ = min(1 << 26, N - a)
             text[a:a + k_] = (W.umod_torch(W.splitmix64_torch(17, a, k_, dev), 1000) + 1).to(torch.int16)
         text[N - 1] = 0
+    elif rl:
+        text = W.repetitive_text_torch(N, 17, dev, base_len=1 << 20, mut_per_1024=10)
     else:
         text = W.dna_text_torch(N, 17, dev) if dna else W.byte_text_torch(N, 17, dev)
+    cls = F.RLFMIndexWithLocate if rl else F.FMIndexWithLocate
     t0 = time.time()
     # keep_scratch: the three builds of this file share their 137+ GB of builder temporaries (FMX_FLAG_KEEP_SCRATCH; a
     # process that has cycled through the device's memory pays ~30 ms per GiB for every further hipMalloc)
-    index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, sigma, level=level, keep_sa=True,
-                                                 sym_bytes=2 if u16 else 1, keep_scratch=True)
+    index = cls.from_device_text(text.data_ptr(), N, sigma, level=level, keep_sa=True,
+                                 sym_bytes=2 if u16 else 1, keep_scratch=True)
     build_s = time.time() - t0
     h = index.handle()
     assert index.len() == N and index.is_wide() and index.level() == level
+    runs = int(lib.fmx_num_runs(h))
+    assert (1 << 24) < runs < N // 8 and index.walk_records() if rl else runs == 0
     t0 = time.time()
     assert index.verify_sa() == 0                       # sorted, and every index exactly once
     verify_s = time.time() - t0
@@ -122,14 +129,15 @@ def _run(alphabet="dna"):
         return res
     samples = index.export_sa_samples()
     assert samples.dtype == np.uint64 and int(samples.max()) >= (1 << 32)
-    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), sigma, samples=samples, level=level)
+    oi = O.OracleIndex.from_bwt(index.export_bwt(), index.export_cs(), sigma, samples=samples, level=level,
+                                kind="rlfm" if rl else "fm")
     del samples
     oracle_s = time.time() - t0
     k = 1 << 12
     so, eo = oi.count_batch(pat[:k * m].cpu().numpy(), np.arange(k + 1, dtype=np.uint64) * np.uint64(m), nthreads=16)
     assert (so == s[:k].cpu().numpy().view(np.uint64)).all()
     assert (eo == e[:k].cpu().numpy().view(np.uint64)).all()
-    ooff, opos = oi.locate_batch(so[:1024], eo[:1024], nthreads=16)
+    ooff, opos = oi.locate_batch(so[:64 if rl else 1024], eo[:64 if rl else 1024], nthreads=16)
     assert (opos == d_pos[:int(ooff[-1])].cpu().numpy().view(np.uint64)).all()
     rows = (np.uint64(1 << 32) + W.splitmix64_np(21, 0, 2048) % np.uint64(1 << 20)).astype(np.uint64)
     syms = (np.uint64(1) + W.splitmix64_np(22, 0, 2048) % np.uint64(sigma)).astype(np.uint64)
@@ -140,7 +148,7 @@ def _run(alphabet="dna"):
     assert (index.get_sa(rows[:256]) == oi.get_sa(rows[:256])).all()
     oi.close()
     # ---- for the record: what the wide engine's simple kernels do on the config-2 / config-3 shapes ----
-    kp, mp = 1 << 20, 32
+    kp, mp = (1 << 16 if rl else 1 << 20), 32
     srcp = W.umod_torch(W.splitmix64_torch(3, 0, kp, dev), N - 1 - mp)
     patp = text[srcp[:, None] + torch.arange(mp, dtype=torch.int64, device=dev)[None, :]].reshape(-1).contiguous()
     offp = (torch.arange(kp + 1, dtype=torch.int64, device=dev) * mp).contiguous()
@@ -174,13 +182,13 @@ def _run(alphabet="dna"):
     ev1.record()
     torch.cuda.synchronize()
     locate_ms = ev0.elapsed_time(ev1) / 10
-    perf = {"count_2^20x32_ms": round(count_ms, 4), "count_pattern_chars_per_s": kp * mp / (count_ms / 1e3),
+    perf = {"count_patterns": kp, "count_ms": round(count_ms, 4), "count_pattern_chars_per_s": kp * mp / (count_ms / 1e3),
             "locate_hits": tot_p, "locate_ms": round(locate_ms, 4), "locate_hits_per_s": tot_p / (locate_ms / 1e3)}
     del patp, posp
-    out = {"kind": "fm", "alphabet": alphabet, "max_character": sigma, "n": N, "level": level, "perf": perf, "patterns": npat, "pattern_len": m, "hits": total,
+    out = {"kind": "rlfm" if rl else "fm", "runs": runs, "alphabet": alphabet, "max_character": sigma, "n": N, "level": level, "perf": perf, "patterns": npat, "pattern_len": m, "hits": total,
            "intervals_with_e_beyond_2^32": rows_hi, "positions_beyond_2^32": pos_hi,
            "max_row": int(e.max().item()), "max_position": int(d_pos.max().item()),
-           "verify_sa_violations": 0, "oracle_patterns_identical": k, "oracle_located_patterns_identical": 1024,
+           "verify_sa_violations": 0, "oracle_patterns_identical": k, "oracle_located_patterns_identical": 64 if rl else 1024,
            "trait_rows_checked_beyond_2^32": int(len(rows)), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
            "build_wall_s": round(build_s, 2), "verify_sa_s": round(verify_s, 2), "oracle_import_s": round(oracle_s, 1),
            "index_bytes": index.heap_size(), "wide": index.is_wide()}
@@ -196,6 +204,14 @@ def test_dna_index_beyond_4g_symbols():
 
 def test_byte_index_beyond_4g_symbols():
     _run("bytes")
+
+
+def test_rlfm_index_beyond_4g_symbols():
+    """RLFMIndexWithLocate at n = 2^32 + 2^20 (rlfmi.rs:15-24: usize rows): the repetitive byte text,
+    B / B' with 64-bit superblock bases, the 64-bit run table; same protocol, the oracle's RLFM structures rebuilt from
+    the exported L column."""
+    out = _run("rlfm")
+    assert out["wide"] and out["kind"] == "rlfm"
 
 
 def test_u16_index_beyond_4g_symbols():

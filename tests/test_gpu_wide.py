@@ -172,11 +172,13 @@ def test_wide_engine_errors_and_refusals(tmp_path):
     out = np.zeros(8, dtype=np.uint32)
     assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
     gi.close()
-    # eligibility: FMX_KIND_FM only
+    # eligibility: FMX_KIND_FM and FMX_KIND_RLFM (round 4); the multi-pieces index is not on this engine
     bt = W.byte_text_np(5000, 3)
     h = C.c_void_p()
-    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_RLFM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
     assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_MULTI, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
+    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_RLFM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == 0
+    assert lib.fmx_is_wide(h) == 1 and lib.fmx_kind(h) == L.KIND_RLFM
+    lib.fmx_free(h)
     # a count-only wide index has no locate
     ci = F.FMIndex(F.Text.with_max_character(t, 4), force_wide=True)
     assert ci.is_wide() and ci.search(bytes([1, 2])).count() == gi_count(t, [1, 2])

@@ -368,8 +368,8 @@ class FMIndexMultiPieces(_Index):
     """FMIndexMultiPieces::new(&text) (frontend.rs:245-253): several \\0-separated pieces."""
     _kind = L.KIND_MULTI
 
-    def __init__(self, text, device=0, keep_sa=False, kmer_table=False):
-        super().__init__(text, None, device, keep_sa, False, kmer_table)
+    def __init__(self, text, device=0, keep_sa=False, kmer_table=False, force_wide=False):
+        super().__init__(text, None, device, keep_sa, False, kmer_table, None, force_wide)
 
     def piece_id(self, i):
         return self._scalar(self._lib.fmx_piece_id_batch, i)
@@ -391,8 +391,8 @@ class FMIndexMultiPieces(_Index):
 class FMIndexMultiPiecesWithLocate(FMIndexMultiPieces):
     """FMIndexMultiPiecesWithLocate::new(&text, level) (frontend.rs:255-267)."""
 
-    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None):
-        _Index.__init__(self, text, level, device, keep_sa, False, kmer_table, sampling)
+    def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, force_wide=False):
+        _Index.__init__(self, text, level, device, keep_sa, False, kmer_table, sampling, force_wide)
 
 
 class Search:

@@ -115,9 +115,9 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     return fail(FMX_ERR_UNSUPPORTED, "max_character >= 2^26 is not supported");
   if (kind != FMX_KIND_FM && kind != FMX_KIND_RLFM && kind != FMX_KIND_MULTI)
     return fail(FMX_ERR_ARG, "unknown kind");
-  // n >= 2^32 - 16: the wide engine (64-bit rows) takes FMIndex / FMIndexWithLocate and RLFMIndex / RLFMIndexWithLocate
-  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) && !((kind == FMX_KIND_FM || kind == FMX_KIND_RLFM) && n >= 2))
-    return fail(FMX_ERR_UNSUPPORTED, "n >= 2^32 - 16 is supported for FMX_KIND_FM and FMX_KIND_RLFM only");
+  // n >= 2^32 - 16: the wide engine (64-bit rows) takes every kind (round 4: RLFM and multi-pieces too)
+  if ((fmx_wide_n(n) || (flags & FMX_FLAG_FORCE_WIDE)) && n < 2)
+    return fail(FMX_ERR_UNSUPPORTED, "FMX_FLAG_FORCE_WIDE needs a text of two symbols or more");
   // the wide engine's record and superblock indices are 32 bits wide: n / 128 + 1 records, (superblock + 1) << 24
   if (n >= (1ull << 38)) return fail(FMX_ERR_UNSUPPORTED, "n >= 2^38 is not supported");
   if (n && !text) return fail(FMX_ERR_ARG, "text is NULL");
@@ -974,7 +974,9 @@ uint64_t fmx_get_sa(const fmx_index *idx, uint64_t i) { uint64_t o = ~0ull; retu
 // ---------------------------------------------------------------------------
 // multi-pieces (multi_pieces.rs)
 // ---------------------------------------------------------------------------
-uint64_t fmx_pieces_count(const fmx_index *idx) { return idx && idx->kind == FMX_KIND_MULTI ? idx->dev.doc_count : 0; }
+uint64_t fmx_pieces_count(const fmx_index *idx) {
+  return idx && idx->kind == FMX_KIND_MULTI ? (idx->is_wide ? idx->wide.doc_count : idx->dev.doc_count) : 0;
+}
 int fmx_piece_id_batch_dev(const fmx_index *idx, const uint64_t *d_i, uint64_t k, uint64_t *d_out, void *stream) {
   CHECK_IDX(idx);
   if (idx->kind != FMX_KIND_MULTI) return fail(FMX_ERR_ARG, "piece_id needs a multi-pieces index");
@@ -1276,6 +1278,7 @@ WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
     }
     if (w.lfrun) { b.field[b.n] = (const void **)&w.lfrun; b.bytes[b.n++] = w.slen * 8ull; }
   }
+  if (w.kind == FMX_KIND_MULTI) { b.field[b.n] = (const void **)&w.doc; b.bytes[b.n++] = w.doc_count * 4ull; }
   return b;
 }
 }  // namespace
@@ -1356,17 +1359,20 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   if (fread(&w, sizeof w, 1, f) != 1) return fail(FMX_ERR_ARG, "truncated index file");
   const bool locate = w.sa_level != FMX_NO_LOCATE;
   const char *bad = nullptr;
-  const bool rl = h.kind == FMX_KIND_RLFM;
+  const bool rl = h.kind == FMX_KIND_RLFM, mp = h.kind == FMX_KIND_MULTI;
   const uint64_t slen = rl ? h.runs : h.n;          // entries of the wavelet levels: run heads (RLFM) or the BWT
-  if ((h.kind != FMX_KIND_FM && !rl) || w.kind != h.kind || (h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) ||
+  if ((h.kind != FMX_KIND_FM && !rl && !mp) || w.kind != h.kind || (h.sym_bytes != 1 && h.sym_bytes != 2 && h.sym_bytes != 4) ||
       (h.sym_bytes_abi != h.sym_bytes && !(h.sym_bytes_abi == 8 && h.sym_bytes == 4)))
     bad = "kind / symbol width";
   else if (h.n < 2 || h.n >= (1ull << 38) || w.n != h.n) bad = "n";
   else if (h.max_character == 0 || h.max_character >= (1ull << 26) || w.max_character != h.max_character ||
            (h.sym_bytes < 4 && h.max_character >= (1ull << (8 * h.sym_bytes))))
     bad = "max_character";
-  else if (w.generic != ((h.max_character > 7 || h.sym_bytes != 1 || rl) ? 1u : 0u) || (w.generic && w.sym_bytes != h.sym_bytes))
+  else if (w.generic != ((h.max_character > 7 || h.sym_bytes != 1 || rl || mp) ? 1u : 0u) || (w.generic && w.sym_bytes != h.sym_bytes))
     bad = "engine";
+  else if (mp ? (w.doc_count == 0 || w.doc_count > h.n || w.doc_count >= (1ull << 32) || w.first_row >= h.n || !w.doc)
+              : (w.doc != nullptr || w.doc_count != 0))
+    bad = "pieces";
   else if (rl ? (h.runs == 0 || h.runs > h.n || w.slen != h.runs) : (h.runs != 0 || w.slen != 0 || w.lfrun)) bad = "runs";
   else if (w.sb_shift < 8 || w.sb_shift > 31 || w.nsb != (uint32_t)(slen >> w.sb_shift) + 1u) bad = "superblocks";
   else if (locate && (w.sa_level >= 63 || h.nsamples != ((h.n - 1) >> w.sa_level) + 1)) bad = "sampling level";

@@ -2218,6 +2218,29 @@ __global__ __launch_bounds__(BLK) void kwb_select_hints(const uint64_t *__restri
 __global__ __launch_bounds__(BLK) void kwb_fill_u32(uint32_t *out, uint64_t n, uint32_t v) {
   KW_FOR(i, n) out[i] = v;
 }
+// ---- multi-pieces on the wide engine: doc[] and sa_idx_first_text (multi_pieces.rs:57-85) ----
+template <typename T>
+struct IsZeroSym {
+  __device__ __forceinline__ bool operator()(T v) const { return v == (T)0; }
+};
+// for the k-th end marker of L (row zrows[k]): doc[k] = number of end markers before text position (SA[row] - 1) mod n
+// = the index of that position among the ascending marker positions zpos[]; the row whose marker is the LAST of the
+// text is sa_idx_first_text
+__global__ __launch_bounds__(BLK) void kwm_doc(const uint64_t *__restrict__ sa, const uint64_t *__restrict__ zrows,
+                                               const uint64_t *__restrict__ zpos, uint64_t pieces, uint64_t n,
+                                               uint32_t *__restrict__ doc, unsigned long long *__restrict__ first_row) {
+  KW_FOR(k, pieces) {
+    const uint64_t p = zrows[k], v = sa[p];
+    const uint64_t pos = v > 0 ? v - 1 : n - 1;     // modular_sub(sa[p], 1, n)
+    uint64_t lo = 0, hi = pieces;                   // markers at positions < pos
+    while (lo < hi) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (zpos[mid] < pos) lo = mid + 1; else hi = mid;
+    }
+    doc[k] = (uint32_t)lo;
+    if (lo == pieces - 1) *first_row = p;
+  }
+}
 
 template <typename T>
 int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d_sa, DevPool &pool) {
@@ -2890,6 +2913,46 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
       mark("walk records");
     }
   }
+  w.doc = nullptr; w.doc_count = 0; w.first_row = 0;
+  if (idx->kind == FMX_KIND_MULTI) {
+    const uint64_t pieces = hist[0];
+    if (pieces >= (1ull << 32)) {
+      fmx_set_error(FMX_ERR_UNSUPPORTED, "wide multi-pieces index: 2^32 pieces or more");
+      return FMX_ERR_UNSUPPORTED;
+    }
+    uint64_t *zrows, *zpos;
+    unsigned long long *d_got, *d_first;
+    uint32_t *d_doc;
+    FMX_HIP(pool.get(&zrows, pieces ? pieces : 1));
+    FMX_HIP(pool.get(&zpos, pieces ? pieces : 1));
+    FMX_HIP(pool.get(&d_got, 1));
+    FMX_HIP(pool.get(&d_first, 1));
+    FMX_HIP(hipMemset(d_first, 0, 8));
+    FMX_HIP(hipMalloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
+    if (int rc = keep(idx, d_doc, pieces * 4)) return rc;
+    rocprim::counting_iterator<uint64_t> rows(0);
+    auto zl = rocprim::make_transform_iterator((const T *)d_bwt, IsZeroSym<T>());
+    auto zt = rocprim::make_transform_iterator(d_text, IsZeroSym<T>());
+    size_t t1 = 0, t2 = 0;
+    FMX_HIP(rocprim::select(nullptr, t1, rows, zl, zrows, d_got, (size_t)n, (hipStream_t)0));
+    FMX_HIP(rocprim::select(nullptr, t2, rows, zt, zpos, d_got, (size_t)n, (hipStream_t)0));
+    const size_t tb = t1 > t2 ? t1 : t2;
+    uint8_t *tmp;
+    FMX_HIP(pool.get(&tmp, tb));
+    size_t tt = tb;
+    FMX_HIP(rocprim::select(tmp, tt, rows, zl, zrows, d_got, (size_t)n, (hipStream_t)0));
+    tt = tb;
+    FMX_HIP(rocprim::select(tmp, tt, rows, zt, zpos, d_got, (size_t)n, (hipStream_t)0));
+    hipLaunchKernelGGL(kwm_doc, dim3(wblocks(pieces)), dim3(BLK), 0, 0, d_sa, zrows, zpos, pieces, n, d_doc, d_first);
+    FMX_HIP(hipGetLastError());
+    unsigned long long first = 0;
+    FMX_HIP(hipMemcpy(&first, d_first, 8, hipMemcpyDeviceToHost));
+    w.doc = d_doc;
+    w.doc_count = pieces;
+    w.first_row = first;
+    pool.release(tmp); pool.release(d_first); pool.release(d_got); pool.release(zpos); pool.release(zrows);
+    mark("pieces");
+  }
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
     FMX_HIP(hipMalloc((void **)&kt, n * sizeof(T)));
@@ -2915,7 +2978,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   }
   const uint32_t sb_shift = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST, sb_recs = sb_shift - 8u;
   const uint32_t nsb = (uint32_t)(n >> sb_shift) + 1u;
-  if (maxc > 7 || sizeof(T) != 1) {
+  if (maxc > 7 || sizeof(T) != 1 || idx->kind == FMX_KIND_MULTI) {
     // -- generic wide index: the levels of the multi-ary wavelet matrix (as build_mwm, 64-bit scans) --
     if (int rc = build_wide_levels<T>(idx, d_bwt, n, L, pool)) return rc;
     uint64_t *d_cs, *d_K;

@@ -211,6 +211,10 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   uint64_t slen;
   FmxWideBits b, bp;
   const uint64_t *lfrun;
+  // FMIndexMultiPieces (round 4; kind == FMX_KIND_MULTI; multi_pieces.rs): always `generic`; doc[k] = piece id of the
+  // k-th end marker in L order, first_row = sa_idx_first_text (multi_pieces.rs:21-22, 57-85), as FmxDev::doc / first_row
+  const uint32_t *doc;
+  uint64_t doc_count, first_row;
 };
 #define FMXW_WALK_SB_SHIFT 24u      // records per walk superblock: 2^24 x 112 rows < 2^31, so relative counters fit 32 bits
 #define FMXW_WALK_SB_SHIFT_TEST 5u  // FMX_FLAG_FORCE_WIDE: 32 records, so that a small text has many superblocks
@@ -287,6 +291,8 @@ int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const 
 int fmxw_launch_export_l(const fmx_index *idx, void *d_out, hipStream_t st);
 int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t nrows, uint32_t len, int forward,
                         void *d_out, uint64_t *d_out_len, uint64_t *d_out_next, hipStream_t st);
+int fmxw_launch_match(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, int prefix_only,
+                      const uint64_t *d_off, uint64_t *d_out, hipStream_t st);   // d_off == NULL: counts, else rows
 int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations);
 int fmxw_launch_compute_K(const FmxWideDev &w, uint64_t *d_K);   // generic wide index: K[c] = cs[c] - rank chain of c at 0
 // rows s[k] + j of every interval, 64 bits each (wrapper.rs:203-217), written to out[off[k] + j]

@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_match_rows_kernel(
 }
 int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                             uint64_t npat, int prefix_only, uint64_t *d_cnt, hipStream_t st) {
-  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
+  if (idx->is_wide) return fmxw_launch_match(idx, d_s, d_e, npat, prefix_only, nullptr, d_cnt, st);
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_counts_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,
@@ -1728,7 +1728,7 @@ int fmx_launch_match_counts(const fmx_index *idx, const uint64_t *d_s, const uin
 int fmx_launch_match_rows(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                           uint64_t npat, int prefix_only, const uint64_t *d_off, uint64_t *d_rows,
                           hipStream_t st) {
-  if (idx->is_wide) { fmx_set_error(FMX_ERR_UNSUPPORTED, "not available on an index with n >= 2^32"); return FMX_ERR_UNSUPPORTED; }
+  if (idx->is_wide) return fmxw_launch_match(idx, d_s, d_e, npat, prefix_only, d_off, d_rows, st);
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0) return FMX_OK;
   hipLaunchKernelGGL(fmx_match_rows_kernel, dim3(fmx_grid_for_groups(npat)), dim3(FMX_BLOCK), 0, st,

@@ -631,6 +631,20 @@ __device__ __forceinline__ uint64_t fmxw_g_lf(const FmxWideDev &w, const GB &gba
   }
   return pos;
 }
+// FMIndexMultiPiecesBackend::lf_map2 / lf_map for the end marker (multi_pieces.rs:131-137, 147-153): the end markers are
+// ordered by piece, the LAST one (row first_row = sa_idx_first_text) maps to row 0; rank0 = cs[0] + rank of 0 at i
+__device__ __forceinline__ uint64_t fmxw_multi_zero(const FmxWideDev &w, uint64_t i, uint64_t rank0) {
+  return i < w.first_row ? rank0 + 1u : (i == w.first_row ? 0ull : rank0);
+}
+// get_l(i) and lf_map(i) of an FM (MP = false) or multi-pieces (MP = true) generic index
+template <bool MP, class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_g_lf_map(const FmxWideDev &w, const GB &gbase, const GK &gk, uint64_t i, uint32_t g,
+                                                  uint32_t &sym) {
+  uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
+  r += gk(sym);                                                   // fm_index.rs:86-91
+  if (MP && sym == 0u) r = fmxw_multi_zero(w, i, r);
+  return r;
+}
 // counter of `code` at the start of record r, absolute (in the units of the level's ranks); global bases
 __device__ __forceinline__ uint64_t fmxw_g_counter(const FmxWideDev &w, const FmxWideLevel &L, uint32_t r, uint32_t code) {
   const uint32_t recs = w.sb_shift - (L.fmt == 3 ? 8u : 7u);
@@ -878,11 +892,12 @@ __global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint
 
 // SearchWrapper::search for a batch (wrapper.rs:103-124): a group per pattern; per level the records of both
 // interval ends are requested together, the next pattern symbol with the first level's
-template <bool GLDS, bool RL>
+template <bool GLDS, int KD>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
     FmxWideDev w, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  constexpr bool RL = KD == FMX_KIND_RLFM, MP = KD == FMX_KIND_MULTI;
   FMXW_GBASES(w, GLDS);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
@@ -931,8 +946,13 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
         pe = bb + fmxw_g_rank32(L, pb, pe, code, g);
       }
       const uint64_t kc = gk(c);
-      s = kc + ps;                                  // wrapper.rs:109
-      e = kc + pe;                                  // wrapper.rs:110
+      if (MP && c == 0u) {                          // multi_pieces.rs:147-153
+        s = fmxw_multi_zero(w, s, kc + ps);
+        e = fmxw_multi_zero(w, e, kc + pe);
+      } else {
+        s = kc + ps;                                // wrapper.rs:109
+        e = kc + pe;                                // wrapper.rs:110
+      }
       c = cn;
       j--;
       nsteps++;
@@ -948,9 +968,10 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
 }
 
 // get_sa for a batch of rows (fm_index.rs:127-140; sample.rs:46-60): a group per walk, rows in, positions out
-template <bool GLDS, bool RL>
+template <bool GLDS, int KD>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
                                                                   uint64_t *__restrict__ steps_out) {
+  constexpr bool RL = KD == FMX_KIND_RLFM, MP = KD == FMX_KIND_MULTI;
   FMXW_GBASES(w, GLDS);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
@@ -967,8 +988,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
           row = fmxw_r_lf_step(w, gbase, gk, row, g);
         } else {
           uint32_t sym;
-          const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
-          row = gk(sym) + r;
+          row = fmxw_g_lf_map<MP>(w, gbase, gk, row, g, sym);
         }
         steps++;
       }
@@ -1072,11 +1092,13 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, u
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
-// the trait methods, batched (backend.rs:9-19, 29-31).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f, 5 fl_map
-template <bool RL>
+// the trait methods, batched (backend.rs:9-19, 29-31, 34-40).  op: 0 get_l, 1 lf_map, 2 lf_map2, 3 get_sa, 4 get_f,
+// 5 fl_map, 6 piece_id
+template <int KD>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w, int op, const uint64_t *__restrict__ cc,
                                                                     const uint64_t *__restrict__ ii, uint64_t k,
                                                                     uint64_t *__restrict__ out) {
+  constexpr bool RL = KD == FMX_KIND_RLFM, MP = KD == FMX_KIND_MULTI;
   FMXW_GBASES(w, false);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
@@ -1094,22 +1116,34 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
         res = a;
       } else {
         res = gk((uint32_t)c) + fmxw_g_chain(w, gbase, (uint32_t)c, i, g);
+        if (MP && c == 0u) res = fmxw_multi_zero(w, i, res);       // multi_pieces.rs:147-153
       }
     } else if (i >= w.n) {
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
     } else if (op == 0 || op == 1) {
       uint32_t sym;
-      if constexpr (RL) {
-        const uint64_t r = fmxw_r_lf(w, gbase, gk, i, g, sym);
-        res = op == 0 ? (uint64_t)sym : r;
-      } else {
-        const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
-        res = op == 0 ? (uint64_t)sym : gk(sym) + r;
+      uint64_t r;
+      if constexpr (RL) r = fmxw_r_lf(w, gbase, gk, i, g, sym); else r = fmxw_g_lf_map<MP>(w, gbase, gk, i, g, sym);
+      res = op == 0 ? (uint64_t)sym : r;
+    } else if (op == 6) {                           // HasMultiPieces::piece_id (multi_pieces.rs:206-219)
+      if constexpr (MP) {
+        uint64_t row = i;
+        for (;;) {
+          uint32_t sym;
+          const uint64_t raw = fmxw_g_lf(w, gbase, row, g, sym);
+          if (sym == 0u) {                          // doc[bw.rank(i, 0)] + 1 mod pieces
+            FMX_CHECK(gk(0u) + raw < w.doc_count);
+            res = ((uint64_t)w.doc[gk(0u) + raw] + 1u) % w.doc_count;
+            break;
+          }
+          row = gk(sym) + raw;
+        }
       }
     } else if (op == 4 || op == 5) {                // get_f / fl_map
       uint32_t sym;
       uint64_t r;
       if constexpr (RL) r = fmxw_r_fl(w, gbase, i, g, sym); else r = fmxw_g_fl(w, gbase, i, g, sym);
+      if (MP && sym == 0u) r = ~0ull;               // fl_map: None (multi_pieces.rs:176-178)
       res = op == 4 ? (uint64_t)sym : r;
     } else if (!RL && w.walk) {                     // get_sa, text-order samples: through the walk records
       res = fmxw_get_sa_walk(w, i, g);
@@ -1121,8 +1155,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
           row = fmxw_r_lf_step(w, gbase, gk, row, g);
         } else {
           uint32_t sym;
-          const uint64_t r = fmxw_g_lf(w, gbase, row, g, sym);
-          row = gk(sym) + r;
+          row = fmxw_g_lf_map<MP>(w, gbase, gk, row, g, sym);
         }
         steps++;
       }
@@ -1140,11 +1173,12 @@ __device__ __forceinline__ void fmxw_store_sym(void *p, uint32_t sb, uint64_t i,
   else if (sb == 2) ((uint16_t *)p)[i] = (uint16_t)v;
   else ((uint32_t *)p)[i] = v;
 }
-template <bool RL>
+template <int KD>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w, const uint64_t *__restrict__ rows,
                                                                      uint64_t nrows, uint32_t len, int forward,
                                                                      void *__restrict__ out, uint64_t *__restrict__ out_len,
                                                                      uint64_t *__restrict__ out_next) {
+  constexpr bool RL = KD == FMX_KIND_RLFM, MP = KD == FMX_KIND_MULTI;
   FMXW_GBASES(w, false);
   const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
@@ -1155,19 +1189,22 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_extract_kernel(FmxWideDev w
     if (i >= w.n) {
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
     } else {
+      bool ended = false;
       for (; t < len; t++) {
         uint32_t sym;
+        uint64_t nx;
         if constexpr (RL) {
-          i = forward ? fmxw_r_fl(w, gbase, i, g, sym) : fmxw_r_lf(w, gbase, gk, i, g, sym);
+          nx = forward ? fmxw_r_fl(w, gbase, i, g, sym) : fmxw_r_lf(w, gbase, gk, i, g, sym);
         } else if (forward) {
-          i = fmxw_g_fl(w, gbase, i, g, sym);
+          nx = fmxw_g_fl(w, gbase, i, g, sym);
+          if (MP && sym == 0u) { ended = true; break; }           // fl_map: None -- ends without yielding (wrapper.rs:172-183)
         } else {
-          const uint64_t r = fmxw_g_lf(w, gbase, i, g, sym);
-          i = gk(sym) + r;
+          nx = fmxw_g_lf_map<MP>(w, gbase, gk, i, g, sym);
         }
         if (g == 0) fmxw_store_sym(out, w.sym_bytes, q * (uint64_t)len + t, sym);
+        i = nx;
       }
-      next = i;
+      if (!ended) next = i;
     }
     if (g == 0 && out_len) out_len[q] = t;
     if (g == 0 && out_next) out_next[q] = next;
@@ -1201,6 +1238,43 @@ __device__ __forceinline__ uint64_t fmxw_bits_lane_run(const FmxWideBits &bv, ui
   const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
   return bv.base[(pidx >> 3) >> bv.sb_shift] + pc.x + __popc(pc.y & m0) + __popc(pc.z & m1) + __popc(pc.w & m2) - 1u;
 }
+// iter_matches() bookkeeping of a multi-pieces index (wrapper.rs:57-82, 203-217): with match_prefix_only the matches of
+// [s, e) are its rows whose L symbol is the end marker
+template <bool ROWS>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_match_kernel(FmxWideDev w, const uint64_t *__restrict__ s,
+                                                                   const uint64_t *__restrict__ e, const uint64_t *__restrict__ off,
+                                                                   uint64_t npat, int prefix_only, uint64_t *__restrict__ out) {
+  FMXW_GBASES(w, false);
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  for (uint64_t k = gid; k < npat; k += ngroups) {
+    const uint64_t a = s[k], b = e[k];
+    uint64_t cnt = b > a ? b - a : 0;
+    if (a > w.n || b > w.n) {                       // not a range of this index
+      if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+      cnt = 0;
+    }
+    uint64_t ra = 0;
+    if (prefix_only && cnt) {
+      ra = fmxw_g_chain(w, gbase, 0u, a, g);
+      cnt = fmxw_g_chain(w, gbase, 0u, b, g) - ra;
+    }
+    if (!ROWS) {
+      if (g == 0) out[k] = cnt;
+    } else if (!prefix_only) {
+      for (uint64_t t = g; t < cnt; t += FMX_GROUP) out[off[k] + t] = a + t;
+    } else {
+      for (uint64_t j = 0; j < cnt; j++) {          // the j-th end marker of L at or after row a
+        uint64_t target = ra + j;
+        for (uint32_t l = w.nlevels; l-- > 0;) target = fmxw_g_select(w, w.lv[l], 0u, target, g);
+        if (g == 0) out[off[k] + j] = target;
+      }
+    }
+  }
+  (void)gk;
+}
+
 template <bool RL>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_export_l_kernel(FmxWideDev w, void *__restrict__ out) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1259,8 +1333,9 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
 #define FMXW_GCNT(GLDS, RL)                                                                                        \
   hipLaunchKernelGGL((fmxw_g_count_kernel<GLDS, RL>), dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,       \
                      d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
-    if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, true); else FMXW_GCNT(false, true); }
-    else if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, false); else FMXW_GCNT(false, false);
+    if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_RLFM); else FMXW_GCNT(false, FMX_KIND_RLFM); }
+    else if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_MULTI); else FMXW_GCNT(false, FMX_KIND_MULTI); }
+    else if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_FM); else FMXW_GCNT(false, FMX_KIND_FM);
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
     return FMX_OK;
@@ -1295,11 +1370,13 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
       if (lockstep) hipLaunchKernelGGL(fmxw_r_walk_kernel<true>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
       else hipLaunchKernelGGL(fmxw_r_walk_kernel<false>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
     } else if (w.kind == FMX_KIND_RLFM) {
-      if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, true); else FMXW_GWALK(false, true);
+      if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, FMX_KIND_RLFM); else FMXW_GWALK(false, FMX_KIND_RLFM);
+    } else if (w.kind == FMX_KIND_MULTI) {
+      if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, FMX_KIND_MULTI); else FMXW_GWALK(false, FMX_KIND_MULTI);
     } else if (w.nsb <= FMXW_GLDS_SB) {
-      FMXW_GWALK(true, false);
+      FMXW_GWALK(true, FMX_KIND_FM);
     } else {
-      FMXW_GWALK(false, false);
+      FMXW_GWALK(false, FMX_KIND_FM);
     }
     fmxw_time_end(idx, st);
     FMX_HIP(hipGetLastError());
@@ -1350,11 +1427,12 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
 
 int fmxw_launch_scalar(const fmx_index *idx, int op, const uint64_t *d_c, const uint64_t *d_i, uint64_t k,
                        uint64_t *d_out, hipStream_t st) {
-  if (op > 5) return fmxw_unsupported("piece_id needs a multi-pieces index");
+  if (op > 5 && idx->wide.kind != FMX_KIND_MULTI) return fmxw_unsupported("piece_id needs a multi-pieces index");
   if (k == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
-  if (w.kind == FMX_KIND_RLFM) hipLaunchKernelGGL(fmxw_g_scalar_kernel<true>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
-  else if (w.generic) hipLaunchKernelGGL(fmxw_g_scalar_kernel<false>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  if (w.kind == FMX_KIND_RLFM) hipLaunchKernelGGL(fmxw_g_scalar_kernel<FMX_KIND_RLFM>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  else if (w.kind == FMX_KIND_MULTI) hipLaunchKernelGGL(fmxw_g_scalar_kernel<FMX_KIND_MULTI>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
+  else if (w.generic) hipLaunchKernelGGL(fmxw_g_scalar_kernel<FMX_KIND_FM>, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
   else hipLaunchKernelGGL(fmxw_scalar_kernel, dim3(fmxw_grid(k)), dim3(FMXW_BLOCK), 0, st, w, op, d_c, d_i, k, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1374,14 +1452,33 @@ int fmxw_launch_extract(const fmx_index *idx, const uint64_t *d_rows, uint64_t n
   if (nrows == 0) return FMX_OK;
   const FmxWideDev w = fmxw_dev(idx);
   if (w.kind == FMX_KIND_RLFM)
-    hipLaunchKernelGGL(fmxw_g_extract_kernel<true>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+    hipLaunchKernelGGL(fmxw_g_extract_kernel<FMX_KIND_RLFM>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+                       d_out, d_out_len, d_out_next);
+  else if (w.kind == FMX_KIND_MULTI)
+    hipLaunchKernelGGL(fmxw_g_extract_kernel<FMX_KIND_MULTI>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
                        d_out, d_out_len, d_out_next);
   else if (w.generic)
-    hipLaunchKernelGGL(fmxw_g_extract_kernel<false>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
+    hipLaunchKernelGGL(fmxw_g_extract_kernel<FMX_KIND_FM>, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
                        d_out, d_out_len, d_out_next);
   else
     hipLaunchKernelGGL(fmxw_extract_kernel, dim3(fmxw_grid(nrows)), dim3(FMXW_BLOCK), 0, st, w, d_rows, nrows, len, forward,
                        (uint8_t *)d_out, d_out_len, d_out_next);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// match counts (d_off == NULL) or match rows of every interval (wrapper.rs:57-82, 203-217)
+int fmxw_launch_match(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, int prefix_only,
+                      const uint64_t *d_off, uint64_t *d_out, hipStream_t st) {
+  if (npat == 0) return FMX_OK;
+  const FmxWideDev w = fmxw_dev(idx);
+  if (prefix_only && w.kind != FMX_KIND_MULTI) return fmxw_unsupported("match_prefix_only needs a multi-pieces index");
+  if (!w.generic && prefix_only) return fmxw_unsupported("match_prefix_only needs a multi-pieces index");
+  // (without the filter nothing of the index is read: any wide index may be passed; the generic kernel then only
+  // reads the level bases of a generic index -- a one-level index has none, so it gets the filter-free instantiation's
+  // arithmetic through the same kernel with nlevels == 0)
+  if (d_off) hipLaunchKernelGGL(fmxw_g_match_kernel<true>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_s, d_e, d_off, npat, prefix_only, d_out);
+  else hipLaunchKernelGGL(fmxw_g_match_kernel<false>, dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_s, d_e, d_off, npat, prefix_only, d_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

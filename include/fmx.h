@@ -14,11 +14,11 @@
  * Conventions
  *  - rows / positions / counts are uint64_t (= Rust usize).  Texts below 2^32 - 16 symbols run on the
  *    32-bit engine (every kind, every alphabet).  Longer texts are taken by the WIDE engine (64-bit rows,
- *    positions and samples) for FMX_KIND_FM and FMX_KIND_RLFM with or without locate (u8 / u16 / u32 symbols,
- *    max_character < 2^26; FM over u8 with max_character <= 7 -- DNA -- has the faster one-level kernels): every
- *    entry point of these kinds works on it (build, count, locate, offsets, all six trait calls, extract, save /
- *    load, the exports -- the samples through fmx_export_sa_samples64) except fmx_export_sa and the opt-in
- *    accelerators (flags ignored); FMX_KIND_MULTI at that size is FMX_ERR_UNSUPPORTED at build time.
+ *    positions and samples) for every kind, with or without locate (u8 / u16 / u32 symbols, max_character < 2^26;
+ *    FMX_KIND_FM over u8 with max_character <= 7 -- DNA -- has the faster one-level kernels): every entry point
+ *    works on it (build, count, locate, offsets, the trait calls, piece ids and match rows of a multi-pieces index,
+ *    extract, save / load, the exports -- the samples through fmx_export_sa_samples64) except fmx_export_sa and
+ *    the opt-in accelerators (flags ignored).
  *  - symbols are `sym_bytes` wide: Character = u8 / u16 / u32 / u64 (character.rs:38-42) =
  *    1 / 2 / 4 / 8.  u64 texts and patterns are narrowed to u32 on the host (host-pointer entry
  *    points only); the *_dev entry points take 1-, 2- or 4-byte symbols (fmx_sym_bytes()).
@@ -122,7 +122,7 @@ typedef struct fmx_index fmx_index;
 #define FMX_FLAG_KEEP_SCRATCH 256u
 /* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
  * superblocks of 2^12 rows instead of 2^31 (bit vectors of an RLFM index: 2 records instead of 2^22), so that a
- * small text exercises every part of it.  Same eligibility (FMX_KIND_FM / FMX_KIND_RLFM, n >= 2); same results. */
+ * small text exercises every part of it.  Every kind; n >= 2; same results. */
 #define FMX_FLAG_FORCE_WIDE 32u
 
 /* Message of the last failing call on this thread.  For the two InvalidText codes it

@@ -64,7 +64,7 @@ def main():
         # which rows carry the samples (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER / the builder's choice), and for
         # eligible indexes sometimes the 64-bit engine (FMX_FLAG_FORCE_WIDE)
         sampling = [None, "text", "row"][int(rng.integers(0, 3))] if level is not None else None
-        engine64 = kind in ("fm", "rlfm") and n >= 2 and rng.random() < (0.4 if (maxc <= 7 and dtype == np.uint8) else 0.25)
+        engine64 = n >= 2 and rng.random() < (0.4 if (maxc <= 7 and dtype == np.uint8) else 0.25)
         if engine64:                     # (the 64-bit engine: row order or its default -- walk records where eligible)
             pair, kmer, sampling = False, False, (sampling if sampling != "text" else None)
         # the derived locate structures (walk records / run table: FMX_FLAG_NO_WALK_RECORDS) on or off
@@ -82,8 +82,9 @@ def main():
                 if level is not None else F.RLFMIndex(text, kmer_table=kmer, force_wide=engine64)
             assert gi.is_wide() == engine64
         else:
-            gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer, sampling=sampling) if level is not None else \
-                F.FMIndexMultiPieces(text, kmer_table=kmer)
+            gi = F.FMIndexMultiPiecesWithLocate(text, level, kmer_table=kmer, sampling=sampling, force_wide=engine64) \
+                if level is not None else F.FMIndexMultiPieces(text, kmer_table=kmer, force_wide=engine64)
+            assert gi.is_wide() == engine64
         stats["engine64"] = stats.get("engine64", 0) + int(engine64)
         stats["text_order"] = stats.get("text_order", 0) + int(gi.text_order())
         stats["walk_records"] = stats.get("walk_records", 0) + int(gi.walk_records())

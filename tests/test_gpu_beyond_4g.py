@@ -33,7 +33,7 @@ def _run(alphabet="dna"):
     torch.cuda.empty_cache()
     dev = torch.device("cuda", 0)
     lib = L.lib()
-    dna, u16, rl = alphabet == "dna", alphabet == "u16", alphabet == "rlfm"
+    dna, u16, rl, mp = alphabet == "dna", alphabet == "u16", alphabet == "rlfm", alphabet == "multi"
     # DNA: the one-level engine; bytes: the generic wide engine (two 4-bit wavelet levels); u16: 2-byte symbols,
     # sigma = 1000 (4 + 3 + 3 bits), without the
     # oracle -- its u32 copy of the 2^32 symbols plus the exports would need ~50 GB of host memory
@@ -48,9 +48,14 @@ def _run(alphabet="dna"):
         text[N - 1] = 0
     elif rl:
         text = W.repetitive_text_torch(N, 17, dev, base_len=1 << 20, mut_per_1024=10)
+    elif mp:                                            # the byte text cut into 65 552 pieces of 2^16 symbols
+        text = W.byte_text_torch(N, 17, dev)
+        zpos = torch.arange(1, N >> 16, dtype=torch.int64, device=dev) * (1 << 16) + 100
+        text[zpos] = 0
+        zpos = torch.cat([zpos, torch.tensor([N - 1], dtype=torch.int64, device=dev)])
     else:
         text = W.dna_text_torch(N, 17, dev) if dna else W.byte_text_torch(N, 17, dev)
-    cls = F.RLFMIndexWithLocate if rl else F.FMIndexWithLocate
+    cls = F.RLFMIndexWithLocate if rl else F.FMIndexMultiPiecesWithLocate if mp else F.FMIndexWithLocate
     t0 = time.time()
     # keep_scratch: the three builds of this file share their 137+ GB of builder temporaries (FMX_FLAG_KEEP_SCRATCH; a
     # process that has cycled through the device's memory pays ~30 ms per GiB for every further hipMalloc)
@@ -76,11 +81,17 @@ def _run(alphabet="dna"):
         hi = (win[:-8] == 1000) & (win[1:-7] >= 800)    # the top 201 / 1000^2 of the rows
     else:
         hi = (win[:-8] == 255) & (win[1:-7] >= 245)
-    src_b = torch.nonzero(hi).flatten()[:1 << 13]
+    src_b = torch.nonzero(hi).flatten()
+    if mp:                                              # no pattern runs over an end marker (they sit at k 2^16 + 100)
+        src_b = src_b[((100 - src_b) & 65535) >= m]
+    src_b = src_b[:1 << 13]
     assert src_b.numel() >= 1 << 12
     del hi, win
     src_a = W.umod_torch(W.splitmix64_torch(13, 0, 1 << 15, dev), N - 1 - m)
     src_c = (1 << 32) + W.umod_torch(W.splitmix64_torch(14, 0, 1 << 14, dev), (1 << 20) - 1 - m)
+    if mp:
+        src_a = torch.where(((100 - src_a) & 65535) < m, src_a - m, src_a)
+        src_c = torch.where(((100 - src_c) & 65535) < m, src_c - m, src_c)
     src = torch.cat([src_b, src_a, src_c])
     npat = int(src.numel())
     pat = text[src[:, None] + torch.arange(m, dtype=torch.int64, device=dev)[None, :]].reshape(-1).contiguous()
@@ -117,6 +128,37 @@ def _run(alphabet="dna"):
     assert pos_hi >= int(src_c.numel())
     # ---- the oracle, from the exported L column and the exported 64-bit samples ----
     t0 = time.time()
+    if mp:
+        # ---- multi-pieces (multi_pieces.rs; no oracle import at this size): piece ids, the prefix filter, the end ----
+        # ---- markers' rows, against the text                                                                       ----
+        assert index.pieces_count() == int(zpos.numel())
+        sel = torch.arange(0, total, max(1, total // (1 << 16)), device=dev)[:1 << 16]
+        hrow = (s[hit[sel]] + (sel - d_off[hit[sel]])).cpu().numpy().view(np.uint64)       # the rows of those hits
+        ids = index.piece_id(hrow)
+        want = torch.searchsorted(zpos, d_pos[sel]).cpu().numpy()      # end markers before the position
+        assert (ids == want.astype(np.uint64)).all()
+        # search_prefix: patterns cut right behind an end marker; every match row's position is a piece start
+        starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), zpos[:4095] + 1])
+        ppat = text[starts[:, None] + torch.arange(4, dtype=torch.int64, device=dev)[None, :]].cpu().numpy()
+        pb = index.search_many(flat=ppat.reshape(-1), off=np.arange(4097, dtype=np.uint64) * 4)
+        poff, prow = index.match_rows_many(pb.s, pb.e, True)
+        assert (np.diff(poff.astype(np.int64)) >= 1).all()
+        ppos = torch.from_numpy(index.get_sa(prow).astype(np.int64)).to(dev)
+        assert bool(((ppos == 0) | (text[torch.clamp(ppos - 1, min=0)] == 0)).all())
+        assert bool(torch.isin(starts, ppos).all())
+        # lf_map2(0, .): the end markers' rows are rows 0 .. pieces - 1 in piece order, the last piece's first
+        zr = index.lf_map2(np.zeros(2, np.uint64), np.array([0, N], np.uint64))
+        assert zr.tolist() == [1, index.pieces_count()]                # multi_pieces.rs:147-153 at both ends
+        res = {"kind": "multi", "alphabet": alphabet, "max_character": sigma, "n": N, "level": level,
+               "pieces": index.pieces_count(), "patterns": npat, "pattern_len": m, "hits": total,
+               "intervals_with_e_beyond_2^32": rows_hi, "positions_beyond_2^32": pos_hi, "verify_sa_violations": 0,
+               "piece_ids_checked": int(sel.numel()), "prefix_patterns": 4096, "oracle": "not run (no multi import)",
+               "build_ms": round(float(lib.fmx_build_ms(h)), 1), "verify_sa_s": round(verify_s, 2),
+               "index_bytes": index.heap_size(), "wide": index.is_wide()}
+        index.close()
+        del text, pat, d_pos
+        torch.cuda.empty_cache()
+        return res
     if u16:
         res = {"kind": "fm", "alphabet": alphabet, "max_character": sigma, "sym_bytes": 2, "n": N, "level": level,
                "patterns": npat, "pattern_len": m, "hits": total, "intervals_with_e_beyond_2^32": rows_hi,
@@ -212,6 +254,13 @@ def test_rlfm_index_beyond_4g_symbols():
     the exported L column."""
     out = _run("rlfm")
     assert out["wide"] and out["kind"] == "rlfm"
+
+
+def test_multi_pieces_index_beyond_4g_symbols():
+    """FMIndexMultiPiecesWithLocate at n = 2^32 + 2^20 (multi_pieces.rs is usize throughout; VERDICT r3 missing 2): the byte
+    text cut into 65 552 pieces; the text properties, piece ids against the marker positions, the prefix filter."""
+    out = _run("multi")
+    assert out["wide"] and out["kind"] == "multi" and out["pieces"] == (N >> 16)
 
 
 def test_u16_index_beyond_4g_symbols():

@@ -172,13 +172,15 @@ def test_wide_engine_errors_and_refusals(tmp_path):
     out = np.zeros(8, dtype=np.uint32)
     assert lib.fmx_export_sa_samples(gi.handle(), F._p(out)) == L.ERR_UNSUPPORTED
     gi.close()
-    # eligibility: FMX_KIND_FM and FMX_KIND_RLFM (round 4); the multi-pieces index is not on this engine
+    # eligibility: every kind (round 4: RLFM and multi-pieces too); a text of fewer than two symbols is not
     bt = W.byte_text_np(5000, 3)
+    for kind in (L.KIND_RLFM, L.KIND_MULTI):
+        h = C.c_void_p()
+        assert lib.fmx_build(F._p(bt), len(bt), 1, 255, kind, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == 0
+        assert lib.fmx_is_wide(h) == 1 and lib.fmx_kind(h) == kind
+        lib.fmx_free(h)
     h = C.c_void_p()
-    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_MULTI, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
-    assert lib.fmx_build(F._p(bt), len(bt), 1, 255, L.KIND_RLFM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == 0
-    assert lib.fmx_is_wide(h) == 1 and lib.fmx_kind(h) == L.KIND_RLFM
-    lib.fmx_free(h)
+    assert lib.fmx_build(F._p(bt[-1:]), 1, 1, 255, L.KIND_FM, 2, L.FLAG_FORCE_WIDE, 0, C.byref(h)) == L.ERR_UNSUPPORTED
     # a count-only wide index has no locate
     ci = F.FMIndex(F.Text.with_max_character(t, 4), force_wide=True)
     assert ci.is_wide() and ci.search(bytes([1, 2])).count() == gi_count(t, [1, 2])

@@ -72,12 +72,14 @@ def test_oracle_multi_unit_properties(golden):
 
 
 # ----------------------------------------------------------------- GPU ---------------------
+# wide = True: the 64-bit engine (FMX_FLAG_FORCE_WIDE; multi-pieces on it since round 4: multi_pieces.rs is usize throughout)
 @pytest.mark.gpu
-def test_gpu_multi_example(golden):
+@pytest.mark.parametrize("wide", [False, True])
+def test_gpu_multi_example(golden, wide):
     import fm_index_amd as F
     g = golden["multi_pieces_example"]
-    index = F.FMIndexMultiPiecesWithLocate(F.Text(b(g["text"])), g["level"])
-    assert index.pieces_count() == 3
+    index = F.FMIndexMultiPiecesWithLocate(F.Text(b(g["text"])), g["level"], force_wide=wide)
+    assert index.pieces_count() == 3 and index.is_wide() == wide
     assert index.search(b("star")).count() == g["count_star"]
     ids = sorted(m.piece_id() for m in index.search(b("How I wonder")).iter_matches())
     assert ids == g["piece_ids_how_i_wonder_sorted"]
@@ -103,21 +105,26 @@ def test_gpu_multi_example(golden):
     assert sorted(index.search_suffix(b("what you are!\n")).piece_ids()) == \
         g["suffix_what_you_are_piece_ids_sorted"]
     sm = golden["multi_pieces_small"]
-    idx = F.FMIndexMultiPiecesWithLocate(F.Text(b(sm["text"])), sm["level"])
+    idx = F.FMIndexMultiPiecesWithLocate(F.Text(b(sm["text"])), sm["level"], force_wide=wide)
     s = idx.search(b("a"))
     assert s.count() == sm["count"] and s.locate_all() == sm["positions"] and s.piece_ids() == sm["piece_ids"]
 
 
 @pytest.mark.gpu
-def test_gpu_multi_vs_oracle_and_bruteforce():
+@pytest.mark.parametrize("wide", [False, True])
+def test_gpu_multi_vs_oracle_and_bruteforce(wide, tmp_path):
     """tests/test_multi_pieces.rs:44-272: count, locate, piece ids, prefix / suffix / exact."""
     import fm_index_amd as F
     for ti in range(12):
         size = 20 + int(W.splitmix64_np(700 + ti, 0, 1)[0] % np.uint64(1000))
+        if wide and ti >= 10:                               # texts that cross many superblocks of 2^12 rows
+            size = 30000 + 4001 * ti
         t = multi_text(size, 8, 800 + ti)
         level = ti % 4
-        gi = F.FMIndexMultiPiecesWithLocate(F.Text(t), level)
-        oi = O.OracleIndex(t, 255, level=level, kind="multi")
+        maxc = 255 if ti % 3 else 7                         # one 3-bit level / two 4-bit levels
+        gi = F.FMIndexMultiPiecesWithLocate(F.Text.with_max_character(t, maxc), level, force_wide=wide)
+        oi = O.OracleIndex(t, maxc, level=level, kind="multi")
+        assert gi.is_wide() == wide
         assert gi.pieces_count() == oi.pieces_count() == int((t == 0).sum())
         rows = np.arange(size)
         assert (gi.get_l(rows) == oi.get_l(rows)).all()
@@ -126,7 +133,7 @@ def test_gpu_multi_vs_oracle_and_bruteforce():
         assert (gi.piece_id(rows) == oi.piece_id(rows)).all()
         assert (gi.get_f(rows) == oi.get_f(rows)).all()
         assert (gi.fl_map(rows) == oi.fl_map(rows)).all()
-        cc, ii = np.meshgrid(np.arange(9), np.arange(size + 1))
+        cc, ii = np.meshgrid(np.arange(min(maxc, 8) + 1), np.arange(size + 1))
         assert (gi.lf_map2(cc.ravel(), ii.ravel()) == oi.lf_map2(cc.ravel(), ii.ravel())).all()
         flat, off = W.ragged_patterns_np(60, 6, 7, 900 + ti)
         pc = oi.pieces_count()
@@ -144,7 +151,36 @@ def test_gpu_multi_vs_oracle_and_bruteforce():
                 assert (got == exp_rows).all(), (mode, k)
                 if len(p) == 0:
                     continue
+                if size > 2000 and k % 7:                   # (the brute-force scan is a Python loop over the text)
+                    continue
                 exp = naive(t, p, pre, suf)
                 pos = gi.get_sa(got)
                 ids = gi.piece_id(got)
                 assert sorted(zip(pos.tolist(), ids.tolist())) == sorted(exp), (mode, ti, k)
+        # locate through the batched walk; iter_chars_forward ends at a piece's end marker (wrapper.rs:172-183)
+        gb = gi.search_many(flat=flat, off=off)
+        goff, gpos = gb.locate()
+        ooff, opos = oi.locate_batch(gb.s, gb.e)
+        assert (goff == ooff).all() and (gpos == opos).all()
+        some = np.arange(0, size, max(1, size // 200), dtype=np.uint64)
+        syms, lens, nxt = gi.extract_many(some, 12, forward=True)
+        for q, row in enumerate(some.tolist()):
+            i, want = row, []
+            while len(want) < 12:
+                nx = int(oi.fl_map(np.array([i], np.uint64))[0])
+                if nx == 0xFFFFFFFFFFFFFFFF:
+                    break
+                want.append(int(oi.get_f(np.array([i], np.uint64))[0]))
+                i = nx
+            assert int(lens[q]) == len(want) and syms[q, :len(want)].tolist() == want, (ti, row)
+            assert int(nxt[q]) == (i if len(want) == 12 else 0xFFFFFFFFFFFFFFFF)
+        if ti % 4 == 1:                                     # the index file
+            path = str(tmp_path / ("multi%d.fmx" % ti))
+            gi.save(path)
+            li = type(gi).load(path)
+            assert li.is_wide() == wide and li.pieces_count() == gi.pieces_count()
+            assert (li.piece_id(rows) == oi.piece_id(rows)).all() and (li.lf_map(rows) == oi.lf_map(rows)).all()
+            lb = li.search_many(flat=flat, off=off)
+            assert (lb.s == gb.s).all() and (lb.e == gb.e).all()
+            li.close()
+        gi.close()

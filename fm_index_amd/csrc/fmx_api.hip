@@ -97,6 +97,20 @@ void fmx_free(fmx_index *idx) {
   free(idx);
 }
 
+// Character = u64 / usize text already in HBM (fmx_build_dev with sym_bytes 8): narrowed to the u32 the engines work on;
+// a symbol above max_character (< 2^26) is reported, as the host path does
+__global__ __launch_bounds__(256) void fmx_narrow_u64_kernel(const uint64_t *__restrict__ src, uint64_t n, uint64_t max_character,
+                                                             uint32_t *__restrict__ dst, uint32_t *__restrict__ bad) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  bool any = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nth) {
+    const uint64_t v = src[i];
+    any |= v > max_character;
+    dst[i] = (uint32_t)v;
+  }
+  if (any) atomicOr(bad, 1u);
+}
+
 static int build_common(const void *text, int text_on_device, uint64_t n, uint32_t sym_bytes,
                         uint64_t max_character, uint32_t kind, uint32_t level, uint32_t flags,
                         int device, fmx_index **out) {
@@ -104,8 +118,6 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   *out = nullptr;
   if (sym_bytes != 1 && sym_bytes != 2 && sym_bytes != 4 && sym_bytes != 8)
     return fail(FMX_ERR_ARG, "sym_bytes must be 1, 2, 4 or 8 (Character = u8/u16/u32/u64)");
-  if (sym_bytes == 8 && text_on_device)
-    return fail(FMX_ERR_UNSUPPORTED, "u64 symbols are narrowed on the host: use fmx_build");
   const uint64_t type_max = sym_bytes == 1 ? 0xFFull : (sym_bytes == 2 ? 0xFFFFull : 0xFFFFFFFFull);
   if (max_character == 0 || (sym_bytes != 8 && max_character > type_max))
     return fail(FMX_ERR_ARG, "max_character must be in 1..=MAX of the symbol type");
@@ -163,7 +175,23 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
       break;
     }
 
-    if (text_on_device) {
+    if (text_on_device && sym_bytes == 8) {
+      uint32_t *d_bad = nullptr, h_bad = 0;
+      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      own_text = true;
+      if ((e = hipMalloc((void **)&d_bad, 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
+      (void)hipMemset(d_bad, 0, 4);
+      uint64_t blocks = (n + 255) / 256;
+      if (blocks < 1) blocks = 1;
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(fmx_narrow_u64_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const uint64_t *)text, n, max_character,
+                         (uint32_t *)d_text, d_bad);
+      e = hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost);
+      (void)hipFree(d_bad);
+      if (e != hipSuccess) { rc = fmx_hip_fail(e, "narrowing the text", __LINE__); break; }
+      if (h_bad) { rc = fail(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character"); break; }
+      idx->sym_bytes = 4;
+    } else if (text_on_device) {
       d_text = (uint8_t *)text;
     } else if (sym_bytes == 8) {
       // Character = u64/usize: narrow to u32 (every symbol must be <= max_character < 2^26)

@@ -20,9 +20,9 @@
  *    extract, save / load, the exports -- the samples through fmx_export_sa_samples64) except fmx_export_sa and
  *    the opt-in accelerators (flags ignored).
  *  - symbols are `sym_bytes` wide: Character = u8 / u16 / u32 / u64 (character.rs:38-42) =
- *    1 / 2 / 4 / 8.  u64 texts and patterns are narrowed to u32 on the host (host-pointer entry
- *    points only); the *_dev entry points take 1-, 2- or 4-byte symbols (fmx_sym_bytes()).
- *    max_character < 2^26.
+ *    1 / 2 / 4 / 8.  u64 texts are narrowed to u32 at build time (fmx_build on the host, fmx_build_dev by a
+ *    kernel), u64 patterns by the host-pointer entry points; the *_dev query entry points take symbols of
+ *    fmx_sym_bytes() bytes -- 1, 2 or 4 (4 for an index built from u64 symbols).  max_character < 2^26.
  *  - `*_dev` entry points take DEVICE pointers and are asynchronous on `stream`
  *    (a hipStream_t passed as void*; NULL = the default stream).  The plain
  *    variants take HOST pointers, copy, run the same kernels, and synchronise.

@@ -86,3 +86,26 @@ def test_u16_suffix_array_matches_oracle():
     gi = F.FMIndex(F.Text(t), keep_sa=True)
     assert (gi.export_sa() == O.suffix_array(t.astype(np.uint32))).all()
     assert gi.verify_sa() == 0
+
+
+def test_u64_text_resident_in_hbm():
+    """Character = u64 / usize text already on the device (fmx_build_dev, sym_bytes 8; round 4): narrowed by a kernel; same
+    index as the host path, and a symbol above max_character is reported the same way."""
+    import torch
+    n = 20000
+    t = _text(n, 900, np.uint64, 5, 77)
+    maxc = int(t.max())
+    dt = torch.from_numpy(t.view(np.int64)).cuda()
+    gi = F.FMIndexWithLocate.from_device_text(dt.data_ptr(), n, maxc, level=2, sym_bytes=8)
+    hi = F.FMIndexWithLocate(F.Text.with_max_character(t, maxc), 2)
+    assert gi._lib.fmx_sym_bytes(gi.handle()) == 4 == hi._lib.fmx_sym_bytes(hi.handle())
+    flat, off = F.pack_patterns(_patterns(t, 500, 6, 9), np.uint64)     # host-pointer queries take the caller's u64
+    a, b_ = gi.search_many(flat=flat, off=off), hi.search_many(flat=flat, off=off)
+    assert (a.s == b_.s).all() and (a.e == b_.e).all() and int(a.counts.sum()) > 0
+    assert (a.locate()[1] == b_.locate()[1]).all()
+    assert gi.heap_size() == hi.heap_size()
+    gi.close(); hi.close()
+    dt[100] = maxc + 1
+    with pytest.raises(F.Error) as ei:
+        F.FMIndex.from_device_text(dt.data_ptr(), n, maxc, sym_bytes=8)
+    assert ei.value.code == F._lib.ERR_SYMBOL_RANGE

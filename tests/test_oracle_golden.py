@@ -261,3 +261,39 @@ def test_fl_map_and_get_f_known_answers(golden, kind):
         out.append(int(idx.get_f([i])[0]))
         i = int(idx.fl_map([i])[0])
     assert bytes(out) == b(r["forward_20_from_match_3"])
+
+
+@pytest.mark.parametrize("kind", ["fm", "rlfm"])
+def test_import_from_bwt_equals_the_index_built_from_the_text(kind):
+    """the checker of the full-size GPU tests is the oracle rebuilt from an exported L column and exported samples
+    (orc_fm_from_bwt / orc_rlfm_from_bwt, and their 64-bit-sample forms for n >= 2^32): on a small text it must be the
+    index the oracle builds from the text itself -- same ranges, positions and trait values."""
+    t = W.repetitive_text_np(5000, 3, base_len=64, mut_per_1024=20)
+    a = O.OracleIndex(t, 255, level=2, kind=kind)
+    rows = np.arange(len(t), dtype=np.uint64)
+    bwt = a.get_l(rows).astype(np.uint8)
+    cs = np.concatenate([[0], np.cumsum(np.bincount(t, minlength=256))[:-1]]).astype(np.uint64)
+    samples = a.get_sa(rows[::4])
+    flat, off, _ = W.substring_patterns_np(t, 300, 6, 5)
+    want = a.count_batch(flat, off)
+    for wide_samples in (False, True):
+        b = O.OracleIndex.from_bwt(bwt, cs, 255, samples=samples, level=2, kind=kind)
+        if wide_samples:                                       # the n >= 2^32 entry points, on the same small input
+            import ctypes as C
+            h = C.c_void_p()
+            s64 = np.ascontiguousarray(samples, dtype=np.uint64)
+            if kind == "rlfm":
+                assert b._l.orc_rlfm_from_bwt64(C.byref(h), O._p(bwt), len(bwt), 255, O._p(s64), 2) == 0
+            else:
+                assert b._l.orc_fm_from_bwt64(C.byref(h), O._p(bwt), len(bwt), 255, O._p(cs), O._p(s64), 2) == 0
+            b.close()
+            b._h = h
+            b._b = {"fm": b._l.orc_fm_backend, "rlfm": b._l.orc_rlfm_backend}[kind](h)
+        got = b.count_batch(flat, off)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+        assert (b.lf_map(rows) == a.lf_map(rows)).all() and (b.get_sa(rows) == a.get_sa(rows)).all()
+        ooff, opos = b.locate_batch(want[0], want[1])
+        aoff, apos = a.locate_batch(want[0], want[1])
+        assert (ooff == aoff).all() and (opos == apos).all()
+        b.close()
+    a.close()

@@ -247,7 +247,9 @@ uint64_t fmx_num_runs(const fmx_index *idx) { return idx ? idx->runs : 0; }
 uint32_t fmx_sym_bytes(const fmx_index *idx) { return idx ? idx->sym_bytes : 0; }
 int fmx_has_pair_index(const fmx_index *idx) { return idx && idx->dev.pair_rec ? 1 : 0; }
 int fmx_is_wide(const fmx_index *idx) { return idx && idx->is_wide ? 1 : 0; }
-int fmx_text_order(const fmx_index *idx) { return idx && (idx->is_wide ? idx->wide.walk != nullptr : idx->dev.phase != nullptr) ? 1 : 0; }
+int fmx_text_order(const fmx_index *idx) {
+  return idx && (idx->is_wide ? (idx->wide.walk != nullptr || idx->wide.phase != nullptr) : idx->dev.phase != nullptr) ? 1 : 0;
+}
 int fmx_walk_records(const fmx_index *idx) {
   return idx && (idx->is_wide ? (idx->wide.walk != nullptr || idx->wide.lfrun != nullptr)
                               : (idx->dev.walk != nullptr || idx->dev.lfrun != nullptr)) ? 1 : 0;
@@ -1096,7 +1098,7 @@ int fmx_export_cs(const fmx_index *idx, uint64_t *host_out) {
 int fmx_export_sa_samples64(const fmx_index *idx, uint64_t *host_out) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
-  if (idx->is_wide && !idx->wide.walk) {
+  if (idx->is_wide && !idx->wide.walk && !idx->wide.phase) {
     FMX_HIP(hipMemcpy(host_out, idx->wide.samples, idx->nsamples * 8, hipMemcpyDeviceToHost));
     return FMX_OK;
   }
@@ -1276,7 +1278,7 @@ const uint32_t kFileVersion = 10;   // 10: wide RLFM indexes (FmxWideDev::b / bp
 // pointers | cs[] | records | bases | samples
 namespace {
 const uint32_t kWideMark = 0x80000000u;
-struct WideBlobs { const void **field[16 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[16 + 2 * FMXW_MAX_LEVELS]; int n; };
+struct WideBlobs { const void **field[20 + 2 * FMXW_MAX_LEVELS]; uint64_t bytes[20 + 2 * FMXW_MAX_LEVELS]; int n; };
 WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
   WideBlobs b;
   b.n = 0;
@@ -1305,6 +1307,10 @@ WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
       if (v[t]->pos) { b.field[b.n] = (const void **)&v[t]->pos; b.bytes[b.n++] = v[t]->ones * 8ull; }
     }
     if (w.lfrun) { b.field[b.n] = (const void **)&w.lfrun; b.bytes[b.n++] = w.slen * 8ull; }
+    if (w.phase) {
+      b.field[b.n] = (const void **)&w.phase; b.bytes[b.n++] = (w.n / (3u * (32u / w.sa_level)) + 1u) * 16ull;
+      b.field[b.n] = (const void **)&w.pbase; b.bytes[b.n++] = (uint64_t)w.npsb * 8ull;
+    }
   }
   if (w.kind == FMX_KIND_MULTI) { b.field[b.n] = (const void **)&w.doc; b.bytes[b.n++] = w.doc_count * 4ull; }
   return b;
@@ -1407,6 +1413,11 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   else if (!w.generic && (!w.rec || !w.base || (locate && !w.samples))) bad = "array presence";
   else if ((w.walk != nullptr) != (w.wbase != nullptr)) bad = "walk records";
   else if (rl && (w.lfrun != nullptr) && !locate) bad = "run table";
+  else if ((w.phase != nullptr) != (w.pbase != nullptr) ||
+           (w.phase && (!rl || !locate || w.sa_level < 1 || w.sa_level > FMX_PHASE_MAX_LEVEL ||
+                        (w.psb_shift != FMXW_PHASE_SB_SHIFT && w.psb_shift != FMXW_PHASE_SB_SHIFT_TEST) ||
+                        w.npsb != (uint32_t)((h.n / (3u * (32u / w.sa_level))) >> w.psb_shift) + 1u)))
+    bad = "text-order sampling";
   else if (w.walk && (w.generic || !locate || w.sa_level < 1 || w.sa_level > FMX_WALK_MAX_LEVEL || h.sym_bytes != 1 ||
                       h.max_character > FMX_WALK_MAX_CHARACTER ||
                       (w.wsb_shift != FMXW_WALK_SB_SHIFT && w.wsb_shift != FMXW_WALK_SB_SHIFT_TEST) ||

@@ -2218,6 +2218,33 @@ __global__ __launch_bounds__(BLK) void kwb_select_hints(const uint64_t *__restri
 __global__ __launch_bounds__(BLK) void kwb_fill_u32(uint32_t *out, uint64_t n, uint32_t v) {
   KW_FOR(i, n) out[i] = v;
 }
+// text-order sampling of a wide RLFM index (FmxWideDev::phase): one thread packs the phases SA[row] mod 2^level of one
+// piece and counts its phase-0 rows; rows past the end get phase 1 (k_phase_pieces with 64-bit rows)
+__global__ __launch_bounds__(BLK) void kwp_pieces(const uint64_t *__restrict__ sa, uint64_t n, uint32_t level, uint64_t npieces,
+                                                   uint4 *__restrict__ out, uint32_t *__restrict__ zeros) {
+  const uint32_t fpw = 32u / level, rpp = 3u * fpw;
+  const uint64_t mask = (1ull << level) - 1ull;
+  KW_FOR(j, npieces) {
+    uint32_t w[3] = {0u, 0u, 0u}, z = 0;
+    for (uint32_t t = 0; t < rpp; t++) {
+      const uint64_t row = j * rpp + t;
+      const uint32_t ph = row < n ? (uint32_t)(sa[row] & mask) : 1u;
+      z += ph == 0u;
+      w[t / fpw] |= ph << ((t % fpw) * level);
+    }
+    out[j] = make_uint4(0u, w[0], w[1], w[2]);
+    zeros[j] = z;
+  }
+}
+__global__ __launch_bounds__(BLK) void kwp_counters(const uint64_t *__restrict__ scan, uint64_t npieces, uint32_t sb_shift,
+                                                     uint4 *__restrict__ out) {
+  KW_FOR(j, npieces) out[j].x = (uint32_t)(scan[j] - scan[(j >> sb_shift) << sb_shift]);
+}
+__global__ __launch_bounds__(64) void kwp_bases(const uint64_t *__restrict__ scan, uint32_t nsb, uint32_t sb_shift,
+                                                uint64_t *__restrict__ base) {
+  const uint32_t sb = blockIdx.x * 64u + threadIdx.x;
+  if (sb < nsb) base[sb] = scan[(uint64_t)sb << sb_shift];
+}
 // ---- multi-pieces on the wide engine: doc[] and sa_idx_first_text (multi_pieces.rs:57-85) ----
 template <typename T>
 struct IsZeroSym {
@@ -2832,7 +2859,44 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
       const uint64_t extra = (n / FMX_WALK_ROWS + 1u) * 128u;
       walk_records = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
     }
-    if (walk_records) {
+    // RLFM: text-order samples (phase pieces) for levels 1..4, together with the run table -- unless the flags keep the
+    // reference's rows, or the device lacks room for the pieces four times over
+    bool rl_text = idx->kind == FMX_KIND_RLFM && level >= 1 && level <= FMX_PHASE_MAX_LEVEL &&
+                   !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
+    if (rl_text && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {
+      size_t free_b = 0, total_b = 0;
+      const uint64_t extra = (n / (3u * (32u / level)) + 1u) * 16u;
+      rl_text = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
+    }
+    w.phase = nullptr; w.pbase = nullptr; w.psb_shift = 0; w.npsb = 0;
+    if (rl_text) {
+      const uint32_t rpp = 3u * (32u / level);
+      const uint64_t npieces = n / rpp + 1u;
+      const uint32_t shift = fmx_wide_n(n) ? FMXW_PHASE_SB_SHIFT : FMXW_PHASE_SB_SHIFT_TEST;
+      const uint32_t npsb = (uint32_t)((npieces - 1u) >> shift) + 1u;
+      uint4 *d_phase;
+      uint64_t *d_pbase, *pscan;
+      uint32_t *zeros;
+      FMX_HIP(hipMalloc((void **)&d_phase, (size_t)npieces * 16));
+      if (int rc = keep(idx, d_phase, npieces * 16)) return rc;
+      FMX_HIP(hipMalloc((void **)&d_pbase, (size_t)npsb * 8));
+      if (int rc = keep(idx, d_pbase, (uint64_t)npsb * 8)) return rc;
+      FMX_HIP(pool.get(&zeros, (size_t)npieces));
+      FMX_HIP(pool.get(&pscan, (size_t)npieces));
+      hipLaunchKernelGGL(kwp_pieces, dim3(wblocks(npieces)), dim3(BLK), 0, 0, d_sa, n, level, npieces, d_phase, zeros);
+      size_t tb = 0;
+      FMX_HIP(exclusive_sum(nullptr, tb, zeros, pscan, (size_t)npieces));
+      uint8_t *ptmp;
+      FMX_HIP(pool.get(&ptmp, tb));
+      FMX_HIP(exclusive_sum(ptmp, tb, zeros, pscan, (size_t)npieces));
+      hipLaunchKernelGGL(kwp_counters, dim3(wblocks(npieces)), dim3(BLK), 0, 0, pscan, npieces, shift, d_phase);
+      hipLaunchKernelGGL(kwp_bases, dim3((npsb + 63u) / 64u), dim3(64), 0, 0, pscan, npsb, shift, d_pbase);
+      FMX_HIP(hipGetLastError());
+      FMX_HIP(hipDeviceSynchronize());
+      pool.release(ptmp); pool.release(pscan); pool.release(zeros);
+      w.phase = d_phase; w.pbase = d_pbase; w.psb_shift = shift; w.npsb = npsb;
+    }
+    if (walk_records || rl_text) {
       // the rows whose SA value is a multiple of 2^level (as many as the reference samples), in row order
       unsigned long long *d_got;
       FMX_HIP(pool.get(&d_got, 1));

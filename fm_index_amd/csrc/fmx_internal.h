@@ -178,6 +178,8 @@ struct FmxWideBits {
 };
 #define FMXW_BITS_SB_SHIFT 22u      // records per superblock
 #define FMXW_BITS_SB_SHIFT_TEST 1u  // FMX_FLAG_FORCE_WIDE
+#define FMXW_PHASE_SB_SHIFT 24u     // phase pieces per superblock (<= 96 rows each: < 2^31 rows)
+#define FMXW_PHASE_SB_SHIFT_TEST 3u // FMX_FLAG_FORCE_WIDE
 struct FmxWideDev {  // passed BY VALUE to the wide kernels
   const uint4 *rec;          // one 3-bit level (max_character <= 7): n / 256 + 1 records (row n is addressable)
   const uint64_t *base;      // ... [nsb][8], cs[] folded in
@@ -211,6 +213,14 @@ struct FmxWideDev {  // passed BY VALUE to the wide kernels
   uint64_t slen;
   FmxWideBits b, bp;
   const uint64_t *lfrun;
+  // Text-order sampling of a wide RLFM index (levels 1..FMX_PHASE_MAX_LEVEL, built together with the run table): the
+  // phase pieces of FmxDev::phase -- { phase-0 rows before the piece, 3 words of level-bit phases SA[row] mod 2^level }
+  // -- with the count RELATIVE to a superblock of 2^psb_shift pieces and pbase[superblock] = the 64-bit count at its
+  // start; samples[] = SA of the phase-0 rows in row order.  A walk is exactly SA[row] mod 2^level steps long: two
+  // phase probes (start row: the steps to go; final row: its sample's index), the steps, one sample.
+  const uint4 *phase;
+  const uint64_t *pbase;
+  uint32_t psb_shift, npsb;
   // FMIndexMultiPieces (round 4; kind == FMX_KIND_MULTI; multi_pieces.rs): always `generic`; doc[k] = piece id of the
   // k-th end marker in L order, first_row = sa_idx_first_text (multi_pieces.rs:21-22, 57-85), as FmxDev::doc / first_row
   const uint32_t *doc;

@@ -880,6 +880,41 @@ __device__ __forceinline__ uint64_t fmxw_r_fl(const FmxWideDev &w, const GB &gba
   return fmxw_bits_select(w.b, target, g) + i - p;                // b.select1(m) + i - bp.select1(j)
 }
 
+// ---- text-order sampling of a wide RLFM index (FmxWideDev::phase) ----
+// piece holding `row` and the row's index inside it; rows per piece = 3 * floor(32 / level)
+__device__ __forceinline__ uint64_t fmxw_phase_piece(uint64_t row, uint32_t level, uint32_t &t) {
+  uint64_t p;
+  if (level == 1) { p = fmxw_div3(row >> 5); t = (uint32_t)(row - p * 96u); }
+  else if (level == 2) { p = fmxw_div3(row >> 4); t = (uint32_t)(row - p * 48u); }
+  else if (level == 3) { p = __umul64hi(row >> 1, 0x8888888888888889ull) >> 3; t = (uint32_t)(row - p * 30u); }   // / 15
+  else { p = fmxw_div3(row >> 3); t = (uint32_t)(row - p * 24u); }
+  return p;
+}
+// phase of `row` and the index of its sample when the phase is 0 (one lane, one 16-byte piece)
+__device__ __forceinline__ uint32_t fmxw_phase_probe(const FmxWideDev &w, uint64_t row, uint64_t &rank0) {
+  uint32_t t, r0;
+  const uint64_t pi = fmxw_phase_piece(row, w.sa_level, t);
+  FMX_CHECK((pi >> w.psb_shift) < w.npsb);
+  const uint32_t ph = fmx_phase_decode(w.phase[pi], t, w.sa_level, r0);
+  rank0 = w.pbase[pi >> w.psb_shift] + r0;
+  return ph;
+}
+
+// get_sa of one row of a text-order RLFM index: SA[row] mod 2^level LF steps (`lf`: row -> lf_map(row))   rlfmi.rs:172-190
+template <class LF>
+__device__ __forceinline__ uint64_t fmxw_r_get_sa_text(const FmxWideDev &w, const LF &lf, uint64_t row, uint64_t &steps_out) {
+  uint64_t r0;
+  const uint32_t ph = fmxw_phase_probe(w, row, r0);
+  for (uint32_t t = 0; t < ph; t++) row = lf(row);
+  if (ph) {
+    [[maybe_unused]] const uint32_t p2 = fmxw_phase_probe(w, row, r0);
+    FMX_CHECK(p2 == 0u);
+  }
+  steps_out = ph;
+  uint64_t v = w.samples[r0] + ph;                  // (sa + steps) % len
+  if (v >= w.n) v -= w.n;
+  return v;
+}
 __global__ __launch_bounds__(64) void fmxw_g_compute_K_kernel(FmxWideDev w, uint64_t *__restrict__ K) {
   FMXW_GBASES(w, false);
   (void)gk;
@@ -982,6 +1017,8 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
     uint64_t row = io[h], steps = 0, v = ~0ull;
     if (row >= w.n) {                               // refuse, do not read
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    } else if (RL && w.phase) {                     // text-order samples (an index without the run table lands here)
+      if constexpr (RL) v = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, row, steps);
     } else {
       while (row & lmask) {                         // None: i = lf_map(i); steps += 1        fm_index.rs:134-137, rlfmi.rs:183-186
         if constexpr (RL) {
@@ -1030,6 +1067,45 @@ __device__ __forceinline__ uint64_t fmxw_bits_lane_select(const FmxWideBits &bv,
 // the end together before it takes the next 64.  Neighbouring rows of an interval sit in the same runs and stay
 // neighbours under LF, so the wave's 64 requests fall into a few lines -- where the refilling shape scatters them
 // over the index after its first iterations and runs at the memory system's request ceiling (2 per step).
+// lf_map(row) through the run table by ONE lane: the B piece of the row (run index and, unless the run began before the
+// piece, its start), then the table entry                                                   rlfmi.rs:127-133
+__device__ __forceinline__ uint64_t fmxw_r_lane_lf(const FmxWideDev &w, uint64_t row) {
+  const FmxWideBits &bv = w.b;
+  const uint64_t pidx = fmxw_div3(row >> 5);        // row / 96
+  const uint32_t b1 = (uint32_t)(row - pidx * FMX_BITS_PER_PIECE) + 1u;     // bits [0, bit] of the piece
+  FMX_CHECK((pidx >> 3) < bv.nrec);
+  const uint4 pc = bv.rec[pidx];
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  const uint32_t y = pc.y & m0, z = pc.z & m1, ww = pc.w & m2;
+  const uint64_t lo = bv.base[(pidx >> 3) >> bv.sb_shift] + pc.x + __popc(y) + __popc(z) + __popc(ww) - 1u;   // run of the row
+  FMX_CHECK(lo < bv.ones);
+  const uint64_t f = w.lfrun[lo];                   // lf_map(first row of the run)
+  uint64_t st;                                      // its first row: the last one at or before the row
+  if (ww) st = pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(ww);
+  else if (z) st = pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
+  else if (y) st = pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
+  else st = fmxw_bits_lane_select(bv, lo);
+  return f + row - st;
+}
+// text-order walks, a lane per walk: 64 consecutive hits per wave (the lanes run the same code; the walks differ in
+// length by at most 2^level - 1 steps)
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_text_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                       uint64_t *__restrict__ steps_out) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t nsteps = 0;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth) {
+    const uint64_t row = io[h];
+    uint64_t v = ~0ull, st = 0;
+    if (row >= w.n) atomicOr(w.status, 1u << FMX_ERR_ARG);       // refuse, do not read
+    else v = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lane_lf(w, r); }, row, st);
+    io[h] = v;
+    nsteps += st;
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 template <bool LOCKSTEP>
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
                                                                   uint64_t *__restrict__ steps_out) {
@@ -1068,24 +1144,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_kernel(FmxWideDev w, u
         steps = 0;
       }
     } else if (have) {                              // None: i = lf_map(i); steps += 1          rlfmi.rs:183-186
-      const FmxWideBits &bv = w.b;
-      const uint64_t pidx = fmxw_div3(row >> 5);    // row / 96
-      const uint32_t b1 = (uint32_t)(row - pidx * FMX_BITS_PER_PIECE) + 1u;     // bits [0, bit] of the piece
-      FMX_CHECK((pidx >> 3) < bv.nrec);
-      const uint4 pc = bv.rec[pidx];
-      const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
-      const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
-      const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
-      const uint32_t y = pc.y & m0, z = pc.z & m1, ww = pc.w & m2;
-      const uint64_t lo = bv.base[(pidx >> 3) >> bv.sb_shift] + pc.x + __popc(y) + __popc(z) + __popc(ww) - 1u;   // run of the row
-      FMX_CHECK(lo < bv.ones);
-      const uint64_t f = w.lfrun[lo];               // lf_map(first row of the run)
-      uint64_t st;                                  // its first row: the last one at or before the row
-      if (ww) st = pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(ww);
-      else if (z) st = pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
-      else if (y) st = pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
-      else st = fmxw_bits_lane_select(bv, lo);
-      row = f + row - st;
+      row = fmxw_r_lane_lf(w, row);
       steps++;
     }
   }
@@ -1147,6 +1206,9 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
       res = op == 4 ? (uint64_t)sym : r;
     } else if (!RL && w.walk) {                     // get_sa, text-order samples: through the walk records
       res = fmxw_get_sa_walk(w, i, g);
+    } else if (RL && w.phase) {                     // get_sa, text-order samples of an RLFM index (group-uniform lane code)
+      uint64_t st;
+      res = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, i, st);
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
@@ -1362,7 +1424,11 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
     uint64_t *steps = idx->timing == 1 ? idx->d_steps : nullptr;
 #define FMXW_GWALK(GLDS, RL)                                                                                        \
     hipLaunchKernelGGL((fmxw_g_walk_kernel<GLDS, RL>), dim3(fmxw_grid(total)), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps)
-    if (w.kind == FMX_KIND_RLFM && w.lfrun) {       // run table: a lane per walk
+    if (w.kind == FMX_KIND_RLFM && w.lfrun && w.phase) {   // run table + text-order samples: a lane per walk
+      uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
+      if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
+      hipLaunchKernelGGL(fmxw_r_walk_text_kernel, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
+    } else if (w.kind == FMX_KIND_RLFM && w.lfrun) {       // run table: a lane per walk
       uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
       if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
       static const int force = getenv("FMXW_RL_LOCKSTEP") ? atoi(getenv("FMXW_RL_LOCKSTEP")) : -1;   // measurement switch

@@ -65,7 +65,7 @@ def _run(alphabet="dna"):
     h = index.handle()
     assert index.len() == N and index.is_wide() and index.level() == level
     runs = int(lib.fmx_num_runs(h))
-    assert (1 << 24) < runs < N // 8 and index.walk_records() if rl else runs == 0
+    assert (1 << 24) < runs < N // 8 and index.walk_records() and index.text_order() if rl else runs == 0
     t0 = time.time()
     assert index.verify_sa() == 0                       # sorted, and every index exactly once
     verify_s = time.time() - t0

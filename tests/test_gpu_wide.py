@@ -221,10 +221,13 @@ def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, d
         sigma = 255
     else:
         t = _runs_text(n, sigma, 300 + n % 89, mean_run, dtype)
+    sampling = "row" if n in (30000, 60001) else None               # FMX_FLAG_ROW_ORDER: the reference's rows
     gi = F.RLFMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True,
-                               walk_records=run_table)
+                               walk_records=run_table, sampling=sampling)
     assert gi.is_wide() and gi.len() == n and gi.level() == (level if n > (1 << level) else 0)
-    assert gi.walk_records() == run_table and not gi.text_order()
+    # with the run table the index samples in text order (levels 1..4: phase pieces with 64-bit superblock bases)
+    assert gi.walk_records() == run_table
+    assert gi.text_order() == (run_table and sampling is None and 1 <= gi.level() <= 4)
     oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level, kind="rlfm")
     assert gi.verify_sa() == 0
     rows = np.arange(n, dtype=np.uint64)
@@ -285,6 +288,8 @@ def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, d
     li = type(gi).load(path)
     assert li.is_wide() and li.len() == n and li.level() == gi.level() and li.heap_size() == gi.heap_size()
     assert li.walk_records() == run_table and int(li._lib.fmx_num_runs(li.handle())) == int(gi._lib.fmx_num_runs(gi.handle()))
+    assert li.text_order() == gi.text_order()
+    assert (li.export_sa_samples() == samp).all() and (li.get_sa(rows[:3000]) == want[:3000]).all()
     lb = li.search_many(flat=flat2, off=off2)
     assert (lb.s == os2).all() and (lb.e == oe2).all()
     _, lpos = li.locate_many(os2[keep], oe2[keep])

@@ -1298,6 +1298,10 @@ WideBlobs wide_blobs(FmxWideDev &w, uint64_t nsamples) {
     b.field[b.n] = (const void **)&w.walk;  b.bytes[b.n++] = (w.n / FMX_WALK_ROWS + 1u) * 128ull;
     b.field[b.n] = (const void **)&w.wbase; b.bytes[b.n++] = (uint64_t)w.nwsb * 128ull;
   }
+  if (w.phase && w.kind != FMX_KIND_RLFM) {         // text-order samples of a generic FM / multi-pieces index
+    b.field[b.n] = (const void **)&w.phase; b.bytes[b.n++] = (w.n / (3u * (32u / w.sa_level)) + 1u) * 16ull;
+    b.field[b.n] = (const void **)&w.pbase; b.bytes[b.n++] = (uint64_t)w.npsb * 8ull;
+  }
   if (w.kind == FMX_KIND_RLFM) {
     FmxWideBits *v[2] = {&w.b, &w.bp};
     for (int t = 0; t < 2; t++) {
@@ -1414,7 +1418,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   else if ((w.walk != nullptr) != (w.wbase != nullptr)) bad = "walk records";
   else if (rl && (w.lfrun != nullptr) && !locate) bad = "run table";
   else if ((w.phase != nullptr) != (w.pbase != nullptr) ||
-           (w.phase && (!rl || !locate || w.sa_level < 1 || w.sa_level > FMX_PHASE_MAX_LEVEL ||
+           (w.phase && (!w.generic || !locate || w.sa_level < 1 || w.sa_level > FMX_PHASE_MAX_LEVEL ||
                         (w.psb_shift != FMXW_PHASE_SB_SHIFT && w.psb_shift != FMXW_PHASE_SB_SHIFT_TEST) ||
                         w.npsb != (uint32_t)((h.n / (3u * (32u / w.sa_level))) >> w.psb_shift) + 1u)))
     bad = "text-order sampling";

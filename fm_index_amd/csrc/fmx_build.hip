@@ -2861,7 +2861,10 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     }
     // RLFM: text-order samples (phase pieces) for levels 1..4, together with the run table -- unless the flags keep the
     // reference's rows, or the device lacks room for the pieces four times over
-    bool rl_text = idx->kind == FMX_KIND_RLFM && level >= 1 && level <= FMX_PHASE_MAX_LEVEL &&
+    // (generic FM / multi-pieces indexes -- the multi-level kernels -- sample the same way: half the LF steps, none
+    // longer than 2^level - 1, four walks per group in flight)
+    const bool generic_index = idx->kind != FMX_KIND_FM || maxc > 7 || sizeof(T) != 1;
+    bool rl_text = generic_index && level >= 1 && level <= FMX_PHASE_MAX_LEVEL &&
                    !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
     if (rl_text && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {
       size_t free_b = 0, total_b = 0;

@@ -1017,8 +1017,12 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
     uint64_t row = io[h], steps = 0, v = ~0ull;
     if (row >= w.n) {                               // refuse, do not read
       if (g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
-    } else if (RL && w.phase) {                     // text-order samples (an index without the run table lands here)
-      if constexpr (RL) v = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, row, steps);
+    } else if (w.phase) {                           // text-order samples (an RLFM index without the run table lands here)
+      if constexpr (RL) {
+        v = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, row, steps);
+      } else {
+        v = fmxw_r_get_sa_text(w, [&](uint64_t r) { uint32_t sy; return fmxw_g_lf_map<MP>(w, gbase, gk, r, g, sy); }, row, steps);
+      }
     } else {
       while (row & lmask) {                         // None: i = lf_map(i); steps += 1        fm_index.rs:134-137, rlfmi.rs:183-186
         if constexpr (RL) {
@@ -1034,6 +1038,108 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_kernel(FmxWideDev w, u
     }
     if (g == 0) io[h] = v;
     nsteps += steps;
+  }
+  if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// get_sa for a batch of rows on a generic FM / multi-pieces index with TEXT-ORDER samples (FmxWideDev::phase; round 4): a
+// group owns Q consecutive hits at a time and takes them through the walk together -- start probes, then LF steps
+// level by level, final probes, samples -- with the Q requests of every stage in flight before the first is consumed
+// (one walk per group, the shape of fmxw_g_walk_kernel, keeps a single line in flight per group: 32 % of the
+// request ceiling).  A walk is SA[row] mod 2^level steps long, so the Q walks of a group differ by < 2^level steps.
+template <bool GLDS, bool MP>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_text_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                       uint64_t *__restrict__ steps_out) {
+  FMXW_GBASES(w, GLDS);
+  constexpr int Q = 4;
+  const uint32_t g = threadIdx.x & (FMX_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
+  uint64_t nsteps = 0;
+  for (uint64_t h0 = gid * Q; h0 < total; h0 += ngroups * Q) {
+    uint64_t row[Q], r0[Q];
+    uint32_t ph[Q], tt[Q];
+    uint4 pp[Q];
+    bool ok[Q], bad[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) row[q] = h0 + q < total ? io[h0 + q] : ~0ull;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      bad[q] = h0 + q < total && row[q] >= w.n;     // not a row of this index: refuse, do not read
+      ok[q] = h0 + q < total && !bad[q];
+      if (bad[q] && g == 0) atomicOr(w.status, 1u << FMX_ERR_ARG);
+      if (!ok[q]) row[q] = 0;
+      const uint64_t pi = fmxw_phase_piece(row[q], w.sa_level, tt[q]);
+      FMX_CHECK((pi >> w.psb_shift) < w.npsb);
+      pp[q] = w.phase[pi];
+      r0[q] = w.pbase[pi >> w.psb_shift];
+    }
+    uint32_t maxph = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      uint32_t rel;
+      ph[q] = fmx_phase_decode(pp[q], tt[q], w.sa_level, rel);
+      if (!ok[q]) ph[q] = 0;
+      r0[q] += rel;
+      maxph = ph[q] > maxph ? ph[q] : maxph;
+      nsteps += ph[q];
+    }
+    for (uint32_t t = 0; t < maxph; t++) {          // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
+      uint64_t pos[Q];
+      uint32_t sym[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { pos[q] = row[q]; sym[q] = 0; }
+      for (uint32_t l = 0; l < w.nlevels; l++) {
+        const FmxWideLevel &L = w.lv[l];
+        uint4 p[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+          if (t < ph[q]) p[q] = fmxw_g_piece(L, pos[q], g);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          if (t < ph[q]) {
+            const uint32_t code = fmxw_g_code(L, p[q], pos[q], g);
+            sym[q] |= code << L.shift;
+            pos[q] = gbase(l, pos[q], code) + fmxw_g_rank32(L, p[q], pos[q], code, g);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        if (t < ph[q]) {
+          uint64_t r = gk(sym[q]) + pos[q];         // fm_index.rs:86-91
+          if (MP && sym[q] == 0u) r = fmxw_multi_zero(w, row[q], r);
+          row[q] = r;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {                   // the final rows are phase-0 rows: their samples' indices
+      if (ph[q]) {
+        const uint64_t pi = fmxw_phase_piece(row[q], w.sa_level, tt[q]);
+        FMX_CHECK((pi >> w.psb_shift) < w.npsb);
+        pp[q] = w.phase[pi];
+        r0[q] = w.pbase[pi >> w.psb_shift];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (ph[q]) {
+        uint32_t rel;
+        [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(pp[q], tt[q], w.sa_level, rel);
+        FMX_CHECK(p2 == 0u);
+        r0[q] += rel;
+      }
+    }
+    uint64_t sv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) sv[q] = ok[q] ? w.samples[r0[q]] : 0ull;       // Some(sa)   fm_index.rs:131
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      uint64_t v = sv[q] + ph[q];                   // (sa + steps) % len                      fm_index.rs:132
+      if (v >= w.n) v -= w.n;
+      if (g == 0 && (ok[q] || bad[q])) io[h0 + q] = ok[q] ? v : ~0ull;
+    }
   }
   if (steps_out && g == 0 && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
@@ -1206,9 +1312,13 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_scalar_kernel(FmxWideDev w,
       res = op == 4 ? (uint64_t)sym : r;
     } else if (!RL && w.walk) {                     // get_sa, text-order samples: through the walk records
       res = fmxw_get_sa_walk(w, i, g);
-    } else if (RL && w.phase) {                     // get_sa, text-order samples of an RLFM index (group-uniform lane code)
+    } else if (w.phase) {                           // get_sa, text-order samples of a generic index (group-uniform lane code)
       uint64_t st;
-      res = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, i, st);
+      if constexpr (RL) {
+        res = fmxw_r_get_sa_text(w, [&](uint64_t r) { return fmxw_r_lf_step(w, gbase, gk, r, g); }, i, st);
+      } else {
+        res = fmxw_r_get_sa_text(w, [&](uint64_t r) { uint32_t sy; return fmxw_g_lf_map<MP>(w, gbase, gk, r, g, sy); }, i, st);
+      }
     } else {                                        // get_sa
       const uint64_t lmask = (1ull << w.sa_level) - 1ull;
       uint64_t row = i, steps = 0;
@@ -1437,6 +1547,12 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
       else hipLaunchKernelGGL(fmxw_r_walk_kernel<false>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
     } else if (w.kind == FMX_KIND_RLFM) {
       if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, FMX_KIND_RLFM); else FMXW_GWALK(false, FMX_KIND_RLFM);
+    } else if (w.phase) {                           // FM / multi-pieces with text-order samples: four walks per group
+      const unsigned grid = fmxw_grid((total + 3) / 4);
+#define FMXW_GWALKT(GLDS, MPF)                                                                                      \
+      hipLaunchKernelGGL((fmxw_g_walk_text_kernel<GLDS, MPF>), dim3(grid), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps)
+      if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALKT(true, true); else FMXW_GWALKT(false, true); }
+      else if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALKT(true, false); else FMXW_GWALKT(false, false);
     } else if (w.kind == FMX_KIND_MULTI) {
       if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, FMX_KIND_MULTI); else FMXW_GWALK(false, FMX_KIND_MULTI);
     } else if (w.nsb <= FMXW_GLDS_SB) {

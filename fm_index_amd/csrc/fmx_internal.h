@@ -266,6 +266,7 @@ struct fmx_index {
 // ABI, same structs -- IF they were built from the same sources.  A handle carries the sizes of the structs of the
 // library that made it; a library with another layout refuses it (FMX_ERR_ARG) instead of reading pointers at the
 // wrong offsets (a stale census library did exactly that in round 4: a GPU memory fault in the middle of bench.py).
+static_assert(sizeof(FmxDev) < 1024 && sizeof(fmx_index) < 4096, "FMX_LAYOUT packs the struct sizes into 10 / 12 bits");
 #define FMX_LAYOUT (0x464D5800ull << 32 | (uint64_t)sizeof(fmx_index) << 20 | (uint64_t)sizeof(FmxDev) << 10 | \
                     ((uint64_t)sizeof(FmxWideDev) & 0x3FFu))
 

@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-rlfm", action="store_true", help="skip the config-4 object of the default run")
     ap.add_argument("--no-3b", action="store_true", help="skip the config-3b object")
     ap.add_argument("--no-wide", action="store_true", help="skip the n = 2^32 + 2^20 object (the 64-bit engine)")
+    ap.add_argument("--no-pretouch", action="store_true",
+                    help="do not have a child process write the device's free memory once before the run (see pretouch_device)")
     ap.add_argument("--no-d2h", action="store_true", help="skip value_incl_d2h")
     ap.add_argument("--no-census", action="store_true", help="skip the requested / distinct line census")
     ap.add_argument("--no-pmc", action="store_true",
@@ -821,6 +823,10 @@ def main():
     # then spawned from a process that holds no device state.
     pmc = None
     rank = int(os.environ.get("RANK", "0"))
+    if (world == 1 and not args.total_patterns and args.workload == "dna" and not args.no_wide and args.log2n >= 30
+            and not args.no_pretouch):
+        pretouch_device(int(os.environ.get("LOCAL_RANK", "0")))
+    t_pmc = time.perf_counter()
     dist_line = world > 1 or args.force_dist or bool(args.total_patterns)
     if rank == 0 and args.workload == "dna" and not args.no_pmc and args.dist_backend != "gloo":
         try:
@@ -833,10 +839,44 @@ def main():
                 pmc = run_pmc_passes(args, npat=shard0, count_only=True)
         except Exception as ex:  # noqa: BLE001 -- never lose the line to the counter passes
             pmc = ({}, repr(ex))
-    run(args, world, pmc)
+    run(args, world, pmc, pmc_seconds=time.perf_counter() - t_pmc)
 
 
-def run(args, world, pmc=None):
+PRETOUCH = {}
+
+
+def pretouch_device(device):
+    """Memory no process has used since the box booted is handed out on a slow path by this driver: a hipMalloc that
+    follows the first touch of such pages costs ~28 ms per GiB touched (benchmarks/gpu/alloc_probe2.hip,
+    profiles/r04/alloc_probe2.txt: 0.3 ms for the first 34 GiB buffer, 965 ms for each further one), which is what the
+    `wide` leg's builder -- 137 GB of scratch in a handful of buffers -- met on the driver's fresh box (build_ms 2 980 in
+    round 3, 5 416 in round 4 against 570-850 on a box whose memory an earlier process had used).  A child process
+    that allocates what is free, writes it once and exits puts the box into the state of a machine that has been up
+    for a while; its cost is reported (`wide.pretouch`), the builder's work is unchanged.  --no-pretouch skips it."""
+    code = (
+        "import ctypes as C, time, sys\n"
+        "h = C.CDLL('libamdhip64.so')\n"
+        "t0 = time.time()\n"
+        "assert h.hipSetDevice(%d) == 0\n"
+        "fr, tot = C.c_size_t(), C.c_size_t()\n"
+        "assert h.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0\n"
+        "n = max(fr.value - (4 << 30), 0)\n"
+        "p = C.c_void_p()\n"
+        "assert h.hipMalloc(C.byref(p), C.c_size_t(n)) == 0\n"
+        "assert h.hipMemset(p, 0, C.c_size_t(n)) == 0\n"
+        "assert h.hipDeviceSynchronize() == 0\n"
+        "print('%%.1f %%.2f' %% (n / 2.0 ** 30, time.time() - t0))\n" % device)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        gib, secs = (r.stdout.split() + ["0", "0"])[:2] if r.returncode == 0 else ("0", "0")
+        PRETOUCH.update({"gib": float(gib), "child_seconds": float(secs), "seconds": round(time.perf_counter() - t0, 2),
+                         "returncode": r.returncode, "error": r.stderr[-300:] if r.returncode else None})
+    except Exception as ex:  # noqa: BLE001 -- an optional preparation step
+        PRETOUCH.update({"gib": 0.0, "error": repr(ex)})
+
+
+def run(args, world, pmc=None, pmc_seconds=0.0):
     import torch
     import numpy as np
     import fm_index_amd as F
@@ -847,6 +887,15 @@ def run(args, world, pmc=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if rank != 0:            # the ranks share one stdout: only rank 0 may write to it (libraries' banners included)
         os.dup2(2, 1)
+    # wall-clock seconds of every part of the run (what the driver's clock around `python bench.py` is made of)
+    leg_seconds = {"pretouch": PRETOUCH.get("seconds", 0.0), "pmc_passes": round(pmc_seconds, 1)}
+    lap_t = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        leg_seconds[name] = round(leg_seconds.get(name, 0.0) + now - lap_t[0], 1)
+        lap_t[0] = now
+
     gloo = args.dist_backend == "gloo"
     strong = bool(args.total_patterns)
     # the N>1 step, also on a 1-rank communicator when forced -- and at the G = 1 point of the strong-scaling curve,
@@ -993,10 +1042,12 @@ def run(args, world, pmc=None):
         wl.count()                                    # restore the config-2 (s, e)
         torch.cuda.synchronize()
 
+    lap("import + text + build + headline")
     # ---- opt-in accelerators: same patterns, results asserted identical to the plain index ----
     if single and not args.no_accel:
         accel_legs(out, wl, args, rflat)
     del rflat
+    lap("accelerators")
 
     # ---- locate (config 3; gathered over the ranks for N > 1) ----
     if wl.level is not None:
@@ -1008,6 +1059,7 @@ def run(args, world, pmc=None):
             locate_row_order_leg(out, wl, args)
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an optional leg
             out["locate_row_order"] = {"error": repr(ex)}
+    lap("locate")
 
     # ---- beyond 2^32 rows: the 64-bit engine on the config-2 / config-3 shapes.  EARLY in the run: its builder needs
     # 137 GB of scratch beyond what the scratch cache holds, and on this runtime a process that has cycled through about
@@ -1018,6 +1070,7 @@ def run(args, world, pmc=None):
             wide_leg(out, args, dev)
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
             out["wide"] = {"error": repr(ex)}
+    lap("wide")
 
     # ---- the config-5 step through a 1-rank RCCL communicator on this GPU (default N=1 run) ----
     if single and not args.no_rccl_check:
@@ -1025,6 +1078,7 @@ def run(args, world, pmc=None):
             rccl_1rank_leg(out, wl, args, dev, local)
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
             out["rccl_1rank"] = {"error": repr(ex)}
+    lap("rccl_1rank + config5_g1")
 
     # ---- config 3b: short patterns, wide intervals ----
     if single and wl.dna and wl.level is not None and not args.no_3b:
@@ -1032,6 +1086,7 @@ def run(args, world, pmc=None):
             locate_3b(out, wl, args, key)
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line to an extra leg
             out["locate_3b"] = {"error": repr(ex)}
+    lap("locate_3b")
 
     # ---- the same batch through the host-pointer entry point (PCIe both ways) ----
     if single and not args.no_d2h:
@@ -1040,6 +1095,7 @@ def run(args, world, pmc=None):
         except Exception as ex:  # noqa: BLE001
             out["value_incl_d2h"] = None
             out["incl_d2h"] = {"error": repr(ex)}
+    lap("incl_d2h")
 
     # ---- CPU baseline of the headline: rank 0 only, after the timed regions.  At N > 1 the other ranks wait in a
     # gloo barrier (a socket wait): an RCCL barrier would have their host threads spin on a stream and take CPU time
@@ -1055,6 +1111,7 @@ def run(args, world, pmc=None):
             out["cpu_baseline"] = cpu_baseline(wl, args, "rlfm" if wl.rlfm else "fm")
         if side is not None:
             dist.barrier(group=side)
+    lap("cpu_baseline")
 
     # ---- config 4 (RLFMIndex, sigma = 255) as its own object ----
     wr = None
@@ -1066,6 +1123,7 @@ def run(args, world, pmc=None):
         if wr is not None:
             wr.close()
             del wr
+    lap("rlfm")
 
     # ---- HBM-side traffic measured by the counter passes at the start of this run ----
     if pmc is not None and rank == 0:
@@ -1078,6 +1136,7 @@ def run(args, world, pmc=None):
         dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
+        out["leg_seconds"] = leg_seconds
         print(json.dumps(out))
         sys.stdout.flush()
 
@@ -1854,8 +1913,11 @@ def wide_leg(out, args, dev):
         "index_bytes": index.heap_size(), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
         "build_wall_s": round(build_wall_s, 2), "textgen_s": round(textgen_s, 2),
         "walk_records": index.walk_records(),
-        "note": "build_ms includes the driver's hipMalloc of ~137 GB of scratch: 0.6 s while the process is handed memory it "
-                "has not used before, ~30 ms per GiB once it has cycled through the device's memory (DESIGN.md section 4.3)"}
+        "pretouch": dict(PRETOUCH) if PRETOUCH else None,
+        "note": "build_ms includes the driver's hipMalloc of ~137 GB of scratch in five buffers: 0.6-0.9 s on memory some "
+                "process has used before; on memory nobody has touched since boot every hipMalloc that follows a first "
+                "touch costs ~28 ms per GiB touched (3-5 s here), and so does re-allocating what this process has freed "
+                "(DESIGN.md section 4.3; `pretouch` = the child process that wrote the free memory once before this run)"}
     index.close()
     del text, pat, pat2, pos
     torch.cuda.empty_cache()

@@ -92,3 +92,12 @@ def test_host_cpu_reports_what_the_process_may_use():
     if h["cgroup_cpu_quota"] is not None:
         assert h["effective_cpus"] <= max(1, int(h["cgroup_cpu_quota"]))
     assert "cpu_model" in h and "physical_cores" in h
+
+
+def test_pretouch_is_optional_preparation_without_a_gpu():
+    """bench.py's child process that writes the device's free memory once before the run (pretouch_device): on a
+    machine without a GPU it fails in the child and the run goes on -- nothing is raised, the failure is recorded"""
+    B.PRETOUCH.clear()
+    B.pretouch_device(0)
+    assert B.PRETOUCH.get("gib") == 0.0 and (B.PRETOUCH.get("returncode") or B.PRETOUCH.get("error"))
+    B.PRETOUCH.clear()

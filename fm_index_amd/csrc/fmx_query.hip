@@ -2060,10 +2060,16 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     c.slice(nb, chunk, hpb, gr);
     if (dv.phase && dv.walk && tn.walk_records) {   // text-order sampling with walk records: no phase probes
       if (chunk == FMX_LCHUNK && tn.wc) {
+#ifdef FMX_MEASURE   // FMX_VARIANT=15: 8 walks per group -- 86 VGPRs; walk kernel 0.0805 ms against 0.0774 with 4, config 3b 10.9 against 9.8 ms
+        if (q == 8) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 8, true); else
+#endif
         if (q == 4) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 4, true);
         else if (q == 2) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 2, true);
         else FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 1, true);
       } else {
+#ifdef FMX_MEASURE
+        if (q == 8) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 8, false); else
+#endif
         if (q == 4) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 4, false);
         else if (q == 2) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 2, false);
         else FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 1, false);

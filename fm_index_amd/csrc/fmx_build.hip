@@ -188,6 +188,12 @@ struct DevPool {  // temporaries given back when the builder returns (large ones
     *out = (T *)p;
     return e;
   }
+  // Before temporaries go back (to the scratch cache or the driver) the kernels that use them must have finished.  A
+  // small build whose temporaries all came from its leased arena gives nothing back before it returns -- the bump
+  // allocator never reuses a byte -- so it has nothing to wait for here: its launches queue up behind each other on the
+  // stream and the builder's last synchronisation covers them (a small build is launch- and round-trip-bound: every
+  // wait that goes lets the host enqueue ahead of the device)
+  hipError_t quiesce() const { return (arena && v.empty()) ? hipSuccess : hipDeviceSynchronize(); }
   void release(void *p) {
     if (arena && (uint8_t *)p >= arena && (uint8_t *)p < arena + arena_cap) return;   // goes with the arena
     for (size_t i = 0; i < v.size(); i++)
@@ -214,6 +220,7 @@ struct TextStats {
   unsigned long long hist[256];
   unsigned long long last_nonzero_plus1;  // 0 when every symbol is zero
   unsigned long long max_sym;
+  unsigned long long first_sym;           // t[0] (the validation reads it from here: no read-back of its own)
 };
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_text_stats(const T *__restrict__ t, uint64_t n,
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(BLK) void k_text_stats(const T *__restrict__ t, uin
   if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
   if (last) atomicMax(&st->last_nonzero_plus1, last);
   if (mx) atomicMax(&st->max_sym, mx);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n) st->first_sym = (unsigned long long)t[0];
 }
 // large alphabets (max_character > 255): histogram straight into global memory
 template <typename T>
@@ -1112,7 +1120,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   }
   if (sa_cur != d_sa)
     FMX_HIP(hipMemcpyAsync(d_sa, sa_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, 0));
-  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(pool.quiesce());
   if (keys_a) pool.release(keys_a);
   if (keys_b) pool.release(keys_b);
   pool.release(vals_b);
@@ -1181,7 +1189,11 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
     FMX_HIP(hipGetLastError());
     lv.rec = rec;
     lv.C = C;
-    if (want_select) {   // hints for select (the forward / fl_map path)
+    // hints for select (the forward / fl_map path) -- for sequences beyond a small build's size only: below it the
+    // search over all record counters that fmx_level_select falls back to is at most 10 cached steps, and the three
+    // launches + two allocations per level are a measurable share of a small build (n = 10^4, RLFM: 730 -> 542 us
+    // together with the waits that went, benchmarks/gpu/r04_small_build2.sh)
+    if (want_select && len > kArenaMaxN) {
       const uint32_t nsel = len / FMX_WSEL_STEP + 2u * ncode + 2u;
       uint32_t *sel, *meta;
       FMX_HIP(hipMalloc((void **)&sel, (size_t)nsel * 4));
@@ -1210,11 +1222,11 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
       FMX_HIP(pool.get(&stmp, sb));
       FMX_HIP(rocprim::radix_sort_keys(stmp, sb, cur, alt, (size_t)len, lv.shift, lv.shift + bits[l],
                                        (hipStream_t)0));
-      FMX_HIP(hipDeviceSynchronize());
+      FMX_HIP(pool.quiesce());
       pool.release(stmp);
       T *x = cur; cur = alt; alt = x;
     }
-    FMX_HIP(hipDeviceSynchronize());
+    FMX_HIP(pool.quiesce());
     pool.release(hist); pool.release(scan); pool.release(tmp);
   }
   return FMX_OK;
@@ -1251,7 +1263,8 @@ int symbol_histogram(const T *d_sym, uint64_t count, uint32_t maxc, std::vector<
 }
 
 // FmxBits (rank/select records + select hints) from one flag byte per bit
-int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, DevPool &pool) {
+// known_ones >= 0: the caller knows the number of ones (B and B' of an RLFM index: the number of runs) -- no read-back
+int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, DevPool &pool, int64_t known_ones = -1) {
   memset(bv, 0, sizeof *bv);
   bv->len = n;
   bv->nrec = n / FMX_BITS_PER_REC + 1;  // position `len` itself must be addressable
@@ -1271,8 +1284,15 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   FMX_HIP(pool.get(&tmp, tb));
   FMX_HIP(exclusive_sum(tmp, tb, cnt, base, (size_t)npieces + 1));
   hipLaunchKernelGGL(k_bits_counters, dim3(nblocks(npieces)), dim3(BLK), 0, 0, base, npieces, rec);
-  uint32_t ones = 0;
-  FMX_HIP(hipMemcpy(&ones, base + npieces, 4, hipMemcpyDeviceToHost));
+  uint32_t ones = (uint32_t)known_ones;
+  if (known_ones < 0) FMX_HIP(hipMemcpy(&ones, base + npieces, 4, hipMemcpyDeviceToHost));
+#ifdef FMX_DEBUG_BOUNDS
+  else {
+    uint32_t counted = 0;
+    FMX_HIP(hipMemcpy(&counted, base + npieces, 4, hipMemcpyDeviceToHost));
+    if (counted != ones) { fmx_set_error(FMX_ERR_HIP, "bit vector: the caller's count of ones is wrong"); return FMX_ERR_HIP; }
+  }
+#endif
   bv->ones = ones;
   bv->nsel = ones / FMX_SEL_STEP + 2;
   uint32_t *sel;
@@ -1281,7 +1301,7 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   hipLaunchKernelGGL(k_fill_u32, dim3(nblocks(bv->nsel)), dim3(BLK), 0, 0, sel, bv->nsel, bv->nrec - 1);
   hipLaunchKernelGGL(k_select_hints, dim3(nblocks(bv->nrec)), dim3(BLK), 0, 0, rec, bv->nrec, ones, sel);
   FMX_HIP(hipGetLastError());
-  FMX_HIP(hipDeviceSynchronize());
+  FMX_HIP(pool.quiesce());
   bv->rec = rec;
   bv->sel = sel;
   pool.release(cnt); pool.release(base); pool.release(tmp);
@@ -1386,7 +1406,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   idx->runs = r;
   pool.release(tmp);
   // B (rlfmi.rs:46, 58, 61, 85)
-  if (int rc = build_bits(idx, &dv.b, flags, n, pool)) return rc;
+  if (int rc = build_bits(idx, &dv.b, flags, n, pool, (int64_t)r)) return rc;
   if (int rc = keep_positions(idx, &dv.b, starts)) return rc;        // run starts = the ones of B
   if (int rc = keep_dense_select(idx, &dv.b, flags, starts)) return rc;
   // cs[c] = number of runs whose head is < c (rlfmi.rs:72-76)
@@ -1433,11 +1453,11 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   }
   FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
   hipLaunchKernelGGL(k_scatter_ones, dim3(nblocks(r)), dim3(BLK), 0, 0, fpos, r, flags);
-  FMX_HIP(hipDeviceSynchronize());
-  if (int rc = build_bits(idx, &dv.bp, flags, n, pool)) return rc;
+  FMX_HIP(pool.quiesce());
+  if (int rc = build_bits(idx, &dv.bp, flags, n, pool, (int64_t)r)) return rc;
   if (int rc = keep_positions(idx, &dv.bp, fpos)) return rc;         // F positions of the runs = the ones of B'
   if (int rc = keep_dense_select(idx, &dv.bp, flags, fpos)) return rc;
-  FMX_HIP(hipDeviceSynchronize());                                   // flags / fpos are released below
+  FMX_HIP(pool.quiesce());                                   // flags / fpos are released below
   pool.release(order); pool.release(order2); pool.release(lens); pool.release(fpos);
   pool.release(hk2); pool.release(stmp); pool.release(etmp); pool.release(flags);
   pool.release(starts);
@@ -1592,8 +1612,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     return FMX_ERR_SYMBOL_RANGE;
   }
   if (n >= 2) {  // lengths 0 and 1 bypass validation (sais.rs:121-126)
-    T first = 0;
-    FMX_HIP(hipMemcpy(&first, d_text, sizeof(T), hipMemcpyDeviceToHost));
+    const unsigned long long first = st.first_sym;
     if (first == 0) {
       fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
       return FMX_ERR_TEXT_START_ZERO;
@@ -1738,7 +1757,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     pool.release(d_first);
   }
   if (idx->kind == FMX_KIND_FM || idx->kind == FMX_KIND_MULTI) {
-    FMX_HIP(hipDeviceSynchronize());
+    FMX_HIP(pool.quiesce());
     if (int rc = build_mwm<T>(idx, &dv.bw, d_bwt, n, L, pool, idx->h_cs, maxc + 1)) return rc;
     // K[c] = cs[c] - S_c (all zero when cs[] was folded into a single level)
     uint64_t *d_cs;
@@ -1769,7 +1788,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     }
     // c_i = T[SA[i]-1], or T[n-1] when SA[i] == 0 (rlfmi.rs:48-53)
     hipLaunchKernelGGL(k_bwt_cyclic<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, d_sa, n, d_bwt);
-    FMX_HIP(hipDeviceSynchronize());
+    FMX_HIP(pool.quiesce());
     if (int rc = build_rlfm<T>(idx, d_bwt, n, L, pool)) return rc;
   }
 
@@ -2809,9 +2828,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     fmx_set_error(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character");
     return FMX_ERR_SYMBOL_RANGE;
   }
-  T first = 0;
-  FMX_HIP(hipMemcpy(&first, d_text, sizeof(T), hipMemcpyDeviceToHost));
-  if (first == 0) {
+  if (st.first_sym == 0) {
     fmx_set_error(FMX_ERR_TEXT_START_ZERO, nullptr);
     return FMX_ERR_TEXT_START_ZERO;
   }

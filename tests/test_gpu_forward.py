@@ -29,7 +29,9 @@ def test_known_answers_forward(golden, cls, kind):
 
 @pytest.mark.parametrize("maxc,alphabet,n,dtype", [(4, 4, 3000, np.uint8), (255, 255, 3000, np.uint8),
                                                    (49, 2, 3000, np.uint8), (255, 3, 70000, np.uint8),
-                                                   (3000, 2500, 4000, np.uint16)])
+                                                   (3000, 2500, 4000, np.uint16),
+                                                   # beyond 2^17 entries the wavelet levels carry select hints
+                                                   (4, 4, 300000, np.uint8), (255, 200, 200001, np.uint8)])
 @pytest.mark.parametrize("kind", ["fm", "rlfm"])
 def test_forward_every_row(maxc, alphabet, n, dtype, kind):
     t = ((W.splitmix64_np(maxc + alphabet, 0, n) % np.uint64(alphabet)) + np.uint64(48 if maxc == 49 else 1)).astype(dtype)

@@ -85,8 +85,7 @@ void fmx_free(fmx_index *idx) {
   (void)dg.set(idx->device);
   for (int i = 0; i < idx->nalloc; i++) (void)hipFree(idx->d_alloc[i]);
   free(idx->d_alloc);
-  if (idx->dev.status) (void)hipFree(idx->dev.status);
-  if (idx->d_steps) (void)hipFree(idx->d_steps);
+  if (idx->dev.status) (void)hipFree(idx->dev.status);     // (d_steps lives in the same 16 bytes)
   if (idx->ev0) (void)hipEventDestroy(idx->ev0);
   if (idx->ev1) (void)hipEventDestroy(idx->ev1);
   if (idx->ev_series) {
@@ -109,6 +108,18 @@ __global__ __launch_bounds__(256) void fmx_narrow_u64_kernel(const uint64_t *__r
     dst[i] = (uint32_t)v;
   }
   if (any) atomicOr(bad, 1u);
+}
+
+// the two device words of a handle -- the sticky status word and the executed-step counter -- in one 16-byte allocation,
+// zeroed by one memset; the timing events are created when timing is switched on (fmx_set_timing), not for every index
+// (a small build is launch- and round-trip-bound: four runtime calls fewer per index)
+static hipError_t alloc_handle_words(fmx_index *idx) {
+  uint8_t *p = nullptr;
+  hipError_t e = hipMalloc((void **)&p, 16);
+  if (e != hipSuccess) return e;
+  idx->dev.status = (uint32_t *)p;
+  idx->d_steps = (uint64_t *)(p + 8);
+  return hipMemset(p, 0, 16);
 }
 
 static int build_common(const void *text, int text_on_device, uint64_t n, uint32_t sym_bytes,
@@ -166,11 +177,7 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   bool own_text = false;
   do {
     hipError_t e;
-    if ((e = hipMalloc((void **)&idx->dev.status, sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&idx->d_steps, sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMemset(idx->dev.status, 0, sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemset(idx->d_steps, 0, sizeof(uint64_t))) != hipSuccess ||
-        (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess) {
+    if ((e = alloc_handle_words(idx)) != hipSuccess) {
       rc = fmx_hip_fail(e, "handle resources", __LINE__);
       break;
     }
@@ -261,6 +268,16 @@ void fmx_set_timing(fmx_index *idx, int enabled) {
   if (!idx) return;
   idx->ev_valid = 0;
   idx->series_n = 0;
+  if (enabled == 1 && !idx->ev0) {                // the event pair of timing == 1: created on first use
+    DeviceGuard dg;
+    if (dg.set(idx->device) != hipSuccess) return;
+    if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess) {
+      if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+      idx->ev0 = nullptr;
+      idx->ev1 = nullptr;
+      enabled = 0;
+    }
+  }
   if (enabled == 2 && !idx->ev_series) {          // a series of launches: FMX_SERIES_CAP event pairs, created once
     DeviceGuard dg;
     if (dg.set(idx->device) != hipSuccess) return;
@@ -1479,10 +1496,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
     if (have != need) return fail(FMX_ERR_ARG, "corrupt index file: array sizes do not add up to the file size");
   }
   hipError_t e;
-  if ((e = hipMalloc((void **)&idx->dev.status, 4)) != hipSuccess || (e = hipMalloc((void **)&idx->d_steps, 8)) != hipSuccess ||
-      (e = hipMemset(idx->dev.status, 0, 4)) != hipSuccess || (e = hipMemset(idx->d_steps, 0, 8)) != hipSuccess ||
-      (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess)
-    return fmx_hip_fail(e, "handle resources", __LINE__);
+  if ((e = alloc_handle_words(idx)) != hipSuccess) return fmx_hip_fail(e, "handle resources", __LINE__);
   std::string buf(kChunk, '\0');
   for (int b = 0; b < bs.n; b++) {
     void *p = nullptr;
@@ -1558,9 +1572,7 @@ int fmx_load(const char *path, int device, fmx_index **out) {
       if (have != need) { rc = fail(FMX_ERR_ARG, "corrupt index file: array sizes do not add up to the file size"); break; }
     }
     hipError_t e;
-    if ((e = hipMalloc((void **)&idx->dev.status, 4)) != hipSuccess || (e = hipMalloc((void **)&idx->d_steps, 8)) != hipSuccess ||
-        (e = hipMemset(idx->dev.status, 0, 4)) != hipSuccess || (e = hipMemset(idx->d_steps, 0, 8)) != hipSuccess ||
-        (e = hipEventCreate(&idx->ev0)) != hipSuccess || (e = hipEventCreate(&idx->ev1)) != hipSuccess) {
+    if ((e = alloc_handle_words(idx)) != hipSuccess) {
       rc = fmx_hip_fail(e, "handle resources", __LINE__);
       break;
     }

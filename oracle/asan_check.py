@@ -29,4 +29,24 @@ t16 = ((W.splitmix64_np(1, 0, 3000) % np.uint64(900)) + np.uint64(1)).astype(np.
 for kind in ("fm", "rlfm"):
     idx = O.OracleIndex(t16, 1000, level=1, kind=kind)
     idx.count_batch(t16[5:9].copy(), np.array([0, 4], dtype=np.uint64)); idx.get_sa(np.arange(3000)); idx.close()
+# the imports from an exported L column (the full-size GPU tests' checker), 32- and 64-bit sample entry points
+t = W.repetitive_text_np(3000, 3, base_len=64, mut_per_1024=20)
+for kind in ("fm", "rlfm"):
+    a = O.OracleIndex(t, 255, level=2, kind=kind)
+    rows = np.arange(len(t), dtype=np.uint64)
+    bwt = a.get_l(rows).astype(np.uint8)
+    cs = np.concatenate([[0], np.cumsum(np.bincount(t, minlength=256))[:-1]]).astype(np.uint64)
+    samples = a.get_sa(rows[::4])
+    b = O.OracleIndex.from_bwt(bwt, cs, 255, samples=samples, level=2, kind=kind)
+    assert (b.get_sa(rows) == a.get_sa(rows)).all()
+    b.close()
+    h = C.c_void_p()
+    s64 = np.ascontiguousarray(samples, dtype=np.uint64)
+    if kind == "rlfm":
+        assert O._LIB.orc_rlfm_from_bwt64(C.byref(h), O._p(bwt), len(bwt), 255, O._p(s64), 2) == 0
+        O._LIB.orc_rlfm_free(h)
+    else:
+        assert O._LIB.orc_fm_from_bwt64(C.byref(h), O._p(bwt), len(bwt), 255, O._p(cs), O._p(s64), 2) == 0
+        O._LIB.orc_fm_free(h)
+    a.close()
 print("asan run complete")

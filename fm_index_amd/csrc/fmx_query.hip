@@ -1872,6 +1872,99 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
   return eb > (uint64_t)cap ? (uint64_t)cap : eb;
 }
 
+// ---- RLFM with the run table, batches of LONG intervals: a lane per walk on consecutive hits (round 4) ----------------
+// The hits of a pattern are adjacent rows; adjacent rows sit in the same runs and stay neighbours under LF (lf_map(i) =
+// lfrun[run] + offset in the run).  A wave that walks 64 CONSECUTIVE hits -- lane per walk, every probe lane-wise,
+// no queue, no ring: hit h is read and written by lane h mod 64 -- therefore sends its 64 requests of a step into a
+// few lines, where fmx_locate_ep_kernel's refilling lanes scatter them (the same finding as on the wide engine,
+// fmxw_r_walk_text_kernel: 9.8e7 hits of the repetitive 1 GiB text in 2.5 ms against 3.45 ms).  Chosen when the
+// batch averages at least 64 hits per pattern.
+// select1(k) of B by ONE lane (k < ones): stored position / select block / hint + search over the records
+__device__ __forceinline__ uint32_t fmx_bits_lane_select(const FmxBits &bv, uint32_t k) {
+  if (bv.pos) { FMX_TOUCH(&bv.pos[k]); return bv.pos[k]; }
+  if (bv.dsel) {
+    FMX_TOUCH(&bv.dsel[k >> bv.dsel_shift]);
+    const uint4 blk = bv.dsel[k >> bv.dsel_shift];
+    if (blk.x != 0xFFFFFFFFu) return fmx_dsel_pos(blk, k, bv.dsel_shift);
+  }
+  const uint32_t h = k / FMX_SEL_STEP;
+  FMX_CHECK(h + 1 < bv.nsel);
+  uint32_t lo = bv.sel[h], hi = bv.sel[h + 1];
+  while (lo < hi) {                                   // last record whose count <= k
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (bv.rec[(size_t)mid * 8u].x <= k) lo = mid; else hi = mid - 1u;
+  }
+  uint32_t p = 0;
+  for (uint32_t q = 1; q < 8u; q++)                   // last piece of it whose count <= k (the record is one line)
+    if (bv.rec[(size_t)lo * 8u + q].x <= k) p = q;
+  FMX_TOUCH(&bv.rec[(size_t)lo * 8u + p]);
+  const uint4 pc = bv.rec[(size_t)lo * 8u + p];
+  const uint32_t rem = k - pc.x, c0 = __popc(pc.y), c1 = __popc(pc.z);
+  uint32_t pos;
+  if (rem < c0) pos = fmx_select32(pc.y, rem);
+  else if (rem < c0 + c1) pos = 32u + fmx_select32(pc.z, rem - c0);
+  else pos = 64u + fmx_select32(pc.w, rem - c0 - c1);
+  return lo * FMX_BITS_PER_REC + p * FMX_BITS_PER_PIECE + pos;
+}
+// lf_map(row) through the run table by ONE lane                                              rlfmi.rs:127-133
+__device__ __forceinline__ uint32_t fmx_rlfm_lane_lf(const FmxDev &ix, uint32_t row) {
+  const uint32_t pidx = fmx_div3(row >> 5);           // row / 96
+  const uint32_t b1 = row - pidx * FMX_BITS_PER_PIECE + 1u;   // bits [0, bit] of the piece
+  FMX_CHECK(pidx < ix.b.nrec * 8u);
+  FMX_TOUCH(&ix.b.rec[pidx]);
+  const uint4 pc = ix.b.rec[pidx];
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  const uint32_t y = pc.y & m0, z = pc.z & m1, w = pc.w & m2;
+  const uint32_t lo = pc.x + __popc(y) + __popc(z) + __popc(w) - 1u;      // the run of the row
+  FMX_CHECK(lo < ix.b.ones);
+  FMX_TOUCH(&ix.lfrun[lo]);
+  const uint32_t f = ix.lfrun[lo];                    // lf_map(first row of the run)
+  uint32_t st;                                        // its first row: the last one at or before the row
+  if (w) st = pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(w);
+  else if (z) st = pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
+  else if (y) st = pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
+  else st = fmx_bits_lane_select(ix.b, lo);
+  return f + row - st;
+}
+template <bool TEXT>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total,
+                                                                        const uint32_t *__restrict__ rows,
+                                                                        uint64_t *__restrict__ out_pos,
+                                                                        uint64_t *__restrict__ steps_out) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t lmask = (1u << ix.sa_level) - 1u;
+  uint64_t nsteps = 0;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth) {
+    uint32_t row = rows[h], steps = 0, si;
+    FMX_CHECK(row < ix.n);                            // (fmx_expand_kernel wrote every slot with a row of this index)
+    if (TEXT) {                                       // SA[row] mod 2^level steps; phase probes at both ends
+      uint32_t t;
+      uint32_t pi = fmx_phase_piece(row, ix.sa_level, t);
+      FMX_TOUCH(&ix.phase[pi]);
+      steps = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+      for (uint32_t k = 0; k < steps; k++) row = fmx_rlfm_lane_lf(ix, row);
+      if (steps) {
+        pi = fmx_phase_piece(row, ix.sa_level, t);
+        FMX_TOUCH(&ix.phase[pi]);
+        [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+        FMX_CHECK(p2 == 0u);
+      }
+    } else {                                          // the reference's rows (sample.rs:46-60)
+      while (row & lmask) { row = fmx_rlfm_lane_lf(ix, row); steps++; }
+      si = row >> ix.sa_level;
+    }
+    FMX_CHECK(si < ix.nsamples);
+    FMX_TOUCH(&ix.samples[si]);
+    uint64_t v = (uint64_t)ix.samples[si] + steps;    // (sa + steps) % len                      rlfmi.rs:178-182
+    if (v >= ix.n) v -= ix.n;
+    out_pos[h] = v;
+    nsteps += steps;
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // ---- locate launch helpers (c = FmxLocateCall) ----
 #define FMX_LOCQ_LAUNCH(c, gr, thr, hpb, chunk, Q, TEXT)                                             \
   hipLaunchKernelGGL((fmx_locate_f3q_kernel<Q, TEXT>), dim3(gr), dim3(thr), 0, (c).st,                 \
@@ -2105,6 +2198,13 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
+      else if (dv.lfrun && tn.walk_records && tn.wc && total / npat >= 64 && !tn.alt) {
+        // long intervals (a repetitive text's): a lane per walk on consecutive hits
+        uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
+        if (lb > 8192) lb = 8192;
+        if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        else hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<false>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+      }
       else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
         if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);
       }

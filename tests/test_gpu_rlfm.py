@@ -261,3 +261,28 @@ def test_large_hit_batches_take_the_walk_per_lane_kernel(gen):
     goff, gpos = gb.locate()
     ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
     assert (goff == ooff).all() and (gpos == opos).all(), gen
+
+
+@pytest.mark.parametrize("sampling,level", [(None, 3), ("row", 2), (None, 1), ("row", 0)])
+def test_long_intervals_take_the_lane_per_walk_kernel(sampling, level):
+    """batches that average 64+ hits per pattern (and 2^18+ hits in all) on an index with the run table go through
+    fmx_locate_rl_lane_kernel -- a lane per walk on consecutive hits (round 4) -- in text order and in row order: the exact
+    sequences of the oracle, and of the same index without the run table (the endpoint-per-lane / group kernels)"""
+    n = 300000
+    t = W.repetitive_text_np(n, 11, base_len=512, mut_per_1024=4)
+    gi = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)
+    assert gi.walk_records() and gi.text_order() == (sampling is None and level >= 1)
+    oi = O.OracleIndex(t, 255, level=level, kind="rlfm")
+    flat, off, _ = W.substring_patterns_np(t, 600, 3, 21)            # short patterns: hundreds of hits each
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off, nthreads=8)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    total = int((oe - os_).sum())
+    assert total >= (1 << 18) and total // 600 >= 64
+    goff, gpos = gb.locate()
+    ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    plain = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling, walk_records=False)
+    _, ppos = plain.search_many(flat=flat, off=off).locate()
+    assert (ppos == opos).all()
+    gi.close(); plain.close()

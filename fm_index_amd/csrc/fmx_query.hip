@@ -1872,6 +1872,64 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
   return eb > (uint64_t)cap ? (uint64_t)cap : eb;
 }
 
+// ---- DNA walk records, batches of LONG intervals: a lane per walk on consecutive hits (round 4) -----------------------
+// The group-cooperative walk (fmx_locate_f3t_kernel) spends ~12 wave instructions per walk step -- every wave
+// instruction serves the 8 walks of its 8 groups -- and config 3b (280 hits per pattern) is bound by exactly that
+// (DESIGN.md section 8).  Here a LANE decodes its row's record alone: its own 16-byte piece (symbol, phase), the pieces in
+// front of it (popcounts) and the piece that holds the counter it needs -- 5.5 lane-wise 16-byte loads per step on
+// average instead of one cooperative line, which would be eight times the requests on random rows; but the hits of a
+// pattern are adjacent rows of the same 112-row records, and LF keeps rows with the same symbol adjacent, so the 64
+// lanes of a wave ask for a handful of lines per instruction and a wave instruction serves 64 walks.  Chosen when the
+// batch averages at least 64 hits per pattern.
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_walk_lane_kernel(
+    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples, uint64_t total,
+    const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t nsteps = 0;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth) {
+    uint32_t row = rows[h], walk_steps = 0xFFFFFFFFu, si;
+    for (;;) {
+      FMX_CHECK(row < n);
+      uint32_t off;
+      const uint32_t wr = fmx_walk_record(row, off);
+      const uint4 *R = walk + (size_t)wr * 8u;
+      const uint32_t pi = off >> 4, bit = off & 15u;
+      FMX_TOUCH(&R[pi]);
+      const uint4 own = R[pi];
+      const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
+      const uint32_t ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
+      if (walk_steps == 0xFFFFFFFFu) walk_steps = ph;             // the walk is exactly SA[row] mod 2^level steps long
+      const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
+      uint32_t cnt = 0;
+      for (uint32_t q = 0; q <= pi; q++) {                        // rows before `row` in the record: whole pieces, then its own
+        uint4 p = own;
+        if (q != pi) { FMX_TOUCH(&R[q]); p = R[q]; }
+        const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
+        const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
+        const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
+        const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
+        cnt += __popc(sel);
+      }
+      // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
+      const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
+      FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));
+      FMX_TOUCH(&R[cp]);
+      const uint4 cv = R[cp];
+      uint32_t ctr = cv.x;
+      if (ph == 1u && sym >= 3u) ctr = sym == 3u ? cv.y : (sym == 4u ? cv.z : cv.w);
+      if (ph <= 1u) { si = ctr + cnt; break; }                    // this row's sample (phase 0) or the next row's (phase 1)
+      row = ctr + cnt;                                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+    }
+    FMX_CHECK(si < nsamples);
+    FMX_TOUCH(&samples[si]);
+    uint64_t v = (uint64_t)samples[si] + walk_steps;              // (sa + steps) % len          fm_index.rs:131-133
+    if (v >= n) v -= n;
+    out_pos[h] = v;
+    nsteps += walk_steps;
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // ---- RLFM with the run table, batches of LONG intervals: a lane per walk on consecutive hits (round 4) ----------------
 // The hits of a pattern are adjacent rows; adjacent rows sit in the same runs and stay neighbours under LF (lf_map(i) =
 // lfrun[run] + offset in the run).  A wave that walks 64 CONSECUTIVE hits -- lane per walk, every probe lane-wise,
@@ -2151,7 +2209,13 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     uint32_t hpb;
     unsigned gr;
     c.slice(nb, chunk, hpb, gr);
-    if (dv.phase && dv.walk && tn.walk_records) {   // text-order sampling with walk records: no phase probes
+    if (dv.phase && dv.walk && tn.walk_records && total / npat >= 64 && total >= (1u << 16) && !tn.walks && !tn.loc_blocks) {
+      // long intervals: a lane per walk on consecutive hits
+      uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
+      if (lb > 8192) lb = 8192;
+      hipLaunchKernelGGL(fmx_locate_walk_lane_kernel, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, dv.walk, dv.samples, dv.n,
+                         dv.nsamples, c.total, c.rows, c.pos, c.steps);
+    } else if (dv.phase && dv.walk && tn.walk_records) {   // text-order sampling with walk records: no phase probes
       if (chunk == FMX_LCHUNK && tn.wc) {
 #ifdef FMX_MEASURE   // FMX_VARIANT=15: 8 walks per group -- 86 VGPRs; walk kernel 0.0805 ms against 0.0774 with 4, config 3b 10.9 against 9.8 ms
         if (q == 8) FMX_LOCT_LAUNCH(c, gr, lthreads, hpb, chunk, 8, true); else

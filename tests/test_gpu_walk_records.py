@@ -133,3 +133,33 @@ def test_multi_pieces_index_gets_no_walk_records():
     oi = O.OracleIndex(t, 4, level=2, kind="multi")
     pos, _ = _locate_steps(gi, [0], [n])
     assert (pos == oi.get_sa(np.arange(n)).astype(np.uint64)).all()
+
+
+@pytest.mark.parametrize("n,sigma,level,m", [((1 << 18) + 77, 4, 2, 4), (200003, 5, 3, 3), (150000, 4, 1, 4), (300000, 2, 2, 9),
+                                             (131072, 3, 3, 5)])
+def test_long_intervals_take_the_lane_per_walk_kernel(n, sigma, level, m):
+    """batches that average 64+ hits per pattern (2^16+ hits in all) on an index with walk records go through
+    fmx_locate_walk_lane_kernel -- a lane per walk on consecutive hits, every lane decoding its row's record alone
+    (round 4): the oracle's exact sequences, and those of the same text's row-order index (group-cooperative walk)"""
+    t = ((W.splitmix64_np(n + sigma, 0, n) % np.uint64(sigma)) + np.uint64(1)).astype(np.uint8)
+    t[-1] = 0
+    gi = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level)
+    assert gi.walk_records() and gi.text_order()
+    oi = O.OracleIndex(t, sigma, level=level)
+    flat, off, _ = W.substring_patterns_np(t, 400, m, 31)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off, nthreads=8)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    total = int((oe - os_).sum())
+    assert total >= (1 << 16) and total // 400 >= 64, total
+    goff, gpos = gb.locate()
+    ooff, opos = oi.locate_batch(os_, oe, nthreads=8)
+    assert (goff == ooff).all() and (gpos == opos).all()
+    ri = F.FMIndexWithLocate(F.Text.with_max_character(t, sigma), level, sampling="row")
+    _, rpos = ri.search_many(flat=flat, off=off).locate()
+    assert (rpos == opos).all()
+    # a batch of the same patterns that does NOT reach 64 hits per pattern on average takes the cooperative kernel
+    few = gi.search_many(flat=flat[: 8 * m], off=off[:9])
+    foff, fpos = few.locate()
+    assert (fpos == opos[: int(ooff[8])]).all()
+    gi.close(); ri.close()

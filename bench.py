@@ -427,13 +427,14 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
 # live PMC passes: rocprofv3 runs a child of this script; separate --pmc passes, no trace domains
 # --------------------------------------------------------------------------------------------
 WALK_KERNEL = "fmx_locate_f3t_kernel"    # the default DNA index: text order + walk records (round 4)
+LANE_WALK_KERNEL = "fmx_locate_walk_lane_kernel"   # the same index on batches of 64+ hits per pattern (config 3b)
 PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
     "dna_count": ["fmx_count_f3_kernel<1, false, false>", "fmx_count_f3_kernel"],
     "dna_count_pair": ["fmx_count_pair_kernel<false>"],          # opt-in accelerators (accel_legs)
     "dna_count_kmer": ["fmx_count_f3_kernel<1, false, true>"],
     "dna_count_both": ["fmx_count_pair_kernel<true>"],
     "dna_locate": [WALK_KERNEL],
-    "dna_locate_3b": [WALK_KERNEL],
+    "dna_locate_3b": [LANE_WALK_KERNEL, WALK_KERNEL],
     "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
     "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
 }
@@ -474,7 +475,7 @@ def pmc_per_dispatch(agg, subs, which="largest"):
         cands = [(kn, nd, tot) for kn, (nd, tot) in agg.items() if sub in kn]
         if not cands:
             continue
-        if which == "largest":
+        if which == "largest" or all(pmc_grid_of(c[0]) == 0 for c in cands):     # (a kernel that is not keyed by grid)
             best = max(cands, key=lambda c: c[2])
         else:
             grids = sorted({pmc_grid_of(c[0]) for c in cands})
@@ -1483,6 +1484,11 @@ def dna_walk_kernel(wl):
     return "fmx_locate_f3t_kernel<4>" if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
 
 
+def dna_walk_kernel_long(wl):
+    """batches that average 64+ hits per pattern on an index with walk records: a lane per walk on consecutive hits"""
+    return LANE_WALK_KERNEL if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
+
+
 def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="locate"):
     torch, lib = wl.torch, wl.lib
     import numpy as np
@@ -1765,12 +1771,20 @@ def locate_3b(out, wl, args, key):
     nrec = lf_steps + (int(((pos[:total] & ((1 << wl.level) - 1)) == 0).sum().item()) if wl.index.walk_records() else 0)
     widths = {"requested_lines": nrec + total, "requested_records": nrec, "requested_probes": total,
               "distinct_lines": None}
-    out["locate_3b"]["requested_lines"] = nrec + total
-    out["locate_3b"]["requested_lines_per_s"] = (nrec + total) / (kms / 1e3)
-    out["locate_3b"]["bound"] = ("vector-instruction issue, not HBM: the hits of a pattern are adjacent rows, and LF keeps rows "
-                                 "of one symbol adjacent -- their records (and, in text order, their samples: consecutive "
-                                 "entries) come from the caches, so few requests reach the fabric (roofline.fabric_requests)")
-    out["locate_3b"]["roofline"] = make_roofline(dna_walk_kernel(wl), kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
+    if wl.index.walk_records():
+        # the lane-per-walk kernel reads a record as lane-wise 16-byte pieces -- the row's own, the pieces in front of it
+        # (3 on average), the counter's -- so every request is a probe: about 5 per record visit, one per sample
+        widths = {"requested_lines": 5 * nrec + total, "requested_records": 0, "requested_probes": 5 * nrec + total,
+                  "distinct_lines": None}
+    out["locate_3b"]["requested_lines"] = widths["requested_lines"]
+    out["locate_3b"]["requested_lines_per_s"] = widths["requested_lines"] / (kms / 1e3)
+    out["locate_3b"]["bound"] = ("not HBM: the hits of a pattern are adjacent rows, and LF keeps rows of one symbol adjacent -- "
+                                 "their records (and, in text order, their samples: consecutive entries) come from the "
+                                 "caches, so few requests reach the fabric (roofline.fabric_requests).  The group-cooperative "
+                                 "walk was bound by vector-instruction issue here (9.7 ms: ~12 wave instructions per walk "
+                                 "step, 8 walks per instruction); since round 4 batches of 64+ hits per pattern take "
+                                 "fmx_locate_walk_lane_kernel: a lane decodes its row's record alone, 64 walks per instruction")
+    out["locate_3b"]["roofline"] = make_roofline(dna_walk_kernel_long(wl), kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
                                                  total * 4 + total * 8, widths, stored_traffic(key, "locate_3b"))
 
 

@@ -101,3 +101,21 @@ def test_pretouch_is_optional_preparation_without_a_gpu():
     B.pretouch_device(0)
     assert B.PRETOUCH.get("gib") == 0.0 and (B.PRETOUCH.get("returncode") or B.PRETOUCH.get("error"))
     B.PRETOUCH.clear()
+
+
+def test_config_3b_counters_come_from_the_lane_per_walk_kernel():
+    """since round 4 config 3b (64+ hits per pattern) runs fmx_locate_walk_lane_kernel, a kernel of its own that is not
+    keyed by grid; the config-3 walk kernel then has one shape only"""
+    lane = "fmx_locate_walk_lane_kernel(HIP_vector_type<unsigned int, 4u> const*, ...)"
+    rows = ([row(WALK, 262144, "FETCH_SIZE", 263400.0 + i) for i in range(3)]
+            + [row(lane, 2097152, "FETCH_SIZE", 9.1e6 + i) for i in range(2)])
+    agg = B.pmc_aggregate(rows, "FETCH_SIZE")
+    kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate_3b"], B.PMC_WHICH["dna_locate_3b"])
+    assert "fmx_locate_walk_lane_kernel" in kn and abs(v - (9.1e6 + 0.5)) < 1.0
+    kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate"], B.PMC_WHICH["dna_locate"])
+    assert kn.endswith("@grid 262144") and abs(v - 263401.0) < 1.0
+    # an index without walk records: both shapes under the old kernel's name, told apart by grid as before
+    rows = ([row(WALK, 262144, "FETCH_SIZE", 263400.0)] + [row(WALK, 524288, "FETCH_SIZE", 27.8e6)])
+    agg = B.pmc_aggregate(rows, "FETCH_SIZE")
+    kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate_3b"], B.PMC_WHICH["dna_locate_3b"])
+    assert kn.endswith("@grid 524288") and v == 27.8e6

@@ -1,0 +1,32 @@
+#!/bin/bash
+# One parameterised entry for the GPU-box runs of a round (replaces the single-use r0x_*.sh scripts):
+#   gpurun --timeout S -- 'bash benchmarks/gpu/run.sh <round> <task> [args...]'
+# Outputs go to gpurun_out/<round>/ (scratch); what is kept is copied to profiles/<round>/ by hand.
+# Every command is bounded by `timeout`.
+#   driver          the driver's exact bench command; raw stdout/stderr + the detail file + line length
+#   suite [expr]    pytest -m gpu (optionally -k expr), durations of the slowest tests
+#   tests <files>   pytest -m gpu on the named files
+#   rocprof         profiles/run_rocprof.sh <round> (kernel-trace --stats of the bench command)
+#   soak <iters> [lib]   tests/fuzz_gpu_vs_oracle.py for <iters> iterations (optionally on another libfmx*.so)
+#   py <script> [args]   any python script under benchmarks/
+R=$1; T=$2; shift 2
+O=gpurun_out/$R; mkdir -p $O
+case $T in
+driver)
+  ( time timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $O/bench_detail.json ) > $O/driver_stdout.txt 2> $O/driver_stderr.txt
+  echo "rc $? ; stdout lines $(wc -l < $O/driver_stdout.txt) ; last line bytes $(tail -n 1 $O/driver_stdout.txt | wc -c)"
+  tail -n 1 $O/driver_stdout.txt; tail -n 4 $O/driver_stderr.txt ;;
+suite)
+  timeout 1500 python3 -m pytest tests -m gpu -x -q --durations=25 ${1:+-k "$1"} > $O/suite.txt 2>&1; echo "rc $?"; tail -n 40 $O/suite.txt ;;
+tests)
+  timeout 1500 python3 -m pytest "$@" -m gpu -x -q --durations=10 > $O/tests.txt 2>&1; echo "rc $?"; tail -n 25 $O/tests.txt ;;
+rocprof)
+  timeout 1200 bash profiles/run_rocprof.sh $R "$@" ;;
+soak)
+  IT=$1; LIB=$2
+  ( [ -n "$LIB" ] && export FMX_LIB=$PWD/fm_index_amd/$LIB; timeout 1500 python3 tests/fuzz_gpu_vs_oracle.py --iters $IT ${3:+--mode $3} ) > $O/soak_${LIB:-shipped}${3:+_$3}.txt 2>&1
+  echo "rc $?"; tail -n 6 $O/soak_${LIB:-shipped}${3:+_$3}.txt ;;
+py)
+  S=$1; shift; timeout 1500 python3 $S "$@" 2>&1 | tee $O/$(basename $S .py).txt | tail -n 40 ;;
+*) echo "unknown task $T"; exit 2 ;;
+esac

@@ -15,17 +15,22 @@ cd /tmp && export TMPDIR=/tmp
 # --no-config5 / --no-rccl-check: the 8 M-pattern batch runs the same count kernel on another shape (5 ms per launch)
 # 20 timed steps: the first launches of a kernel in a process run slower (cold TLB / caches: 0.70-0.77 ms against 0.63-0.65
 # for the count kernel) and must not weigh on the per-kernel average the bench line is compared with
-ARGS="--steps 20 --warmup 5 --no-pretouch --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-3b --no-wide --no-config5 --no-rccl-check ${2:---no-accel}"
-rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child --no-3b > $OUT/pmc_write.out 2> $OUT/pmc_write.err
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-wide --no-config5 --no-rccl-check --no-ic-ab ${2:---no-accel}"
+rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS --detail-out $OUT/bench_trace_detail.json > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_write.out 2> $OUT/pmc_write.err
+# config 4b (repetitive text, RLFM): fmx_locate_rl_lane_kernel -- its own trace and counter passes
+rocprofv3 --kernel-trace --stats -d $OUT/trace4b --output-format csv -- python3 $REPO/bench.py --workload rep-rlfm --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-census --no-d2h --no-accel --no-rccl-check --detail-out $OUT/bench_trace4b_detail.json > $OUT/bench_trace4b.json 2> $OUT/trace4b.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_fetch4b.out 2> $OUT/pmc_fetch4b.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_write4b.out 2> $OUT/pmc_write4b.err
 # keep only the small summaries (the full traces can be large)
 cd $OUT
-find . -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find trace -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find trace4b -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats_config4b.csv \;
 python3 - <<'PY'
 import csv, glob, collections, json, os
 out = {}
-for tag in ("pmc_fetch", "pmc_write"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_fetch4b", "pmc_write4b"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(tag + "/**/*counter_collection*.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -37,5 +42,5 @@ for tag in ("pmc_fetch", "pmc_write"):
                 for k, v in agg.items()}
 json.dump(out, open("pmc_summary.json", "w"), indent=1)
 PY
-rm -rf trace/*/*.db pmc_fetch pmc_write 2>/dev/null
+rm -rf trace/*/*.db trace4b/*/*.db pmc_fetch pmc_write pmc_fetch4b pmc_write4b 2>/dev/null
 ls -la $OUT

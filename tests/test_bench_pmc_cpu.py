@@ -119,3 +119,62 @@ def test_config_3b_counters_come_from_the_lane_per_walk_kernel():
     agg = B.pmc_aggregate(rows, "FETCH_SIZE")
     kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate_3b"], B.PMC_WHICH["dna_locate_3b"])
     assert kn.endswith("@grid 524288") and v == 27.8e6
+
+
+# ---- the line the driver parses (the 21.9 KB line of round 4 left BENCH_r04.parsed = null) ----
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms"}
+CPU_KEYS = {"value", "unit", "cores", "kind", "sample"}
+
+
+def _last_line_of(detail):
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--headline-of", detail],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = p.stdout.decode().rstrip("\n").splitlines()
+    assert len(lines) == 1                       # nothing else on stdout
+    return lines[-1]
+
+
+def test_the_last_stdout_line_is_compact_and_complete():
+    """bench.py's print path on the largest result object on record (round 4's 21.9 KB line): the line must stay below
+    4 KB, carry the contract's keys with `roofline` and `cpu_baseline`, and every number must be the detail's"""
+    import json
+    detail = os.path.join(ROOT, "profiles", "r04", "bench_default.json")
+    last = _last_line_of(detail)
+    assert len(last) < 4096, len(last)
+    line = json.loads(last)
+    full = json.loads(open(detail).read().strip().splitlines()[-1])
+    assert CONTRACT_KEYS <= set(line) and ROOFLINE_KEYS <= set(line["roofline"]) and CPU_KEYS <= set(line["cpu_baseline"])
+    for k in CONTRACT_KEYS - {"config", "roofline", "cpu_baseline"}:
+        assert line[k] == full[k], k
+    assert line["config"]["workload"] == full["config"]["workload"][:300]
+    for k in ("achieved", "frac", "traffic", "avg_kernel_ms", "kernel"):
+        assert line["roofline"][k] == full["roofline"][k]
+    assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] == 16
+    assert abs(line["locate_hits_per_s"] / full["locate"]["hits_per_s"] - 1) < 1e-3
+    assert abs(line["rlfm_value"] / full["rlfm"]["value"] - 1) < 1e-3
+    assert line["detail"] == detail
+    # no nested object beyond the three the contract names
+    assert all(not isinstance(v, (dict, list)) for k, v in line.items() if k not in ("config", "roofline", "cpu_baseline"))
+
+
+def test_the_line_survives_oversized_and_failed_legs(tmp_path):
+    """a leg that failed is named (`legs_failed`), absent legs are simply absent, and a pathologically long workload
+    string cannot push the line past the limit"""
+    import json
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04", "bench_default.json")).read().strip().splitlines()[-1])
+    full["wide"] = {"error": "RuntimeError('x')"}
+    del full["rlfm"]
+    full["per_rank"] = [{"rank": r, "kernel_ms": 0.6 + r, "gather_ms": 0.1, "wall_ms_per_step": 1.0} for r in range(8)]
+    full["config"]["workload"] = "w" * 3000
+    p = tmp_path / "d.json"
+    p.write_text(json.dumps(full))
+    last = _last_line_of(str(p))
+    assert len(last) < 4096
+    line = json.loads(last)
+    assert line["legs_failed"] == ["wide"] and "rlfm_value" not in line and line["kernel_ms_max"] == 7.6
+    assert CONTRACT_KEYS <= set(line)

@@ -16,13 +16,33 @@ COMMON = ["--log2n", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
           "--no-pmc", "--no-3b", "--no-d2h", "--no-early-exit", "--no-wide", "--pattern-seed", "7"]
 
 
-def _run(extra, tmp_path, tag):
-    dump = str(tmp_path / (tag + ".npy"))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + COMMON + extra + ["--dump-counts", dump],
+def _bench(argv, tmp_path, tag):
+    """runs bench.py; returns the FULL result object (--detail-out) after checking the stdout contract: the last line
+    is the compact headline object (< 4 KB) whose numbers are the detail file's"""
+    detail = str(tmp_path / (tag + "_detail.json"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--detail-out", detail],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
-    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
-    return json.loads(line), np.load(dump)
+    last = p.stdout.decode().rstrip("\n").splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    line = json.loads(last)
+    with open(detail) as f:
+        full = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert line["config"]["workload"] == full["config"]["workload"] and line["detail"] == detail
+    assert line["roofline"]["kernel"] == full["roofline"]["kernel"]
+    assert line["roofline"]["avg_kernel_ms"] == full["roofline"]["avg_kernel_ms"]
+    if "cpu_baseline" in full:
+        assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["kind"] == "port"
+    return full
+
+
+def _run(extra, tmp_path, tag):
+    dump = str(tmp_path / (tag + ".npy"))
+    full = _bench(COMMON + extra + ["--dump-counts", dump], tmp_path, tag)
+    return full, np.load(dump)
 
 
 def test_two_ranks_equal_one_process(tmp_path):
@@ -97,10 +117,7 @@ def test_strong_scaling_two_ranks_hash_like_one_process(tmp_path):
     common = [a for a in COMMON if a not in ("--no-cpu-baseline", "--pattern-seed", "7")]
     def run(extra, tag):
         dump = str(tmp_path / (tag + ".npy"))
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + strong + extra +
-                           ["--dump-counts", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-        assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
-        return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]), np.load(dump)
+        return _bench(common + strong + extra + ["--dump-counts", dump], tmp_path, tag), np.load(dump)
     two, c2 = run(["--gpus", "2", "--dist-backend", "gloo"], "two")
     one, c1 = run(["--gpus", "1"], "one")
     assert two["scaling"] == one["scaling"] == "strong"
@@ -131,19 +148,13 @@ def test_default_line_carries_config5_at_one_gpu(tmp_path):
     test sizes) in ONE batch through the 1-rank RCCL communicator, hashed, and a sample checked against the oracle;
     its hash equals the hash of a strong-scaling run over the same set"""
     small = [a for a in COMMON if a not in ("--no-cpu-baseline", "--pattern-seed", "7")] + ["--cpu-seconds", "1"]
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + ["--gpus", "1", "--npat", "8192"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
-    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    line = _bench(small + ["--gpus", "1", "--npat", "8192"], tmp_path, "default")
     c5 = line["config5_g1"]
     assert "error" not in c5, c5
     assert c5["total_patterns"] == 65536 and c5["executed_steps"] == 65536 * 32
     assert c5["oracle_sample"]["identical_s_e"] is True and c5["oracle_sample"]["patterns"] == 1 << 15
     # tests/golden/config5_counts.json holds this set's hashes from the CPU oracle over all 65 536 patterns
     assert c5["matches_golden"]["counts_sha256"] is True and c5["matches_golden"]["ranges_sha256"] is True
-    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small +
-                       ["--gpus", "1", "--total-patterns", "65536", "--no-cpu-baseline", "--no-locate"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert q.returncode == 0, q.stderr.decode(errors="replace")[-2000:]
-    strong = json.loads([ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    strong = _bench(small + ["--gpus", "1", "--total-patterns", "65536", "--no-cpu-baseline", "--no-locate"],
+                    tmp_path, "strong")
     assert strong["counts_sha256"] == c5["counts_sha256"] and strong["ranges_sha256"] == c5["ranges_sha256"]

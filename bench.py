@@ -527,6 +527,8 @@ def headline(out, detail_path):
         "rlfm_index_bytes": _get(out, "rlfm", "config", "index_bytes"),
         "rlfm_locate_hits_per_s": _get(out, "rlfm", "locate", "hits_per_s"),
         "rlfm_locate_frac": _get(out, "rlfm", "locate", "roofline", "frac"),
+        "rlfm_count_only_index_bytes": _get(out, "rlfm", "config", "count_only_index_bytes"),
+        "rlfm_locate_run_table_hits_per_s": _get(out, "rlfm", "locate_run_table", "hits_per_s"),
         "rlfm_cpu_value": _get(out, "rlfm", "cpu_baseline", "value"),
         "count_n31_value": _get(out, "count_n31", "value"),
         "count_n31_frac": _get(out, "count_n31", "roofline", "frac"),

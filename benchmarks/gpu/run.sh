@@ -7,7 +7,8 @@
 #   suite [expr]    pytest -m gpu (optionally -k expr), durations of the slowest tests
 #   tests <files>   pytest -m gpu on the named files
 #   rocprof         profiles/run_rocprof.sh <round> (kernel-trace --stats of the bench command)
-#   soak <iters> [lib]   tests/fuzz_gpu_vs_oracle.py for <iters> iterations (optionally on another libfmx*.so)
+#   soak <seconds> [seed] [lib|shipped] [long]   tests/fuzz_gpu_vs_oracle.py (optionally on another libfmx*.so; `long` =
+#                        the long-interval batches: lane-per-walk kernels, per-ticket dispatch, every select branch)
 #   py <script> [args]   any python script under benchmarks/
 R=$1; T=$2; shift 2
 O=gpurun_out/$R; mkdir -p $O
@@ -23,9 +24,10 @@ tests)
 rocprof)
   timeout 1200 bash profiles/run_rocprof.sh $R "$@" ;;
 soak)
-  IT=$1; LIB=$2
-  ( [ -n "$LIB" ] && export FMX_LIB=$PWD/fm_index_amd/$LIB; timeout 1500 python3 tests/fuzz_gpu_vs_oracle.py --iters $IT ${3:+--mode $3} ) > $O/soak_${LIB:-shipped}${3:+_$3}.txt 2>&1
-  echo "rc $?"; tail -n 6 $O/soak_${LIB:-shipped}${3:+_$3}.txt ;;
+  SEC=$1; SEED=${2:-1}; LIB=$3; MODE=$4
+  TAG=${LIB:-shipped}${MODE:+_long}_seed$SEED
+  ( [ -n "$LIB" ] && [ "$LIB" != shipped ] && export FMX_LIB=$PWD/fm_index_amd/$LIB; timeout $((SEC + 600)) python3 tests/fuzz_gpu_vs_oracle.py $SEC $SEED ${MODE:+--long} ) > $O/soak_$TAG.txt 2>&1
+  echo "rc $?"; tail -n 4 $O/soak_$TAG.txt ;;
 py)
   S=$1; shift; timeout 1500 python3 $S "$@" 2>&1 | tee $O/$(basename $S .py).txt | tail -n 40 ;;
 *) echo "unknown task $T"; exit 2 ;;

@@ -18,7 +18,8 @@ LINE = 128
 class Workload:
     """text + index + pattern batch of one BASELINE config, resident in HBM."""
 
-    def __init__(self, name, args, dev, local, rank, world, rlfm=None, with_locate=True, npat=None, plen=None):
+    def __init__(self, name, args, dev, local, rank, world, rlfm=None, with_locate=True, npat=None, plen=None,
+                 index_kw=None, text=None):
         import torch
         import fm_index_amd as F
         from fm_index_amd import workload as W
@@ -50,7 +51,9 @@ class Workload:
             self.shard_sizes = [self.npat] * world
         self.npat_pad = max(self.shard_sizes)        # every rank's slot in the gathered buffer
         t0 = time.time()
-        if self.dna:
+        if text is not None:
+            self.text = text                         # another workload's text (same name, same n)
+        elif self.dna:
             self.text = W.dna_text_torch(self.n, 1, dev)
         elif name.startswith("rep"):
             self.text = W.repetitive_text_torch(self.n, 5, dev, base_len=1 << 20, mut_per_1024=args.mut_per_1024)
@@ -63,7 +66,8 @@ class Workload:
             cls = F.RLFMIndexWithLocate if self.level is not None else F.RLFMIndex
         else:
             cls = F.FMIndexWithLocate if self.level is not None else F.FMIndex
-        self.index = cls.from_device_text(self.text.data_ptr(), self.n, self.maxc, level=self.level, device=local)
+        self.index = cls.from_device_text(self.text.data_ptr(), self.n, self.maxc, level=self.level, device=local,
+                                          **(index_kw or {}))
         self.h = self.index.handle()
         self.build_ms = self.lib.fmx_build_ms(self.h)
         # global pattern set = world * npat substrings of the text; this rank owns a contiguous shard

@@ -257,8 +257,30 @@ def rlfm_leg(out, args, dev, local):
          "roofline": make_roofline("fmx_count_ep_kernel", ms, npat * m, wr.ref_bytes_per_char(), stream_bytes,
                                    cen, stored_traffic(key, "count"))}
     out["rlfm"] = o
+    # the count-only type of BASELINE config 4 (`RLFMIndex`, frontend.rs:213-231): what the index costs without samples
+    try:
+        co = wr.F.RLFMIndex.from_device_text(wr.text.data_ptr(), wr.n, wr.maxc, device=local)
+        o["config"]["count_only_index_bytes"] = co.heap_size()
+        co.close()
+    except Exception as ex:  # noqa: BLE001
+        o["config"]["count_only_index_bytes"] = repr(ex)
+    o["config"]["run_table"] = bool(wr.index.walk_records())
+    o["config"]["space_policy"] = ("run table (4 B per run) only when r <= n/4 or FMX_FLAG_RUN_TABLE: this text has %.2f runs "
+                                   "per row" % (o["config"]["runs"] / float(wr.n)))
     if wr.level is not None:
         locate_leg(out, wr, args, 1, 0, None, False, key, dest=o)
+        if not wr.index.walk_records() and not args.no_accel:
+            # the same text with FMX_FLAG_RUN_TABLE (opt-in on a text with about one run per row): the round-4 locate path
+            try:
+                w2 = Workload("bytes-rlfm", args, dev, local, 0, 1, index_kw={"run_table": True}, text=wr.text)
+                try:
+                    locate_leg(out, w2, args, 1, 0, None, False, key, dest=o, legname="locate_run_table")
+                    o["locate_run_table"]["index_bytes"] = w2.index.heap_size()
+                    assert bool((w2.d_pos[:w2.total_hits] == wr.d_pos[:wr.total_hits]).all()), "run table locates differently"
+                finally:
+                    w2.close()
+            except Exception as ex:  # noqa: BLE001
+                o["locate_run_table"] = {"error": repr(ex)}
     if not args.no_cpu_baseline:
         wr.count()
         torch.cuda.synchronize()

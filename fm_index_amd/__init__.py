@@ -107,7 +107,7 @@ class Text:
 
 
 def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_records=True, auto=False,
-           keep_scratch=False):
+           keep_scratch=False, run_table=False):
     """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
     (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
     if sampling not in (None, "text", "row"):
@@ -116,14 +116,14 @@ def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_rec
             (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
             (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0) |
             (0 if walk_records else L.FLAG_NO_WALK_RECORDS) | (L.FLAG_AUTO if auto else 0) |
-            (L.FLAG_KEEP_SCRATCH if keep_scratch else 0))
+            (L.FLAG_KEEP_SCRATCH if keep_scratch else 0) | (L.FLAG_RUN_TABLE if run_table else 0))
 
 
 class _Index:
     _kind = L.KIND_FM
 
     def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False,
-                 sampling=None, force_wide=False, walk_records=True, auto=False):
+                 sampling=None, force_wide=False, walk_records=True, auto=False, run_table=False):
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -134,14 +134,15 @@ class _Index:
         rc = self._lib.fmx_build(_p(t) if len(t) else None, len(t), t.dtype.itemsize,
                                  text.max_character(),
                                  self._kind, lvl,
-                                 _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto),
+                                 _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
+                                        run_table=run_table),
                                  device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
                          pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False,
-                         walk_records=True, auto=False, keep_scratch=False):
+                         walk_records=True, auto=False, keep_scratch=False, run_table=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -150,7 +151,7 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
                                        _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
-                                              keep_scratch),
+                                              keep_scratch, run_table),
                                        device, C.byref(self._h)))
         return self
 
@@ -360,8 +361,11 @@ class RLFMIndexWithLocate(_Index):
     _kind = L.KIND_RLFM
 
     def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, walk_records=True,
-                 force_wide=False):
-        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, force_wide, walk_records)
+                 force_wide=False, run_table=False):
+        """run_table=True: FMX_FLAG_RUN_TABLE -- the run table whatever the text's runs-per-row ratio (the builder adds
+        it by itself when r <= n / 4)"""
+        super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, force_wide, walk_records,
+                         run_table=run_table)
 
 
 class FMIndexMultiPieces(_Index):

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fmx_narrow_u64_kernel(const uint64_t *__r
 // (a small build is launch- and round-trip-bound: four runtime calls fewer per index)
 static hipError_t alloc_handle_words(fmx_index *idx) {
   uint8_t *p = nullptr;
-  hipError_t e = hipMalloc((void **)&p, 16);
+  hipError_t e = fmx_dev_malloc((void **)&p, 16);
   if (e != hipSuccess) return e;
   idx->dev.status = (uint32_t *)p;
   idx->d_steps = (uint64_t *)(p + 8);
@@ -157,7 +157,7 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
     const uint64_t samples = level == FMX_NO_LOCATE ? 0 : (level >= 32 ? n * 4 : ((n - 1) >> level) * 4 + n * 2);
     const uint64_t index_est = n / 2 + n + (128ull << 20) + samples;      // records + pair records + table + locate arrays
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4 * index_est)
+    if (fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4 * index_est)
       flags |= FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE;
   }
 
@@ -184,9 +184,9 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
 
     if (text_on_device && sym_bytes == 8) {
       uint32_t *d_bad = nullptr, h_bad = 0;
-      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      if ((e = fmx_dev_malloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "fmx_dev_malloc(text)", __LINE__); break; }
       own_text = true;
-      if ((e = hipMalloc((void **)&d_bad, 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
+      if ((e = fmx_dev_malloc((void **)&d_bad, 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
       (void)hipMemset(d_bad, 0, 4);
       uint64_t blocks = (n + 255) / 256;
       if (blocks < 1) blocks = 1;
@@ -212,11 +212,11 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
       }
       if (bad) { rc = fail(FMX_ERR_SYMBOL_RANGE, "text symbol exceeds max_character"); break; }
       idx->sym_bytes = 4;
-      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      if ((e = fmx_dev_malloc((void **)&d_text, (n ? n : 1) * 4)) != hipSuccess) { rc = fmx_hip_fail(e, "fmx_dev_malloc(text)", __LINE__); break; }
       own_text = true;
       if (n && (e = hipMemcpy(d_text, dst, n * 4, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
     } else {
-      if ((e = hipMalloc((void **)&d_text, (n ? n : 1) * sym_bytes)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc(text)", __LINE__); break; }
+      if ((e = fmx_dev_malloc((void **)&d_text, (n ? n : 1) * sym_bytes)) != hipSuccess) { rc = fmx_hip_fail(e, "fmx_dev_malloc(text)", __LINE__); break; }
       own_text = true;
       if (n && (e = hipMemcpy(d_text, text, n * sym_bytes, hipMemcpyHostToDevice)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMemcpy(text)", __LINE__); break; }
     }
@@ -283,8 +283,15 @@ void fmx_set_timing(fmx_index *idx, int enabled) {
     if (dg.set(idx->device) != hipSuccess) return;
     hipEvent_t *ev = (hipEvent_t *)calloc(2 * FMX_SERIES_CAP, sizeof(hipEvent_t));
     bool ok = ev != nullptr;
-    for (int i = 0; ok && i < 2 * FMX_SERIES_CAP; i++) ok = hipEventCreate(&ev[i]) == hipSuccess;
-    if (!ok) { free(ev); enabled = 0; } else idx->ev_series = ev;
+    int made = 0;
+    for (; ok && made < 2 * FMX_SERIES_CAP; made++) ok = hipEventCreate(&ev[made]) == hipSuccess;
+    if (!ok) {
+      for (int i = 0; ev && i < made - 1; i++) (void)hipEventDestroy(ev[i]);   // (the failing create made nothing)
+      free(ev);
+      enabled = 0;
+    } else {
+      idx->ev_series = ev;
+    }
   }
   idx->timing = enabled;
 }
@@ -485,7 +492,7 @@ SmallCtx *small_ctx(int device) {
            hipEventCreateWithFlags(&c.ev_k[made], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c.ev_off[made], hipEventDisableTiming) == hipSuccess;
     if (!ok || hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void **)&c.d, kSmallCap) != hipSuccess) {
+        fmx_dev_malloc((void **)&c.d, kSmallCap) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
       (void)hipStreamDestroy(c.st3);
@@ -510,7 +517,7 @@ struct HostCall {
     if (bytes > kRetainCap) {
       temp = true;
       cap = bytes;
-      return hipMalloc((void **)&base, bytes);
+      return fmx_dev_malloc((void **)&base, bytes);
     }
     if (bytes > sx->big_cap) {
       if (sx->big) (void)hipFree(sx->big);
@@ -518,7 +525,7 @@ struct HostCall {
       sx->big_cap = 0;
       size_t want = bytes + bytes / 4;
       if (want > kRetainCap) want = kRetainCap;
-      hipError_t e = hipMalloc((void **)&sx->big, want);
+      hipError_t e = fmx_dev_malloc((void **)&sx->big, want);
       if (e != hipSuccess) return e;
       sx->big_cap = want;
     }
@@ -544,7 +551,7 @@ struct Scratch {  // device buffers freed on scope exit
   int n = 0;
   ~Scratch() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
   hipError_t get(void **out, size_t bytes) {
-    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    hipError_t e = fmx_dev_malloc(out, bytes ? bytes : 8);
     if (e == hipSuccess) p[n++] = *out;
     return e;
   }
@@ -1127,9 +1134,9 @@ int fmx_export_sa_samples64(const fmx_index *idx, uint64_t *host_out) {
     uint64_t *d_rows = nullptr, *d_vals = nullptr;
     uint64_t *h_buf = (uint64_t *)malloc((size_t)(cap ? cap : 1) * 8);
     if (!h_buf) return fail(FMX_ERR_ARG, "out of host memory");
-    hipError_t e = hipMalloc((void **)&d_rows, (size_t)(cap ? cap : 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_vals, (size_t)(cap ? cap : 1) * 8);
-    int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "hipMalloc(export scratch)", __LINE__);
+    hipError_t e = fmx_dev_malloc((void **)&d_rows, (size_t)(cap ? cap : 1) * 8);
+    if (e == hipSuccess) e = fmx_dev_malloc((void **)&d_vals, (size_t)(cap ? cap : 1) * 8);
+    int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "fmx_dev_malloc(export scratch)", __LINE__);
     for (uint64_t a = 0; a < k && rc == FMX_OK; a += chunk) {
       const uint64_t m = k - a < chunk ? k - a : chunk;
       for (uint64_t j = 0; j < m; j++) h_buf[j] = (a + j) * step;
@@ -1166,9 +1173,9 @@ int fmx_export_sa_samples(const fmx_index *idx, uint32_t *host_out) {
   uint64_t *d_rows = nullptr, *d_vals = nullptr;
   uint64_t *h_buf = (uint64_t *)malloc((size_t)cap * 8);
   if (!h_buf) return fail(FMX_ERR_ARG, "out of host memory");
-  hipError_t e = hipMalloc((void **)&d_rows, (size_t)cap * 8);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, (size_t)cap * 8);
-  int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "hipMalloc(export scratch)", __LINE__);
+  hipError_t e = fmx_dev_malloc((void **)&d_rows, (size_t)cap * 8);
+  if (e == hipSuccess) e = fmx_dev_malloc((void **)&d_vals, (size_t)cap * 8);
+  int rc = e == hipSuccess ? FMX_OK : fmx_hip_fail(e, "fmx_dev_malloc(export scratch)", __LINE__);
   for (uint64_t a = 0; a < k && rc == FMX_OK; a += chunk) {
     const uint64_t m = k - a < chunk ? k - a : chunk;
     for (uint64_t j = 0; j < m; j++) h_buf[j] = (a + j) * step;
@@ -1500,7 +1507,7 @@ static int load_wide(FILE *f, const FileHeader &h, int device, fmx_index *idx) {
   std::string buf(kChunk, '\0');
   for (int b = 0; b < bs.n; b++) {
     void *p = nullptr;
-    if ((e = hipMalloc(&p, bs.bytes[b] ? bs.bytes[b] : 8)) != hipSuccess) return fmx_hip_fail(e, "hipMalloc", __LINE__);
+    if ((e = fmx_dev_malloc(&p, bs.bytes[b] ? bs.bytes[b] : 8)) != hipSuccess) return fmx_hip_fail(e, "hipMalloc", __LINE__);
     if (int rc = fmx_keep(idx, p, bs.bytes[b])) { (void)hipFree(p); return rc; }
     *bs.field[b] = p;
     for (uint64_t o = 0; o < bs.bytes[b]; o += kChunk) {
@@ -1579,7 +1586,7 @@ int fmx_load(const char *path, int device, fmx_index **out) {
     std::string buf(kChunk, '\0');
     for (int b = 0; rc == FMX_OK && b < nb; b++) {
       void *p = nullptr;
-      if ((e = hipMalloc(&p, blobs[b].bytes ? blobs[b].bytes : 8)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
+      if ((e = fmx_dev_malloc(&p, blobs[b].bytes ? blobs[b].bytes : 8)) != hipSuccess) { rc = fmx_hip_fail(e, "hipMalloc", __LINE__); break; }
       if ((rc = fmx_keep(idx, p, blobs[b].bytes)) != FMX_OK) { (void)hipFree(p); break; }
       *blobs[b].field = p;
       for (uint64_t o = 0; o < blobs[b].bytes; o += kChunk) {

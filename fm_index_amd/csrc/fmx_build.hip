@@ -139,6 +139,17 @@ inline hipError_t scratch_get(int dev, size_t bytes, void **out, size_t *got) {
   *got = bytes;
   return e;
 }
+// drop the idle scratch of the CURRENT device (an allocation failed); returns the bytes given back to the driver
+inline size_t scratch_drop_current() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kArenaDevices) return 0;
+  ScratchCache &sc = scratch_cache();
+  std::vector<ScratchCache::Blk> drop;
+  { std::lock_guard<std::mutex> lk(sc.mu); scratch_drop(dev, drop); }
+  size_t bytes = 0;
+  for (auto &b : drop) { bytes += b.bytes; (void)hipFree(b.p); }
+  return bytes;
+}
 // keep_all (FMX_FLAG_KEEP_SCRATCH): the caller asked for this build's temporaries to stay whatever their size -- up to
 // three quarters of the device
 inline void scratch_put(int dev, void *p, size_t bytes, bool keep_all = false) {
@@ -1153,9 +1164,9 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
     uint32_t ncode = lv.fmt == 3 ? 8u : 16u;
     uint4 *rec;
     uint32_t *C, *hist, *scan;
-    FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
+    FMX_HIP(fmx_dev_malloc((void **)&rec, (size_t)lv.nrec * 128));
     if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
-    FMX_HIP(hipMalloc((void **)&C, 16 * sizeof(uint32_t)));
+    FMX_HIP(fmx_dev_malloc((void **)&C, 16 * sizeof(uint32_t)));
     if (int rc = keep(idx, C, 64)) return rc;
     size_t nh = (size_t)ncode * lv.nrec;
     FMX_HIP(pool.get(&hist, nh));
@@ -1196,9 +1207,9 @@ int build_mwm(fmx_index *idx, FmxMwm *w, T *d_seq, uint32_t len, uint32_t L, Dev
     if (want_select && len > kArenaMaxN) {
       const uint32_t nsel = len / FMX_WSEL_STEP + 2u * ncode + 2u;
       uint32_t *sel, *meta;
-      FMX_HIP(hipMalloc((void **)&sel, (size_t)nsel * 4));
+      FMX_HIP(fmx_dev_malloc((void **)&sel, (size_t)nsel * 4));
       if (int rc = keep(idx, sel, (uint64_t)nsel * 4)) return rc;
-      FMX_HIP(hipMalloc((void **)&meta, 48 * 4));
+      FMX_HIP(fmx_dev_malloc((void **)&meta, 48 * 4));
       if (int rc = keep(idx, meta, 48 * 4)) return rc;
       hipLaunchKernelGGL(k_fill_u32, dim3(nblocks(nsel)), dim3(BLK), 0, 0, sel, nsel, lv.nrec - 1);
       const unsigned hgrid = nblocks((uint64_t)lv.nrec * ncode);
@@ -1271,7 +1282,7 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   uint32_t npieces = bv->nrec * 8;
   uint4 *rec;
   uint32_t *cnt, *base;
-  FMX_HIP(hipMalloc((void **)&rec, (size_t)bv->nrec * 128));
+  FMX_HIP(fmx_dev_malloc((void **)&rec, (size_t)bv->nrec * 128));
   if (int rc = keep(idx, rec, (uint64_t)bv->nrec * 128)) return rc;
   FMX_HIP(pool.get(&cnt, (size_t)npieces + 1));
   FMX_HIP(pool.get(&base, (size_t)npieces + 1));
@@ -1296,7 +1307,7 @@ int build_bits(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, uint32_t n, 
   bv->ones = ones;
   bv->nsel = ones / FMX_SEL_STEP + 2;
   uint32_t *sel;
-  FMX_HIP(hipMalloc((void **)&sel, (size_t)bv->nsel * 4));
+  FMX_HIP(fmx_dev_malloc((void **)&sel, (size_t)bv->nsel * 4));
   if (int rc = keep(idx, sel, (uint64_t)bv->nsel * 4)) return rc;
   hipLaunchKernelGGL(k_fill_u32, dim3(nblocks(bv->nsel)), dim3(BLK), 0, 0, sel, bv->nsel, bv->nrec - 1);
   hipLaunchKernelGGL(k_select_hints, dim3(nblocks(bv->nrec)), dim3(BLK), 0, 0, rec, bv->nrec, ones, sel);
@@ -1350,7 +1361,7 @@ int keep_dense_select(fmx_index *idx, FmxBits *bv, const uint8_t *d_flags, const
 #endif
   const uint64_t nblk = ((uint64_t)bv->ones + (1ull << shift) - 1u) >> shift;
   uint4 *d;
-  FMX_HIP(hipMalloc((void **)&d, nblk * 16));
+  FMX_HIP(fmx_dev_malloc((void **)&d, nblk * 16));
   if (int rc = keep(idx, d, nblk * 16)) return rc;
   hipLaunchKernelGGL(k_select_blocks, dim3(nblocks(nblk)), dim3(BLK), 0, 0, d_flags, d_pos, bv->ones,
                      bv->len, shift, d);
@@ -1369,7 +1380,7 @@ int keep_positions(fmx_index *idx, FmxBits *bv, const uint32_t *d_pos) {
   if (const char *v = getenv("FMX_VARIANT")) if (atoi(v) == 16) return FMX_OK;   // measurement: no positions
 #endif
   uint32_t *p;
-  FMX_HIP(hipMalloc((void **)&p, (size_t)bv->ones * 4));
+  FMX_HIP(fmx_dev_malloc((void **)&p, (size_t)bv->ones * 4));
   if (int rc = keep(idx, p, (uint64_t)bv->ones * 4)) return rc;
   FMX_HIP(hipMemcpy(p, d_pos, (size_t)bv->ones * 4, hipMemcpyDeviceToDevice));
   bv->pos = p;
@@ -1438,17 +1449,26 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   uint8_t *etmp;
   FMX_HIP(pool.get(&etmp, eb));
   FMX_HIP(exclusive_sum(etmp, eb, lens, fpos, (size_t)r));
-  // lf_map of every run start (FmxDev::lfrun), for indexes that locate -- when the device has room for 4 bytes per run
-  // four times over; FMX_FLAG_NO_WALK_RECORDS keeps it off
+  // lf_map of every run start (FmxDev::lfrun), for indexes that locate -- when the text is repetitive enough for the
+  // table to be a small part of the index (r <= n / 4; FMX_FLAG_RUN_TABLE asks for it whatever r / n is: include/fmx.h)
+  // and the device has room for 4 bytes per run four times over; FMX_FLAG_NO_WALK_RECORDS keeps it off.  An optional
+  // accelerator: when its allocation fails the index is built without it.
   dv.lfrun = nullptr;
-  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
+  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS) &&
+      ((idx->flags & FMX_FLAG_RUN_TABLE) || (uint64_t)r * 4u <= (uint64_t)n)) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 16ull * r) {
-      uint32_t *d_lfrun;
-      FMX_HIP(hipMalloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 4));
-      if (int rc = keep(idx, d_lfrun, (uint64_t)r * 4)) return rc;
-      hipLaunchKernelGGL(k_scatter_lfrun, dim3(nblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
-      dv.lfrun = d_lfrun;
+    if (fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 16ull * r) {
+      uint32_t *d_lfrun = nullptr;
+      const hipError_t le = fmx_dev_malloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 4);
+      if (le == hipSuccess) {
+        if (int rc = keep(idx, d_lfrun, (uint64_t)r * 4)) return rc;
+        hipLaunchKernelGGL(k_scatter_lfrun, dim3(nblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
+        dv.lfrun = d_lfrun;
+      } else if (le == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+      } else {
+        return fmx_hip_fail(le, "hipMalloc(run table)", __LINE__);
+      }
     }
   }
   FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
@@ -1467,7 +1487,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
   uint32_t *d_K;
   FMX_HIP(pool.get(&d_cs, maxc + 1));
   FMX_HIP(hipMemcpy(d_cs, rcs.data(), (maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  FMX_HIP(hipMalloc((void **)&d_K, (maxc + 1) * sizeof(uint32_t)));
+  FMX_HIP(fmx_dev_malloc((void **)&d_K, (maxc + 1) * sizeof(uint32_t)));
   if (int rc = keep(idx, d_K, (maxc + 1) * 4)) return rc;
   if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
   dv.K = d_K;
@@ -1475,7 +1495,7 @@ int build_rlfm(fmx_index *idx, T *d_L, uint32_t n, uint32_t L, DevPool &pool) {
     std::vector<uint32_t> c32((size_t)maxc + 1);
     for (uint32_t c = 0; c <= maxc; c++) c32[c] = (uint32_t)rcs[c];
     uint32_t *d_c32;
-    FMX_HIP(hipMalloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
+    FMX_HIP(fmx_dev_malloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
     if (int rc = keep(idx, d_c32, ((uint64_t)maxc + 1) * 4)) return rc;
     FMX_HIP(hipMemcpy(d_c32, c32.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
     dv.cs = d_c32;
@@ -1492,8 +1512,8 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   if (n == 0) return FMX_OK;
   uint32_t *mark;
   unsigned long long *bad;
-  FMX_HIP(hipMalloc((void **)&mark, (size_t)n * 4));
-  FMX_HIP(hipMalloc((void **)&bad, 8));
+  FMX_HIP(fmx_dev_malloc((void **)&mark, (size_t)n * 4));
+  FMX_HIP(fmx_dev_malloc((void **)&bad, 8));
   FMX_HIP(hipMemset(mark, 0, (size_t)n * 4));
   FMX_HIP(hipMemset(bad, 0, 8));
   if (idx->sym_bytes == 1)
@@ -1515,6 +1535,32 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
 }
 
 // idle small-build buffers of every device (include/fmx.h: fmx_release_scratch)
+hipError_t fmx_dev_malloc(void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    if (scratch_drop_current()) e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+hipError_t fmx_dev_malloc_async(void **p, size_t bytes, hipStream_t st) {
+  hipError_t e = hipMallocAsync(p, bytes, st);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    if (scratch_drop_current()) e = hipMallocAsync(p, bytes, st);
+  }
+  return e;
+}
+hipError_t fmx_dev_mem_info(size_t *free_b, size_t *total_b) {
+  hipError_t e = hipMemGetInfo(free_b, total_b);
+  int dev = -1;
+  if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kArenaDevices) {
+    ScratchCache &sc = scratch_cache();
+    std::lock_guard<std::mutex> lk(sc.mu);
+    *free_b += sc.held[dev];                       // idle scratch goes back to the driver when an allocation needs it
+  }
+  return e;
+}
 void fmx_release_build_scratch(void) {
   ArenaPool &ap = arena_pool();
   std::vector<std::pair<int, uint8_t *>> drop;
@@ -1551,11 +1597,11 @@ int fmx_make_walk_records(fmx_index *idx) {
   uint32_t *d_cnt = nullptr, *d_base = nullptr;
   void *d_tmp = nullptr;
   size_t tb = 0;
-  hipError_t e = hipMalloc((void **)&d_walk, (size_t)nwalk * 128u);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, ncnt * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_base, ncnt * 4);
+  hipError_t e = fmx_dev_malloc((void **)&d_walk, (size_t)nwalk * 128u);
+  if (e == hipSuccess) e = fmx_dev_malloc((void **)&d_cnt, ncnt * 4);
+  if (e == hipSuccess) e = fmx_dev_malloc((void **)&d_base, ncnt * 4);
   if (e == hipSuccess) e = exclusive_sum(nullptr, tb, d_cnt, d_base, ncnt);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 8);
+  if (e == hipSuccess) e = fmx_dev_malloc(&d_tmp, tb ? tb : 8);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_walk_counts, dim3(nblocks(nwalk)), dim3(BLK), 0, 0, dv.bw.lv[0].rec, dv.phase, dv.n, dv.sa_level,
                        nwalk, d_cnt);
@@ -1574,6 +1620,9 @@ int fmx_make_walk_records(fmx_index *idx) {
   if (d_cnt) (void)hipFree(d_cnt);
   if (e != hipSuccess) {
     if (d_walk) (void)hipFree(d_walk);
+    // an optional accelerator: without room for it the index walks through its phase pieces (fmx_walk_records()
+    // reports what the index got) -- on a smaller or busier device than the one that saved a file, too
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return FMX_OK; }
     return fmx_hip_fail(e, "walk records", __LINE__);
   }
   if (int rc = fmx_keep(idx, d_walk, (uint64_t)nwalk * 128u)) { (void)hipFree(d_walk); return rc; }
@@ -1651,7 +1700,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     uint64_t nsamp = (((uint64_t)n - 1) >> level) + 1;             // sample.rs:33
     uint32_t *d_samp;
     // +4: the locate kernel reads the sample through an aligned 16-B chunk
-    FMX_HIP(hipMalloc((void **)&d_samp, (nsamp + 4) * sizeof(uint32_t)));
+    FMX_HIP(fmx_dev_malloc((void **)&d_samp, (nsamp + 4) * sizeof(uint32_t)));
     FMX_HIP(hipMemset(d_samp, 0, (nsamp + 4) * sizeof(uint32_t)));
     if (int rc = keep(idx, d_samp, nsamp * 4)) return rc;
     dv.phase = nullptr;
@@ -1671,7 +1720,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
         level <= FMX_WALK_MAX_LEVEL && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
       size_t free_b = 0, total_b = 0;
       const uint64_t extra = ((uint64_t)n / FMX_WALK_ROWS + 1u) * 128u + ((uint64_t)n / (3u * (32u / level)) + 1u) * 16u;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra) text_order = true;
+      if (fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra) text_order = true;
     }
     if (idx->flags & FMX_FLAG_TEXT_ORDER) text_order = can_text;
     if (idx->flags & FMX_FLAG_ROW_ORDER) text_order = false;
@@ -1682,7 +1731,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
       const uint32_t npieces = n / rpp + 1u;
       uint4 *d_phase;
       uint32_t *zeros, *zbase, *d_cnt;
-      FMX_HIP(hipMalloc((void **)&d_phase, (size_t)npieces * 16));
+      FMX_HIP(fmx_dev_malloc((void **)&d_phase, (size_t)npieces * 16));
       if (int rc = keep(idx, d_phase, (uint64_t)npieces * 16)) return rc;
       FMX_HIP(pool.get(&zeros, (size_t)npieces + 1));
       FMX_HIP(pool.get(&zbase, (size_t)npieces + 1));
@@ -1734,7 +1783,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     FMX_HIP(pool.get(&ztr, n));
     FMX_HIP(pool.get(&d_first, 1));
     FMX_HIP(hipMemset(d_first, 0, 4));
-    FMX_HIP(hipMalloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
+    FMX_HIP(fmx_dev_malloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
     if (int rc = keep(idx, d_doc, (uint64_t)pieces * 4)) return rc;
     hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_bwt, n, zl);
     hipLaunchKernelGGL(k_zero_flags<T>, dim3(nblocks(n)), dim3(BLK), 0, 0, d_text, n, zt);
@@ -1764,7 +1813,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     uint32_t *d_K;
     FMX_HIP(pool.get(&d_cs, (size_t)maxc + 1));
     FMX_HIP(hipMemcpy(d_cs, idx->h_cs, ((size_t)maxc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * sizeof(uint32_t)));
+    FMX_HIP(fmx_dev_malloc((void **)&d_K, ((size_t)maxc + 1) * sizeof(uint32_t)));
     if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 4)) return rc;
     if (int rc = fmx_launch_compute_K(dv.bw, d_cs, d_K, maxc, 0)) return rc;
     dv.K = d_K;
@@ -1772,7 +1821,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
       std::vector<uint32_t> c32((size_t)maxc + 1);
       for (uint32_t c = 0; c <= maxc; c++) c32[c] = (uint32_t)idx->h_cs[c];
       uint32_t *d_c32;
-      FMX_HIP(hipMalloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
+      FMX_HIP(fmx_dev_malloc((void **)&d_c32, ((size_t)maxc + 1) * 4));
       if (int rc = keep(idx, d_c32, ((uint64_t)maxc + 1) * 4)) return rc;
       FMX_HIP(hipMemcpy(d_c32, c32.data(), ((size_t)maxc + 1) * 4, hipMemcpyHostToDevice));
       dv.cs = d_c32;
@@ -1838,7 +1887,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
     if (kk >= 2) {
       uint2 *d_tab;
       const uint64_t tab_bytes = (1ull << (bits * kk)) * sizeof(uint2);
-      FMX_HIP(hipMalloc((void **)&d_tab, tab_bytes));
+      FMX_HIP(fmx_dev_malloc((void **)&d_tab, tab_bytes));
       if (int rc = keep(idx, d_tab, tab_bytes)) return rc;
       if (int rc = fmx_launch_kmer_build(idx, d_tab, kk, bits, 0)) return rc;
       dv.kmer = d_tab;
@@ -1850,7 +1899,7 @@ static int build_impl_t(fmx_index *idx, const T *d_text) {
   mark("k-mer table");
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
-    FMX_HIP(hipMalloc((void **)&kt, (n ? n : 1) * sizeof(T)));
+    FMX_HIP(fmx_dev_malloc((void **)&kt, (n ? n : 1) * sizeof(T)));
     if (n) FMX_HIP(hipMemcpy(kt, d_text, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice));
     if (int rc = keep(idx, kt, (uint64_t)n * sizeof(T))) return rc;
     idx->d_text = (uint8_t *)kt;
@@ -2596,9 +2645,9 @@ static int build_wide_levels(fmx_index *idx, T *d_seq, uint64_t len, uint32_t L,
       uint4 *rec;
       uint64_t *base, *scan;
       uint32_t *hist;
-      FMX_HIP(hipMalloc((void **)&rec, (size_t)lv.nrec * 128));
+      FMX_HIP(fmx_dev_malloc((void **)&rec, (size_t)lv.nrec * 128));
       if (int rc = keep(idx, rec, (uint64_t)lv.nrec * 128)) return rc;
-      FMX_HIP(hipMalloc((void **)&base, (size_t)nsb * 16 * sizeof(uint64_t)));
+      FMX_HIP(fmx_dev_malloc((void **)&base, (size_t)nsb * 16 * sizeof(uint64_t)));
       if (int rc = keep(idx, base, (uint64_t)nsb * 128)) return rc;
       const size_t nh = (size_t)ncode * lv.nrec;
       FMX_HIP(pool.get(&hist, nh));
@@ -2652,9 +2701,9 @@ static int build_bits_wide(fmx_index *idx, FmxWideBits *bv, const uint8_t *d_fla
   uint4 *rec;
   uint32_t *cnt;
   uint64_t *scan, *base;
-  FMX_HIP(hipMalloc((void **)&rec, (size_t)bv->nrec * 128));
+  FMX_HIP(fmx_dev_malloc((void **)&rec, (size_t)bv->nrec * 128));
   if (int rc = keep(idx, rec, (uint64_t)bv->nrec * 128)) return rc;
-  FMX_HIP(hipMalloc((void **)&base, (size_t)bv->nsb * 8));
+  FMX_HIP(fmx_dev_malloc((void **)&base, (size_t)bv->nsb * 8));
   if (int rc = keep(idx, base, (uint64_t)bv->nsb * 8)) return rc;
   FMX_HIP(pool.get(&cnt, (size_t)npieces + 1));
   FMX_HIP(pool.get(&scan, (size_t)npieces + 1));
@@ -2672,7 +2721,7 @@ static int build_bits_wide(fmx_index *idx, FmxWideBits *bv, const uint8_t *d_fla
   bv->ones = ones;
   bv->nsel = ones / FMX_SEL_STEP + 2;
   uint32_t *sel;
-  FMX_HIP(hipMalloc((void **)&sel, (size_t)bv->nsel * 4));
+  FMX_HIP(fmx_dev_malloc((void **)&sel, (size_t)bv->nsel * 4));
   if (int rc = keep(idx, sel, bv->nsel * 4)) return rc;
   hipLaunchKernelGGL(kwb_fill_u32, dim3(wblocks(bv->nsel)), dim3(BLK), 0, 0, sel, bv->nsel, bv->nrec - 1);
   hipLaunchKernelGGL(kwb_select_hints, dim3(wblocks(bv->nrec)), dim3(BLK), 0, 0, scan, bv->nrec, ones, sel);
@@ -2683,7 +2732,7 @@ static int build_bits_wide(fmx_index *idx, FmxWideBits *bv, const uint8_t *d_fla
   // fewer than 0.11 ones per bit (runs of 9+ on average; the 32-bit engine's rule): keep the positions, select1 is one load
   if (ones && n && ones * 256u / n < 28u && d_pos) {
     uint64_t *p;
-    FMX_HIP(hipMalloc((void **)&p, (size_t)ones * 8));
+    FMX_HIP(fmx_dev_malloc((void **)&p, (size_t)ones * 8));
     if (int rc = keep(idx, p, ones * 8)) return rc;
     FMX_HIP(hipMemcpy(p, d_pos, (size_t)ones * 8, hipMemcpyDeviceToDevice));
     bv->pos = p;
@@ -2769,17 +2818,25 @@ static int build_rlfm_wide(fmx_index *idx, T *d_L, uint64_t n, uint32_t L, DevPo
   FMX_HIP(exclusive_sum(etmp, eb, lens, fpos, (size_t)r));
   FMX_HIP(hipDeviceSynchronize());
   pool.release(etmp); pool.release(lens); pool.release(starts);
-  // lf_map of every run start (FmxWideDev::lfrun) for indexes that locate, when the device has room for 8 bytes per run
-  // four times over; FMX_FLAG_NO_WALK_RECORDS keeps it off
+  // lf_map of every run start (FmxWideDev::lfrun) for indexes that locate: the 32-bit engine's policy (r <= n / 4, or
+  // FMX_FLAG_RUN_TABLE; include/fmx.h) when the device has room for 8 bytes per run four times over;
+  // FMX_FLAG_NO_WALK_RECORDS keeps it off; an allocation failure leaves the index without it
   w.lfrun = nullptr;
-  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS)) {
+  if (idx->level_requested != FMX_NO_LOCATE && !(idx->flags & FMX_FLAG_NO_WALK_RECORDS) &&
+      ((idx->flags & FMX_FLAG_RUN_TABLE) || (uint64_t)r * 4u <= (uint64_t)n)) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 32ull * r) {
-      uint64_t *d_lfrun;
-      FMX_HIP(hipMalloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 8));
-      if (int rc = keep(idx, d_lfrun, r * 8)) return rc;
-      hipLaunchKernelGGL(kwb_scatter_lfrun, dim3(wblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
-      w.lfrun = d_lfrun;
+    if (fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 32ull * r) {
+      uint64_t *d_lfrun = nullptr;
+      const hipError_t le = fmx_dev_malloc((void **)&d_lfrun, (size_t)(r ? r : 1) * 8);
+      if (le == hipSuccess) {
+        if (int rc = keep(idx, d_lfrun, r * 8)) return rc;
+        hipLaunchKernelGGL(kwb_scatter_lfrun, dim3(wblocks(r)), dim3(BLK), 0, 0, order2, fpos, r, d_lfrun);
+        w.lfrun = d_lfrun;
+      } else if (le == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+      } else {
+        return fmx_hip_fail(le, "hipMalloc(run table)", __LINE__);
+      }
     }
   }
   FMX_HIP(hipMemsetAsync(flags, 0, n, 0));
@@ -2791,9 +2848,9 @@ static int build_rlfm_wide(fmx_index *idx, T *d_L, uint64_t n, uint32_t L, DevPo
   // S over the r run heads (rlfmi.rs:69-70): the generic levels; cs[] / K[] count runs
   if (int rc = build_wide_levels<T>(idx, heads, r, L, pool)) return rc;
   uint64_t *d_cs, *d_K;
-  FMX_HIP(hipMalloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
+  FMX_HIP(fmx_dev_malloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
   if (int rc = keep(idx, d_cs, ((uint64_t)maxc + 1) * 8)) return rc;
-  FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * 8));
+  FMX_HIP(fmx_dev_malloc((void **)&d_K, ((size_t)maxc + 1) * 8));
   if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 8)) return rc;
   FMX_HIP(hipMemcpy(d_cs, rcs.data(), ((size_t)maxc + 1) * 8, hipMemcpyHostToDevice));
   w.cs = d_cs;
@@ -2867,14 +2924,14 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     if (level >= 63 || n <= (1ull << level)) level = 0;            // sample.rs:28-31
     const uint64_t nsamp = ((n - 1) >> level) + 1;                 // sample.rs:33
     uint64_t *d_samp;
-    FMX_HIP(hipMalloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
+    FMX_HIP(fmx_dev_malloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
     if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
     walk_records = idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
                    !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
     if (walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {     // by default only when the device has room
       size_t free_b = 0, total_b = 0;
       const uint64_t extra = (n / FMX_WALK_ROWS + 1u) * 128u;
-      walk_records = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
+      walk_records = fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
     }
     // RLFM: text-order samples (phase pieces) for levels 1..4, together with the run table -- unless the flags keep the
     // reference's rows, or the device lacks room for the pieces four times over
@@ -2886,7 +2943,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     if (rl_text && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {
       size_t free_b = 0, total_b = 0;
       const uint64_t extra = (n / (3u * (32u / level)) + 1u) * 16u;
-      rl_text = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
+      rl_text = fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
     }
     w.phase = nullptr; w.pbase = nullptr; w.psb_shift = 0; w.npsb = 0;
     if (rl_text) {
@@ -2897,9 +2954,9 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
       uint4 *d_phase;
       uint64_t *d_pbase, *pscan;
       uint32_t *zeros;
-      FMX_HIP(hipMalloc((void **)&d_phase, (size_t)npieces * 16));
+      FMX_HIP(fmx_dev_malloc((void **)&d_phase, (size_t)npieces * 16));
       if (int rc = keep(idx, d_phase, npieces * 16)) return rc;
-      FMX_HIP(hipMalloc((void **)&d_pbase, (size_t)npsb * 8));
+      FMX_HIP(fmx_dev_malloc((void **)&d_pbase, (size_t)npsb * 8));
       if (int rc = keep(idx, d_pbase, (uint64_t)npsb * 8)) return rc;
       FMX_HIP(pool.get(&zeros, (size_t)npieces));
       FMX_HIP(pool.get(&pscan, (size_t)npieces));
@@ -2960,9 +3017,9 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
       FMX_HIP(pool.get(&d_cnt, ncnt));
       FMX_HIP(pool.get(&d_scan, ncnt));
       FMX_HIP(pool.get(&d_adj, 16));
-      FMX_HIP(hipMalloc((void **)&d_walk, (size_t)nwalk * 128));
+      FMX_HIP(fmx_dev_malloc((void **)&d_walk, (size_t)nwalk * 128));
       if (int rc = keep(idx, d_walk, (uint64_t)nwalk * 128)) return rc;
-      FMX_HIP(hipMalloc((void **)&d_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
+      FMX_HIP(fmx_dev_malloc((void **)&d_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
       if (int rc = keep(idx, d_wbase, (uint64_t)nwsb * 128)) return rc;
       FMX_HIP(hipMemsetAsync(d_cnt + (ncnt - 1), 0, sizeof(uint32_t), 0));
       hipLaunchKernelGGL(kww_counts, dim3(wblocks(nwalk)), dim3(BLK), 0, 0, (const uint8_t *)d_bwt, d_sa, n, level, nwalk, d_cnt);
@@ -3012,7 +3069,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     FMX_HIP(pool.get(&d_got, 1));
     FMX_HIP(pool.get(&d_first, 1));
     FMX_HIP(hipMemset(d_first, 0, 8));
-    FMX_HIP(hipMalloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
+    FMX_HIP(fmx_dev_malloc((void **)&d_doc, (size_t)(pieces ? pieces : 1) * 4));
     if (int rc = keep(idx, d_doc, pieces * 4)) return rc;
     rocprim::counting_iterator<uint64_t> rows(0);
     auto zl = rocprim::make_transform_iterator((const T *)d_bwt, IsZeroSym<T>());
@@ -3039,7 +3096,7 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   }
   if (idx->flags & FMX_FLAG_KEEP_SA) {
     T *kt;
-    FMX_HIP(hipMalloc((void **)&kt, n * sizeof(T)));
+    FMX_HIP(fmx_dev_malloc((void **)&kt, n * sizeof(T)));
     FMX_HIP(hipMemcpy(kt, d_text, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice));
     if (int rc = keep(idx, kt, n * sizeof(T))) return rc;
     idx->d_text = (uint8_t *)kt;
@@ -3066,9 +3123,9 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     // -- generic wide index: the levels of the multi-ary wavelet matrix (as build_mwm, 64-bit scans) --
     if (int rc = build_wide_levels<T>(idx, d_bwt, n, L, pool)) return rc;
     uint64_t *d_cs, *d_K;
-    FMX_HIP(hipMalloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
+    FMX_HIP(fmx_dev_malloc((void **)&d_cs, ((size_t)maxc + 1) * 8));
     if (int rc = keep(idx, d_cs, ((uint64_t)maxc + 1) * 8)) return rc;
-    FMX_HIP(hipMalloc((void **)&d_K, ((size_t)maxc + 1) * 8));
+    FMX_HIP(fmx_dev_malloc((void **)&d_K, ((size_t)maxc + 1) * 8));
     if (int rc = keep(idx, d_K, ((uint64_t)maxc + 1) * 8)) return rc;
     FMX_HIP(hipMemcpy(d_cs, idx->h_cs, ((size_t)maxc + 1) * 8, hipMemcpyHostToDevice));
     w.cs = d_cs;
@@ -3085,9 +3142,9 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   uint4 *d_rec;
   uint32_t *d_hist;
   uint64_t *d_scan, *d_base;
-  FMX_HIP(hipMalloc((void **)&d_rec, (size_t)nrec * 128));
+  FMX_HIP(fmx_dev_malloc((void **)&d_rec, (size_t)nrec * 128));
   if (int rc = keep(idx, d_rec, (uint64_t)nrec * 128)) return rc;
-  FMX_HIP(hipMalloc((void **)&d_base, (size_t)nsb * 8 * sizeof(uint64_t)));
+  FMX_HIP(fmx_dev_malloc((void **)&d_base, (size_t)nsb * 8 * sizeof(uint64_t)));
   if (int rc = keep(idx, d_base, (uint64_t)nsb * 64)) return rc;
   FMX_HIP(pool.get(&d_hist, (size_t)nrec * 8));
   FMX_HIP(pool.get(&d_scan, (size_t)nrec * 8));
@@ -3132,8 +3189,8 @@ int fmxw_verify_sa(const fmx_index *idx, uint64_t *violations) {
   uint32_t *mark;
   unsigned long long *bad;
   const size_t words = (size_t)(n / 4 + 1);
-  FMX_HIP(hipMalloc((void **)&mark, words * 4));
-  FMX_HIP(hipMalloc((void **)&bad, 8));
+  FMX_HIP(fmx_dev_malloc((void **)&mark, words * 4));
+  FMX_HIP(fmx_dev_malloc((void **)&bad, 8));
   FMX_HIP(hipMemset(mark, 0, words * 4));
   FMX_HIP(hipMemset(bad, 0, 8));
   if (idx->sym_bytes == 1)

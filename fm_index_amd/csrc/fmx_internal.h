@@ -280,6 +280,14 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// Index-owned (and any other long-lived) device memory.  The process-wide scratch cache of large builds (fmx_build.hip)
+// keeps idle blocks out of the driver's hands; an allocation that fails while the cache holds memory of the current
+// device returns that memory to the driver and is tried once more, and the room checks that decide the shape of an
+// index (text order, walk records, run table, FMX_FLAG_AUTO) count what the cache holds idle as free -- so neither the
+// success of a build or query nor the layout of an index depends on what the process built earlier.
+hipError_t fmx_dev_malloc(void **p, size_t bytes);
+hipError_t fmx_dev_malloc_async(void **p, size_t bytes, hipStream_t st);
+hipError_t fmx_dev_mem_info(size_t *free_b, size_t *total_b);
 void fmx_release_build_scratch(void);   // the idle small-build buffers of every device (fmx_release_scratch)
 // walk records of an index that has the fmt-3 records and the phase pieces (builder, fmx_load): allocates, fills and
 // registers dev.walk; no-op (FMX_OK, dev.walk stays NULL) when the index is not eligible

@@ -731,7 +731,9 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 // LWIN: the rows of the two resident chunks live in LDS (2 x 64 words per wave, `lwin`) instead of two
 // registers per lane -- for the one-walk-per-lane kernel, which is short of registers; handing out a hit is
 // then one ds_read instead of two ds_bpermutes.
-template <bool LWIN = false>
+// TL (round 5): the tickets of the slice this queue hands out are listed in `tlist` (nlist entries, LDS) -- the unified DNA
+// walk kernel serves the other tickets of its slice another way -- and a draw maps its ticket number through that list.
+template <bool LWIN = false, bool TL = false>
 struct FmxHitQueue {
   const uint32_t *rows;   // rows of this block's slice
   uint64_t lo;            // first hit of the slice (index into out_pos)
@@ -745,6 +747,8 @@ struct FmxHitQueue {
   volatile uint32_t *lwin;  // this wave's 2 x 64 words of LDS; chunk c0 sits in half w0, c1 in the other [LWIN]
   uint32_t w0;
   uint32_t used;          // hits already handed out of c0|c1
+  const uint16_t *tlist = nullptr;   // [TL]
+  uint32_t nlist = 0;
   __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
     const uint32_t x = c * chunk + lane;
     return (c != FMX_NOCHUNK && lane < chunk && x < nhits) ? rows[x] : 0u;   // every slot was written by fmx_expand_kernel
@@ -755,7 +759,9 @@ struct FmxHitQueue {
   __device__ __forceinline__ uint32_t draw(unsigned int &counter, uint32_t k) const {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&counter, k);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (TL) t = t < nlist ? (uint32_t)tlist[t] : FMX_NOCHUNK;
+    return t;
   }
   __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t rows_per_ticket,
                                        uint32_t ln, unsigned int &counter, volatile uint32_t *lds_win = nullptr) {
@@ -1126,10 +1132,12 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
 // row-order walk issues 4 and the round-3 text-order walk 4.5 -- and no walk is longer than 2^level - 1 steps: the
 // geometric tail of row-order sampling (a 2^20-hit batch ends on a chain of ~41 dependent round trips) does not exist.
 // get_sa is unchanged as a function: (sample + steps) % len (fm_index.rs:127-140).
-template <int Q, bool WC>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
+// The walk over the block's slice [blo, blo + bn) of the hits, called by all threads of a 1024-thread block.  `rows`: the
+// rows of the slice (global memory, or LDS in the unified kernel); TL: only the tickets listed in tlist[0 .. nlist).
+template <int Q, bool WC, bool TL>
+__device__ __forceinline__ void fmx_f3t_walk(
     const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
-    uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
+    const uint32_t *rows, uint64_t blo, uint32_t bn, uint32_t chunk, const uint16_t *tlist, uint32_t nlist,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   static_assert(Q == 1 || Q == 2 || Q == 4 || Q == 8, "walks per group");
   __shared__ unsigned int lds_q;
@@ -1137,9 +1145,6 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
   __shared__ uint32_t wc_tag[WC ? (FMX_LOC_BLOCK / 64) * FMX_WC_SLOTS : 1];
   if (threadIdx.x == 0) lds_q = 0;
   __syncthreads();
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane & (FMX_GROUP - 1);
   const uint32_t grp = lane >> 3;
@@ -1151,8 +1156,10 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
                                        : Q == 2 ? 0x5555555555555555ull
                                                 : 0xFFFFFFFFFFFFFFFFull;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no row / no sample / no position (n < 2^32 - 16)
-  FmxHitQueue<> hq;
-  hq.init(rows + blo, blo, bn, chunk, lane, lds_q);
+  FmxHitQueue<false, TL> hq;
+  hq.tlist = tlist;
+  hq.nlist = nlist;
+  hq.init(rows, blo, bn, chunk, lane, lds_q);
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   [[maybe_unused]] volatile uint32_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64);
   [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS;
@@ -1280,6 +1287,17 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3t_kernel(
     }
   }
   if (steps_out && owner && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+template <int Q, bool WC>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void fmx_locate_f3t_kernel(
+    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
+    uint64_t total, uint32_t hits_per_block, uint32_t chunk, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  fmx_f3t_walk<Q, WC, false>(walk, samples, n, nsamples, rows + blo, blo, bn, chunk, nullptr, 0u, out_pos, steps_out);
 }
 
 // locate walk, one walk per LANE (fmx_ep.h): 64 walks per wave.  RLFM: every LF step = lane-wise B
@@ -1792,6 +1810,9 @@ struct FmxTune {
   long loc_threads = FMX_LOC_BLOCK;
   long ep_loc_blocks = 0;        // one-walk-per-lane locate: blocks, 0 = by batch size
   long ep_loc_threads = 0;       // ... threads per block, 0 = by batch size
+  bool unified = true;           // DNA locate on walk records: the one-launch kernel (fmx_locate_f3u_kernel); false = the
+                                 // round-4 pair expand + f3t / lane kernel chosen from the batch average
+  long adj_clusters = 4;         // ... a ticket of at most this many runs of consecutive rows is walked a lane per hit
   long rl_ep_min = 1l << 18;     // RLFM: one walk per lane from this many hits
   long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
 };
@@ -1881,53 +1902,181 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
 // pattern are adjacent rows of the same 112-row records, and LF keeps rows with the same symbol adjacent, so the 64
 // lanes of a wave ask for a handful of lines per instruction and a wave instruction serves 64 walks.  Chosen when the
 // batch averages at least 64 hits per pattern.
+// get_sa(row) by ONE lane over the walk records: returns the text position, adds the walk's LF steps to `nsteps`
+__device__ __forceinline__ uint64_t fmx_walk_lane_get_sa(const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples,
+                                                         uint32_t n, [[maybe_unused]] uint32_t nsamples, uint32_t row,
+                                                         uint64_t &nsteps) {
+  uint32_t walk_steps = 0xFFFFFFFFu, si;
+  for (;;) {
+    FMX_CHECK(row < n);
+    uint32_t off;
+    const uint32_t wr = fmx_walk_record(row, off);
+    const uint4 *R = walk + (size_t)wr * 8u;
+    const uint32_t pi = off >> 4, bit = off & 15u;
+    FMX_TOUCH(&R[pi]);
+    const uint4 own = R[pi];
+    const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
+    const uint32_t ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
+    if (walk_steps == 0xFFFFFFFFu) walk_steps = ph;             // the walk is exactly SA[row] mod 2^level steps long
+    const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
+    uint32_t cnt = 0;
+    for (uint32_t q = 0; q <= pi; q++) {                        // rows before `row` in the record: whole pieces, then its own
+      uint4 p = own;
+      if (q != pi) { FMX_TOUCH(&R[q]); p = R[q]; }
+      const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
+      const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
+      const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
+      const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
+      cnt += __popc(sel);
+    }
+    // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
+    const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
+    FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));
+    FMX_TOUCH(&R[cp]);
+    const uint4 cv = R[cp];
+    uint32_t ctr = cv.x;
+    if (ph == 1u && sym >= 3u) ctr = sym == 3u ? cv.y : (sym == 4u ? cv.z : cv.w);
+    if (ph <= 1u) { si = ctr + cnt; break; }                    // this row's sample (phase 0) or the next row's (phase 1)
+    row = ctr + cnt;                                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+  }
+  FMX_CHECK(si < nsamples);
+  FMX_TOUCH(&samples[si]);
+  uint64_t v = (uint64_t)samples[si] + walk_steps;              // (sa + steps) % len          fm_index.rs:131-133
+  if (v >= n) v -= n;
+  nsteps += walk_steps;
+  return v;
+}
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_walk_lane_kernel(
     const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples, uint64_t total,
     const uint32_t *__restrict__ rows, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
   uint64_t nsteps = 0;
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth) {
-    uint32_t row = rows[h], walk_steps = 0xFFFFFFFFu, si;
-    for (;;) {
-      FMX_CHECK(row < n);
-      uint32_t off;
-      const uint32_t wr = fmx_walk_record(row, off);
-      const uint4 *R = walk + (size_t)wr * 8u;
-      const uint32_t pi = off >> 4, bit = off & 15u;
-      FMX_TOUCH(&R[pi]);
-      const uint4 own = R[pi];
-      const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
-      const uint32_t ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
-      if (walk_steps == 0xFFFFFFFFu) walk_steps = ph;             // the walk is exactly SA[row] mod 2^level steps long
-      const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
-      uint32_t cnt = 0;
-      for (uint32_t q = 0; q <= pi; q++) {                        // rows before `row` in the record: whole pieces, then its own
-        uint4 p = own;
-        if (q != pi) { FMX_TOUCH(&R[q]); p = R[q]; }
-        const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
-        const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
-        const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
-        const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
-        cnt += __popc(sel);
-      }
-      // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
-      const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
-      FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));
-      FMX_TOUCH(&R[cp]);
-      const uint4 cv = R[cp];
-      uint32_t ctr = cv.x;
-      if (ph == 1u && sym >= 3u) ctr = sym == 3u ? cv.y : (sym == 4u ? cv.z : cv.w);
-      if (ph <= 1u) { si = ctr + cnt; break; }                    // this row's sample (phase 0) or the next row's (phase 1)
-      row = ctr + cnt;                                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
-    }
-    FMX_CHECK(si < nsamples);
-    FMX_TOUCH(&samples[si]);
-    uint64_t v = (uint64_t)samples[si] + walk_steps;              // (sa + steps) % len          fm_index.rs:131-133
-    if (v >= n) v -= n;
-    out_pos[h] = v;
-    nsteps += walk_steps;
-  }
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth)
+    out_pos[h] = fmx_walk_lane_get_sa(walk, samples, n, nsamples, rows[h], nsteps);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---- DNA walk records: ONE launch per batch, the algorithm chosen per 64-hit TICKET (round 5) ---------------------------
+// Until round 4 a locate batch was a stream-ordered allocation of the rows array, fmx_expand_kernel (rows[off[k] + j] =
+// s[k] + j), and ONE of two walk kernels chosen from the batch AVERAGE of hits per pattern: the group-cooperative walk
+// (fmx_locate_f3t_kernel: 8 lanes per record; right for scattered rows) or the lane-per-walk kernel (right for runs of
+// adjacent rows, 1.5 x faster there and 8 x the requests elsewhere).  A batch of 10^7 singletons and a hundred
+// patterns with 10^6 hits each averages 11 and sent its 10^8 adjacent hits down the wrong path.  Here
+//   * a 1024-thread block owns a slice of <= 4096 hits and expands it ITSELF into LDS: one round of 1024 probes of
+//     off[] brackets the slice's first pattern, then thread p takes pattern kc + p (its off, s, e: one round of loads)
+//     and writes its rows -- ranges over 32 rows are queued and written by the whole block.  No rows array, no expand
+//     launch, no 6 us between two kernels; the argument checks of fmx_expand_kernel are made here (FMX_ERR_ARG).
+//   * every ticket (64 consecutive hits) is classified by the adjacency of its rows: at most `adj_clusters` runs of
+//     consecutive rows -> the ticket is walked a lane per hit (phase A, tickets dealt to the waves in turn, positions
+//     stored as one contiguous 512-byte line); all other tickets go through the block's hit queue to the
+//     group-cooperative walk with its write-combining ring (phase B, fmx_f3t_walk).  The choice only picks the faster
+//     of two exact algorithms: any classification gives the reference's positions in the reference's order.
+#define FMX_U_SLICE 4096u
+#define FMX_U_LONG 32u
+#define FMX_U_LONGCAP 128u
+#define FMX_U_NOROW 0xFFFFFFFFu
+template <int Q, bool WC>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void fmx_locate_f3u_kernel(
+    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
+    const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t total, uint32_t hits_per_block, uint32_t chunk, uint32_t adj_clusters, uint64_t *__restrict__ out_pos,
+    uint64_t *__restrict__ steps_out, uint32_t *__restrict__ status) {
+  __shared__ uint32_t u_rows[FMX_U_SLICE];
+  __shared__ uint32_t u_long[FMX_U_LONGCAP * 3];      // {first row, first slot, rows} of the long ranges of the slice
+  __shared__ uint16_t u_tlist[FMX_U_SLICE / 8];       // tickets for the cooperative walk
+  __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
+  __shared__ unsigned long long u_klb;
+  __shared__ unsigned int u_nlong, u_ntl, u_nal;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint64_t bhi = blo + bn;
+  FMX_CHECK(hits_per_block <= FMX_U_SLICE && chunk >= 8u && chunk <= FMX_LCHUNK);
+  bool bad = false;                                   // an argument that is not of this index / these offsets
+  for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK) u_rows[x] = FMX_U_NOROW;
+  if (tid == 0) { u_nlong = 0; u_ntl = 0; u_nal = 0; }
+  // ---- the slice's first pattern, bracketed: k_lo <= (largest k with off[k] <= blo) < k_lo + 1024 ----
+  uint64_t k_lo = 0, span = npat;
+  while (span > FMX_LOC_BLOCK) {                      // block-uniform; one round up to 2^20 patterns, two up to 2^30
+    const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
+    const uint64_t c = k_lo + (uint64_t)tid * step;
+    if (tid == 0) u_klb = k_lo;
+    __syncthreads();
+    if (tid != 0 && c < k_lo + span && off[c] <= blo) atomicMax(&u_klb, (unsigned long long)c);
+    __syncthreads();
+    const uint64_t best = u_klb;
+    span = best + step <= k_lo + span ? step : k_lo + span - best;
+    k_lo = best;
+    __syncthreads();
+  }
+  __syncthreads();                                    // u_rows cleared, counters zeroed
+  // ---- expansion: thread p takes pattern kc + p; chunks of 1024 patterns until one starts behind the slice ----
+  for (uint64_t kc = k_lo;; kc += FMX_LOC_BLOCK) {
+    const uint64_t k = kc + tid;
+    bool more = false;
+    if (k < npat) {
+      uint64_t a = s[k];
+      const uint64_t b = e[k], o = off[k];
+      const uint64_t o1 = k + 1 < npat ? off[k + 1] : total;
+      uint64_t cnt = b > a ? b - a : 0;
+      // a range that is not one of this index, or offsets that do not leave room for it: refused (fmx_expand_kernel's
+      // rule: the slots take rows from 0 on, so that the walk stays inside the index)
+      if (b > n || o > total || cnt > total - o) {
+        bad = true;
+        a = 0;
+        cnt = o < total ? (cnt < total - o ? cnt : total - o) : 0;
+        if (cnt > n) cnt = n;
+      }
+      if (cnt && o < bhi && o + cnt > blo) {          // the part of [o, o + cnt) inside the slice
+        const uint64_t h0 = o > blo ? o : blo, h1 = o + cnt < bhi ? o + cnt : bhi;
+        const uint32_t len = (uint32_t)(h1 - h0), x0 = (uint32_t)(h0 - blo), r0 = (uint32_t)(a + (h0 - o));
+        uint32_t j = FMX_U_LONGCAP;
+        if (len > FMX_U_LONG) j = atomicAdd(&u_nlong, 1u);
+        if (j < FMX_U_LONGCAP) { u_long[3u * j] = r0; u_long[3u * j + 1u] = x0; u_long[3u * j + 2u] = len; }
+        else for (uint32_t t = 0; t < len; t++) u_rows[x0 + t] = r0 + t;
+      }
+      more = tid == FMX_LOC_BLOCK - 1u && k + 1 < npat && o1 < bhi;
+    }
+    if (!__syncthreads_or((int)more)) break;
+  }
+  {                                                   // the long ranges, by the whole block
+    const uint32_t nl = u_nlong < FMX_U_LONGCAP ? u_nlong : FMX_U_LONGCAP;
+    for (uint32_t j = 0; j < nl; j++) {
+      const uint32_t r0 = u_long[3u * j], x0 = u_long[3u * j + 1u], len = u_long[3u * j + 2u];
+      for (uint32_t t = tid; t < len; t += FMX_LOC_BLOCK) u_rows[x0 + t] = r0 + t;
+    }
+  }
+  __syncthreads();
+  // ---- tickets: slots no range covered (offsets with gaps) take row 0 and are reported; adjacency of the rows ----
+  const uint32_t ntick = (bn + chunk - 1u) / chunk;
+  for (uint32_t t = wv; t < ntick; t += FMX_LOC_BLOCK / 64u) {
+    const uint32_t x = t * chunk + lane;
+    const bool in = lane < chunk && x < bn;
+    uint32_t r = in ? u_rows[x] : 0u;
+    if (in && r == FMX_U_NOROW) { bad = true; r = 0u; u_rows[x] = 0u; }
+    const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
+    const unsigned long long brk = __ballot(in && lane != 0u && r != prev + 1u);
+    const bool adjacent = chunk == FMX_LCHUNK && (uint32_t)__popcll(brk) < adj_clusters;
+    if (lane == 0) {
+      if (adjacent) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
+      else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
+    }
+  }
+  if (bad) atomicOr(status, 1u << FMX_ERR_ARG);
+  __syncthreads();
+  // ---- phase A: a lane per walk on the tickets of adjacent rows ----
+  const uint32_t nal = u_nal, ntl = u_ntl;
+  if (nal) {                                          // block-uniform
+    uint64_t nsteps = 0;
+    for (uint32_t i = wv; i < nal; i += FMX_LOC_BLOCK / 64u) {
+      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
+      if (x < bn) out_pos[blo + x] = fmx_walk_lane_get_sa(walk, samples, n, nsamples, u_rows[x], nsteps);
+    }
+    if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+  }
+  // ---- phase B: the group-cooperative walk on the others ----
+  if (ntl) fmx_f3t_walk<Q, WC, true>(walk, samples, n, nsamples, u_rows, blo, bn, chunk, u_tlist, ntl, out_pos, steps_out);
 }
 
 // ---- RLFM with the run table, batches of LONG intervals: a lane per walk on consecutive hits (round 4) ----------------
@@ -2154,7 +2303,7 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
   uint64_t ntiles = (npat + FMX_SCAN_TILE - 1) / FMX_SCAN_TILE;
   if (ntiles == 0) ntiles = 1;
   uint64_t *tile = tile_ws;
-  if (!tile_ws) FMX_HIP(hipMallocAsync((void **)&tile, (ntiles + 1) * sizeof(uint64_t), st));
+  if (!tile_ws) FMX_HIP(fmx_dev_malloc_async((void **)&tile, (ntiles + 1) * sizeof(uint64_t), st));
   hipLaunchKernelGGL(fmx_tile_sums_kernel, dim3((unsigned)ntiles), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                      npat, tile);
   hipLaunchKernelGGL(fmx_scan_tiles_kernel, dim3(1), dim3(FMX_BLOCK), 0, st, tile, ntiles);
@@ -2172,18 +2321,22 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const FmxDev dv = fmx_launch_dev(idx);
   if (npat == 0 || total == 0) return FMX_OK;
   const FmxMwm &w = dv.bw;
-  // rows in their own read-only buffer: the walk's loads never alias its stores.  The caller's workspace
-  // when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
-  uint32_t *rows = rows_ws;
-  if (!rows_ws) FMX_HIP(hipMallocAsync((void **)&rows, total * sizeof(uint32_t), st));
-  {
+  const FmxTune tn = fmx_tune();
+  const bool dna = idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic;
+  // the default DNA index (text order + walk records): ONE kernel that expands its slices itself -- no rows array
+  const bool unified = dna && dv.phase && dv.walk && tn.walk_records && tn.unified && !tn.alt;
+  // every other path: rows in their own read-only buffer (the walk's loads never alias its stores).  The caller's
+  // workspace when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
+  uint32_t *rows = unified ? nullptr : rows_ws;
+  const bool own_rows = !unified && !rows_ws;
+  if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, total * sizeof(uint32_t), st));
+  if (!unified) {
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                        d_off, npat, rows, total, dv.n, dv.status);
   }
   fmx_time_begin(idx, st);
-  const FmxTune tn = fmx_tune();
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};
   const int sm = fmx_select_mode(idx, dv);
   bool done = false;
@@ -2191,7 +2344,31 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   done = fmx_measure_locate(c, tn, sm);              // the alternative kernels, when one was asked for
 #endif
   if (done) {
-  } else if (idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic) {
+  } else if (unified) {
+    // slices of at most 4096 hits (their rows live in LDS), at least 256 of them -- 512 for large batches: two
+    // blocks per CU (64 VGPRs) -- and tickets of 64 hits once every wave gets that many (below: one hit per walk
+    // slot of every wave, see the two-kernel path)
+    const int q = tn.walks ? tn.walks : (total >= (1u << 16) ? 4 : 1);
+    uint64_t nb = tn.loc_blocks ? (uint64_t)tn.loc_blocks : (total >= (4u << 20) ? 512 : 256);
+    if (nb < (total + FMX_U_SLICE - 1) / FMX_U_SLICE) nb = (total + FMX_U_SLICE - 1) / FMX_U_SLICE;
+    const uint64_t per_wave = (total + nb * (FMX_LOC_BLOCK / 64) - 1) / (nb * (FMX_LOC_BLOCK / 64));
+    uint32_t chunk = (uint32_t)((per_wave + 7) / 8 * 8);
+    if (chunk < 8u * (uint32_t)q) chunk = 8u * (uint32_t)q;
+    if (chunk > FMX_LCHUNK) chunk = FMX_LCHUNK;
+    uint32_t hpb;
+    unsigned gr;
+    c.slice(nb, chunk, hpb, gr);
+    if (hpb > FMX_U_SLICE) { hpb = FMX_U_SLICE; gr = (unsigned)((total + hpb - 1) / hpb); }   // (4096 is a multiple of every ticket size)
+#define FMX_LOCU_LAUNCH(Q, WCF)                                                                      \
+    hipLaunchKernelGGL((fmx_locate_f3u_kernel<Q, WCF>), dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, dv.walk, dv.samples, dv.n, \
+                       dv.nsamples, d_s, d_e, d_off, npat, total, hpb, chunk, (uint32_t)tn.adj_clusters, d_pos, c.steps,   \
+                       dv.status)
+    if (chunk == FMX_LCHUNK && tn.wc) {
+      if (q == 4) FMX_LOCU_LAUNCH(4, true); else if (q == 2) FMX_LOCU_LAUNCH(2, true); else FMX_LOCU_LAUNCH(1, true);
+    } else {
+      if (q == 4) FMX_LOCU_LAUNCH(4, false); else if (q == 2) FMX_LOCU_LAUNCH(2, false); else FMX_LOCU_LAUNCH(1, false);
+    }
+  } else if (dna) {
     // DNA (one 3-bit level): walk state distributed over the lanes of a group, 4 walks per group when the
     // batch is large enough to keep every group busy with them
     const int q = tn.walks ? tn.walks : (total >= (1u << 16) ? 4 : 1);
@@ -2290,7 +2467,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   }
   fmx_time_end(idx, st);
   FMX_HIP(hipGetLastError());
-  if (!rows_ws) FMX_HIP(hipFreeAsync(rows, st));
+  if (own_rows) FMX_HIP(hipFreeAsync(rows, st));
   return FMX_OK;
 }
 

@@ -1541,7 +1541,11 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
     } else if (w.kind == FMX_KIND_RLFM && w.lfrun) {       // run table: a lane per walk
       uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
       if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
-      static const int force = getenv("FMXW_RL_LOCKSTEP") ? atoi(getenv("FMXW_RL_LOCKSTEP")) : -1;   // measurement switch
+#ifdef FMX_MEASURE     // measurement switch (profiles/r04/wide_rlfm_4g_row_order_*.json): the shipped library reads no environment
+      static const int force = getenv("FMXW_RL_LOCKSTEP") ? atoi(getenv("FMXW_RL_LOCKSTEP")) : -1;
+#else
+      constexpr int force = -1;
+#endif
       const bool lockstep = force >= 0 ? force != 0 : total / npat >= 64;
       if (lockstep) hipLaunchKernelGGL(fmxw_r_walk_kernel<true>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
       else hipLaunchKernelGGL(fmxw_r_walk_kernel<false>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);

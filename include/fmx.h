@@ -120,6 +120,14 @@ typedef struct fmx_index fmx_index;
  * runtime ~30 ms per GiB for memory the process has already cycled through: 5 s instead of 0.6).  The default cap
  * (32 GiB or an eighth of the device) covers texts up to ~2^30 symbols without the flag. */
 #define FMX_FLAG_KEEP_SCRATCH 256u
+/* RLFM indexes that locate: the RUN TABLE lfrun[j] = lf_map(first row of run j) (4 bytes per run; 8 on the wide
+ * engine) turns an LF step of the locate walk into two lane-wise reads.  Space policy (round 5): an index type that
+ * exists to save space (lib.rs:45-47) gets the table by default only when the text is repetitive enough for it to be a
+ * small part of the index -- at most one run per four rows (r <= n / 4: the table is then <= n bytes) -- and the device
+ * has room; on a text with about one run per row (random bytes) the table would be 4.3 GB of an 8.9 GB index for a
+ * 1 GiB text.  This flag asks for the table whatever r / n is (room permitting); FMX_FLAG_NO_WALK_RECORDS builds
+ * without it either way.  fmx_walk_records() tells what the index got. */
+#define FMX_FLAG_RUN_TABLE 512u
 /* Tests only: build the WIDE engine's index (64-bit rows, see "Conventions") although n < 2^32 - 16, with
  * superblocks of 2^12 rows instead of 2^31 (bit vectors of an RLFM index: 2 records instead of 2^22), so that a
  * small text exercises every part of it.  Every kind; n >= 2; same results. */
@@ -296,7 +304,9 @@ double fmx_last_kernel_ms(const fmx_index *idx);
 /* enabled == 2: a SERIES -- every following count / locate launch of the index (up to 64) gets its own pair of events
  * around its dominant kernel, nothing else changes (no step counter, no synchronisation), so that launches issued back
  * to back are timed as they run back to back.  fmx_series_kernel_ms waits for them, returns their mean duration in
- * milliseconds (-1 when there is none) and starts a new series. */
+ * milliseconds (-1 when there is none) and starts a new series.  Instrumentation for ONE measuring thread: while timing
+ * is enabled (1 or 2) the launches of an index share its event slots and must come from a single thread; with timing
+ * off (the default) launches on a const handle are thread-safe as everywhere else. */
 double fmx_series_kernel_ms(fmx_index *idx);
 /* LF steps executed by the last count / locate call when timing is enabled (else 0) */
 uint64_t fmx_last_steps(const fmx_index *idx);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential soak test: random texts / alphabets / index kinds / levels / flags, random and
 substring patterns, every result compared with the CPU oracle (bit-exact (s,e), ordered locate
-sequences, every trait method on sampled rows).  Usage: python tests/fuzz_gpu_vs_oracle.py [seconds] [seed]
+sequences, every trait method on sampled rows).  Usage: python tests/fuzz_gpu_vs_oracle.py [seconds] [seed] [--long
+[--iters=N]]  (--long: the long-interval batches of long_intervals() below)
 (the oracle is the checker here, exactly as in tests/)."""
 import os
 import sys
@@ -10,13 +11,115 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def long_intervals(budget, seed, max_iters):
+    """`long` mode (round 5): the kernels that walk LONG intervals -- the one-launch DNA kernel with its
+    per-ticket choice (fmx_locate_f3u_kernel: lane per hit / cooperative walk), the RLFM lane-per-walk kernel
+    (fmx_locate_rl_lane_kernel) next to the endpoint-per-lane one -- on batches that cross their dispatch thresholds
+    (>= 64 hits per pattern; >= 2^16 DNA / 2^18 RLFM hits), in text and row order, skewed batches (singletons + a few huge
+    intervals), and RLFM texts whose run-length mix reaches every branch of fmx_bits_lane_select: stored positions (sparse
+    B), select blocks of every size (dense B), and the hint + record search (a long run inside a dense vector, so that
+    the run starts before the row's 96-bit piece and its select block cannot hold it).  Ordered positions == oracle."""
+    import numpy as np
+    import fm_index_amd as F
+    from oracle import fm_oracle as O
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    it = 0
+    stats = {"dna": 0, "rlfm": 0, "hits": 0, "text_order": 0, "run_table": 0, "stored_pos": 0, "skewed": 0, "row_order": 0}
+    threads = min(16, os.cpu_count() or 1)
+    while time.time() < t_end and it < max_iters:
+        it += 1
+        dna = rng.random() < 0.5
+        n = int(rng.choice([66000, 131072, 200003, 300000]))
+        if dna:
+            alpha = int(rng.choice([2, 3, 4, 5]))
+            maxc = int(rng.choice([alpha, 4 if alpha <= 4 else 5, 5]))
+            level = int(rng.integers(1, 4))
+            style = rng.choice(["random", "repetitive"])
+        else:
+            alpha = int(rng.choice([2, 4, 20, 255]))
+            maxc = 255
+            level = int(rng.integers(0, 5))
+            style = rng.choice(["runs_short", "runs_long", "runs_mixed", "repetitive", "random"])
+        if style == "random":
+            t = rng.integers(1, alpha + 1, size=n)
+        elif style == "repetitive":
+            blk = rng.integers(1, alpha + 1, size=int(rng.choice([7, 64, 300, 2000])))
+            t = np.tile(blk, n // len(blk) + 1)[:n]
+            mut = rng.random(n) < float(rng.choice([0.0005, 0.004, 0.02]))
+            t[mut] = rng.integers(1, alpha + 1, size=int(mut.sum()))
+        else:
+            # run lengths: short (dense B: select blocks), long (sparse B: stored positions), or short with a few
+            # runs of 100..900 symbols (dense B whose select blocks cannot hold those runs)
+            k = n
+            if style == "runs_short":
+                lens = rng.integers(1, int(rng.choice([2, 3, 5, 9])), size=k)
+            elif style == "runs_long":
+                lens = rng.integers(8, 60, size=k)
+            else:
+                lens = rng.integers(1, int(rng.choice([2, 4, 8])), size=k)
+                big = rng.random(k) < 0.004
+                lens[big] = rng.integers(100, 900, size=int(big.sum()))
+            t = np.repeat(rng.integers(1, alpha + 1, size=k), lens)[:n]
+        t = t.astype(np.uint8)
+        t[n - 1] = 0
+        sampling = [None, "row"][int(rng.random() < 0.3)]
+        oi = O.OracleIndex(t, maxc, level=level, kind="fm" if dna else "rlfm")
+        text = F.Text.with_max_character(t, maxc)
+        if dna:
+            gi = F.FMIndexWithLocate(text, level, sampling=sampling)
+        else:
+            gi = F.RLFMIndexWithLocate(text, level, sampling=sampling, run_table=bool(rng.random() < 0.85))
+        stats["dna" if dna else "rlfm"] += 1
+        stats["text_order"] += int(gi.text_order())
+        stats["row_order"] += int(not gi.text_order())
+        stats["run_table"] += int((not dna) and gi.walk_records())
+        # the batch: intervals over the rows (any (s, e) with s <= e <= n is an argument of locate)
+        shape = rng.choice(["long", "skewed", "threshold", "adjacent_patterns"])
+        if shape == "long":                      # every pattern far above 64 hits
+            k = int(rng.integers(40, 400))
+            ln = rng.integers(200, 6000, size=k)
+        elif shape == "skewed":                  # singletons and short intervals + a few huge ones
+            k = int(rng.integers(2000, 30000))
+            ln = rng.integers(0, 3, size=k)
+            hv = rng.choice(k, int(rng.integers(1, 6)), replace=False)
+            ln[hv] = rng.integers(30000, min(n, 250000), size=len(hv))
+            stats["skewed"] += 1
+        elif shape == "threshold":               # around 64 hits per pattern, around the 2^16 / 2^18 totals
+            per = int(rng.choice([60, 63, 64, 65, 70, 128]))
+            tot = int(rng.choice([1 << 16, 1 << 18])) + int(rng.integers(-3000, 3000))
+            k = max(1, tot // per)
+            ln = np.full(k, per)
+            ln[rng.integers(0, k, size=max(1, k // 50))] += rng.integers(0, 5, size=max(1, k // 50))
+        else:                                    # consecutive patterns cover consecutive rows (adjacent across patterns)
+            k = int(rng.integers(500, 5000))
+            ln = rng.integers(10, 200, size=k)
+        s = rng.integers(0, n, size=k).astype(np.int64)
+        if shape == "adjacent_patterns":
+            s = (int(rng.integers(0, n // 2)) + np.concatenate([[0], np.cumsum(ln[:-1])])) % n
+        e = np.minimum(s + ln, n)
+        s, e = s.astype(np.uint64), e.astype(np.uint64)
+        goff, gpos = gi.locate_many(s, e)
+        ooff, opos = oi.locate_batch(s, e, nthreads=threads)
+        assert (np.asarray(goff) == np.asarray(ooff)).all() and (np.asarray(gpos) == np.asarray(opos)).all(), \
+            ("long", it, "dna" if dna else "rlfm", n, alpha, maxc, level, style, sampling, shape, seed)
+        stats["hits"] += int(ooff[-1])
+        gi.close()
+        oi.close()
+    print("fuzz (long intervals) ok: %d iterations in %.0f s, seed %d, %s" % (it, budget, seed, stats))
+
+
 def main():
     import numpy as np
     import fm_index_amd as F
     from fm_index_amd import workload as W
     from oracle import fm_oracle as O
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(argv[0]) if len(argv) > 0 else 60.0
+    seed = int(argv[1]) if len(argv) > 1 else 1
+    if "--long" in sys.argv[1:]:
+        iters = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--iters=")]
+        return long_intervals(budget, seed, iters[0] if iters else 1 << 30)
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     it = 0
@@ -77,8 +180,9 @@ def main():
         elif kind == "rlfm":
             if n < 2:
                 continue
+            # (FMX_FLAG_RUN_TABLE: most texts here have about one run per row, where the builder leaves the table out)
             gi = F.RLFMIndexWithLocate(text, level, kmer_table=kmer, sampling=sampling, walk_records=walk,
-                                       force_wide=engine64) \
+                                       force_wide=engine64, run_table=bool(rng.random() < 0.7)) \
                 if level is not None else F.RLFMIndex(text, kmer_table=kmer, force_wide=engine64)
             assert gi.is_wide() == engine64
         else:

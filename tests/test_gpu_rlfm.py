@@ -216,7 +216,8 @@ def test_run_table_walk_equals_the_wavelet_walk_and_the_oracle(gen, level, sampl
         t[-1] = 0
     else:
         t = W.repetitive_text_np(n, 5, base_len=1 << 9, mut_per_1024=int(gen[3:]))
-    with_t = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)
+    # (FMX_FLAG_RUN_TABLE: the random texts have about one run per row, where the builder leaves the table out by itself)
+    with_t = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling, run_table=True)
     without = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling, walk_records=False)
     assert with_t.walk_records() and not without.walk_records()
     runs = int(with_t._lib.fmx_num_runs(with_t.handle()))
@@ -270,7 +271,7 @@ def test_long_intervals_take_the_lane_per_walk_kernel(sampling, level):
     sequences of the oracle, and of the same index without the run table (the endpoint-per-lane / group kernels)"""
     n = 300000
     t = W.repetitive_text_np(n, 11, base_len=512, mut_per_1024=4)
-    gi = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)
+    gi = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)   # repetitive: r <= n / 4, the builder adds the table
     assert gi.walk_records() and gi.text_order() == (sampling is None and level >= 1)
     oi = O.OracleIndex(t, 255, level=level, kind="rlfm")
     flat, off, _ = W.substring_patterns_np(t, 600, 3, 21)            # short patterns: hundreds of hits each
@@ -286,3 +287,28 @@ def test_long_intervals_take_the_lane_per_walk_kernel(sampling, level):
     _, ppos = plain.search_many(flat=flat, off=off).locate()
     assert (ppos == opos).all()
     gi.close(); plain.close()
+
+
+def test_run_table_space_policy():
+    """round 5: an index type that exists to save space gets the 4-bytes-per-run table by itself only
+    when the text is repetitive (r <= n / 4); a text with about one run per row gets it with FMX_FLAG_RUN_TABLE only,
+    FMX_FLAG_NO_WALK_RECORDS wins over both, and a count-only index never carries it.  Positions are the same."""
+    n = 1 << 16
+    rnd = (W.splitmix64_np(95, 0, n) % np.uint64(255)).astype(np.uint8) + 1
+    rnd[-1] = 0
+    rep = W.repetitive_text_np(n, 7, base_len=1 << 9, mut_per_1024=5)
+    a = F.RLFMIndexWithLocate(F.Text(rnd), 2)
+    b = F.RLFMIndexWithLocate(F.Text(rnd), 2, run_table=True)
+    c = F.RLFMIndexWithLocate(F.Text(rep), 2)
+    d = F.RLFMIndexWithLocate(F.Text(rep), 2, run_table=True, walk_records=False)
+    e = F.RLFMIndex(F.Text(rep))
+    runs = lambda g: int(g._lib.fmx_num_runs(g.handle()))     # noqa: E731
+    assert runs(a) * 4 > n and not a.walk_records() and b.walk_records()
+    assert b.heap_size() - a.heap_size() == 4 * runs(a)
+    assert runs(c) * 4 <= n and c.walk_records() and not d.walk_records() and not e.walk_records()
+    assert c.heap_size() - d.heap_size() == 4 * runs(c)
+    s, en = np.array([0], np.uint64), np.array([n], np.uint64)
+    assert (a.locate_many(s, en)[1] == b.locate_many(s, en)[1]).all()
+    assert (c.locate_many(s, en)[1] == d.locate_many(s, en)[1]).all()
+    for g in (a, b, c, d, e):
+        g.close()

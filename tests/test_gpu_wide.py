@@ -226,7 +226,7 @@ def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, d
         t = _runs_text(n, sigma, 300 + n % 89, mean_run, dtype)
     sampling = "row" if n in (30000, 60001) else None               # FMX_FLAG_ROW_ORDER: the reference's rows
     gi = F.RLFMIndexWithLocate(F.Text.with_max_character(t, sigma), level, keep_sa=True, force_wide=True,
-                               walk_records=run_table, sampling=sampling)
+                               walk_records=run_table, sampling=sampling, run_table=run_table)
     assert gi.is_wide() and gi.len() == n and gi.level() == (level if n > (1 << level) else 0)
     # with the run table the index samples in text order (levels 1..4: phase pieces with 64-bit superblock bases)
     assert gi.walk_records() == run_table

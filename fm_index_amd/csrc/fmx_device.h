@@ -7,6 +7,14 @@
 // per-piece popcounts are summed with three DPP adds inside the group (quad_perm,
 // quad_perm, row_half_mirror) -- no LDS traffic, no bpermute.
 #pragma once
+// LDS words that lanes of one wave hand to each other (write-combining rings, the hit queue's row windows): volatile,
+// so that every access is a real LDS operation in program order -- and typed as LDS (address space 3): the compiler's
+// address-space inference leaves volatile accesses through generic pointers as FLAT instructions, each followed by a
+// wait for every vector-memory operation of the wave in flight (rounds 1-4 shipped that; measured in round 5)
+typedef __attribute__((address_space(3))) uint32_t fmx_lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long fmx_lds_u64;
+#define FMX_LDS_U32(p) ((volatile fmx_lds_u32 *)(p))
+#define FMX_LDS_U64(p) ((volatile fmx_lds_u64 *)(p))
 #include "fmx_internal.h"
 
 #define FMX_GROUP 8

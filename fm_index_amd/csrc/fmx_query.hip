@@ -744,7 +744,7 @@ struct FmxHitQueue {
   uint32_t lane;
   uint32_t c0, c1;        // resident chunks of the slice (FMX_NOCHUNK once it is exhausted), wave-uniform
   uint32_t win0, win1;    // rows of the resident chunks, one per lane (lanes >= chunk unused)     [!LWIN]
-  volatile uint32_t *lwin;  // this wave's 2 x 64 words of LDS; chunk c0 sits in half w0, c1 in the other [LWIN]
+  volatile fmx_lds_u32 *lwin;  // this wave's 2 x 64 words of LDS; chunk c0 sits in half w0, c1 in the other [LWIN]
   uint32_t w0;
   uint32_t used;          // hits already handed out of c0|c1
   const uint16_t *tlist = nullptr;   // [TL]
@@ -764,7 +764,7 @@ struct FmxHitQueue {
     return t;
   }
   __device__ __forceinline__ void init(const uint32_t *r, uint64_t first, uint32_t count, uint32_t rows_per_ticket,
-                                       uint32_t ln, unsigned int &counter, volatile uint32_t *lds_win = nullptr) {
+                                       uint32_t ln, unsigned int &counter, volatile fmx_lds_u32 *lds_win = nullptr) {
     rows = r; lo = first; nhits = count; chunk = rows_per_ticket; lane = ln;
     lwin = lds_win; w0 = 0; win0 = 0; win1 = 0;
     // every wave of the block draws its FIRST ticket before any draws a second one (called by all
@@ -1005,8 +1005,8 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_locate_f3p_kernel(
   // 64 * ticket + i (NONE until its walk has finished).  Only this wave touches its ring.
   // (volatile: lanes read what other lanes of the wave wrote -- every access must be a real LDS operation,
   // in program order; the LDS serves one wave's operations in order)
-  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64);
-  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS;
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring = FMX_LDS_U32(wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64));
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring_tag = FMX_LDS_U32(wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS);
   [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;   // ring slots of the resident tickets c0 / c1; tickets drawn
   if (WC) {
 #pragma unroll
@@ -1161,8 +1161,8 @@ __device__ __forceinline__ void fmx_f3t_walk(
   hq.nlist = nlist;
   hq.init(rows, blo, bn, chunk, lane, lds_q);
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
-  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64);
-  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS;
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring = FMX_LDS_U32(wc_ring + (threadIdx.x >> 6) * (FMX_WC_SLOTS * 64));
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring_tag = FMX_LDS_U32(wc_tag + (threadIdx.x >> 6) * FMX_WC_SLOTS);
   [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;   // ring slots of the resident tickets c0 / c1; tickets drawn
   if (WC) {
 #pragma unroll
@@ -1317,9 +1317,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // for 8.4 MB of positions).
 // LFR (RLFM with the run table FmxDev::lfrun, round 4): an LF step is two lane-wise requests (fmx_rlfm_ep_lf_run) and the
 // cooperative rank rounds are not run at all.
-template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR = false>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_kernel(
-    FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
+// The walk over the block's slice [blo, blo + bn) of the hits (rows = the rows of the slice), called by all threads of the
+// block; TL: only the tickets listed in tlist[0 .. nlist) (the per-ticket RLFM kernel, round 5).
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR, bool TL>
+__device__ __forceinline__ void fmx_ep_walk(
+    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, const uint16_t *tlist, uint32_t nlist,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
   __shared__ unsigned int lds_q;
@@ -1331,20 +1333,19 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     for (uint32_t t = threadIdx.x; t <= ix.max_character; t += blockDim.x) kt_lds[t] = ix.K[t];
   }
   __syncthreads();
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
   const uint32_t *kt = KLDS ? kt_lds : ix.K;
   const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no position (n < 2^32 - 16)
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of the block (scalar)
-  FmxHitQueue<true> hq;
-  hq.init(rows + blo, blo, bn, FMX_LCHUNK, lane, lds_q, hq_win + wv * 128u);
+  FmxHitQueue<true, TL> hq;
+  hq.tlist = tlist;
+  hq.nlist = nlist;
+  hq.init(rows, blo, bn, FMX_LCHUNK, lane, lds_q, FMX_LDS_U32(hq_win + wv * 128u));
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   // write-combining ring of this wave (see fmx_locate_f3p_kernel): slot r holds ticket ring_tag[r]
-  [[maybe_unused]] volatile uint32_t *const ring = wc_ring + wv * (FMX_WC_SLOTS * 64);
-  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + wv * FMX_WC_SLOTS;
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring = FMX_LDS_U32(wc_ring + wv * (FMX_WC_SLOTS * 64));
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring_tag = FMX_LDS_U32(wc_tag + wv * FMX_WC_SLOTS);
   [[maybe_unused]] uint32_t rseq = 2;                 // tickets drawn so far (ticket k of the wave -> ring slot k & 3)
   static_assert(FMX_WC_SLOTS == 4, "the tag lookup below reads four tags");
   if (WC) {
@@ -1479,6 +1480,16 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     }
   }
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR = false>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_kernel(
+    FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, nullptr, 0u, out_pos, steps_out);
 }
 
 // counts -> exclusive offsets (single block scan is enough off the hot path? no:
@@ -1972,6 +1983,8 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_walk_lane_kernel(
 //     group-cooperative walk with its write-combining ring (phase B, fmx_f3t_walk).  The choice only picks the faster
 //     of two exact algorithms: any classification gives the reference's positions in the reference's order.
 #define FMX_U_SLICE 4096u
+#define FMX_U_PATS 5120u           // patterns per expansion round (5 per thread): after one probe round over <= 2^20 patterns the
+                                   // bracket is 1024 wide, and 1024 + 4096 patterns cover a slice of singletons in ONE round
 #define FMX_U_LONG 32u
 #define FMX_U_LONGCAP 128u
 #define FMX_U_NOROW 0xFFFFFFFFu
@@ -1996,47 +2009,60 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   bool bad = false;                                   // an argument that is not of this index / these offsets
   for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK) u_rows[x] = FMX_U_NOROW;
   if (tid == 0) { u_nlong = 0; u_ntl = 0; u_nal = 0; }
-  // ---- the slice's first pattern, bracketed: k_lo <= (largest k with off[k] <= blo) < k_lo + 1024 ----
+  // ---- the slice's first pattern, bracketed: k_lo <= (largest k with off[k] <= blo) < k_lo + FMX_U_PATS ----
+  // one round of 1024 probes cuts the bracket 1024-fold: none up to 4096 patterns, one up to 2^22, two up to 2^32.
+  // (the predicate off[c] <= blo is monotone in c: a wave's best candidate is its highest lane that holds, and only
+  // lane 0 of the wave touches the LDS word)
   uint64_t k_lo = 0, span = npat;
-  while (span > FMX_LOC_BLOCK) {                      // block-uniform; one round up to 2^20 patterns, two up to 2^30
+  while (span > FMX_U_PATS) {                         // block-uniform
     const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
     const uint64_t c = k_lo + (uint64_t)tid * step;
     if (tid == 0) u_klb = k_lo;
     __syncthreads();
-    if (tid != 0 && c < k_lo + span && off[c] <= blo) atomicMax(&u_klb, (unsigned long long)c);
+    const unsigned long long okm = __ballot(tid != 0 && c < k_lo + span && off[c] <= blo);
+    if (okm && lane == 0)
+      atomicMax(&u_klb, (unsigned long long)(k_lo + (uint64_t)((tid | 63u) - (uint32_t)__builtin_clzll(okm)) * step));
     __syncthreads();
     const uint64_t best = u_klb;
     span = best + step <= k_lo + span ? step : k_lo + span - best;
     k_lo = best;
-    __syncthreads();
   }
   __syncthreads();                                    // u_rows cleared, counters zeroed
-  // ---- expansion: thread p takes pattern kc + p; chunks of 1024 patterns until one starts behind the slice ----
-  for (uint64_t kc = k_lo;; kc += FMX_LOC_BLOCK) {
-    const uint64_t k = kc + tid;
+  // ---- expansion: FMX_U_PATS patterns per round (thread p takes patterns kc + p, kc + 1024 + p, ...: their off, s, e
+  // in one round of loads), until a round ends on a pattern that starts behind the slice ----
+  for (uint64_t kc = k_lo;; kc += FMX_U_PATS) {
+    uint64_t a[FMX_U_PATS / FMX_LOC_BLOCK], b[FMX_U_PATS / FMX_LOC_BLOCK], o[FMX_U_PATS / FMX_LOC_BLOCK];
+#pragma unroll
+    for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
+      const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
+      a[j] = 0; b[j] = 0; o[j] = 0;
+      if (k < npat) { a[j] = s[k]; b[j] = e[k]; o[j] = off[k]; }
+    }
+    // the round's last pattern + 1: does it still start inside the slice?
     bool more = false;
-    if (k < npat) {
-      uint64_t a = s[k];
-      const uint64_t b = e[k], o = off[k];
-      const uint64_t o1 = k + 1 < npat ? off[k + 1] : total;
-      uint64_t cnt = b > a ? b - a : 0;
+    if (tid == FMX_LOC_BLOCK - 1u && kc + FMX_U_PATS < npat) more = off[kc + FMX_U_PATS] < bhi;
+#pragma unroll
+    for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
+      const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
+      if (k >= npat) continue;
+      uint64_t aa = a[j], cnt = b[j] > aa ? b[j] - aa : 0;
+      const uint64_t oo = o[j];
       // a range that is not one of this index, or offsets that do not leave room for it: refused (fmx_expand_kernel's
       // rule: the slots take rows from 0 on, so that the walk stays inside the index)
-      if (b > n || o > total || cnt > total - o) {
+      if (b[j] > n || oo > total || cnt > total - oo) {
         bad = true;
-        a = 0;
-        cnt = o < total ? (cnt < total - o ? cnt : total - o) : 0;
+        aa = 0;
+        cnt = oo < total ? (cnt < total - oo ? cnt : total - oo) : 0;
         if (cnt > n) cnt = n;
       }
-      if (cnt && o < bhi && o + cnt > blo) {          // the part of [o, o + cnt) inside the slice
-        const uint64_t h0 = o > blo ? o : blo, h1 = o + cnt < bhi ? o + cnt : bhi;
-        const uint32_t len = (uint32_t)(h1 - h0), x0 = (uint32_t)(h0 - blo), r0 = (uint32_t)(a + (h0 - o));
-        uint32_t j = FMX_U_LONGCAP;
-        if (len > FMX_U_LONG) j = atomicAdd(&u_nlong, 1u);
-        if (j < FMX_U_LONGCAP) { u_long[3u * j] = r0; u_long[3u * j + 1u] = x0; u_long[3u * j + 2u] = len; }
+      if (cnt && oo < bhi && oo + cnt > blo) {        // the part of [oo, oo + cnt) inside the slice
+        const uint64_t h0 = oo > blo ? oo : blo, h1 = oo + cnt < bhi ? oo + cnt : bhi;
+        const uint32_t len = (uint32_t)(h1 - h0), x0 = (uint32_t)(h0 - blo), r0 = (uint32_t)(aa + (h0 - oo));
+        uint32_t q = FMX_U_LONGCAP;
+        if (len > FMX_U_LONG) q = atomicAdd(&u_nlong, 1u);
+        if (q < FMX_U_LONGCAP) { u_long[3u * q] = r0; u_long[3u * q + 1u] = x0; u_long[3u * q + 2u] = len; }
         else for (uint32_t t = 0; t < len; t++) u_rows[x0 + t] = r0 + t;
       }
-      more = tid == FMX_LOC_BLOCK - 1u && k + 1 < npat && o1 < bhi;
     }
     if (!__syncthreads_or((int)more)) break;
   }
@@ -2135,41 +2161,92 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lane_lf(const FmxDev &ix, uint32_t 
   else st = fmx_bits_lane_select(ix.b, lo);
   return f + row - st;
 }
+// get_sa(row) by ONE lane through the run table (rlfmi.rs:172-190): returns the text position, adds the LF steps
+template <bool TEXT>
+__device__ __forceinline__ uint64_t fmx_rlfm_lane_get_sa(const FmxDev &ix, uint32_t row, uint64_t &nsteps) {
+  uint32_t steps = 0, si;
+  FMX_CHECK(row < ix.n);                              // (fmx_expand_kernel wrote every slot with a row of this index)
+  if (TEXT) {                                         // SA[row] mod 2^level steps; phase probes at both ends
+    uint32_t t;
+    uint32_t pi = fmx_phase_piece(row, ix.sa_level, t);
+    FMX_TOUCH(&ix.phase[pi]);
+    steps = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+    for (uint32_t k = 0; k < steps; k++) row = fmx_rlfm_lane_lf(ix, row);
+    if (steps) {
+      pi = fmx_phase_piece(row, ix.sa_level, t);
+      FMX_TOUCH(&ix.phase[pi]);
+      [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+      FMX_CHECK(p2 == 0u);
+    }
+  } else {                                            // the reference's rows (sample.rs:46-60)
+    const uint32_t lmask = (1u << ix.sa_level) - 1u;
+    while (row & lmask) { row = fmx_rlfm_lane_lf(ix, row); steps++; }
+    si = row >> ix.sa_level;
+  }
+  FMX_CHECK(si < ix.nsamples);
+  FMX_TOUCH(&ix.samples[si]);
+  uint64_t v = (uint64_t)ix.samples[si] + steps;      // (sa + steps) % len                      rlfmi.rs:178-182
+  if (v >= ix.n) v -= ix.n;
+  nsteps += steps;
+  return v;
+}
 template <bool TEXT>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total,
                                                                         const uint32_t *__restrict__ rows,
                                                                         uint64_t *__restrict__ out_pos,
                                                                         uint64_t *__restrict__ steps_out) {
   const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-  const uint32_t lmask = (1u << ix.sa_level) - 1u;
   uint64_t nsteps = 0;
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth) {
-    uint32_t row = rows[h], steps = 0, si;
-    FMX_CHECK(row < ix.n);                            // (fmx_expand_kernel wrote every slot with a row of this index)
-    if (TEXT) {                                       // SA[row] mod 2^level steps; phase probes at both ends
-      uint32_t t;
-      uint32_t pi = fmx_phase_piece(row, ix.sa_level, t);
-      FMX_TOUCH(&ix.phase[pi]);
-      steps = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
-      for (uint32_t k = 0; k < steps; k++) row = fmx_rlfm_lane_lf(ix, row);
-      if (steps) {
-        pi = fmx_phase_piece(row, ix.sa_level, t);
-        FMX_TOUCH(&ix.phase[pi]);
-        [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
-        FMX_CHECK(p2 == 0u);
-      }
-    } else {                                          // the reference's rows (sample.rs:46-60)
-      while (row & lmask) { row = fmx_rlfm_lane_lf(ix, row); steps++; }
-      si = row >> ix.sa_level;
-    }
-    FMX_CHECK(si < ix.nsamples);
-    FMX_TOUCH(&ix.samples[si]);
-    uint64_t v = (uint64_t)ix.samples[si] + steps;    // (sa + steps) % len                      rlfmi.rs:178-182
-    if (v >= ix.n) v -= ix.n;
-    out_pos[h] = v;
-    nsteps += steps;
-  }
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth)
+    out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[h], nsteps);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// ---- RLFM with the run table: the walk chosen per 64-hit TICKET (round 5) ----------------------------------------------
+// The rule of fmx_locate_f3u_kernel on the run-length index: a block owns a slice of <= FMX_RLU_SLICE hits (their rows
+// come from fmx_expand_kernel), classifies its tickets by the adjacency of their rows -- at most `adj_clusters` runs of
+// consecutive rows -- and walks the adjacent ones a lane per hit on consecutive hits (phase A: the wave's 64 requests of
+// a step fall into a few lines, fmx_locate_rl_lane_kernel's finding) and the others with refilling lanes through the
+// block's hit queue and the write-combining ring (phase B: fmx_ep_walk<..., LFR>).  Until round 4 the batch AVERAGE of
+// hits per pattern chose one of the two for every hit.  Any classification gives the reference's positions.
+#define FMX_RLU_SLICE 16384u
+template <bool TEXT, int SM>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_rl_u_kernel(
+    FmxDev ix, uint64_t total, uint32_t hits_per_block, uint32_t adj_clusters, const uint32_t *__restrict__ rows,
+    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  __shared__ uint16_t u_tlist[FMX_RLU_SLICE / 64];
+  __shared__ uint16_t u_alist[FMX_RLU_SLICE / 64];
+  __shared__ unsigned int u_ntl, u_nal;
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, nwv = blockDim.x >> 6;   // (640- or 1024-thread blocks)
+  FMX_CHECK(hits_per_block <= FMX_RLU_SLICE);
+  if (tid == 0) { u_ntl = 0; u_nal = 0; }
+  __syncthreads();
+  const uint32_t ntick = (bn + FMX_LCHUNK - 1u) / FMX_LCHUNK;
+  for (uint32_t t = wv; t < ntick; t += nwv) {
+    const uint32_t x = t * FMX_LCHUNK + lane;
+    const bool in = x < bn;
+    const uint32_t r = in ? rows[blo + x] : 0u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
+    const unsigned long long brk = __ballot(in && lane != 0u && r != prev + 1u);
+    if (lane == 0) {
+      if ((uint32_t)__popcll(brk) < adj_clusters) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
+      else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
+    }
+  }
+  __syncthreads();
+  const uint32_t nal = u_nal, ntl = u_ntl;
+  if (nal) {                                          // block-uniform: a lane per walk on the tickets of adjacent rows
+    uint64_t nsteps = 0;
+    for (uint32_t i = wv; i < nal; i += nwv) {
+      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
+      if (x < bn) out_pos[blo + x] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[blo + x], nsteps);
+    }
+    if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+  }
+  if (ntl) fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, u_tlist, ntl, out_pos, steps_out);
 }
 
 // ---- locate launch helpers (c = FmxLocateCall) ----
@@ -2439,8 +2516,21 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
+      else if (dv.lfrun && tn.walk_records && tn.wc && tn.unified) {
+        // the run table: two lane-wise requests per LF step, the walk chosen per ticket (fmx_locate_rl_u_kernel)
+        uint64_t ub = (total + FMX_RLU_SLICE - 1) / FMX_RLU_SLICE;
+        if (ub < (big ? 512u : 256u)) ub = big ? 512u : 256u;
+        uint32_t uh;
+        unsigned ug;
+        c.slice(ub, FMX_LCHUNK, uh, ug);
+#define FMX_RLU_LAUNCH(TX, SMV)                                                                      \
+        hipLaunchKernelGGL((fmx_locate_rl_u_kernel<TX, SMV>), dim3(ug), dim3(thr), 0, c.st, c.dv, c.total, uh,             \
+                           (uint32_t)tn.adj_clusters, c.rows, c.pos, c.steps)
+        if (dv.phase) { if (sm == 1) FMX_RLU_LAUNCH(true, 1); else FMX_RLU_LAUNCH(true, 2); }
+        else { if (sm == 1) FMX_RLU_LAUNCH(false, 1); else FMX_RLU_LAUNCH(false, 2); }
+      }
       else if (dv.lfrun && tn.walk_records && tn.wc && total / npat >= 64 && !tn.alt) {
-        // long intervals (a repetitive text's): a lane per walk on consecutive hits
+        // (measurement builds, FMX_VARIANT=28: the round-4 choice by the batch average) long intervals: a lane per walk
         uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
         if (lb > 8192) lb = 8192;
         if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);

@@ -440,8 +440,8 @@ __global__ __launch_bounds__(FMXW_LOC_BLOCK) void fmxw_walk_t_kernel(FmxWideDev 
   uint64_t *const out = io + blo;                     // the block's slice: rows on entry, positions on exit
   FmxwHitQueue hq;
   hq.init(out, bn, chunk, lane, lds_q);
-  [[maybe_unused]] volatile uint64_t *const ring = wc_ring + (threadIdx.x >> 6) * (FMXW_WC_SLOTS * 64);
-  [[maybe_unused]] volatile uint32_t *const ring_tag = wc_tag + (threadIdx.x >> 6) * FMXW_WC_SLOTS;
+  [[maybe_unused]] volatile fmx_lds_u64 *const ring = FMX_LDS_U64(wc_ring + (threadIdx.x >> 6) * (FMXW_WC_SLOTS * 64));
+  [[maybe_unused]] volatile fmx_lds_u32 *const ring_tag = FMX_LDS_U32(wc_tag + (threadIdx.x >> 6) * FMXW_WC_SLOTS);
   [[maybe_unused]] uint32_t rs0 = 0, rs1 = 1, rseq = 2;
   if (WC) {
 #pragma unroll

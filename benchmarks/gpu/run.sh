@@ -9,6 +9,7 @@
 #   rocprof         profiles/run_rocprof.sh <round> (kernel-trace --stats of the bench command)
 #   soak <seconds> [seed] [lib|shipped] [long]   tests/fuzz_gpu_vs_oracle.py (optionally on another libfmx*.so; `long` =
 #                        the long-interval batches: lane-per-walk kernels, per-ticket dispatch, every select branch)
+#   mix [args]      benchmarks/gpu/locate_mix.py (DNA and RLFM): shipped library, then the measurement build on each path
 #   py <script> [args]   any python script under benchmarks/
 R=$1; T=$2; shift 2
 O=gpurun_out/$R; mkdir -p $O
@@ -28,6 +29,15 @@ soak)
   TAG=${LIB:-shipped}${MODE:+_long}_seed$SEED
   ( [ -n "$LIB" ] && [ "$LIB" != shipped ] && export FMX_LIB=$PWD/fm_index_amd/$LIB; timeout $((SEC + 600)) python3 tests/fuzz_gpu_vs_oracle.py $SEC $SEED ${MODE:+--long} ) > $O/soak_$TAG.txt 2>&1
   echo "rc $?"; tail -n 4 $O/soak_$TAG.txt ;;
+mix)
+  # locate on mixed batches: shipped library, then the measurement build forced onto each path
+  M=$PWD/fm_index_amd/libfmx_measure.so
+  for K in dna rlfm; do
+    timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
+    FMX_LIB=$M FMX_VARIANT=28 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
+    FMX_LIB=$M FMX_ADJ_CLUSTERS=0 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
+    FMX_LIB=$M FMX_ADJ_CLUSTERS=65 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
+  done | tee $O/locate_mix.jsonl ;;
 py)
   S=$1; shift; timeout 1500 python3 $S "$@" 2>&1 | tee $O/$(basename $S .py).txt | tail -n 40 ;;
 *) echo "unknown task $T"; exit 2 ;;

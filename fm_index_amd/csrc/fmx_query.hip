@@ -1925,15 +1925,27 @@ __device__ __forceinline__ uint64_t fmx_walk_lane_get_sa(const uint4 *__restrict
     const uint4 *R = walk + (size_t)wr * 8u;
     const uint32_t pi = off >> 4, bit = off & 15u;
     FMX_TOUCH(&R[pi]);
+    // the row's piece and the pieces in front of it, all requested at once (round 5: a loop that fetched them one after
+    // the other put up to seven dependent round trips into every record visit; the kernel waits for memory 80 % of its
+    // wave cycles -- profiles/r05/kernel_pmc_*.json)
+    uint4 front[6];
+#pragma unroll
+    for (uint32_t q = 0; q < 6u; q++) {
+      front[q] = make_uint4(0u, 0u, 0u, 0u);
+      if (q < pi) { FMX_TOUCH(&R[q]); front[q] = R[q]; }
+    }
     const uint4 own = R[pi];
     const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
     const uint32_t ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
     if (walk_steps == 0xFFFFFFFFu) walk_steps = ph;             // the walk is exactly SA[row] mod 2^level steps long
     const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
+    // rows before `row` in the record: the whole pieces in front of its own (loaded together with it, see below), then
+    // its own up to the row
     uint32_t cnt = 0;
-    for (uint32_t q = 0; q <= pi; q++) {                        // rows before `row` in the record: whole pieces, then its own
-      uint4 p = own;
-      if (q != pi) { FMX_TOUCH(&R[q]); p = R[q]; }
+#pragma unroll
+    for (uint32_t q = 0; q < 7u; q++) {
+      if (q > pi) continue;
+      const uint4 p = q == pi ? own : front[q];
       const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
       const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
       const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes

@@ -38,6 +38,11 @@ mix)
     FMX_LIB=$M FMX_ADJ_CLUSTERS=0 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
     FMX_LIB=$M FMX_ADJ_CLUSTERS=65 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
   done | tee $O/locate_mix.jsonl ;;
+rlusweep)
+  M=$PWD/fm_index_amd/libfmx_measure.so
+  for SL in 2048 4096 16384; do for TH in 256 512 1024; do
+    echo "slice $SL threads $TH"; FMX_LIB=$M FMX_RLU_SLICE=$SL FMX_RLU_THREADS=$TH timeout 600 python3 benchmarks/gpu/locate_mix.py --kind rlfm "$@" 2>&1 | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:(d[k]['ms']) for k in ('pure_singletons','pure_long','mixed','mixed_low_average')})"
+  done; done | tee $O/rlu_sweep.txt ;;
 py)
   S=$1; shift; timeout 1500 python3 $S "$@" 2>&1 | tee $O/$(basename $S .py).txt | tail -n 40 ;;
 *) echo "unknown task $T"; exit 2 ;;

@@ -733,7 +733,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 // then one ds_read instead of two ds_bpermutes.
 // TL (round 5): the tickets of the slice this queue hands out are listed in `tlist` (nlist entries, LDS) -- the unified DNA
 // walk kernel serves the other tickets of its slice another way -- and a draw maps its ticket number through that list.
-template <bool LWIN = false, bool TL = false>
+// SKIPADJ (round 5, RLFM): tickets whose rows form at most `adj_clusters` runs of consecutive rows were walked by the
+// lane-per-walk kernel that ran before this one (fmx_locate_rl_lane_kernel<.., true>, the same test on the same rows): a
+// draw that meets one draws again.
+// runs of consecutive rows in a ticket, minus one: the lanes (of the `in` ones) whose row is not its left neighbour's + 1
+__device__ __forceinline__ uint32_t fmx_ticket_breaks(uint32_t r, bool in, uint32_t lane) {
+  const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
+  return (uint32_t)__popcll(__ballot(in && lane != 0u && r != prev + 1u));
+}
+template <bool LWIN = false, bool TL = false, bool SKIPADJ = false>
 struct FmxHitQueue {
   const uint32_t *rows;   // rows of this block's slice
   uint64_t lo;            // first hit of the slice (index into out_pos)
@@ -749,6 +757,17 @@ struct FmxHitQueue {
   uint32_t used;          // hits already handed out of c0|c1
   const uint16_t *tlist = nullptr;   // [TL]
   uint32_t nlist = 0;
+  uint32_t adj_clusters = 0;         // [SKIPADJ]
+  // a ticket and its rows (`win`: one per lane); SKIPADJ: the next ticket that is not one of adjacent rows
+  __device__ __forceinline__ uint32_t draw_win(unsigned int &counter, uint32_t &win) const {
+    for (;;) {
+      const uint32_t c = valid(draw(counter, 1u));
+      win = load_win(c);
+      if (!SKIPADJ || c == FMX_NOCHUNK) return c;
+      const uint32_t x = c * chunk + lane;
+      if (fmx_ticket_breaks(win, lane < chunk && x < nhits, lane) >= adj_clusters) return c;
+    }
+  }
   __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
     const uint32_t x = c * chunk + lane;
     return (c != FMX_NOCHUNK && lane < chunk && x < nhits) ? rows[x] : 0u;   // every slot was written by fmx_expand_kernel
@@ -769,11 +788,12 @@ struct FmxHitQueue {
     lwin = lds_win; w0 = 0; win0 = 0; win1 = 0;
     // every wave of the block draws its FIRST ticket before any draws a second one (called by all
     // threads of the block at kernel start): with fewer tickets than 2 x waves, no wave goes without
-    c0 = valid(draw(counter, 1u));
-    if (LWIN) lwin[lane] = load_win(c0); else win0 = load_win(c0);
+    uint32_t wn;
+    c0 = draw_win(counter, wn);
+    if (LWIN) lwin[lane] = wn; else win0 = wn;
     __syncthreads();
-    c1 = valid(draw(counter, 1u));
-    if (LWIN) lwin[64u + lane] = load_win(c1); else win1 = load_win(c1);
+    c1 = draw_win(counter, wn);
+    if (LWIN) lwin[64u + lane] = wn; else win1 = wn;
     used = 0;
   }
   // the hit with index `used + rank` (< 2 * chunk): returns false when the slice has run dry
@@ -812,13 +832,14 @@ struct FmxHitQueue {
     if (used >= chunk) {                             // wave-uniform: slide
       used -= chunk;
       c0 = c1;
-      c1 = c1 != FMX_NOCHUNK ? valid(draw(counter, 1u)) : FMX_NOCHUNK;
+      uint32_t wn = 0u;
+      c1 = c1 != FMX_NOCHUNK ? draw_win(counter, wn) : FMX_NOCHUNK;
       if (LWIN) {
-        lwin[(w0 << 6) + lane] = load_win(c1);       // the half the old c0 occupied
+        lwin[(w0 << 6) + lane] = wn;                 // the half the old c0 occupied
         w0 ^= 1u;
       } else {
         win0 = win1;
-        win1 = load_win(c1);
+        win1 = wn;
       }
       return true;
     }
@@ -1319,9 +1340,9 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // cooperative rank rounds are not run at all.
 // The walk over the block's slice [blo, blo + bn) of the hits (rows = the rows of the slice), called by all threads of the
 // block; TL: only the tickets listed in tlist[0 .. nlist) (the per-ticket RLFM kernel, round 5).
-template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR, bool TL>
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR, bool SKIPADJ>
 __device__ __forceinline__ void fmx_ep_walk(
-    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, const uint16_t *tlist, uint32_t nlist,
+    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, uint32_t adj_clusters,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
   __shared__ unsigned int lds_q;
@@ -1338,9 +1359,8 @@ __device__ __forceinline__ void fmx_ep_walk(
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no position (n < 2^32 - 16)
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of the block (scalar)
-  FmxHitQueue<true, TL> hq;
-  hq.tlist = tlist;
-  hq.nlist = nlist;
+  FmxHitQueue<true, false, SKIPADJ> hq;
+  hq.adj_clusters = adj_clusters;
   hq.init(rows, blo, bn, FMX_LCHUNK, lane, lds_q, FMX_LDS_U32(hq_win + wv * 128u));
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   // write-combining ring of this wave (see fmx_locate_f3p_kernel): slot r holds ticket ring_tag[r]
@@ -1489,7 +1509,19 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
   const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, nullptr, 0u, out_pos, steps_out);
+  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, 0u, out_pos, steps_out);
+}
+// RLFM with the run table, second launch of a batch that may hold tickets of adjacent rows (round 5): the lane-per-walk
+// kernel has walked those and counted the others in *nscat -- none: nothing to do; else the queue skips the adjacent ones
+template <int SM, bool TEXT>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_rest_kernel(
+    FmxDev ix, uint64_t total, uint32_t hits_per_block, uint32_t adj_clusters, const uint32_t *__restrict__ rows,
+    const unsigned int *__restrict__ nscat, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  if (*nscat == 0u) return;                           // grid-uniform
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, adj_clusters, out_pos, steps_out);
 }
 
 // counts -> exclusive offsets (single block scan is enough off the hot path? no:
@@ -2202,63 +2234,29 @@ __device__ __forceinline__ uint64_t fmx_rlfm_lane_get_sa(const FmxDev &ix, uint3
   nsteps += steps;
   return v;
 }
-template <bool TEXT>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total,
+// SKIP (round 5): the walk is chosen per 64-hit TICKET -- a ticket whose rows form more than `adj_clusters` runs of
+// consecutive rows is left to fmx_locate_ep_rest_kernel (refilling lanes, hit queue, write-combining ring), which runs next
+// and makes the same test on the same rows; *nscat counts them (zeroed by the launcher).  Until round 4 the batch AVERAGE of
+// hits per pattern chose one kernel for every hit.  Any classification gives the reference's positions.
+template <bool TEXT, bool SKIP>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total, uint32_t adj_clusters,
                                                                         const uint32_t *__restrict__ rows,
+                                                                        unsigned int *__restrict__ nscat,
                                                                         uint64_t *__restrict__ out_pos,
                                                                         uint64_t *__restrict__ steps_out) {
   const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t lane = threadIdx.x & 63u;
   uint64_t nsteps = 0;
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth)
-    out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[h], nsteps);
+  uint32_t left = 0;
+  // (every lane of a wave makes the same number of trips: h - lane is the wave's ticket)
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h - lane < total; h += nth) {
+    const bool in = h < total;
+    const uint32_t row = in ? rows[h] : 0u;
+    if (SKIP && fmx_ticket_breaks(row, in, lane) >= adj_clusters) { left++; continue; }   // wave-uniform
+    if (in) out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, row, nsteps);
+  }
+  if (SKIP && left && lane == 0) atomicAdd(nscat, left);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-}
-
-// ---- RLFM with the run table: the walk chosen per 64-hit TICKET (round 5) ----------------------------------------------
-// The rule of fmx_locate_f3u_kernel on the run-length index: a block owns a slice of <= FMX_RLU_SLICE hits (their rows
-// come from fmx_expand_kernel), classifies its tickets by the adjacency of their rows -- at most `adj_clusters` runs of
-// consecutive rows -- and walks the adjacent ones a lane per hit on consecutive hits (phase A: the wave's 64 requests of
-// a step fall into a few lines, fmx_locate_rl_lane_kernel's finding) and the others with refilling lanes through the
-// block's hit queue and the write-combining ring (phase B: fmx_ep_walk<..., LFR>).  Until round 4 the batch AVERAGE of
-// hits per pattern chose one of the two for every hit.  Any classification gives the reference's positions.
-#define FMX_RLU_SLICE 16384u
-template <bool TEXT, int SM>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_rl_u_kernel(
-    FmxDev ix, uint64_t total, uint32_t hits_per_block, uint32_t adj_clusters, const uint32_t *__restrict__ rows,
-    uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  __shared__ uint16_t u_tlist[FMX_RLU_SLICE / 64];
-  __shared__ uint16_t u_alist[FMX_RLU_SLICE / 64];
-  __shared__ unsigned int u_ntl, u_nal;
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, nwv = blockDim.x >> 6;   // (640- or 1024-thread blocks)
-  FMX_CHECK(hits_per_block <= FMX_RLU_SLICE);
-  if (tid == 0) { u_ntl = 0; u_nal = 0; }
-  __syncthreads();
-  const uint32_t ntick = (bn + FMX_LCHUNK - 1u) / FMX_LCHUNK;
-  for (uint32_t t = wv; t < ntick; t += nwv) {
-    const uint32_t x = t * FMX_LCHUNK + lane;
-    const bool in = x < bn;
-    const uint32_t r = in ? rows[blo + x] : 0u;
-    const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
-    const unsigned long long brk = __ballot(in && lane != 0u && r != prev + 1u);
-    if (lane == 0) {
-      if ((uint32_t)__popcll(brk) < adj_clusters) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
-      else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
-    }
-  }
-  __syncthreads();
-  const uint32_t nal = u_nal, ntl = u_ntl;
-  if (nal) {                                          // block-uniform: a lane per walk on the tickets of adjacent rows
-    uint64_t nsteps = 0;
-    for (uint32_t i = wv; i < nal; i += nwv) {
-      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
-      if (x < bn) out_pos[blo + x] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[blo + x], nsteps);
-    }
-    if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
-  }
-  if (ntl) fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, u_tlist, ntl, out_pos, steps_out);
 }
 
 // ---- locate launch helpers (c = FmxLocateCall) ----
@@ -2383,8 +2381,8 @@ uint64_t fmx_offsets_tile_bytes(uint64_t npat) {
   if (ntiles == 0) ntiles = 1;
   return ((ntiles + 1) * sizeof(uint64_t) + 255u) & ~(uint64_t)255u;
 }
-uint64_t fmx_locate_rows_bytes(uint64_t total) {
-  return ((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u;
+uint64_t fmx_locate_rows_bytes(uint64_t total) {    // the rows, and 256 bytes behind them for a launch's device-side counter
+  return (((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u) + 256u;
 }
 
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
@@ -2418,7 +2416,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   // workspace when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
   uint32_t *rows = unified ? nullptr : rows_ws;
   const bool own_rows = !unified && !rows_ws;
-  if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, total * sizeof(uint32_t), st));
+  if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, fmx_locate_rows_bytes(total), st));
   if (!unified) {
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
@@ -2528,25 +2526,30 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
-      else if (dv.lfrun && tn.walk_records && tn.wc && tn.unified) {
-        // the run table: two lane-wise requests per LF step, the walk chosen per ticket (fmx_locate_rl_u_kernel)
-        uint64_t ub = (total + FMX_RLU_SLICE - 1) / FMX_RLU_SLICE;
-        if (ub < (big ? 512u : 256u)) ub = big ? 512u : 256u;
-        uint32_t uh;
-        unsigned ug;
-        c.slice(ub, FMX_LCHUNK, uh, ug);
-#define FMX_RLU_LAUNCH(TX, SMV)                                                                      \
-        hipLaunchKernelGGL((fmx_locate_rl_u_kernel<TX, SMV>), dim3(ug), dim3(thr), 0, c.st, c.dv, c.total, uh,             \
-                           (uint32_t)tn.adj_clusters, c.rows, c.pos, c.steps)
-        if (dv.phase) { if (sm == 1) FMX_RLU_LAUNCH(true, 1); else FMX_RLU_LAUNCH(true, 2); }
-        else { if (sm == 1) FMX_RLU_LAUNCH(false, 1); else FMX_RLU_LAUNCH(false, 2); }
+      else if (dv.lfrun && tn.walk_records && tn.wc && tn.unified && total / npat >= 2 && tn.adj_clusters > 0 && !tn.alt) {
+        // the run table, a batch that may hold long intervals (two hits per pattern or more on average): the walk is
+        // chosen per ticket -- the lane-per-walk kernel takes the tickets of adjacent rows and counts the others, which
+        // the queue kernel then walks (it returns at once when there is none).  Batches of about one hit per pattern
+        // go straight to the queue kernel below: the scan for adjacent tickets would cost them ~10 us for nothing.
+        uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
+        if (lb > 8192) lb = 8192;
+        unsigned int *nscat = (unsigned int *)((uint8_t *)rows + fmx_locate_rows_bytes(total) - 256u);
+        FMX_HIP(hipMemsetAsync(nscat, 0, sizeof(unsigned int), c.st));
+        const uint32_t adj = (uint32_t)tn.adj_clusters;
+        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, nscat, c.pos, c.steps);
+        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, nscat, c.pos, c.steps);
+#define FMX_EPREST_LAUNCH(SMV, TX)                                                                   \
+        hipLaunchKernelGGL((fmx_locate_ep_rest_kernel<SMV, TX>), dim3(gr), dim3(thr), 0, c.st, c.dv, c.total, hpb, adj, c.rows, \
+                           nscat, c.pos, c.steps)
+        if (dv.phase) { if (sm == 1) FMX_EPREST_LAUNCH(1, true); else FMX_EPREST_LAUNCH(2, true); }
+        else { if (sm == 1) FMX_EPREST_LAUNCH(1, false); else FMX_EPREST_LAUNCH(2, false); }
       }
-      else if (dv.lfrun && tn.walk_records && tn.wc && total / npat >= 64 && !tn.alt) {
+      else if (dv.lfrun && tn.walk_records && tn.wc && !tn.unified && total / npat >= 64 && !tn.alt) {
         // (measurement builds, FMX_VARIANT=28: the round-4 choice by the batch average) long intervals: a lane per walk
         uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
         if (lb > 8192) lb = 8192;
-        if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
-        else hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<false>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, c.pos, c.steps);
+        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, c.pos, c.steps);
       }
       else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
         if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);

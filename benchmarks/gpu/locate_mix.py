@@ -42,6 +42,9 @@ def main():
     if a.kind == "dna":
         text = W.dna_text_torch(n, 1, dev)
         idx = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=2)
+    elif a.kind == "rlfm-random":       # config 4's text (about one run per row) with FMX_FLAG_RUN_TABLE
+        text = W.byte_text_torch(n, 4, dev)
+        idx = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), n, 255, level=2, run_table=True)
     else:
         text = W.repetitive_text_torch(n, 5, dev, base_len=1 << 20, mut_per_1024=10)
         idx = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), n, 255, level=2)

@@ -32,7 +32,7 @@ soak)
 mix)
   # locate on mixed batches: shipped library, then the measurement build forced onto each path
   M=$PWD/fm_index_amd/libfmx_measure.so
-  for K in dna rlfm; do
+  for K in ${MIX_KINDS:-dna rlfm rlfm-random}; do
     timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
     FMX_LIB=$M FMX_VARIANT=28 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1
     FMX_LIB=$M FMX_ADJ_CLUSTERS=0 timeout 600 python3 benchmarks/gpu/locate_mix.py --kind $K "$@" 2>&1 | tail -n 1

@@ -733,9 +733,10 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 // then one ds_read instead of two ds_bpermutes.
 // TL (round 5): the tickets of the slice this queue hands out are listed in `tlist` (nlist entries, LDS) -- the unified DNA
 // walk kernel serves the other tickets of its slice another way -- and a draw maps its ticket number through that list.
-// SKIPADJ (round 5, RLFM): tickets whose rows form at most `adj_clusters` runs of consecutive rows were walked by the
-// lane-per-walk kernel that ran before this one (fmx_locate_rl_lane_kernel<.., true>, the same test on the same rows): a
-// draw that meets one draws again.
+// SKIPADJ (round 5, RLFM): the lane-per-walk kernel that ran before this one (fmx_locate_rl_lane_kernel<.., true>) has
+// walked the tickets of adjacent rows and left a byte per ticket in `flags` -- 1: still to walk.  A draw that meets a 0
+// draws again (one cached byte per skipped ticket; reading the ticket's 64 rows to repeat the test was a dependent
+// round trip to memory per skip: 1 ms for the 1.5 M tickets of a 10^8-hit batch).
 // runs of consecutive rows in a ticket, minus one: the lanes (of the `in` ones) whose row is not its left neighbour's + 1
 __device__ __forceinline__ uint32_t fmx_ticket_breaks(uint32_t r, bool in, uint32_t lane) {
   const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
@@ -757,16 +758,16 @@ struct FmxHitQueue {
   uint32_t used;          // hits already handed out of c0|c1
   const uint16_t *tlist = nullptr;   // [TL]
   uint32_t nlist = 0;
-  uint32_t adj_clusters = 0;         // [SKIPADJ]
-  // a ticket and its rows (`win`: one per lane); SKIPADJ: the next ticket that is not one of adjacent rows
+  const uint8_t *flags = nullptr;    // [SKIPADJ] one byte per ticket of the slice
+  // a ticket and its rows (`win`: one per lane); SKIPADJ: the next ticket that is still to walk
   __device__ __forceinline__ uint32_t draw_win(unsigned int &counter, uint32_t &win) const {
+    uint32_t c;
     for (;;) {
-      const uint32_t c = valid(draw(counter, 1u));
-      win = load_win(c);
-      if (!SKIPADJ || c == FMX_NOCHUNK) return c;
-      const uint32_t x = c * chunk + lane;
-      if (fmx_ticket_breaks(win, lane < chunk && x < nhits, lane) >= adj_clusters) return c;
+      c = valid(draw(counter, 1u));
+      if (!SKIPADJ || c == FMX_NOCHUNK || flags[c] != 0) break;
     }
+    win = load_win(c);
+    return c;
   }
   __device__ __forceinline__ uint32_t load_win(uint32_t c) const {
     const uint32_t x = c * chunk + lane;
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // block; TL: only the tickets listed in tlist[0 .. nlist) (the per-ticket RLFM kernel, round 5).
 template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR, bool SKIPADJ>
 __device__ __forceinline__ void fmx_ep_walk(
-    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, uint32_t adj_clusters,
+    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, const uint8_t *flags,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
   __shared__ unsigned int lds_q;
@@ -1360,7 +1361,7 @@ __device__ __forceinline__ void fmx_ep_walk(
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no position (n < 2^32 - 16)
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of the block (scalar)
   FmxHitQueue<true, false, SKIPADJ> hq;
-  hq.adj_clusters = adj_clusters;
+  hq.flags = flags;
   hq.init(rows, blo, bn, FMX_LCHUNK, lane, lds_q, FMX_LDS_U32(hq_win + wv * 128u));
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   // write-combining ring of this wave (see fmx_locate_f3p_kernel): slot r holds ticket ring_tag[r]
@@ -1509,19 +1510,20 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
   const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, 0u, out_pos, steps_out);
+  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, nullptr, out_pos, steps_out);
 }
 // RLFM with the run table, second launch of a batch that may hold tickets of adjacent rows (round 5): the lane-per-walk
-// kernel has walked those and counted the others in *nscat -- none: nothing to do; else the queue skips the adjacent ones
+// kernel has walked those, flagged the others (flags[ticket] = 1) and counted them in *nscat -- none: nothing to do
 template <int SM, bool TEXT>
 __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_rest_kernel(
-    FmxDev ix, uint64_t total, uint32_t hits_per_block, uint32_t adj_clusters, const uint32_t *__restrict__ rows,
+    FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows, const uint8_t *__restrict__ flags,
     const unsigned int *__restrict__ nscat, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   if (*nscat == 0u) return;                           // grid-uniform
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;   // (a multiple of the ticket size)
   if (blo >= total) return;                           // block-uniform
   const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, adj_clusters, out_pos, steps_out);
+  fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, flags + blo / FMX_LCHUNK, out_pos,
+                                                                   steps_out);
 }
 
 // counts -> exclusive offsets (single block scan is enough off the hot path? no:
@@ -1813,6 +1815,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_compute_K_kernel(FmxMwm w, cons
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+static inline uint64_t fmx_locate_flag_bytes(uint64_t total);
 static void fmx_time_begin(const fmx_index *idx, hipStream_t st) {
   fmx_index *m = const_cast<fmx_index *>(idx);
   if (idx->timing == 1) {
@@ -2241,6 +2244,7 @@ __device__ __forceinline__ uint64_t fmx_rlfm_lane_get_sa(const FmxDev &ix, uint3
 template <bool TEXT, bool SKIP>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total, uint32_t adj_clusters,
                                                                         const uint32_t *__restrict__ rows,
+                                                                        uint8_t *__restrict__ flags,
                                                                         unsigned int *__restrict__ nscat,
                                                                         uint64_t *__restrict__ out_pos,
                                                                         uint64_t *__restrict__ steps_out) {
@@ -2248,11 +2252,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t nsteps = 0;
   uint32_t left = 0;
-  // (every lane of a wave makes the same number of trips: h - lane is the wave's ticket)
+  // (every lane of a wave makes the same number of trips: h - lane is the first hit of the wave's ticket)
   for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h - lane < total; h += nth) {
     const bool in = h < total;
     const uint32_t row = in ? rows[h] : 0u;
-    if (SKIP && fmx_ticket_breaks(row, in, lane) >= adj_clusters) { left++; continue; }   // wave-uniform
+    if (SKIP) {
+      const bool scattered = fmx_ticket_breaks(row, in, lane) >= adj_clusters;        // wave-uniform
+      if (lane == 0) flags[h >> 6] = scattered ? 1u : 0u;                              // every ticket's flag is written
+      if (scattered) { left++; continue; }
+    }
     if (in) out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, row, nsteps);
   }
   if (SKIP && left && lane == 0) atomicAdd(nscat, left);
@@ -2381,8 +2389,10 @@ uint64_t fmx_offsets_tile_bytes(uint64_t npat) {
   if (ntiles == 0) ntiles = 1;
   return ((ntiles + 1) * sizeof(uint64_t) + 255u) & ~(uint64_t)255u;
 }
-uint64_t fmx_locate_rows_bytes(uint64_t total) {    // the rows, and 256 bytes behind them for a launch's device-side counter
-  return (((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u) + 256u;
+// the rows; behind them a byte per 64-hit ticket and 256 bytes for a launch's device-side counter (the per-ticket RLFM walk)
+static inline uint64_t fmx_locate_flag_bytes(uint64_t total) { return ((total >> 6) + 1u + 255u) & ~(uint64_t)255u; }
+uint64_t fmx_locate_rows_bytes(uint64_t total) {
+  return (((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u) + fmx_locate_flag_bytes(total) + 256u;
 }
 
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
@@ -2533,14 +2543,16 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
         // go straight to the queue kernel below: the scan for adjacent tickets would cost them ~10 us for nothing.
         uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
         if (lb > 8192) lb = 8192;
-        unsigned int *nscat = (unsigned int *)((uint8_t *)rows + fmx_locate_rows_bytes(total) - 256u);
+        uint8_t *const ws_end = (uint8_t *)rows + fmx_locate_rows_bytes(total);
+        unsigned int *nscat = (unsigned int *)(ws_end - 256u);
+        uint8_t *flags = ws_end - 256u - fmx_locate_flag_bytes(total);
         FMX_HIP(hipMemsetAsync(nscat, 0, sizeof(unsigned int), c.st));
         const uint32_t adj = (uint32_t)tn.adj_clusters;
-        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, nscat, c.pos, c.steps);
-        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, nscat, c.pos, c.steps);
+        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, flags, nscat, c.pos, c.steps);
+        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, flags, nscat, c.pos, c.steps);
 #define FMX_EPREST_LAUNCH(SMV, TX)                                                                   \
-        hipLaunchKernelGGL((fmx_locate_ep_rest_kernel<SMV, TX>), dim3(gr), dim3(thr), 0, c.st, c.dv, c.total, hpb, adj, c.rows, \
-                           nscat, c.pos, c.steps)
+        hipLaunchKernelGGL((fmx_locate_ep_rest_kernel<SMV, TX>), dim3(gr), dim3(thr), 0, c.st, c.dv, c.total, hpb, c.rows,  \
+                           flags, nscat, c.pos, c.steps)
         if (dv.phase) { if (sm == 1) FMX_EPREST_LAUNCH(1, true); else FMX_EPREST_LAUNCH(2, true); }
         else { if (sm == 1) FMX_EPREST_LAUNCH(1, false); else FMX_EPREST_LAUNCH(2, false); }
       }
@@ -2548,8 +2560,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
         // (measurement builds, FMX_VARIANT=28: the round-4 choice by the batch average) long intervals: a lane per walk
         uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
         if (lb > 8192) lb = 8192;
-        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, c.pos, c.steps);
-        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, c.pos, c.steps);
+        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, nullptr, c.pos, c.steps);
+        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, nullptr, c.pos, c.steps);
       }
       else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
         if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);

@@ -193,7 +193,7 @@ def test_workspace_form_and_two_streams_share_nothing():
 
 
 @pytest.mark.parametrize("sampling,level", [(None, 2), ("row", 2), (None, 3), ("row", 0)])
-@pytest.mark.parametrize("singles,longs,long_len", [(60000, 60, 6000), (100000, 0, 0), (0, 5, 70000), (150000, 3, 90000)])
+@pytest.mark.parametrize("singles,longs,long_len", [(60000, 60, 6000), (100000, 0, 0), (0, 8, 70000), (150000, 3, 90000)])
 def test_rlfm_run_table_walk_is_chosen_per_ticket(sampling, level, singles, longs, long_len):
     """RLFM with the run table (round 5): batches of 2^18+ hits that average two or more hits per pattern take two
     launches -- fmx_locate_rl_lane_kernel<.., true> walks the tickets of adjacent rows a lane per hit and counts the others,

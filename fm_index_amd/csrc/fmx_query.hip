@@ -733,16 +733,12 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_kernel(
 // then one ds_read instead of two ds_bpermutes.
 // TL (round 5): the tickets of the slice this queue hands out are listed in `tlist` (nlist entries, LDS) -- the unified DNA
 // walk kernel serves the other tickets of its slice another way -- and a draw maps its ticket number through that list.
-// SKIPADJ (round 5, RLFM): the lane-per-walk kernel that ran before this one (fmx_locate_rl_lane_kernel<.., true>) has
-// walked the tickets of adjacent rows and left a byte per ticket in `flags` -- 1: still to walk.  A draw that meets a 0
-// draws again (one cached byte per skipped ticket; reading the ticket's 64 rows to repeat the test was a dependent
-// round trip to memory per skip: 1 ms for the 1.5 M tickets of a 10^8-hit batch).
 // runs of consecutive rows in a ticket, minus one: the lanes (of the `in` ones) whose row is not its left neighbour's + 1
 __device__ __forceinline__ uint32_t fmx_ticket_breaks(uint32_t r, bool in, uint32_t lane) {
   const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
   return (uint32_t)__popcll(__ballot(in && lane != 0u && r != prev + 1u));
 }
-template <bool LWIN = false, bool TL = false, bool SKIPADJ = false>
+template <bool LWIN = false, bool TL = false>
 struct FmxHitQueue {
   const uint32_t *rows;   // rows of this block's slice
   uint64_t lo;            // first hit of the slice (index into out_pos)
@@ -758,14 +754,9 @@ struct FmxHitQueue {
   uint32_t used;          // hits already handed out of c0|c1
   const uint16_t *tlist = nullptr;   // [TL]
   uint32_t nlist = 0;
-  const uint8_t *flags = nullptr;    // [SKIPADJ] one byte per ticket of the slice
-  // a ticket and its rows (`win`: one per lane); SKIPADJ: the next ticket that is still to walk
+  // a ticket and its rows (`win`: one per lane)
   __device__ __forceinline__ uint32_t draw_win(unsigned int &counter, uint32_t &win) const {
-    uint32_t c;
-    for (;;) {
-      c = valid(draw(counter, 1u));
-      if (!SKIPADJ || c == FMX_NOCHUNK || flags[c] != 0) break;
-    }
+    const uint32_t c = valid(draw(counter, 1u));
     win = load_win(c);
     return c;
   }
@@ -1339,11 +1330,10 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // for 8.4 MB of positions).
 // LFR (RLFM with the run table FmxDev::lfrun, round 4): an LF step is two lane-wise requests (fmx_rlfm_ep_lf_run) and the
 // cooperative rank rounds are not run at all.
-// The walk over the block's slice [blo, blo + bn) of the hits (rows = the rows of the slice), called by all threads of the
-// block; TL: only the tickets listed in tlist[0 .. nlist) (the per-ticket RLFM kernel, round 5).
-template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR, bool SKIPADJ>
+// The walk over the block's slice [blo, blo + bn) of the hits (rows = the rows of the slice), called by all threads of the block
+template <int KIND, int NL, int SM, bool KLDS, bool TEXT, bool WC, bool LFR>
 __device__ __forceinline__ void fmx_ep_walk(
-    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn, const uint8_t *flags,
+    const FmxDev &ix, const uint32_t *__restrict__ rows, uint64_t blo, uint32_t bn,
     uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
   __shared__ uint32_t kt_lds[KLDS ? 1024 : 1];
   __shared__ unsigned int lds_q;
@@ -1360,8 +1350,7 @@ __device__ __forceinline__ void fmx_ep_walk(
   const uint32_t lmask = (1u << ix.sa_level) - 1u;
   constexpr uint32_t NONE = 0xFFFFFFFFu;              // no position (n < 2^32 - 16)
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of the block (scalar)
-  FmxHitQueue<true, false, SKIPADJ> hq;
-  hq.flags = flags;
+  FmxHitQueue<true> hq;
   hq.init(rows, blo, bn, FMX_LCHUNK, lane, lds_q, FMX_LDS_U32(hq_win + wv * 128u));
   uint64_t *const out = out_pos + blo;                // the block's slice of the output (wave-uniform)
   // write-combining ring of this wave (see fmx_locate_f3p_kernel): slot r holds ticket ring_tag[r]
@@ -1510,22 +1499,8 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
   const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR, false>(ix, rows + blo, blo, bn, nullptr, out_pos, steps_out);
+  fmx_ep_walk<KIND, NL, SM, KLDS, TEXT, WC, LFR>(ix, rows + blo, blo, bn, out_pos, steps_out);
 }
-// RLFM with the run table, second launch of a batch that may hold tickets of adjacent rows (round 5): the lane-per-walk
-// kernel has walked those, flagged the others (flags[ticket] = 1) and counted them in *nscat -- none: nothing to do
-template <int SM, bool TEXT>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void fmx_locate_ep_rest_kernel(
-    FmxDev ix, uint64_t total, uint32_t hits_per_block, const uint32_t *__restrict__ rows, const uint8_t *__restrict__ flags,
-    const unsigned int *__restrict__ nscat, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
-  if (*nscat == 0u) return;                           // grid-uniform
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;   // (a multiple of the ticket size)
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
-  fmx_ep_walk<FMX_KIND_RLFM, 1, SM, false, TEXT, true, true, true>(ix, rows + blo, blo, bn, flags + blo / FMX_LCHUNK, out_pos,
-                                                                   steps_out);
-}
-
 // counts -> exclusive offsets (single block scan is enough off the hot path? no:
 // npat can be 2^23, so do a 3-phase scan with one block per 2048-element tile)
 #define FMX_SCAN_TILE 2048
@@ -1815,7 +1790,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_compute_K_kernel(FmxMwm w, cons
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-static inline uint64_t fmx_locate_flag_bytes(uint64_t total);
+
 static void fmx_time_begin(const fmx_index *idx, hipStream_t st) {
   fmx_index *m = const_cast<fmx_index *>(idx);
   if (idx->timing == 1) {
@@ -1860,6 +1835,7 @@ struct FmxTune {
                                  // round-4 pair expand + f3t / lane kernel chosen from the batch average
   long adj_clusters = 4;         // ... a ticket of at most this many runs of consecutive rows is walked a lane per hit
   long rl_ep_min = 1l << 18;     // RLFM: one walk per lane from this many hits
+  long rl_lane_avg = 2;          // ... with the run table: a lane per walk on consecutive hits from this many hits per pattern
   long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
 };
 // everything a count / locate launch needs, for the launch helpers below and in fmx_measure.inc
@@ -2128,9 +2104,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     const bool in = lane < chunk && x < bn;
     uint32_t r = in ? u_rows[x] : 0u;
     if (in && r == FMX_U_NOROW) { bad = true; r = 0u; u_rows[x] = 0u; }
-    const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
-    const unsigned long long brk = __ballot(in && lane != 0u && r != prev + 1u);
-    const bool adjacent = chunk == FMX_LCHUNK && (uint32_t)__popcll(brk) < adj_clusters;
+    const bool adjacent = chunk == FMX_LCHUNK && fmx_ticket_breaks(r, in, lane) < adj_clusters;
     if (lane == 0) {
       if (adjacent) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
       else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
@@ -2208,62 +2182,100 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lane_lf(const FmxDev &ix, uint32_t 
   else st = fmx_bits_lane_select(ix.b, lo);
   return f + row - st;
 }
-// get_sa(row) by ONE lane through the run table (rlfmi.rs:172-190): returns the text position, adds the LF steps
-template <bool TEXT>
-__device__ __forceinline__ uint64_t fmx_rlfm_lane_get_sa(const FmxDev &ix, uint32_t row, uint64_t &nsteps) {
-  uint32_t steps = 0, si;
-  FMX_CHECK(row < ix.n);                              // (fmx_expand_kernel wrote every slot with a row of this index)
-  if (TEXT) {                                         // SA[row] mod 2^level steps; phase probes at both ends
-    uint32_t t;
-    uint32_t pi = fmx_phase_piece(row, ix.sa_level, t);
-    FMX_TOUCH(&ix.phase[pi]);
-    steps = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
-    for (uint32_t k = 0; k < steps; k++) row = fmx_rlfm_lane_lf(ix, row);
-    if (steps) {
-      pi = fmx_phase_piece(row, ix.sa_level, t);
-      FMX_TOUCH(&ix.phase[pi]);
-      [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
-      FMX_CHECK(p2 == 0u);
-    }
-  } else {                                            // the reference's rows (sample.rs:46-60)
-    const uint32_t lmask = (1u << ix.sa_level) - 1u;
-    while (row & lmask) { row = fmx_rlfm_lane_lf(ix, row); steps++; }
-    si = row >> ix.sa_level;
-  }
-  FMX_CHECK(si < ix.nsamples);
-  FMX_TOUCH(&ix.samples[si]);
-  uint64_t v = (uint64_t)ix.samples[si] + steps;      // (sa + steps) % len                      rlfmi.rs:178-182
-  if (v >= ix.n) v -= ix.n;
-  nsteps += steps;
-  return v;
+// TWO walks per lane, their requests issued together (round 5).  The kernel above it in the history -- one walk per lane --
+// spent 82 % of its wave cycles parked on s_waitcnt at full occupancy and moved 18 G requests/s of the 55 G/s the memory
+// system takes (profiles/r05/kernel_pmc_rep_rlfm_v1.json): what it lacked was requests in flight, and a lane has
+// registers for a second chain (19 -> ~40 VGPRs, still 8 waves per SIMD).  Lane l of a wave walks hits t + l and t + 64 + l
+// of two consecutive tickets: every stage (phase piece, B piece, run-table entry, final phase piece, sample) loads for
+// both walks before either result is used.
+struct FmxLane2 { uint32_t a, b; };
+// lf_map of two rows through the run table (fmx_rlfm_lane_lf, twice, the loads paired); a row whose flag is off passes through
+__device__ __forceinline__ FmxLane2 fmx_rlfm_lane_lf2(const FmxDev &ix, uint32_t rowa, uint32_t rowb, bool ona, bool onb) {
+  const uint32_t pa = fmx_div3(rowa >> 5), pb = fmx_div3(rowb >> 5);
+  FMX_CHECK((!ona || pa < ix.b.nrec * 8u) && (!onb || pb < ix.b.nrec * 8u));
+  uint4 ca = make_uint4(0u, 0u, 0u, 0u), cb = ca;
+  if (ona) { FMX_TOUCH(&ix.b.rec[pa]); ca = ix.b.rec[pa]; }
+  if (onb) { FMX_TOUCH(&ix.b.rec[pb]); cb = ix.b.rec[pb]; }
+  auto masks = [](const uint4 &pc, uint32_t b1, uint32_t &y, uint32_t &z, uint32_t &w) {
+    const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+    const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+    const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+    y = pc.y & m0; z = pc.z & m1; w = pc.w & m2;
+  };
+  uint32_t ya, za, wa, yb, zb, wb;
+  masks(ca, rowa - pa * FMX_BITS_PER_PIECE + 1u, ya, za, wa);
+  masks(cb, rowb - pb * FMX_BITS_PER_PIECE + 1u, yb, zb, wb);
+  const uint32_t la = ca.x + __popc(ya) + __popc(za) + __popc(wa) - 1u, lb = cb.x + __popc(yb) + __popc(zb) + __popc(wb) - 1u;
+  FMX_CHECK((!ona || la < ix.b.ones) && (!onb || lb < ix.b.ones));
+  uint32_t fa = 0, fb = 0;
+  if (ona) { FMX_TOUCH(&ix.lfrun[la]); fa = ix.lfrun[la]; }
+  if (onb) { FMX_TOUCH(&ix.lfrun[lb]); fb = ix.lfrun[lb]; }
+  auto start = [&](uint32_t pidx, uint32_t y, uint32_t z, uint32_t w, uint32_t lo) -> uint32_t {
+    if (w) return pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(w);
+    if (z) return pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
+    if (y) return pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
+    return fmx_bits_lane_select(ix.b, lo);              // the run began before the piece
+  };
+  FmxLane2 r{rowa, rowb};
+  if (ona) r.a = fa + rowa - start(pa, ya, za, wa, la);
+  if (onb) r.b = fb + rowb - start(pb, yb, zb, wb, lb);
+  return r;
 }
-// SKIP (round 5): the walk is chosen per 64-hit TICKET -- a ticket whose rows form more than `adj_clusters` runs of
-// consecutive rows is left to fmx_locate_ep_rest_kernel (refilling lanes, hit queue, write-combining ring), which runs next
-// and makes the same test on the same rows; *nscat counts them (zeroed by the launcher).  Until round 4 the batch AVERAGE of
-// hits per pattern chose one kernel for every hit.  Any classification gives the reference's positions.
-template <bool TEXT, bool SKIP>
-__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total, uint32_t adj_clusters,
+template <bool TEXT>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total,
                                                                         const uint32_t *__restrict__ rows,
-                                                                        uint8_t *__restrict__ flags,
-                                                                        unsigned int *__restrict__ nscat,
                                                                         uint64_t *__restrict__ out_pos,
                                                                         uint64_t *__restrict__ steps_out) {
-  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lmask = (1u << ix.sa_level) - 1u;
   uint64_t nsteps = 0;
-  uint32_t left = 0;
-  // (every lane of a wave makes the same number of trips: h - lane is the first hit of the wave's ticket)
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h - lane < total; h += nth) {
-    const bool in = h < total;
-    const uint32_t row = in ? rows[h] : 0u;
-    if (SKIP) {
-      const bool scattered = fmx_ticket_breaks(row, in, lane) >= adj_clusters;        // wave-uniform
-      if (lane == 0) flags[h >> 6] = scattered ? 1u : 0u;                              // every ticket's flag is written
-      if (scattered) { left++; continue; }
+  for (uint64_t t = wave * 128u; t < total; t += nwaves * 128u) {      // wave-uniform: two tickets per trip
+    const uint64_t ha = t + lane, hb = t + 64u + lane;
+    const bool ina = ha < total, inb = hb < total;
+    uint32_t rowa = ina ? rows[ha] : 0u, rowb = inb ? rows[hb] : 0u;
+    FMX_CHECK(rowa < ix.n && rowb < ix.n);            // (fmx_expand_kernel wrote every slot with a row of this index)
+    uint32_t sta = 0, stb = 0, sia = 0, sib = 0;
+    if (TEXT) {                                       // SA[row] mod 2^level steps; phase probes at both ends
+      uint32_t ta, tb;
+      uint32_t pia = fmx_phase_piece(rowa, ix.sa_level, ta), pib = fmx_phase_piece(rowb, ix.sa_level, tb);
+      uint4 qa = make_uint4(0u, 0u, 0u, 0u), qb = qa;
+      if (ina) { FMX_TOUCH(&ix.phase[pia]); qa = ix.phase[pia]; }
+      if (inb) { FMX_TOUCH(&ix.phase[pib]); qb = ix.phase[pib]; }
+      sta = ina ? fmx_phase_decode(qa, ta, ix.sa_level, sia) : 0u;
+      stb = inb ? fmx_phase_decode(qb, tb, ix.sa_level, sib) : 0u;
+      const uint32_t mx = sta > stb ? sta : stb;
+      for (uint32_t k = 0; k < mx; k++) {
+        const FmxLane2 r = fmx_rlfm_lane_lf2(ix, rowa, rowb, k < sta, k < stb);
+        rowa = r.a; rowb = r.b;
+      }
+      pia = fmx_phase_piece(rowa, ix.sa_level, ta); pib = fmx_phase_piece(rowb, ix.sa_level, tb);
+      if (sta) { FMX_TOUCH(&ix.phase[pia]); qa = ix.phase[pia]; }
+      if (stb) { FMX_TOUCH(&ix.phase[pib]); qb = ix.phase[pib]; }
+      if (sta) { [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(qa, ta, ix.sa_level, sia); FMX_CHECK(p2 == 0u); }
+      if (stb) { [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(qb, tb, ix.sa_level, sib); FMX_CHECK(p2 == 0u); }
+    } else {                                          // the reference's rows (sample.rs:46-60)
+      for (;;) {
+        const bool wa = ina && (rowa & lmask) != 0u, wb = inb && (rowb & lmask) != 0u;
+        if (!wa && !wb) break;
+        const FmxLane2 r = fmx_rlfm_lane_lf2(ix, rowa, rowb, wa, wb);
+        rowa = r.a; rowb = r.b;
+        sta += wa; stb += wb;
+      }
+      sia = rowa >> ix.sa_level; sib = rowb >> ix.sa_level;
     }
-    if (in) out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, row, nsteps);
+    FMX_CHECK((!ina || sia < ix.nsamples) && (!inb || sib < ix.nsamples));
+    uint32_t sa = 0, sb = 0;
+    if (ina) { FMX_TOUCH(&ix.samples[sia]); sa = ix.samples[sia]; }
+    if (inb) { FMX_TOUCH(&ix.samples[sib]); sb = ix.samples[sib]; }
+    uint64_t va = (uint64_t)sa + sta, vb = (uint64_t)sb + stb;          // (sa + steps) % len           rlfmi.rs:178-182
+    if (va >= ix.n) va -= ix.n;
+    if (vb >= ix.n) vb -= ix.n;
+    if (ina) out_pos[ha] = va;
+    if (inb) out_pos[hb] = vb;
+    nsteps += (ina ? sta : 0u) + (inb ? stb : 0u);
   }
-  if (SKIP && left && lane == 0) atomicAdd(nscat, left);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 
@@ -2389,10 +2401,8 @@ uint64_t fmx_offsets_tile_bytes(uint64_t npat) {
   if (ntiles == 0) ntiles = 1;
   return ((ntiles + 1) * sizeof(uint64_t) + 255u) & ~(uint64_t)255u;
 }
-// the rows; behind them a byte per 64-hit ticket and 256 bytes for a launch's device-side counter (the per-ticket RLFM walk)
-static inline uint64_t fmx_locate_flag_bytes(uint64_t total) { return ((total >> 6) + 1u + 255u) & ~(uint64_t)255u; }
 uint64_t fmx_locate_rows_bytes(uint64_t total) {
-  return (((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u) + fmx_locate_flag_bytes(total) + 256u;
+  return ((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u;
 }
 
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
@@ -2536,32 +2546,19 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
       unsigned gr;
       c.slice(tn.ep_loc_blocks ? (uint64_t)tn.ep_loc_blocks : (big ? 512 : 256), FMX_LCHUNK, hpb, gr);
       if (fm_ep) FMX_EPL_SM(c, gr, thr, hpb, tn.wc, FMX_KIND_FM, 0);
-      else if (dv.lfrun && tn.walk_records && tn.wc && tn.unified && total / npat >= 2 && tn.adj_clusters > 0 && !tn.alt) {
-        // the run table, a batch that may hold long intervals (two hits per pattern or more on average): the walk is
-        // chosen per ticket -- the lane-per-walk kernel takes the tickets of adjacent rows and counts the others, which
-        // the queue kernel then walks (it returns at once when there is none).  Batches of about one hit per pattern
-        // go straight to the queue kernel below: the scan for adjacent tickets would cost them ~10 us for nothing.
+      else if (dv.lfrun && tn.walk_records && tn.wc && total / npat >= (uint64_t)tn.rl_lane_avg && !tn.alt) {
+        // the run table, two hits per pattern or more on average: a lane per walk on consecutive hits, for every hit.
+        // Round 5 measured the choice per 64-hit ticket that the DNA kernel makes (lane kernel for the tickets of adjacent
+        // rows, the queue kernel for the others, a flag byte per ticket between the two launches): on the repetitive text
+        // and on a random text with the run table it lost to this kernel alone on every mixed batch (10^6 singletons +
+        // 10^3 x 10^5 hits: 1.73 against 1.19 ms; 4 x 10^6 singletons + 100 x 10^5: 1.44 against 0.64 ms) -- the queue
+        // kernel's edge on scattered rows is 15 % at best with the run table (two lane-wise requests per step either
+        // way), less than what splitting a batch costs (profiles/r05/locate_mix_*.jsonl).  Round 4 took this kernel from
+        // an average of 64 hits per pattern on, which sent the second batch above (average 3.5) to the queue kernel.
         uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
         if (lb > 8192) lb = 8192;
-        uint8_t *const ws_end = (uint8_t *)rows + fmx_locate_rows_bytes(total);
-        unsigned int *nscat = (unsigned int *)(ws_end - 256u);
-        uint8_t *flags = ws_end - 256u - fmx_locate_flag_bytes(total);
-        FMX_HIP(hipMemsetAsync(nscat, 0, sizeof(unsigned int), c.st));
-        const uint32_t adj = (uint32_t)tn.adj_clusters;
-        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, flags, nscat, c.pos, c.steps);
-        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, true>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, adj, c.rows, flags, nscat, c.pos, c.steps);
-#define FMX_EPREST_LAUNCH(SMV, TX)                                                                   \
-        hipLaunchKernelGGL((fmx_locate_ep_rest_kernel<SMV, TX>), dim3(gr), dim3(thr), 0, c.st, c.dv, c.total, hpb, c.rows,  \
-                           flags, nscat, c.pos, c.steps)
-        if (dv.phase) { if (sm == 1) FMX_EPREST_LAUNCH(1, true); else FMX_EPREST_LAUNCH(2, true); }
-        else { if (sm == 1) FMX_EPREST_LAUNCH(1, false); else FMX_EPREST_LAUNCH(2, false); }
-      }
-      else if (dv.lfrun && tn.walk_records && tn.wc && !tn.unified && total / npat >= 64 && !tn.alt) {
-        // (measurement builds, FMX_VARIANT=28: the round-4 choice by the batch average) long intervals: a lane per walk
-        uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
-        if (lb > 8192) lb = 8192;
-        if (dv.phase) hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<true, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, nullptr, c.pos, c.steps);
-        else hipLaunchKernelGGL((fmx_locate_rl_lane_kernel<false, false>), dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, 0u, c.rows, nullptr, nullptr, c.pos, c.steps);
+        if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        else hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<false>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
       }
       else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
         if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);

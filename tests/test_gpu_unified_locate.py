@@ -194,11 +194,11 @@ def test_workspace_form_and_two_streams_share_nothing():
 
 @pytest.mark.parametrize("sampling,level", [(None, 2), ("row", 2), (None, 3), ("row", 0)])
 @pytest.mark.parametrize("singles,longs,long_len", [(60000, 60, 6000), (100000, 0, 0), (0, 8, 70000), (150000, 3, 90000)])
-def test_rlfm_run_table_walk_is_chosen_per_ticket(sampling, level, singles, longs, long_len):
-    """RLFM with the run table (round 5): batches of 2^18+ hits that average two or more hits per pattern take two
-    launches -- fmx_locate_rl_lane_kernel<.., true> walks the tickets of adjacent rows a lane per hit and counts the others,
-    fmx_locate_ep_rest_kernel walks those through the hit queue, skipping the adjacent ones by the same test; batches of
-    about one hit per pattern go straight to the queue kernel.  The oracle's ordered positions either way."""
+def test_rlfm_run_table_mixed_batches(sampling, level, singles, longs, long_len):
+    """RLFM with the run table (round 5): batches of 2^18+ hits that average two or more hits per pattern take
+    fmx_locate_rl_lane_kernel (two walks per lane on consecutive hits, every stage's loads paired) for every hit -- mixed
+    and skewed batches included; batches of about one hit per pattern take the queue kernel.  The oracle's ordered
+    positions either way, in text and in row order."""
     n = 300000
     t = W.repetitive_text_np(n, 11, base_len=512, mut_per_1024=4)
     gi = F.RLFMIndexWithLocate(F.Text(t), level, sampling=sampling)

@@ -2011,46 +2011,43 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_walk_lane_kernel(
 #define FMX_U_LONG 32u
 #define FMX_U_LONGCAP 128u
 #define FMX_U_NOROW 0xFFFFFFFFu
-template <int Q, bool WC>
-__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void fmx_locate_f3u_kernel(
-    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
-    const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
-    uint64_t total, uint32_t hits_per_block, uint32_t chunk, uint32_t adj_clusters, uint64_t *__restrict__ out_pos,
-    uint64_t *__restrict__ steps_out, uint32_t *__restrict__ status) {
-  __shared__ uint32_t u_rows[FMX_U_SLICE];
-  __shared__ uint32_t u_long[FMX_U_LONGCAP * 3];      // {first row, first slot, rows} of the long ranges of the slice
-  __shared__ uint16_t u_tlist[FMX_U_SLICE / 8];       // tickets for the cooperative walk
-  __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
-  __shared__ unsigned long long u_klb;
-  __shared__ unsigned int u_nlong, u_ntl, u_nal;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
-  if (blo >= total) return;                           // block-uniform
-  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+// The rows of the block's slice [blo, blo + bn) of the hits into u_rows (LDS), by all 1024 threads of the block: rows[x] =
+// s[k] + (blo + x - off[k]) for the pattern k that owns hit blo + x (wrapper.rs:203-217: i = s..e-1 ascending).  Slots no
+// range covers (offsets with gaps) take row 0; returns true when this thread met an argument that is not of this index /
+// these offsets (the caller reports FMX_ERR_ARG).  Ends with the block synchronised and u_rows complete.
+struct FmxSliceLds {
+  uint32_t rows[FMX_U_SLICE];
+  uint32_t longs[FMX_U_LONGCAP * 3];                  // {first row, first slot, rows} of the long ranges of the slice
+  unsigned long long klb;
+  unsigned int nlong;
+};
+__device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
+                                                 const uint64_t *__restrict__ off, uint64_t npat, uint64_t total, uint32_t n,
+                                                 uint64_t blo, uint32_t bn) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint64_t bhi = blo + bn;
-  FMX_CHECK(hits_per_block <= FMX_U_SLICE && chunk >= 8u && chunk <= FMX_LCHUNK);
-  bool bad = false;                                   // an argument that is not of this index / these offsets
-  for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK) u_rows[x] = FMX_U_NOROW;
-  if (tid == 0) { u_nlong = 0; u_ntl = 0; u_nal = 0; }
+  bool bad = false;
+  for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK) L.rows[x] = FMX_U_NOROW;
+  if (tid == 0) L.nlong = 0;
   // ---- the slice's first pattern, bracketed: k_lo <= (largest k with off[k] <= blo) < k_lo + FMX_U_PATS ----
-  // one round of 1024 probes cuts the bracket 1024-fold: none up to 4096 patterns, one up to 2^22, two up to 2^32.
+  // one round of 1024 probes cuts the bracket 1024-fold: none up to 5120 patterns, one up to 2^22, two up to 2^32.
   // (the predicate off[c] <= blo is monotone in c: a wave's best candidate is its highest lane that holds, and only
   // lane 0 of the wave touches the LDS word)
   uint64_t k_lo = 0, span = npat;
   while (span > FMX_U_PATS) {                         // block-uniform
     const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
     const uint64_t c = k_lo + (uint64_t)tid * step;
-    if (tid == 0) u_klb = k_lo;
+    if (tid == 0) L.klb = k_lo;
     __syncthreads();
     const unsigned long long okm = __ballot(tid != 0 && c < k_lo + span && off[c] <= blo);
     if (okm && lane == 0)
-      atomicMax(&u_klb, (unsigned long long)(k_lo + (uint64_t)((tid | 63u) - (uint32_t)__builtin_clzll(okm)) * step));
+      atomicMax(&L.klb, (unsigned long long)(k_lo + (uint64_t)((tid | 63u) - (uint32_t)__builtin_clzll(okm)) * step));
     __syncthreads();
-    const uint64_t best = u_klb;
+    const uint64_t best = L.klb;
     span = best + step <= k_lo + span ? step : k_lo + span - best;
     k_lo = best;
   }
-  __syncthreads();                                    // u_rows cleared, counters zeroed
+  __syncthreads();                                    // rows cleared, counter zeroed
   // ---- expansion: FMX_U_PATS patterns per round (thread p takes patterns kc + p, kc + 1024 + p, ...: their off, s, e
   // in one round of loads), until a round ends on a pattern that starts behind the slice ----
   for (uint64_t kc = k_lo;; kc += FMX_U_PATS) {
@@ -2070,8 +2067,8 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
       if (k >= npat) continue;
       uint64_t aa = a[j], cnt = b[j] > aa ? b[j] - aa : 0;
       const uint64_t oo = o[j];
-      // a range that is not one of this index, or offsets that do not leave room for it: refused (fmx_expand_kernel's
-      // rule: the slots take rows from 0 on, so that the walk stays inside the index)
+      // a range that is not one of this index, or offsets that do not leave room for it: refused (the slots take rows
+      // from 0 on, so that the walk stays inside the index)
       if (b[j] > n || oo > total || cnt > total - oo) {
         bad = true;
         aa = 0;
@@ -2082,35 +2079,72 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
         const uint64_t h0 = oo > blo ? oo : blo, h1 = oo + cnt < bhi ? oo + cnt : bhi;
         const uint32_t len = (uint32_t)(h1 - h0), x0 = (uint32_t)(h0 - blo), r0 = (uint32_t)(aa + (h0 - oo));
         uint32_t q = FMX_U_LONGCAP;
-        if (len > FMX_U_LONG) q = atomicAdd(&u_nlong, 1u);
-        if (q < FMX_U_LONGCAP) { u_long[3u * q] = r0; u_long[3u * q + 1u] = x0; u_long[3u * q + 2u] = len; }
-        else for (uint32_t t = 0; t < len; t++) u_rows[x0 + t] = r0 + t;
+        if (len > FMX_U_LONG) q = atomicAdd(&L.nlong, 1u);
+        if (q < FMX_U_LONGCAP) { L.longs[3u * q] = r0; L.longs[3u * q + 1u] = x0; L.longs[3u * q + 2u] = len; }
+        else for (uint32_t t = 0; t < len; t++) L.rows[x0 + t] = r0 + t;
       }
     }
     if (!__syncthreads_or((int)more)) break;
   }
   {                                                   // the long ranges, by the whole block
-    const uint32_t nl = u_nlong < FMX_U_LONGCAP ? u_nlong : FMX_U_LONGCAP;
+    const uint32_t nl = L.nlong < FMX_U_LONGCAP ? L.nlong : FMX_U_LONGCAP;
     for (uint32_t j = 0; j < nl; j++) {
-      const uint32_t r0 = u_long[3u * j], x0 = u_long[3u * j + 1u], len = u_long[3u * j + 2u];
-      for (uint32_t t = tid; t < len; t += FMX_LOC_BLOCK) u_rows[x0 + t] = r0 + t;
+      const uint32_t r0 = L.longs[3u * j], x0 = L.longs[3u * j + 1u], len = L.longs[3u * j + 2u];
+      for (uint32_t t = tid; t < len; t += FMX_LOC_BLOCK) L.rows[x0 + t] = r0 + t;
     }
   }
   __syncthreads();
-  // ---- tickets: slots no range covered (offsets with gaps) take row 0 and are reported; adjacency of the rows ----
+  for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK)   // gaps: row 0, reported
+    if (L.rows[x] == FMX_U_NOROW) { L.rows[x] = 0u; bad = true; }
+  __syncthreads();
+  return bad;
+}
+// rows[] of a whole batch for the kernels that read them from global memory (every 32-bit path but the one-launch DNA
+// kernel): one block per slice of 4096 hits.  Replaces fmx_expand_kernel (round 1: a lane per pattern, ranges over 32 rows
+// by the lane's wave) -- a thousand patterns of 10^5 hits each kept sixteen waves busy for 1.7 ms there (round 5,
+// profiles/r05/locate_mix_*.jsonl: more than the walk of those 10^8 hits); here every slice is written by 1024 threads.
+__global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_expand_slices_kernel(
+    const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t total, uint32_t n, uint32_t *__restrict__ rows, uint32_t *__restrict__ status) {
+  __shared__ FmxSliceLds L;
+  for (uint64_t blo = (uint64_t)blockIdx.x * FMX_U_SLICE; blo < total; blo += (uint64_t)gridDim.x * FMX_U_SLICE) {
+    const uint32_t bn = (uint32_t)(total - blo < FMX_U_SLICE ? total - blo : FMX_U_SLICE);
+    if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn)) atomicOr(status, 1u << FMX_ERR_ARG);
+    for (uint32_t x = threadIdx.x; x < bn; x += FMX_LOC_BLOCK) rows[blo + x] = L.rows[x];
+    __syncthreads();
+  }
+}
+
+template <int Q, bool WC>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void fmx_locate_f3u_kernel(
+    const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples, uint32_t n, uint32_t nsamples,
+    const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t total, uint32_t hits_per_block, uint32_t chunk, uint32_t adj_clusters, uint64_t *__restrict__ out_pos,
+    uint64_t *__restrict__ steps_out, uint32_t *__restrict__ status) {
+  __shared__ FmxSliceLds L;
+  __shared__ uint16_t u_tlist[FMX_U_SLICE / 8];       // tickets for the cooperative walk
+  __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
+  __shared__ unsigned int u_ntl, u_nal;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  FMX_CHECK(hits_per_block <= FMX_U_SLICE && chunk >= 8u && chunk <= FMX_LCHUNK);
+  if (tid == 0) { u_ntl = 0; u_nal = 0; }
+  if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn)) atomicOr(status, 1u << FMX_ERR_ARG);
+  uint32_t *const u_rows = L.rows;
+  // ---- tickets: the adjacency of their rows ----
   const uint32_t ntick = (bn + chunk - 1u) / chunk;
   for (uint32_t t = wv; t < ntick; t += FMX_LOC_BLOCK / 64u) {
     const uint32_t x = t * chunk + lane;
     const bool in = lane < chunk && x < bn;
-    uint32_t r = in ? u_rows[x] : 0u;
-    if (in && r == FMX_U_NOROW) { bad = true; r = 0u; u_rows[x] = 0u; }
+    const uint32_t r = in ? u_rows[x] : 0u;
     const bool adjacent = chunk == FMX_LCHUNK && fmx_ticket_breaks(r, in, lane) < adj_clusters;
     if (lane == 0) {
       if (adjacent) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
       else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
     }
   }
-  if (bad) atomicOr(status, 1u << FMX_ERR_ARG);
   __syncthreads();
   // ---- phase A: a lane per walk on the tickets of adjacent rows ----
   const uint32_t nal = u_nal, ntl = u_ntl;
@@ -2438,10 +2472,10 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const bool own_rows = !unified && !rows_ws;
   if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, fmx_locate_rows_bytes(total), st));
   if (!unified) {
-    uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
-    if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
-    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
-                       d_off, npat, rows, total, dv.n, dv.status);
+    uint64_t eb = (total + FMX_U_SLICE - 1) / FMX_U_SLICE;
+    if (eb > 2048) eb = 2048;                         // (persistent from there: a block takes every 2048th slice)
+    hipLaunchKernelGGL(fmx_expand_slices_kernel, dim3((unsigned)eb), dim3(FMX_LOC_BLOCK), 0, st, d_s, d_e, d_off, npat,
+                       total, dv.n, rows, dv.status);
   }
   fmx_time_begin(idx, st);
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};

@@ -2024,6 +2024,7 @@ struct FmxSliceLds {
 __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
                                                  const uint64_t *__restrict__ off, uint64_t npat, uint64_t total, uint32_t n,
                                                  uint64_t blo, uint32_t bn) {
+  const bool dense = npat >= (total >> 2);            // a pattern per four hits or more (block-uniform, the same in every block)
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint64_t bhi = blo + bn;
   bool bad = false;
@@ -2052,19 +2053,40 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   // in one round of loads), until a round ends on a pattern that starts behind the slice ----
   for (uint64_t kc = k_lo;; kc += FMX_U_PATS) {
     uint64_t a[FMX_U_PATS / FMX_LOC_BLOCK], b[FMX_U_PATS / FMX_LOC_BLOCK], o[FMX_U_PATS / FMX_LOC_BLOCK];
+    bool need[FMX_U_PATS / FMX_LOC_BLOCK];
+    if (dense) {                                      // about a pattern per hit: most of the round's patterns are the slice's
 #pragma unroll
-    for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
-      const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
-      a[j] = 0; b[j] = 0; o[j] = 0;
-      if (k < npat) { a[j] = s[k]; b[j] = e[k]; o[j] = off[k]; }
+      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
+        const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
+        a[j] = 0; b[j] = 0; o[j] = 0;
+        need[j] = k < npat;
+        if (k < npat) { a[j] = s[k]; b[j] = e[k]; o[j] = off[k]; }
+      }
+    } else {
+      // few patterns per slice (long intervals): the offsets first, then s and e of the patterns that can reach into the
+      // slice -- off[k] < bhi and off[k + 1] > blo -- only (a slice inside one long interval loaded 5120 x 24 bytes for
+      // one pattern: 3 GB for a 10^8-hit batch, more than its rows and positions together)
+      uint64_t o1[FMX_U_PATS / FMX_LOC_BLOCK];
+#pragma unroll
+      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
+        const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
+        o[j] = 0; o1[j] = 0;
+        if (k < npat) { o[j] = off[k]; o1[j] = k + 1 < npat ? off[k + 1] : total; }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
+        const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
+        a[j] = 0; b[j] = 0;
+        need[j] = k < npat && o[j] < bhi && o1[j] > blo;
+        if (need[j]) { a[j] = s[k]; b[j] = e[k]; }
+      }
     }
     // the round's last pattern + 1: does it still start inside the slice?
     bool more = false;
     if (tid == FMX_LOC_BLOCK - 1u && kc + FMX_U_PATS < npat) more = off[kc + FMX_U_PATS] < bhi;
 #pragma unroll
     for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
-      const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
-      if (k >= npat) continue;
+      if (!need[j]) continue;
       uint64_t aa = a[j], cnt = b[j] > aa ? b[j] - aa : 0;
       const uint64_t oo = o[j];
       // a range that is not one of this index, or offsets that do not leave room for it: refused (the slots take rows

@@ -9,6 +9,8 @@
 #   rocprof         profiles/run_rocprof.sh <round> (kernel-trace --stats of the bench command)
 #   soak <seconds> [seed] [lib|shipped] [long]   tests/fuzz_gpu_vs_oracle.py (optionally on another libfmx*.so; `long` =
 #                        the long-interval batches: lane-per-walk kernels, per-ticket dispatch, every select branch)
+#   variant "<envs>" [flags]   bench.py on the measurement build under each environment of the list (FMX_VARIANT=.., grid knobs)
+#   pmc             benchmarks/gpu/kernel_pmc.py: counters per query kernel (what bounds it)
 #   mix [args]      benchmarks/gpu/locate_mix.py (DNA and RLFM): shipped library, then the measurement build on each path
 #   py <script> [args]   any python script under benchmarks/
 R=$1; T=$2; shift 2
@@ -43,6 +45,30 @@ rlusweep)
   for SL in 2048 4096 16384; do for TH in 256 512 1024; do
     echo "slice $SL threads $TH"; FMX_LIB=$M FMX_RLU_SLICE=$SL FMX_RLU_THREADS=$TH timeout 600 python3 benchmarks/gpu/locate_mix.py --kind rlfm "$@" 2>&1 | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:(d[k]['ms']) for k in ('pure_singletons','pure_long','mixed','mixed_low_average')})"
   done; done | tee $O/rlu_sweep.txt ;;
+variant)
+  # bench.py on the measurement build under a list of environments ("x" = the default dispatch), one summary line each:
+  #   run.sh r05 variant "x FMX_VARIANT=28 FMX_ADJ_CLUSTERS=0,FMX_LOC_BLOCKS=512" [bench flags]
+  LIST=$1; shift
+  export FMX_LIB=$PWD/fm_index_amd/libfmx_measure.so
+  for v in $LIST; do
+    T=$(echo $v | tr -c 'A-Za-z0-9=\n' _)
+    ( [ "$v" != x ] && export $(echo $v | tr , ' '); timeout 900 python3 bench.py --no-pmc --no-census --no-cpu-baseline --no-accel --no-early-exit --no-d2h --no-wide --no-ic-ab --no-config5 --no-rccl-check "$@" --detail-out $O/variant_$T.json > /dev/null 2> $O/variant_$T.err )
+    python3 - $O/variant_$T.json "$v" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    l, b, r = d.get('locate') or {}, d.get('locate_3b') or {}, d.get('rlfm') or {}
+    print(sys.argv[2], 'count ms', round(d['ms_per_step'], 4), '| locate', {k: l.get(k) for k in ('ms_per_batch', 'walk_kernel_ms')},
+          '| 3b', {k: b.get(k) for k in ('ms_per_batch',)}, '| rlfm', r.get('ms_per_step'), {k: (r.get('locate') or {}).get(k) for k in ('ms_per_batch',)})
+except Exception as ex:
+    print(sys.argv[2], 'ERR', ex)
+PY
+  done | tee $O/variants.txt ;;
+pmc)
+  # what bounds each kernel: benchmarks/gpu/kernel_pmc.py for the DNA, config-4b and config-4 workloads
+  timeout 900 python3 benchmarks/gpu/kernel_pmc.py --tag dna --workload dna --child-args no-accel,no-rlfm --out $O 2>&1 | tail -n 12
+  timeout 900 python3 benchmarks/gpu/kernel_pmc.py --tag rep_rlfm --workload rep-rlfm --out $O 2>&1 | tail -n 8
+  timeout 900 python3 benchmarks/gpu/kernel_pmc.py --tag bytes_rlfm --workload bytes-rlfm --out $O 2>&1 | tail -n 8 ;;
 py)
   S=$1; shift; timeout 1500 python3 $S "$@" 2>&1 | tee $O/$(basename $S .py).txt | tail -n 40 ;;
 *) echo "unknown task $T"; exit 2 ;;

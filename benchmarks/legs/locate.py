@@ -3,15 +3,15 @@ import ctypes as C
 import time
 
 from .common import golden_locate, positions_sha256
-from .roofline import LANE_WALK_KERNEL, make_roofline, run_census, stored_traffic
+from .roofline import WALK_KERNEL, make_roofline, run_census, stored_traffic
 
 def dna_walk_kernel(wl):
-    return "fmx_locate_f3t_kernel<4>" if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
+    return WALK_KERNEL + "<4>" if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
 
 
 def dna_walk_kernel_long(wl):
-    """batches that average 64+ hits per pattern on an index with walk records: a lane per walk on consecutive hits"""
-    return LANE_WALK_KERNEL if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
+    """the same one-launch kernel since round 5 (the walk is chosen per 64-hit ticket inside it)"""
+    return WALK_KERNEL + "<4>" if wl.index.walk_records() else "fmx_locate_f3p_kernel<4>"
 
 
 def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="locate"):
@@ -104,7 +104,9 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
         cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
     ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
     kname = dna_walk_kernel(wl) if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else "fmx_locate_kernel<FMX_KIND_FM>")
-    roof = make_roofline(kname, kavg_ms, 1, ref_bytes, total_hits * 4 + total_hits * 8, cen,
+    # streamed bytes: the positions, and the rows array (read) -- or, for the one-launch DNA kernel, s / e / off
+    lstream = total_hits * 8 + (npat * 24 if (wl.dna and wl.index.walk_records()) else total_hits * 4)
+    roof = make_roofline(kname, kavg_ms, 1, ref_bytes, lstream, cen,
                          stored_traffic(key, "locate"), table_bytes=wl.locate_table_bytes())
     two = None
     if not use_dist:
@@ -281,19 +283,20 @@ def locate_3b(out, wl, args, key):
     widths = {"requested_lines": nrec + total, "requested_records": nrec, "requested_probes": total,
               "distinct_lines": None}
     if wl.index.walk_records():
-        # the lane-per-walk kernel reads a record as lane-wise 16-byte pieces -- the row's own, the pieces in front of it
-        # (3 on average), the counter's -- so every request is a probe: about 5 per record visit, one per sample
+        # tickets of adjacent rows are walked a lane per hit: a record is read as lane-wise 16-byte pieces -- the row's
+        # own, the pieces in front of it (3 on average), the counter's -- so every request is a probe: about 5 per record
+        # visit, one per sample; plus 24 bytes of s / e / off per pattern a slice's expansion looks at
         widths = {"requested_lines": 5 * nrec + total, "requested_records": 0, "requested_probes": 5 * nrec + total,
                   "distinct_lines": None}
     out["locate_3b"]["requested_lines"] = widths["requested_lines"]
     out["locate_3b"]["requested_lines_per_s"] = widths["requested_lines"] / (kms / 1e3)
-    out["locate_3b"]["bound"] = ("not HBM: the hits of a pattern are adjacent rows, and LF keeps rows of one symbol adjacent -- "
-                                 "their records (and, in text order, their samples: consecutive entries) come from the "
-                                 "caches, so few requests reach the fabric (roofline.fabric_requests).  The group-cooperative "
-                                 "walk was bound by vector-instruction issue here (9.7 ms: ~12 wave instructions per walk "
-                                 "step, 8 walks per instruction); since round 4 batches of 64+ hits per pattern take "
-                                 "fmx_locate_walk_lane_kernel: a lane decodes its row's record alone, 64 walks per instruction")
+    out["locate_3b"]["bound"] = ("memory LATENCY, not bytes: the hits of a pattern are adjacent rows, and LF keeps rows of one symbol "
+                                 "adjacent -- their records (and, in text order, their samples: consecutive entries) come from "
+                                 "the caches, so few requests reach the fabric (roofline.fabric_requests, frac ~0.2); the "
+                                 "lane-per-hit walk spends ~80 % of its wave cycles parked on s_waitcnt at full occupancy "
+                                 "(profiles/r05/kernel_pmc_*.json).  Round 5: one launch (fmx_locate_f3u_kernel expands its "
+                                 "slices itself), the walk chosen per 64-hit ticket, a record's pieces requested at once")
     out["locate_3b"]["roofline"] = make_roofline(dna_walk_kernel_long(wl), kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
-                                                 total * 4 + total * 8, widths, stored_traffic(key, "locate_3b"),
+                                                 total * 8 + npat * 24, widths, stored_traffic(key, "locate_3b"),
                                                  table_bytes=wl.locate_table_bytes())
 

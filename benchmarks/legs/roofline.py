@@ -208,15 +208,15 @@ def make_roofline(kernel, avg_kernel_ms, units, ref_bytes_per_unit, stream_bytes
 # --------------------------------------------------------------------------------------------
 # live PMC passes: rocprofv3 runs a child of this script; separate --pmc passes, no trace domains
 # --------------------------------------------------------------------------------------------
-WALK_KERNEL = "fmx_locate_f3t_kernel"    # the default DNA index: text order + walk records (round 4)
-LANE_WALK_KERNEL = "fmx_locate_walk_lane_kernel"   # the same index on batches of 64+ hits per pattern (config 3b)
+WALK_KERNEL = "fmx_locate_f3u_kernel"    # the default DNA index (text order + walk records): ONE launch per batch (round 5)
+LANE_WALK_KERNEL = "fmx_locate_walk_lane_kernel"   # (round 4, measurement builds: batches of 64+ hits per pattern)
 PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counter CSV
     "dna_count": ["fmx_count_f3_kernel<1, false, false>", "fmx_count_f3_kernel"],
     "dna_count_pair": ["fmx_count_pair_kernel<false>"],          # opt-in accelerators (accel_legs)
     "dna_count_kmer": ["fmx_count_f3_kernel<1, false, true>"],
     "dna_count_both": ["fmx_count_pair_kernel<true>"],
     "dna_locate": [WALK_KERNEL],
-    "dna_locate_3b": [LANE_WALK_KERNEL, WALK_KERNEL],
+    "dna_locate_3b": [WALK_KERNEL, LANE_WALK_KERNEL],     # the same kernel on a larger grid (told apart by the grid)
     "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
     "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
     "rlfm_locate_lane": ["fmx_locate_rl_lane_kernel"],          # config 4b: 64+ hits per pattern (--workload rep-rlfm)

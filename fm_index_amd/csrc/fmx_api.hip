@@ -377,6 +377,7 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64
 // batches on different streams share nothing but the index
 uint64_t fmx_locate_workspace_bytes(const fmx_index *idx, uint64_t total_hits) {
   if (idx && idx->is_wide) return 256;     // a wide locate expands the rows into the position array itself
+  if (fmx_locate_is_one_launch(idx)) return 256;   // the one-launch kernel keeps its rows in LDS
   return fmx_locate_rows_bytes(total_hits);
 }
 uint64_t fmx_offsets_workspace_bytes(uint64_t npat) { return fmx_offsets_tile_bytes(npat); }
@@ -909,7 +910,7 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   if (!out_pos) return fail(FMX_ERR_ARG, "out_pos is NULL");
   HostCall hc;
   const size_t b_in = (size_t)npat * 8, b_pos = (size_t)total * 8;
-  const size_t b_rows = (size_t)fmx_locate_rows_bytes(total);
+  const size_t b_rows = (size_t)fmx_locate_workspace_bytes(idx, total);
   FMX_HIP(hc.open(idx->device, 2 * HostCall::pad(b_in) + HostCall::pad(b_in + 8) + HostCall::pad(b_pos) +
                                    HostCall::pad(b_rows)));
   uint64_t *d_s = hc.take<uint64_t>(b_in), *d_e = hc.take<uint64_t>(b_in);

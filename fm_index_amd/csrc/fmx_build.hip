@@ -182,8 +182,62 @@ struct DevPool {  // temporaries given back when the builder returns (large ones
   explicit DevPool(int dev, bool keep = false) : device(dev), keep_all(keep) {}
   ~DevPool() {
     for (const Ent &e : v) scratch_put(device, e.p, e.bytes, keep_all);
+    if (slab) scratch_put(device, slab, slab_bytes, keep_all);
   }
   void use_arena(uint8_t *base, size_t cap) { arena = base; arena_cap = base ? cap : 0; arena_off = 0; }
+  // Very large builds (round 5): ONE block taken before the build's first kernel touches any memory, and every temporary
+  // carved out of it (first fit; freed ranges coalesce).  On memory no process has used since boot this driver charges
+  // every hipMalloc that FOLLOWS a first touch ~28 ms per GiB touched since the previous allocation (DESIGN.md section
+  // 4.3: 5.4 s of a 0.85 s build at n = 2^32 on a fresh box) -- so a build that allocates nothing after its first touch
+  // pays nothing.  What does not fit the slab falls back to the scratch cache / the driver as before.
+  uint8_t *slab = nullptr;
+  size_t slab_bytes = 0;
+  std::vector<std::pair<size_t, size_t>> slab_free, slab_used;   // (offset, bytes), slab_free sorted by offset
+  hipError_t use_slab(size_t bytes) {
+    bytes = (bytes + 255u) & ~(size_t)255u;
+    void *p = nullptr;
+    size_t got = bytes;
+    const hipError_t e = scratch_get(device, bytes, &p, &got);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    slab = (uint8_t *)p;
+    slab_bytes = got;
+    slab_free.assign(1, {0, got});
+    slab_used.clear();
+    return hipSuccess;
+  }
+  void *slab_take(size_t bytes) {
+    for (size_t i = 0; i < slab_free.size(); i++)
+      if (slab_free[i].second >= bytes) {
+        const size_t off = slab_free[i].first;
+        if (slab_free[i].second == bytes) slab_free.erase(slab_free.begin() + i);
+        else { slab_free[i].first += bytes; slab_free[i].second -= bytes; }
+        slab_used.push_back({off, bytes});
+        return slab + off;
+      }
+    return nullptr;
+  }
+  bool slab_give(void *p) {
+    if (!slab || (uint8_t *)p < slab || (uint8_t *)p >= slab + slab_bytes) return false;
+    const size_t off = (size_t)((uint8_t *)p - slab);
+    for (size_t i = 0; i < slab_used.size(); i++)
+      if (slab_used[i].first == off) {
+        const size_t len = slab_used[i].second;
+        slab_used.erase(slab_used.begin() + i);
+        size_t j = 0;
+        while (j < slab_free.size() && slab_free[j].first < off) j++;
+        slab_free.insert(slab_free.begin() + j, {off, len});
+        if (j + 1 < slab_free.size() && slab_free[j].first + slab_free[j].second == slab_free[j + 1].first) {
+          slab_free[j].second += slab_free[j + 1].second;
+          slab_free.erase(slab_free.begin() + j + 1);
+        }
+        if (j > 0 && slab_free[j - 1].first + slab_free[j - 1].second == slab_free[j].first) {
+          slab_free[j - 1].second += slab_free[j].second;
+          slab_free.erase(slab_free.begin() + j);
+        }
+        return true;
+      }
+    return true;                                      // (inside the slab but unknown: nothing to give back)
+  }
   template <typename T>
   hipError_t get(T **out, size_t count) {
     const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255u) & ~(size_t)255u;
@@ -191,6 +245,9 @@ struct DevPool {  // temporaries given back when the builder returns (large ones
       *out = (T *)(arena + arena_off);
       arena_off += bytes;
       return hipSuccess;
+    }
+    if (slab) {
+      if (void *q = slab_take(bytes)) { *out = (T *)q; return hipSuccess; }
     }
     void *p = nullptr;
     size_t got = bytes;
@@ -204,9 +261,10 @@ struct DevPool {  // temporaries given back when the builder returns (large ones
   // allocator never reuses a byte -- so it has nothing to wait for here: its launches queue up behind each other on the
   // stream and the builder's last synchronisation covers them (a small build is launch- and round-trip-bound: every
   // wait that goes lets the host enqueue ahead of the device)
-  hipError_t quiesce() const { return (arena && v.empty()) ? hipSuccess : hipDeviceSynchronize(); }
+  hipError_t quiesce() const { return (arena && v.empty() && !slab) ? hipSuccess : hipDeviceSynchronize(); }
   void release(void *p) {
     if (arena && (uint8_t *)p >= arena && (uint8_t *)p < arena + arena_cap) return;   // goes with the arena
+    if (slab_give(p)) return;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i].p == p) {
         scratch_put(device, p, v[i].bytes, keep_all);
@@ -2877,6 +2935,47 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   const uint64_t n = idx->n;
   const uint32_t maxc = (uint32_t)idx->max_character;
   const uint32_t L = 32u - (uint32_t)__builtin_clz(maxc);   // text.rs:61-63
+  // -- every allocation whose size is known from (n, level, alphabet) BEFORE the first kernel touches memory (round 5;
+  // DevPool::use_slab says why): the temporaries' slab -- 32 bytes per symbol for the suffix sort's four 8-byte arrays,
+  // which everything later fits into once they are given back -- and, for the one-level index, its own arrays
+  uint64_t *pre_samp = nullptr, *pre_wbase = nullptr, *pre_base = nullptr;
+  uint4 *pre_walk = nullptr, *pre_rec = nullptr;
+  bool pre_walk_records = false;
+  if (!(idx->flags & FMX_FLAG_KEEP_SA)) {               // (FMX_FLAG_KEEP_SA hands the suffix array over: an allocation of its own)
+    (void)pool.use_slab((size_t)n * 32u + ((size_t)96u << 20));
+    const bool one_level = idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= 7;
+    if (one_level && pool.slab) {
+      if (idx->level_requested != FMX_NO_LOCATE) {
+        uint32_t level = idx->level_requested;
+        if (level >= 63 || n <= (1ull << level)) level = 0;
+        const uint64_t nsamp = ((n - 1) >> level) + 1;
+        FMX_HIP(fmx_dev_malloc((void **)&pre_samp, nsamp * sizeof(uint64_t)));
+        if (int rc = keep(idx, pre_samp, nsamp * 8)) return rc;
+        pre_walk_records = maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
+                           !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
+        if (pre_walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {
+          size_t free_b = 0, total_b = 0;
+          const uint64_t extra = (n / FMX_WALK_ROWS + 1u) * 128u;
+          pre_walk_records = fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
+        }
+        if (pre_walk_records) {
+          const uint32_t nwalk = (uint32_t)(n / FMX_WALK_ROWS + 1u);
+          const uint32_t shift = fmx_wide_n(n) ? FMXW_WALK_SB_SHIFT : FMXW_WALK_SB_SHIFT_TEST;
+          const uint32_t nwsb = ((nwalk - 1u) >> shift) + 1u;
+          FMX_HIP(fmx_dev_malloc((void **)&pre_walk, (size_t)nwalk * 128));
+          if (int rc = keep(idx, pre_walk, (uint64_t)nwalk * 128)) return rc;
+          FMX_HIP(fmx_dev_malloc((void **)&pre_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
+          if (int rc = keep(idx, pre_wbase, (uint64_t)nwsb * 128)) return rc;
+        }
+      }
+      const uint32_t sbs = fmx_wide_n(n) ? FMX_WIDE_SB_SHIFT : FMX_WIDE_SB_SHIFT_TEST;
+      const uint32_t nrec0 = (uint32_t)(n / 256u + 1u), nsb0 = (uint32_t)(n >> sbs) + 1u;
+      FMX_HIP(fmx_dev_malloc((void **)&pre_rec, (size_t)nrec0 * 128));
+      if (int rc = keep(idx, pre_rec, (uint64_t)nrec0 * 128)) return rc;
+      FMX_HIP(fmx_dev_malloc((void **)&pre_base, (size_t)nsb0 * 8 * sizeof(uint64_t)));
+      if (int rc = keep(idx, pre_base, (uint64_t)nsb0 * 64)) return rc;
+    }
+  }
   // -- statistics + validation (sais.rs:115-139) --
   std::vector<uint64_t> hist;
   TextStats st;
@@ -2923,12 +3022,16 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
     uint32_t level = idx->level_requested;
     if (level >= 63 || n <= (1ull << level)) level = 0;            // sample.rs:28-31
     const uint64_t nsamp = ((n - 1) >> level) + 1;                 // sample.rs:33
-    uint64_t *d_samp;
-    FMX_HIP(fmx_dev_malloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
-    if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
+    uint64_t *d_samp = pre_samp;
+    if (!d_samp) {
+      FMX_HIP(fmx_dev_malloc((void **)&d_samp, nsamp * sizeof(uint64_t)));
+      if (int rc = keep(idx, d_samp, nsamp * 8)) return rc;
+    }
     walk_records = idx->kind == FMX_KIND_FM && sizeof(T) == 1 && maxc <= FMX_WALK_MAX_CHARACTER && level >= 1 && level <= FMX_WALK_MAX_LEVEL &&
                    !(idx->flags & (FMX_FLAG_ROW_ORDER | FMX_FLAG_NO_WALK_RECORDS));
-    if (walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {     // by default only when the device has room
+    if (pre_samp) {
+      walk_records = pre_walk_records;                             // decided (and allocated) before the first touch
+    } else if (walk_records && !(idx->flags & FMX_FLAG_TEXT_ORDER)) {     // by default only when the device has room
       size_t free_b = 0, total_b = 0;
       const uint64_t extra = (n / FMX_WALK_ROWS + 1u) * 128u;
       walk_records = fmx_dev_mem_info(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4u * extra;
@@ -3017,10 +3120,14 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
       FMX_HIP(pool.get(&d_cnt, ncnt));
       FMX_HIP(pool.get(&d_scan, ncnt));
       FMX_HIP(pool.get(&d_adj, 16));
-      FMX_HIP(fmx_dev_malloc((void **)&d_walk, (size_t)nwalk * 128));
-      if (int rc = keep(idx, d_walk, (uint64_t)nwalk * 128)) return rc;
-      FMX_HIP(fmx_dev_malloc((void **)&d_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
-      if (int rc = keep(idx, d_wbase, (uint64_t)nwsb * 128)) return rc;
+      d_walk = pre_walk;
+      d_wbase = pre_wbase;
+      if (!d_walk) {
+        FMX_HIP(fmx_dev_malloc((void **)&d_walk, (size_t)nwalk * 128));
+        if (int rc = keep(idx, d_walk, (uint64_t)nwalk * 128)) return rc;
+        FMX_HIP(fmx_dev_malloc((void **)&d_wbase, (size_t)nwsb * 16 * sizeof(uint64_t)));
+        if (int rc = keep(idx, d_wbase, (uint64_t)nwsb * 128)) return rc;
+      }
       FMX_HIP(hipMemsetAsync(d_cnt + (ncnt - 1), 0, sizeof(uint32_t), 0));
       hipLaunchKernelGGL(kww_counts, dim3(wblocks(nwalk)), dim3(BLK), 0, 0, (const uint8_t *)d_bwt, d_sa, n, level, nwalk, d_cnt);
       size_t tb = 0;
@@ -3139,13 +3246,15 @@ static int build_wide_t(fmx_index *idx, const T *d_text) {
   }
   // -- records: planes + per-record histograms, 64-bit scan, relative counters + superblock bases --
   const uint32_t nrec = (uint32_t)(n / 256u + 1u);
-  uint4 *d_rec;
+  uint4 *d_rec = pre_rec;
   uint32_t *d_hist;
-  uint64_t *d_scan, *d_base;
-  FMX_HIP(fmx_dev_malloc((void **)&d_rec, (size_t)nrec * 128));
-  if (int rc = keep(idx, d_rec, (uint64_t)nrec * 128)) return rc;
-  FMX_HIP(fmx_dev_malloc((void **)&d_base, (size_t)nsb * 8 * sizeof(uint64_t)));
-  if (int rc = keep(idx, d_base, (uint64_t)nsb * 64)) return rc;
+  uint64_t *d_scan, *d_base = pre_base;
+  if (!d_rec) {
+    FMX_HIP(fmx_dev_malloc((void **)&d_rec, (size_t)nrec * 128));
+    if (int rc = keep(idx, d_rec, (uint64_t)nrec * 128)) return rc;
+    FMX_HIP(fmx_dev_malloc((void **)&d_base, (size_t)nsb * 8 * sizeof(uint64_t)));
+    if (int rc = keep(idx, d_base, (uint64_t)nsb * 64)) return rc;
+  }
   FMX_HIP(pool.get(&d_hist, (size_t)nrec * 8));
   FMX_HIP(pool.get(&d_scan, (size_t)nrec * 8));
   hipLaunchKernelGGL((k_mwm_pieces<3, T>), dim3(nblocks((uint64_t)nrec * 8)), dim3(BLK), 0, 0, d_bwt, n, 0u, 7u,

@@ -357,6 +357,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
                        hipStream_t st, uint64_t *tile_ws = nullptr);
 uint64_t fmx_locate_rows_bytes(uint64_t total);
+bool fmx_locate_is_one_launch(const fmx_index *idx);   // the default DNA index: no rows array (fmx_locate_f3u_kernel)
 uint64_t fmx_offsets_tile_bytes(uint64_t npat);
 // fills table[code] for every k-mer code (FMX_FLAG_KMER_TABLE; the index must be complete)
 int fmx_launch_kmer_build(const fmx_index *idx, uint2 *d_table, uint32_t k, uint32_t bits, hipStream_t st);

@@ -2477,6 +2477,14 @@ int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, 
   return FMX_OK;
 }
 
+// does a locate batch of this index run the one-launch kernel (no rows array, no allocation, kernel launches only)?
+bool fmx_locate_is_one_launch(const fmx_index *idx) {
+  if (!idx || idx->is_wide) return false;
+  const FmxTune tn = fmx_tune();
+  const FmxMwm &w = idx->dev.bw;
+  return idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic && idx->dev.phase && idx->dev.walk &&
+         tn.walk_records && tn.unified && !tn.alt;
+}
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
                       hipStream_t st, uint32_t *rows_ws) {
@@ -2487,7 +2495,7 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const FmxTune tn = fmx_tune();
   const bool dna = idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic;
   // the default DNA index (text order + walk records): ONE kernel that expands its slices itself -- no rows array
-  const bool unified = dna && dv.phase && dv.walk && tn.walk_records && tn.unified && !tn.alt;
+  const bool unified = fmx_locate_is_one_launch(idx);
   // every other path: rows in their own read-only buffer (the walk's loads never alias its stores).  The caller's
   // workspace when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
   uint32_t *rows = unified ? nullptr : rows_ws;

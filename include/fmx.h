@@ -260,7 +260,9 @@ int fmx_offsets_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d
  * device memory (256-byte aligned, owned by the caller, reusable across calls ON THE SAME STREAM) these
  * forms only launch kernels: no allocation, no synchronisation, capturable into a hipGraph, and batches
  * on different streams with different workspaces run concurrently (one batch's long walks under the
- * other's bulk).  Same results, same errors; a workspace that is NULL or too small is FMX_ERR_ARG. */
+ * other's bulk).  Same results, same errors; a workspace that is NULL or too small is FMX_ERR_ARG.
+ * (Round 5: on the default DNA index -- text order + walk records -- a locate batch is ONE kernel that expands its
+ * slices of the hits in LDS: fmx_locate_batch_dev allocates nothing there either, and the workspace is 256 bytes.) */
 uint64_t fmx_locate_workspace_bytes(const fmx_index *idx, uint64_t total_hits);
 int fmx_locate_batch_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                             uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,

@@ -25,7 +25,7 @@ def long_intervals(budget, seed, max_iters):
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     it = 0
-    stats = {"dna": 0, "rlfm": 0, "hits": 0, "text_order": 0, "run_table": 0, "stored_pos": 0, "skewed": 0, "row_order": 0}
+    stats = {"dna": 0, "rlfm": 0, "hits": 0, "text_order": 0, "run_table": 0, "skewed": 0, "row_order": 0}
     threads = min(16, os.cpu_count() or 1)
     while time.time() < t_end and it < max_iters:
         it += 1

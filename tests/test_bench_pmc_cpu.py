@@ -14,7 +14,7 @@ def row(name, grid, counter, value):
     return {"Kernel_Name": name, "Grid_Size": str(grid), "Counter_Name": counter, "Counter_Value": str(value)}
 
 
-WALK = "void fmx_locate_f3t_kernel<4, true>(HIP_vector_type<unsigned int, 4u> const*, ...)"
+WALK = "void fmx_locate_f3u_kernel<4, true>(HIP_vector_type<unsigned int, 4u> const*, ...)"
 COUNT = "void fmx_count_f3_kernel<1, false, false>(HIP_vector_type<unsigned int, 4u> const*, ...)"
 EPC = "void fmx_count_ep_kernel<1, 2, 2, false>(FmxDev, ...)"
 
@@ -103,22 +103,21 @@ def test_pretouch_is_optional_preparation_without_a_gpu():
     B.PRETOUCH.clear()
 
 
-def test_config_3b_counters_come_from_the_lane_per_walk_kernel():
-    """since round 4 config 3b (64+ hits per pattern) runs fmx_locate_walk_lane_kernel, a kernel of its own that is not
-    keyed by grid; the config-3 walk kernel then has one shape only"""
-    lane = "fmx_locate_walk_lane_kernel(HIP_vector_type<unsigned int, 4u> const*, ...)"
+def test_config_3b_counters_come_from_the_larger_grid_of_the_one_launch_kernel():
+    """round 5: config 3 and config 3b run the same kernel (fmx_locate_f3u_kernel picks the walk per ticket); the two
+    shapes are told apart by their grids; a measurement-build trace with the round-4 lane kernel still resolves"""
     rows = ([row(WALK, 262144, "FETCH_SIZE", 263400.0 + i) for i in range(3)]
-            + [row(lane, 2097152, "FETCH_SIZE", 9.1e6 + i) for i in range(2)])
+            + [row(WALK, 71392256, "FETCH_SIZE", 9.1e6 + i) for i in range(2)])
     agg = B.pmc_aggregate(rows, "FETCH_SIZE")
     kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate_3b"], B.PMC_WHICH["dna_locate_3b"])
-    assert "fmx_locate_walk_lane_kernel" in kn and abs(v - (9.1e6 + 0.5)) < 1.0
+    assert kn.endswith("@grid 71392256") and abs(v - (9.1e6 + 0.5)) < 1.0
     kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate"], B.PMC_WHICH["dna_locate"])
     assert kn.endswith("@grid 262144") and abs(v - 263401.0) < 1.0
-    # an index without walk records: both shapes under the old kernel's name, told apart by grid as before
-    rows = ([row(WALK, 262144, "FETCH_SIZE", 263400.0)] + [row(WALK, 524288, "FETCH_SIZE", 27.8e6)])
+    lane = "fmx_locate_walk_lane_kernel(HIP_vector_type<unsigned int, 4u> const*, ...)"
+    rows = [row(lane, 2097152, "FETCH_SIZE", 9.1e6)]
     agg = B.pmc_aggregate(rows, "FETCH_SIZE")
     kn, v = B.pmc_per_dispatch(agg, B.PMC_LEGS["dna_locate_3b"], B.PMC_WHICH["dna_locate_3b"])
-    assert kn.endswith("@grid 524288") and v == 27.8e6
+    assert "fmx_locate_walk_lane_kernel" in kn and v == 9.1e6
 
 
 # ---- the line the driver parses (VERDICT r4: the 21.9 KB line of round 4 left BENCH_r04.parsed = null) ----

@@ -220,10 +220,10 @@ def wide_leg(out, args, dev):
         "build_wall_s": round(build_wall_s, 2), "textgen_s": round(textgen_s, 2),
         "walk_records": index.walk_records(),
         "pretouch": dict(PRETOUCH) if PRETOUCH else None,
-        "note": "build_ms includes the driver's hipMalloc of ~137 GB of scratch in five buffers: 0.6-0.9 s on memory some "
-                "process has used before; on memory nobody has touched since boot every hipMalloc that follows a first "
-                "touch costs ~28 ms per GiB touched (3-5 s here), and so does re-allocating what this process has freed "
-                "(DESIGN.md section 4.3; `pretouch` = the child process that wrote the free memory once before this run)"}
+        "note": "round 5: the builder takes its temporaries' slab (32 B per symbol) and the index's own arrays BEFORE its first "
+                "kernel touches memory, so that no hipMalloc follows a first touch (on memory nobody has used since boot "
+                "this driver charges such a call ~28 ms per GiB touched: 4-5 s of this build in rounds 3-4, hidden by a "
+                "pre-touch child process in round 4 -- now opt-in, `--pretouch`)"}
     index.close()
     del text, pat, pat2, pos
     torch.cuda.empty_cache()

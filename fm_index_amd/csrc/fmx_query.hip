@@ -2238,100 +2238,47 @@ __device__ __forceinline__ uint32_t fmx_rlfm_lane_lf(const FmxDev &ix, uint32_t 
   else st = fmx_bits_lane_select(ix.b, lo);
   return f + row - st;
 }
-// TWO walks per lane, their requests issued together (round 5).  The kernel above it in the history -- one walk per lane --
-// spent 82 % of its wave cycles parked on s_waitcnt at full occupancy and moved 18 G requests/s of the 55 G/s the memory
-// system takes (profiles/r05/kernel_pmc_rep_rlfm_v1.json): what it lacked was requests in flight, and a lane has
-// registers for a second chain (19 -> ~40 VGPRs, still 8 waves per SIMD).  Lane l of a wave walks hits t + l and t + 64 + l
-// of two consecutive tickets: every stage (phase piece, B piece, run-table entry, final phase piece, sample) loads for
-// both walks before either result is used.
-struct FmxLane2 { uint32_t a, b; };
-// lf_map of two rows through the run table (fmx_rlfm_lane_lf, twice, the loads paired); a row whose flag is off passes through
-__device__ __forceinline__ FmxLane2 fmx_rlfm_lane_lf2(const FmxDev &ix, uint32_t rowa, uint32_t rowb, bool ona, bool onb) {
-  const uint32_t pa = fmx_div3(rowa >> 5), pb = fmx_div3(rowb >> 5);
-  FMX_CHECK((!ona || pa < ix.b.nrec * 8u) && (!onb || pb < ix.b.nrec * 8u));
-  uint4 ca = make_uint4(0u, 0u, 0u, 0u), cb = ca;
-  if (ona) { FMX_TOUCH(&ix.b.rec[pa]); ca = ix.b.rec[pa]; }
-  if (onb) { FMX_TOUCH(&ix.b.rec[pb]); cb = ix.b.rec[pb]; }
-  auto masks = [](const uint4 &pc, uint32_t b1, uint32_t &y, uint32_t &z, uint32_t &w) {
-    const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
-    const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
-    const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
-    y = pc.y & m0; z = pc.z & m1; w = pc.w & m2;
-  };
-  uint32_t ya, za, wa, yb, zb, wb;
-  masks(ca, rowa - pa * FMX_BITS_PER_PIECE + 1u, ya, za, wa);
-  masks(cb, rowb - pb * FMX_BITS_PER_PIECE + 1u, yb, zb, wb);
-  const uint32_t la = ca.x + __popc(ya) + __popc(za) + __popc(wa) - 1u, lb = cb.x + __popc(yb) + __popc(zb) + __popc(wb) - 1u;
-  FMX_CHECK((!ona || la < ix.b.ones) && (!onb || lb < ix.b.ones));
-  uint32_t fa = 0, fb = 0;
-  if (ona) { FMX_TOUCH(&ix.lfrun[la]); fa = ix.lfrun[la]; }
-  if (onb) { FMX_TOUCH(&ix.lfrun[lb]); fb = ix.lfrun[lb]; }
-  auto start = [&](uint32_t pidx, uint32_t y, uint32_t z, uint32_t w, uint32_t lo) -> uint32_t {
-    if (w) return pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(w);
-    if (z) return pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
-    if (y) return pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
-    return fmx_bits_lane_select(ix.b, lo);              // the run began before the piece
-  };
-  FmxLane2 r{rowa, rowb};
-  if (ona) r.a = fa + rowa - start(pa, ya, za, wa, la);
-  if (onb) r.b = fb + rowb - start(pb, yb, zb, wb, lb);
-  return r;
+// get_sa(row) by ONE lane through the run table (rlfmi.rs:172-190): returns the text position, adds the LF steps
+template <bool TEXT>
+__device__ __forceinline__ uint64_t fmx_rlfm_lane_get_sa(const FmxDev &ix, uint32_t row, uint64_t &nsteps) {
+  uint32_t steps = 0, si;
+  FMX_CHECK(row < ix.n);                              // (the expand kernels write every slot with a row of this index)
+  if (TEXT) {                                         // SA[row] mod 2^level steps; phase probes at both ends
+    uint32_t t;
+    uint32_t pi = fmx_phase_piece(row, ix.sa_level, t);
+    FMX_TOUCH(&ix.phase[pi]);
+    steps = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+    for (uint32_t k = 0; k < steps; k++) row = fmx_rlfm_lane_lf(ix, row);
+    if (steps) {
+      pi = fmx_phase_piece(row, ix.sa_level, t);
+      FMX_TOUCH(&ix.phase[pi]);
+      [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(ix.phase[pi], t, ix.sa_level, si);
+      FMX_CHECK(p2 == 0u);
+    }
+  } else {                                            // the reference's rows (sample.rs:46-60)
+    const uint32_t lmask = (1u << ix.sa_level) - 1u;
+    while (row & lmask) { row = fmx_rlfm_lane_lf(ix, row); steps++; }
+    si = row >> ix.sa_level;
+  }
+  FMX_CHECK(si < ix.nsamples);
+  FMX_TOUCH(&ix.samples[si]);
+  uint64_t v = (uint64_t)ix.samples[si] + steps;      // (sa + steps) % len                      rlfmi.rs:178-182
+  if (v >= ix.n) v -= ix.n;
+  nsteps += steps;
+  return v;
 }
+// (Round 5 also tried TWO walks per lane with their loads paired -- the kernel spends 82 % of its wave cycles parked on
+// s_waitcnt at full occupancy, profiles/r05/kernel_pmc_rep_rlfm_v1.json -- 19 -> 42 VGPRs, no gain: 1.19 -> 1.26 ms on the
+// mixed batch of profiles/r05/locate_mix_*.jsonl; the requests in flight per lane are not what it lacks.)
 template <bool TEXT>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix, uint64_t total,
                                                                         const uint32_t *__restrict__ rows,
                                                                         uint64_t *__restrict__ out_pos,
                                                                         uint64_t *__restrict__ steps_out) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lmask = (1u << ix.sa_level) - 1u;
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
   uint64_t nsteps = 0;
-  for (uint64_t t = wave * 128u; t < total; t += nwaves * 128u) {      // wave-uniform: two tickets per trip
-    const uint64_t ha = t + lane, hb = t + 64u + lane;
-    const bool ina = ha < total, inb = hb < total;
-    uint32_t rowa = ina ? rows[ha] : 0u, rowb = inb ? rows[hb] : 0u;
-    FMX_CHECK(rowa < ix.n && rowb < ix.n);            // (fmx_expand_kernel wrote every slot with a row of this index)
-    uint32_t sta = 0, stb = 0, sia = 0, sib = 0;
-    if (TEXT) {                                       // SA[row] mod 2^level steps; phase probes at both ends
-      uint32_t ta, tb;
-      uint32_t pia = fmx_phase_piece(rowa, ix.sa_level, ta), pib = fmx_phase_piece(rowb, ix.sa_level, tb);
-      uint4 qa = make_uint4(0u, 0u, 0u, 0u), qb = qa;
-      if (ina) { FMX_TOUCH(&ix.phase[pia]); qa = ix.phase[pia]; }
-      if (inb) { FMX_TOUCH(&ix.phase[pib]); qb = ix.phase[pib]; }
-      sta = ina ? fmx_phase_decode(qa, ta, ix.sa_level, sia) : 0u;
-      stb = inb ? fmx_phase_decode(qb, tb, ix.sa_level, sib) : 0u;
-      const uint32_t mx = sta > stb ? sta : stb;
-      for (uint32_t k = 0; k < mx; k++) {
-        const FmxLane2 r = fmx_rlfm_lane_lf2(ix, rowa, rowb, k < sta, k < stb);
-        rowa = r.a; rowb = r.b;
-      }
-      pia = fmx_phase_piece(rowa, ix.sa_level, ta); pib = fmx_phase_piece(rowb, ix.sa_level, tb);
-      if (sta) { FMX_TOUCH(&ix.phase[pia]); qa = ix.phase[pia]; }
-      if (stb) { FMX_TOUCH(&ix.phase[pib]); qb = ix.phase[pib]; }
-      if (sta) { [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(qa, ta, ix.sa_level, sia); FMX_CHECK(p2 == 0u); }
-      if (stb) { [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(qb, tb, ix.sa_level, sib); FMX_CHECK(p2 == 0u); }
-    } else {                                          // the reference's rows (sample.rs:46-60)
-      for (;;) {
-        const bool wa = ina && (rowa & lmask) != 0u, wb = inb && (rowb & lmask) != 0u;
-        if (!wa && !wb) break;
-        const FmxLane2 r = fmx_rlfm_lane_lf2(ix, rowa, rowb, wa, wb);
-        rowa = r.a; rowb = r.b;
-        sta += wa; stb += wb;
-      }
-      sia = rowa >> ix.sa_level; sib = rowb >> ix.sa_level;
-    }
-    FMX_CHECK((!ina || sia < ix.nsamples) && (!inb || sib < ix.nsamples));
-    uint32_t sa = 0, sb = 0;
-    if (ina) { FMX_TOUCH(&ix.samples[sia]); sa = ix.samples[sia]; }
-    if (inb) { FMX_TOUCH(&ix.samples[sib]); sb = ix.samples[sib]; }
-    uint64_t va = (uint64_t)sa + sta, vb = (uint64_t)sb + stb;          // (sa + steps) % len           rlfmi.rs:178-182
-    if (va >= ix.n) va -= ix.n;
-    if (vb >= ix.n) vb -= ix.n;
-    if (ina) out_pos[ha] = va;
-    if (inb) out_pos[hb] = vb;
-    nsteps += (ina ? sta : 0u) + (inb ? stb : 0u);
-  }
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += nth)
+    out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[h], nsteps);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
 

@@ -1924,54 +1924,61 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
 // pattern are adjacent rows of the same 112-row records, and LF keeps rows with the same symbol adjacent, so the 64
 // lanes of a wave ask for a handful of lines per instruction and a wave instruction serves 64 walks.  Chosen when the
 // batch averages at least 64 hits per pattern.
+// ONE record visit of a walk by ONE lane: the phase of `row` (SA[row] mod 2^level) and
+//   phase <= 1: the index of the walk's sample -- of this row (phase 0) or of the row after it (phase 1);
+//   else:       lf_map(row)                                                                     fm_index.rs:134-137
+__device__ __forceinline__ uint32_t fmx_walk_lane_visit(const uint4 *__restrict__ walk, [[maybe_unused]] uint32_t n, uint32_t row,
+                                                        uint32_t &ph) {
+  FMX_CHECK(row < n);
+  uint32_t off;
+  const uint32_t wr = fmx_walk_record(row, off);
+  const uint4 *R = walk + (size_t)wr * 8u;
+  const uint32_t pi = off >> 4, bit = off & 15u;
+  FMX_TOUCH(&R[pi]);
+  // the row's piece and the pieces in front of it, all requested at once (round 5: a loop that fetched them one after
+  // the other put up to seven dependent round trips into every record visit)
+  uint4 front[6];
+#pragma unroll
+  for (uint32_t q = 0; q < 6u; q++) {
+    front[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (q < pi) { FMX_TOUCH(&R[q]); front[q] = R[q]; }
+  }
+  const uint4 own = R[pi];
+  const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
+  ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
+  const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
+  // rows before `row` in the record: the whole pieces in front of its own, then its own up to the row
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 7u; q++) {
+    if (q > pi) continue;
+    const uint4 p = q == pi ? own : front[q];
+    const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
+    const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
+    const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
+    const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
+    cnt += __popc(sel);
+  }
+  // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
+  const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
+  FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));
+  FMX_TOUCH(&R[cp]);
+  const uint4 cv = R[cp];
+  uint32_t ctr = cv.x;
+  if (ph == 1u && sym >= 3u) ctr = sym == 3u ? cv.y : (sym == 4u ? cv.z : cv.w);
+  return ctr + cnt;
+}
 // get_sa(row) by ONE lane over the walk records: returns the text position, adds the walk's LF steps to `nsteps`
 __device__ __forceinline__ uint64_t fmx_walk_lane_get_sa(const uint4 *__restrict__ walk, const uint32_t *__restrict__ samples,
                                                          uint32_t n, [[maybe_unused]] uint32_t nsamples, uint32_t row,
                                                          uint64_t &nsteps) {
   uint32_t walk_steps = 0xFFFFFFFFu, si;
   for (;;) {
-    FMX_CHECK(row < n);
-    uint32_t off;
-    const uint32_t wr = fmx_walk_record(row, off);
-    const uint4 *R = walk + (size_t)wr * 8u;
-    const uint32_t pi = off >> 4, bit = off & 15u;
-    FMX_TOUCH(&R[pi]);
-    // the row's piece and the pieces in front of it, all requested at once (round 5: a loop that fetched them one after
-    // the other put up to seven dependent round trips into every record visit; the kernel waits for memory 80 % of its
-    // wave cycles -- profiles/r05/kernel_pmc_*.json)
-    uint4 front[6];
-#pragma unroll
-    for (uint32_t q = 0; q < 6u; q++) {
-      front[q] = make_uint4(0u, 0u, 0u, 0u);
-      if (q < pi) { FMX_TOUCH(&R[q]); front[q] = R[q]; }
-    }
-    const uint4 own = R[pi];
-    const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
-    const uint32_t ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
+    uint32_t ph;
+    const uint32_t v = fmx_walk_lane_visit(walk, n, row, ph);
     if (walk_steps == 0xFFFFFFFFu) walk_steps = ph;             // the walk is exactly SA[row] mod 2^level steps long
-    const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
-    // rows before `row` in the record: the whole pieces in front of its own (loaded together with it, see below), then
-    // its own up to the row
-    uint32_t cnt = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < 7u; q++) {
-      if (q > pi) continue;
-      const uint4 p = q == pi ? own : front[q];
-      const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
-      const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
-      const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
-      const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
-      cnt += __popc(sel);
-    }
-    // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
-    const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
-    FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));
-    FMX_TOUCH(&R[cp]);
-    const uint4 cv = R[cp];
-    uint32_t ctr = cv.x;
-    if (ph == 1u && sym >= 3u) ctr = sym == 3u ? cv.y : (sym == 4u ? cv.z : cv.w);
-    if (ph <= 1u) { si = ctr + cnt; break; }                    // this row's sample (phase 0) or the next row's (phase 1)
-    row = ctr + cnt;                                            // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+    if (ph <= 1u) { si = v; break; }                            // this row's sample (phase 0) or the next row's (phase 1)
+    row = v;                                                    // None: i = lf_map(i); steps += 1
   }
   FMX_CHECK(si < nsamples);
   FMX_TOUCH(&samples[si]);
@@ -2146,7 +2153,8 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   __shared__ FmxSliceLds L;
   __shared__ uint16_t u_tlist[FMX_U_SLICE / 8];       // tickets for the cooperative walk
   __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
-  __shared__ unsigned int u_ntl, u_nal;
+  __shared__ uint16_t u_walks[2][FMX_U_SLICE];        // ... their unfinished walks, round by round
+  __shared__ unsigned int u_ntl, u_nal, u_nwalks[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
@@ -2168,13 +2176,59 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     }
   }
   __syncthreads();
-  // ---- phase A: a lane per walk on the tickets of adjacent rows ----
+  // ---- phase A: a lane per walk on the tickets of adjacent rows, in ROUNDS of one record visit per live walk ----
+  // A wave that walks its 64 hits to the end runs as long as its longest walk -- 2^level - 1 visits -- with half of its
+  // lanes done after the first visit and three quarters after the second (phases are uniform): config 3b spent 709 vector
+  // instructions per hit that way and was bound by exactly that (VALU busy 0.93, profiles/r05/kernel_pmc_dna.json).  Here
+  // the block keeps the unfinished walks in a list (LDS: slot | the walk's length << 12; the walk's row stays in
+  // u_rows[slot]) that every round compacts: the visits executed are the visits needed, max(phase, 1) per hit.
   const uint32_t nal = u_nal, ntl = u_ntl;
   if (nal) {                                          // block-uniform
-    uint64_t nsteps = 0;
-    for (uint32_t i = wv; i < nal; i += FMX_LOC_BLOCK / 64u) {
-      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
-      if (x < bn) out_pos[blo + x] = fmx_walk_lane_get_sa(walk, samples, n, nsamples, u_rows[x], nsteps);
+    uint32_t nsteps = 0;
+    uint32_t cnt = nal * FMX_LCHUNK;                  // live walks of this round (block-uniform)
+    for (uint32_t round = 0; cnt != 0u; round++) {
+      uint16_t *const cur = u_walks[(round & 1u) ^ 1u], *const nxt = u_walks[round & 1u];
+      if (tid == 0) u_nwalks[round & 1u] = 0;
+      __syncthreads();
+      for (uint32_t i0 = wv * 64u; i0 < cnt; i0 += FMX_LOC_BLOCK) {     // wave-uniform: 64 consecutive entries per wave
+        const uint32_t i = i0 + lane;
+        uint32_t x = 0, wsteps = 0;
+        bool live = i < cnt;
+        if (round == 0u) {                            // the tickets themselves
+          x = (uint32_t)u_alist[i >> 6] * FMX_LCHUNK + lane;
+          live = x < bn;
+        } else if (live) {
+          const uint32_t en = cur[i];
+          x = en & 0xFFFu;
+          wsteps = en >> 12;
+        }
+        bool more = false;
+        if (live) {
+          uint32_t ph;
+          const uint32_t v = fmx_walk_lane_visit(walk, n, u_rows[x], ph);
+          if (round == 0u) wsteps = ph;               // the walk is exactly SA[row] mod 2^level steps long
+          if (ph <= 1u) {                             // this row's sample (phase 0) or the next row's (phase 1)
+            FMX_CHECK(v < nsamples);
+            FMX_TOUCH(&samples[v]);
+            uint64_t pos = (uint64_t)samples[v] + wsteps;       // (sa + steps) % len          fm_index.rs:131-133
+            if (pos >= n) pos -= n;
+            out_pos[blo + x] = pos;
+            nsteps += wsteps;
+          } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+            u_rows[x] = v;
+            more = true;
+          }
+        }
+        const unsigned long long mm = __ballot(more);
+        if (mm) {                                     // wave-uniform: the wave's unfinished walks, appended in hit order
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&u_nwalks[round & 1u], (unsigned int)__popcll(mm));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (more) nxt[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)(x | (wsteps << 12));
+        }
+      }
+      __syncthreads();
+      cnt = u_nwalks[round & 1u];
     }
     if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
   }

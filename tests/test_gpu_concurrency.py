@@ -161,7 +161,9 @@ def test_locate_workspace_form_is_graph_capturable_and_stream_independent(kind):
     h, npat, total = gi.handle(), d_s.numel(), int(ooff[-1])
     wsb = int(lib.fmx_locate_workspace_bytes(h, total))
     osb = int(lib.fmx_offsets_workspace_bytes(npat))
-    assert wsb >= 4 * total and wsb % 256 == 0 and osb % 256 == 0
+    # (round 5: the default DNA index locates in ONE kernel that keeps its rows in LDS -- its workspace is 256 bytes;
+    # every other index expands 4 bytes per hit into the workspace)
+    assert (wsb == 256 if gi.walk_records() and kind == "fm" else wsb >= 4 * total) and wsb % 256 == 0 and osb % 256 == 0
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(2)]
     ows = [torch.empty(osb, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -204,7 +206,7 @@ def test_locate_workspace_form_is_graph_capturable_and_stream_independent(kind):
                                        None, wsb, sp) == L.ERR_ARG
     assert lib.fmx_locate_batch_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
                                        C.c_void_p(d_off[0].data_ptr()), total, C.c_void_p(d_pos[0].data_ptr()),
-                                       C.c_void_p(ws[0].data_ptr()), 4 * total - 4, sp) == L.ERR_ARG
+                                       C.c_void_p(ws[0].data_ptr()), wsb - 4, sp) == L.ERR_ARG
     assert lib.fmx_offsets_ws_dev(h, C.c_void_p(d_s.data_ptr()), C.c_void_p(d_e.data_ptr()), npat,
                                   C.c_void_p(d_off[0].data_ptr()), None, osb, sp) == L.ERR_ARG
     gi.close()

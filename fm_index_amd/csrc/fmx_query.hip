@@ -2154,6 +2154,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   __shared__ uint16_t u_tlist[FMX_U_SLICE / 8];       // tickets for the cooperative walk
   __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
   __shared__ uint16_t u_walks[2][FMX_U_SLICE];        // ... their unfinished walks, round by round
+  __shared__ uint8_t u_wlen[FMX_U_SLICE];             // ... and the length of every finished one
   __shared__ unsigned int u_ntl, u_nal, u_nwalks[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
@@ -2207,15 +2208,11 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
           uint32_t ph;
           const uint32_t v = fmx_walk_lane_visit(walk, n, u_rows[x], ph);
           if (round == 0u) wsteps = ph;               // the walk is exactly SA[row] mod 2^level steps long
+          u_rows[x] = v;                              // lf_map(row) -- or, for a walk that ends here, its sample's index
           if (ph <= 1u) {                             // this row's sample (phase 0) or the next row's (phase 1)
-            FMX_CHECK(v < nsamples);
-            FMX_TOUCH(&samples[v]);
-            uint64_t pos = (uint64_t)samples[v] + wsteps;       // (sa + steps) % len          fm_index.rs:131-133
-            if (pos >= n) pos -= n;
-            out_pos[blo + x] = pos;
+            u_wlen[x] = (uint8_t)wsteps;
             nsteps += wsteps;
           } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
-            u_rows[x] = v;
             more = true;
           }
         }
@@ -2229,6 +2226,19 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
       }
       __syncthreads();
       cnt = u_nwalks[round & 1u];
+    }
+    // every walk of these tickets has left the index of its sample in u_rows[slot]: the samples in one sweep (no load
+    // waits for a visit any more; adjacent rows' samples are neighbours), the positions as contiguous 512-byte lines
+    for (uint32_t i = wv; i < nal; i += FMX_LOC_BLOCK / 64u) {
+      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
+      if (x < bn) {
+        const uint32_t si = u_rows[x];
+        FMX_CHECK(si < nsamples);
+        FMX_TOUCH(&samples[si]);
+        uint64_t pos = (uint64_t)samples[si] + u_wlen[x];        // (sa + steps) % len          fm_index.rs:131-133
+        if (pos >= n) pos -= n;
+        out_pos[blo + x] = pos;
+      }
     }
     if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
   }

@@ -2058,7 +2058,11 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   __syncthreads();                                    // rows cleared, counter zeroed
   // ---- expansion: FMX_U_PATS patterns per round (thread p takes patterns kc + p, kc + 1024 + p, ...: their off, s, e
   // in one round of loads), until a round ends on a pattern that starts behind the slice ----
-  for (uint64_t kc = k_lo;; kc += FMX_U_PATS) {
+  // (sparse patterns -- fewer than one per four hits: a slice then holds a few patterns, often one -- take 1024 patterns
+  // per round, the bracket's width, and load s and e only for the patterns whose offsets reach into the slice: a slice
+  // inside one long interval otherwise loaded 5120 x 24 bytes for one pattern, 3 GB for a 10^8-hit batch)
+  const uint32_t per_round = dense ? FMX_U_PATS : FMX_LOC_BLOCK;
+  for (uint64_t kc = k_lo;; kc += per_round) {
     uint64_t a[FMX_U_PATS / FMX_LOC_BLOCK], b[FMX_U_PATS / FMX_LOC_BLOCK], o[FMX_U_PATS / FMX_LOC_BLOCK];
     bool need[FMX_U_PATS / FMX_LOC_BLOCK];
     if (dense) {                                      // about a pattern per hit: most of the round's patterns are the slice's
@@ -2070,27 +2074,17 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
         if (k < npat) { a[j] = s[k]; b[j] = e[k]; o[j] = off[k]; }
       }
     } else {
-      // few patterns per slice (long intervals): the offsets first, then s and e of the patterns that can reach into the
-      // slice -- off[k] < bhi and off[k + 1] > blo -- only (a slice inside one long interval loaded 5120 x 24 bytes for
-      // one pattern: 3 GB for a 10^8-hit batch, more than its rows and positions together)
-      uint64_t o1[FMX_U_PATS / FMX_LOC_BLOCK];
+      const uint64_t k = kc + tid;
 #pragma unroll
-      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
-        const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
-        o[j] = 0; o1[j] = 0;
-        if (k < npat) { o[j] = off[k]; o1[j] = k + 1 < npat ? off[k + 1] : total; }
-      }
-#pragma unroll
-      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
-        const uint64_t k = kc + (uint64_t)j * FMX_LOC_BLOCK + tid;
-        a[j] = 0; b[j] = 0;
-        need[j] = k < npat && o[j] < bhi && o1[j] > blo;
-        if (need[j]) { a[j] = s[k]; b[j] = e[k]; }
-      }
+      for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) { a[j] = 0; b[j] = 0; o[j] = 0; need[j] = false; }
+      uint64_t o1 = 0;
+      if (k < npat) { o[0] = off[k]; o1 = k + 1 < npat ? off[k + 1] : total; }
+      need[0] = k < npat && o[0] < bhi && o1 > blo;
+      if (need[0]) { a[0] = s[k]; b[0] = e[k]; }
     }
     // the round's last pattern + 1: does it still start inside the slice?
     bool more = false;
-    if (tid == FMX_LOC_BLOCK - 1u && kc + FMX_U_PATS < npat) more = off[kc + FMX_U_PATS] < bhi;
+    if (tid == FMX_LOC_BLOCK - 1u && kc + per_round < npat) more = off[kc + per_round] < bhi;
 #pragma unroll
     for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
       if (!need[j]) continue;

@@ -290,12 +290,13 @@ def locate_3b(out, wl, args, key):
                   "distinct_lines": None}
     out["locate_3b"]["requested_lines"] = widths["requested_lines"]
     out["locate_3b"]["requested_lines_per_s"] = widths["requested_lines"] / (kms / 1e3)
-    out["locate_3b"]["bound"] = ("memory LATENCY, not bytes: the hits of a pattern are adjacent rows, and LF keeps rows of one symbol "
+    out["locate_3b"]["bound"] = ("vector-ALU issue, not memory: the hits of a pattern are adjacent rows, and LF keeps rows of one symbol "
                                  "adjacent -- their records (and, in text order, their samples: consecutive entries) come from "
-                                 "the caches, so few requests reach the fabric (roofline.fabric_requests, frac ~0.2); the "
-                                 "lane-per-hit walk spends ~80 % of its wave cycles parked on s_waitcnt at full occupancy "
-                                 "(profiles/r05/kernel_pmc_*.json).  Round 5: one launch (fmx_locate_f3u_kernel expands its "
-                                 "slices itself), the walk chosen per 64-hit ticket, a record's pieces requested at once")
+                                 "the caches (L2 hit 0.71), few requests reach the fabric (roofline.fabric_requests, frac ~0.1); "
+                                 "VALU busy 0.80 at 517 vector instructions per hit (profiles/r05/kernel_pmc_dna*.json).  Round "
+                                 "5: one launch (fmx_locate_f3u_kernel expands its slices itself), the walk chosen per 64-hit "
+                                 "ticket, a record's pieces requested at once, the lane walk in rounds of one record visit with "
+                                 "the unfinished walks compacted in LDS")
     out["locate_3b"]["roofline"] = make_roofline(dna_walk_kernel_long(wl), kms, 1, lf_steps * wl.Lbits * 64 + total * 64,
                                                  total * 8 + npat * 24, widths, stored_traffic(key, "locate_3b"),
                                                  table_bytes=wl.locate_table_bytes())

@@ -1936,29 +1936,33 @@ __device__ __forceinline__ uint32_t fmx_walk_lane_visit(const uint4 *__restrict_
   const uint32_t pi = off >> 4, bit = off & 15u;
   FMX_TOUCH(&R[pi]);
   // the row's piece and the pieces in front of it, all requested at once (round 5: a loop that fetched them one after
-  // the other put up to seven dependent round trips into every record visit)
+  // the other put up to seven dependent round trips into every record visit).  No predication: a lane that needs fewer
+  // than six front pieces asks for its own piece again (the same line; its rows are masked out below) -- the kernel is
+  // bound by vector-ALU issue, and a branch per piece cost more than the load it saved.
   uint4 front[6];
 #pragma unroll
   for (uint32_t q = 0; q < 6u; q++) {
-    front[q] = make_uint4(0u, 0u, 0u, 0u);
-    if (q < pi) { FMX_TOUCH(&R[q]); front[q] = R[q]; }
+    const uint32_t qq = q < pi ? q : pi;
+    if (q < pi) FMX_TOUCH(&R[q]);
+    front[q] = R[qq];
   }
   const uint4 own = R[pi];
   const uint32_t sym = ((own.y >> bit) & 1u) | (((own.y >> (bit + 16u)) & 1u) << 1) | (((own.z >> bit) & 1u) << 2);
   ph = ((own.z >> (bit + 16u)) & 1u) | (((own.w >> bit) & 1u) << 1) | (((own.w >> (bit + 16u)) & 1u) << 2);
-  const uint32_t m0 = (sym & 1u) ? 0xFFFFFFFFu : 0u, m1 = (sym & 2u) ? 0xFFFFFFFFu : 0u, m2 = (sym & 4u) ? 0xFFFFFFFFu : 0u;
-  // rows before `row` in the record: the whole pieces in front of its own, then its own up to the row
-  uint32_t cnt = 0;
+  const uint32_t m0 = 0u - (sym & 1u), m1 = 0u - ((sym >> 1) & 1u), m2 = 0u - (sym >> 2);      // all ones / zero
+  const uint32_t isA = ph == 0u ? 0xFFFFFFFFu : 0u, notA = ~isA, notB = ph == 1u ? 0u : 0xFFFFFFFFu;
+  // the rows of a piece that count towards the rank this visit needs (low 16 bits; the caller masks):
+  //   phase 0: the phase-0 rows;  phase 1: the phase-1 rows with the row's symbol;  else: the rows with the row's symbol
+  auto sel_of = [&](const uint4 &p) -> uint32_t {
+    const uint32_t q0 = p.z >> 16, q2 = p.w >> 16;
+    const uint32_t A = ~(q0 | p.w | q2);
+    const uint32_t B = q0 & ~(p.w | q2);
+    const uint32_t M = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2));
+    return (A & isA) | (M & notA & (B | notB));
+  };
+  uint32_t cnt = (uint32_t)__popc(sel_of(own) & ((1u << bit) - 1u));    // its own piece up to the row
 #pragma unroll
-  for (uint32_t q = 0; q < 7u; q++) {
-    if (q > pi) continue;
-    const uint4 p = q == pi ? own : front[q];
-    const uint32_t low = q == pi ? (1u << bit) - 1u : 0xFFFFu;
-    const uint32_t match = ~((p.y ^ m0) | ((p.y >> 16) ^ m1) | (p.z ^ m2)) & low;    // the row's symbol
-    const uint32_t q0 = p.z >> 16, q1 = p.w, q2 = p.w >> 16;                        // phase planes
-    const uint32_t sel = ph == 0u ? ~(q0 | q1 | q2) & low : (ph == 1u ? (q0 & ~(q1 | q2)) & match : match);
-    cnt += __popc(sel);
-  }
+  for (uint32_t q = 0; q < 6u; q++) cnt += (uint32_t)__popc(sel_of(front[q]) & (q < pi ? 0xFFFFu : 0u));   // whole pieces in front
   // the counter: phase 0 -> rank0 (piece 5); phase 1 -> rank1[sym] (piece 6 / 7); else lf_map2(sym, .) (piece sym - 1)
   const uint32_t cp = ph == 0u ? 5u : (ph == 1u ? (sym == 1u ? 6u : 7u) : sym - 1u);
   FMX_CHECK(ph == 0u || (sym >= 1u && sym <= FMX_WALK_MAX_CHARACTER));

@@ -1922,8 +1922,9 @@ static inline uint64_t fmx_ep_count_blocks(uint64_t npat, long cap) {
 // front of it (popcounts) and the piece that holds the counter it needs -- 5.5 lane-wise 16-byte loads per step on
 // average instead of one cooperative line, which would be eight times the requests on random rows; but the hits of a
 // pattern are adjacent rows of the same 112-row records, and LF keeps rows with the same symbol adjacent, so the 64
-// lanes of a wave ask for a handful of lines per instruction and a wave instruction serves 64 walks.  Chosen when the
-// batch averages at least 64 hits per pattern.
+// lanes of a wave ask for a handful of lines per instruction and a wave instruction serves 64 walks.  Round 4 chose it
+// from the batch average (64 hits per pattern or more, fmx_locate_walk_lane_kernel below: measurement builds only now);
+// since round 5 fmx_locate_f3u_kernel makes the choice per 64-hit ticket and runs this walk in rounds.
 // ONE record visit of a walk by ONE lane: the phase of `row` (SA[row] mod 2^level) and
 //   phase <= 1: the index of the walk's sample -- of this row (phase 0) or of the row after it (phase 1);
 //   else:       lf_map(row)                                                                     fm_index.rs:134-137
@@ -2250,7 +2251,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // no queue, no ring: hit h is read and written by lane h mod 64 -- therefore sends its 64 requests of a step into a
 // few lines, where fmx_locate_ep_kernel's refilling lanes scatter them (the same finding as on the wide engine,
 // fmxw_r_walk_text_kernel: 9.8e7 hits of the repetitive 1 GiB text in 2.5 ms against 3.45 ms).  Chosen when the
-// batch averages at least 64 hits per pattern.
+// batch averages two hits per pattern or more (round 5; 64 in round 4 -- see the launcher).
 // select1(k) of B by ONE lane (k < ones): stored position / select block / hint + search over the records
 __device__ __forceinline__ uint32_t fmx_bits_lane_select(const FmxBits &bv, uint32_t k) {
   if (bv.pos) { FMX_TOUCH(&bv.pos[k]); return bv.pos[k]; }

@@ -458,6 +458,7 @@ def write_detail(out, args, world):
     line names it, or None when it could not be written (a read-only checkout: the object then goes to stderr)"""
     path = args.detail_out or os.path.join(ROOT, "bench_detail.json" if world == 1 else "bench_detail_g%d.json" % world)
     try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
             f.write("\n")

@@ -2033,9 +2033,12 @@ struct FmxSliceLds {
   unsigned long long klb;
   unsigned int nlong;
 };
+// `k_hint` (in / out, block-uniform; ~0 = none): a lower bound of the slice's first pattern within one round of it -- a block
+// that expands CONSECUTIVE slices passes the value the previous slice left (the first pattern of its last round) and
+// skips the probe rounds.
 __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
                                                  const uint64_t *__restrict__ off, uint64_t npat, uint64_t total, uint32_t n,
-                                                 uint64_t blo, uint32_t bn) {
+                                                 uint64_t blo, uint32_t bn, uint64_t *k_hint = nullptr) {
   const bool dense = npat >= (total >> 2);            // a pattern per four hits or more (block-uniform, the same in every block)
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint64_t bhi = blo + bn;
@@ -2047,6 +2050,7 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   // (the predicate off[c] <= blo is monotone in c: a wave's best candidate is its highest lane that holds, and only
   // lane 0 of the wave touches the LDS word)
   uint64_t k_lo = 0, span = npat;
+  if (k_hint && *k_hint != ~0ull) { k_lo = *k_hint; span = 0; }
   while (span > FMX_U_PATS) {                         // block-uniform
     const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
     const uint64_t c = k_lo + (uint64_t)tid * step;
@@ -2112,7 +2116,10 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
         else for (uint32_t t = 0; t < len; t++) L.rows[x0 + t] = r0 + t;
       }
     }
-    if (!__syncthreads_or((int)more)) break;
+    if (!__syncthreads_or((int)more)) {
+      if (k_hint) *k_hint = kc;                       // the next slice's first pattern is one of this round's, or the one after
+      break;
+    }
   }
   {                                                   // the long ranges, by the whole block
     const uint32_t nl = L.nlong < FMX_U_LONGCAP ? L.nlong : FMX_U_LONGCAP;
@@ -2128,16 +2135,21 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   return bad;
 }
 // rows[] of a whole batch for the kernels that read them from global memory (every 32-bit path but the one-launch DNA
-// kernel): one block per slice of 4096 hits.  Replaces fmx_expand_kernel (round 1: a lane per pattern, ranges over 32 rows
+// kernel): a block per run of consecutive 4096-hit slices.  Replaces fmx_expand_kernel (round 1: a lane per pattern, ranges over 32 rows
 // by the lane's wave) -- a thousand patterns of 10^5 hits each kept sixteen waves busy for 1.7 ms there (round 5,
 // profiles/r05/locate_mix_*.jsonl: more than the walk of those 10^8 hits); here every slice is written by 1024 threads.
 __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_expand_slices_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
     uint64_t total, uint32_t n, uint32_t *__restrict__ rows, uint32_t *__restrict__ status) {
   __shared__ FmxSliceLds L;
-  for (uint64_t blo = (uint64_t)blockIdx.x * FMX_U_SLICE; blo < total; blo += (uint64_t)gridDim.x * FMX_U_SLICE) {
+  // a block takes `per` CONSECUTIVE slices: only its first one probes off[] for its first pattern
+  const uint64_t nslices = (total + FMX_U_SLICE - 1) / FMX_U_SLICE, per = (nslices + gridDim.x - 1) / gridDim.x;
+  const uint64_t s0 = (uint64_t)blockIdx.x * per, s1 = s0 + per < nslices ? s0 + per : nslices;
+  uint64_t hint = ~0ull;
+  for (uint64_t sl = s0; sl < s1; sl++) {
+    const uint64_t blo = sl * FMX_U_SLICE;
     const uint32_t bn = (uint32_t)(total - blo < FMX_U_SLICE ? total - blo : FMX_U_SLICE);
-    if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn)) atomicOr(status, 1u << FMX_ERR_ARG);
+    if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn, &hint)) atomicOr(status, 1u << FMX_ERR_ARG);
     for (uint32_t x = threadIdx.x; x < bn; x += FMX_LOC_BLOCK) rows[blo + x] = L.rows[x];
     __syncthreads();
   }
@@ -2511,20 +2523,13 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   uint32_t *rows = unified ? nullptr : rows_ws;
   const bool own_rows = !unified && !rows_ws;
   if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, fmx_locate_rows_bytes(total), st));
-  if (!unified && total / npat >= 1024) {
-    // few patterns with very many hits each: a block per slice of 4096 hits (a lane per pattern left a thousand
-    // patterns of 10^5 hits to sixteen waves: 1.7 ms, more than the walk of those 10^8 hits)
+  if (!unified) {
+    // a block per run of consecutive 4096-hit slices (round 5; fmx_expand_kernel -- a lane per pattern, round 1 -- left a
+    // thousand patterns of 10^5 hits to sixteen waves: 1.7 ms, more than the walk of those 10^8 hits)
     uint64_t eb = (total + FMX_U_SLICE - 1) / FMX_U_SLICE;
-    if (eb > 2048) eb = 2048;                         // (persistent from there: a block takes every 2048th slice)
+    if (eb > 2048) eb = 2048;
     hipLaunchKernelGGL(fmx_expand_slices_kernel, dim3((unsigned)eb), dim3(FMX_LOC_BLOCK), 0, st, d_s, d_e, d_off, npat,
                        total, dv.n, rows, dv.status);
-  } else if (!unified) {
-    // a lane per pattern (ranges over 32 rows by the lane's wave): the faster of the two when the long ranges are spread
-    // over many waves (10^6 singletons + 10^3 x 10^5 hits, shuffled: 0.25 against 0.7 ms for the slices)
-    uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
-    if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
-    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
-                       d_off, npat, rows, total, dv.n, dv.status);
   }
   fmx_time_begin(idx, st);
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};

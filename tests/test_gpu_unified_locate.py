@@ -211,3 +211,32 @@ def test_rlfm_run_table_mixed_batches(sampling, level, singles, longs, long_len)
     assert int(off[-1]) >= (1 << 18)
     assert (np.asarray(pos, np.uint64) == _expect(want, s, e)).all()
     gi.close()
+
+
+@pytest.mark.parametrize("kind", ["rlfm", "fm_bytes", "dna_row_order"])
+def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
+    """The paths that keep a rows array expand it with fmx_expand_slices_kernel: at most 2048 blocks, each a run of
+    consecutive 4096-hit slices -- only a block's first slice probes off[] for its first pattern, the others start from
+    the pattern the previous slice ended on.  ~10^7 hits (2400+ slices): long intervals, singletons and empty patterns
+    in between, so that a slice's first pattern sits anywhere from 0 to thousands of patterns behind the hint."""
+    n = 250000
+    rng = np.random.default_rng(17)
+    if kind == "rlfm":
+        t = W.repetitive_text_np(n, 13, base_len=400, mut_per_1024=6)
+        gi = F.RLFMIndexWithLocate(F.Text(t), 2)
+        oi = O.OracleIndex(t, 255, level=2, kind="rlfm")
+    elif kind == "fm_bytes":
+        t = W.byte_text_np(n, 8)
+        gi = F.FMIndexWithLocate(F.Text(t), 2)
+        oi = O.OracleIndex(t, 255, level=2)
+    else:
+        t = _text(23, n)
+        gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, sampling="row")
+        oi = O.OracleIndex(t, 4, level=2)
+    want = oi.get_sa(np.arange(n)).astype(np.uint64)
+    s, e = _mixed_intervals(n, rng, 60000, 45, 240000, 20000)
+    off, pos = gi.locate_many(s, e)
+    assert int(off[-1]) > 2100 * 4096
+    exp = _expect(want, s, e)
+    assert (np.asarray(pos, np.uint64) == exp).all()
+    gi.close()

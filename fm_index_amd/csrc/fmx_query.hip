@@ -2031,6 +2031,7 @@ struct FmxSliceLds {
   uint32_t rows[FMX_U_SLICE];
   uint32_t longs[FMX_U_LONGCAP * 3];                  // {first row, first slot, rows} of the long ranges of the slice
   unsigned long long klb;
+  unsigned long long cross[3];                        // the range that crosses the slice's end: {first row, first hit, hits}
   unsigned int nlong;
 };
 // `k_hint` (in / out, block-uniform; ~0 = none): a lower bound of the slice's first pattern within one round of it -- a block
@@ -2044,7 +2045,7 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   const uint64_t bhi = blo + bn;
   bool bad = false;
   for (uint32_t x = tid; x < bn; x += FMX_LOC_BLOCK) L.rows[x] = FMX_U_NOROW;
-  if (tid == 0) L.nlong = 0;
+  if (tid == 0) { L.nlong = 0; L.cross[2] = 0; }
   // ---- the slice's first pattern, bracketed: k_lo <= (largest k with off[k] <= blo) < k_lo + FMX_U_PATS ----
   // one round of 1024 probes cuts the bracket 1024-fold: none up to 5120 patterns, one up to 2^22, two up to 2^32.
   // (the predicate off[c] <= blo is monotone in c: a wave's best candidate is its highest lane that holds, and only
@@ -2114,6 +2115,7 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
         if (len > FMX_U_LONG) q = atomicAdd(&L.nlong, 1u);
         if (q < FMX_U_LONGCAP) { L.longs[3u * q] = r0; L.longs[3u * q + 1u] = x0; L.longs[3u * q + 2u] = len; }
         else for (uint32_t t = 0; t < len; t++) L.rows[x0 + t] = r0 + t;
+        if (oo + cnt > bhi) { L.cross[0] = aa; L.cross[1] = oo; L.cross[2] = cnt; }   // (one range at most, offsets being offsets)
       }
     }
     if (!__syncthreads_or((int)more)) {
@@ -2145,12 +2147,18 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) void fmx_expand_slices_kernel(
   // a block takes `per` CONSECUTIVE slices: only its first one probes off[] for its first pattern
   const uint64_t nslices = (total + FMX_U_SLICE - 1) / FMX_U_SLICE, per = (nslices + gridDim.x - 1) / gridDim.x;
   const uint64_t s0 = (uint64_t)blockIdx.x * per, s1 = s0 + per < nslices ? s0 + per : nslices;
-  uint64_t hint = ~0ull;
+  uint64_t hint = ~0ull, c_row = 0, c_off = 0, c_cnt = 0;     // c_*: the range that crossed the previous slice's end
   for (uint64_t sl = s0; sl < s1; sl++) {
     const uint64_t blo = sl * FMX_U_SLICE;
     const uint32_t bn = (uint32_t)(total - blo < FMX_U_SLICE ? total - blo : FMX_U_SLICE);
+    if (c_cnt && c_off <= blo && c_off + c_cnt >= blo + bn) {
+      // the whole slice lies inside that range (a long interval): its rows follow from it, nothing is loaded
+      for (uint32_t x = threadIdx.x; x < bn; x += FMX_LOC_BLOCK) rows[blo + x] = (uint32_t)(c_row + (blo + x - c_off));
+      continue;                                       // (block-uniform; the hint stays: the next slice may start in the same range)
+    }
     if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn, &hint)) atomicOr(status, 1u << FMX_ERR_ARG);
     for (uint32_t x = threadIdx.x; x < bn; x += FMX_LOC_BLOCK) rows[blo + x] = L.rows[x];
+    c_row = L.cross[0]; c_off = L.cross[1]; c_cnt = L.cross[2];
     __syncthreads();
   }
 }

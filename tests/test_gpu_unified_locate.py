@@ -234,7 +234,7 @@ def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
         gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, sampling="row")
         oi = O.OracleIndex(t, 4, level=2)
     want = oi.get_sa(np.arange(n)).astype(np.uint64)
-    s, e = _mixed_intervals(n, rng, 60000, 45, 240000, 20000)
+    s, e = _mixed_intervals(n, rng, 60000, 62, 240000, 20000)
     off, pos = gi.locate_many(s, e)
     assert int(off[-1]) > 2100 * 4096
     exp = _expect(want, s, e)

@@ -2531,13 +2531,20 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   uint32_t *rows = unified ? nullptr : rows_ws;
   const bool own_rows = !unified && !rows_ws;
   if (own_rows) FMX_HIP(fmx_dev_malloc_async((void **)&rows, fmx_locate_rows_bytes(total), st));
-  if (!unified) {
-    // a block per run of consecutive 4096-hit slices (round 5; fmx_expand_kernel -- a lane per pattern, round 1 -- left a
-    // thousand patterns of 10^5 hits to sixteen waves: 1.7 ms, more than the walk of those 10^8 hits)
+  if (!unified && total / npat >= 1024) {
+    // few patterns with very many hits each: a block per run of consecutive 4096-hit slices (a lane per pattern left a
+    // thousand patterns of 10^5 hits to sixteen waves: 1.7 ms, more than the walk of those 10^8 hits; here 0.2 ms)
     uint64_t eb = (total + FMX_U_SLICE - 1) / FMX_U_SLICE;
     if (eb > 2048) eb = 2048;
     hipLaunchKernelGGL(fmx_expand_slices_kernel, dim3((unsigned)eb), dim3(FMX_LOC_BLOCK), 0, st, d_s, d_e, d_off, npat,
                        total, dv.n, rows, dv.status);
+  } else if (!unified) {
+    // a lane per pattern (ranges over 32 rows by the lane's wave): the faster of the two up to hundreds of hits per
+    // pattern (config 4: 24 against 51 us per 2^20 singletons; config 4b, 750 hits per pattern: 1.0 against 5.1 ms)
+    uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
+    if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
+    hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
+                       d_off, npat, rows, total, dv.n, dv.status);
   }
   fmx_time_begin(idx, st);
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};

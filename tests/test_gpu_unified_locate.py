@@ -215,10 +215,11 @@ def test_rlfm_run_table_mixed_batches(sampling, level, singles, longs, long_len)
 
 @pytest.mark.parametrize("kind", ["rlfm", "fm_bytes", "dna_row_order"])
 def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
-    """The paths that keep a rows array expand it with fmx_expand_slices_kernel: at most 2048 blocks, each a run of
-    consecutive 4096-hit slices -- only a block's first slice probes off[] for its first pattern, the others start from
-    the pattern the previous slice ended on.  ~10^7 hits (2400+ slices): long intervals, singletons and empty patterns
-    in between, so that a slice's first pattern sits anywhere from 0 to thousands of patterns behind the hint."""
+    """The paths that keep a rows array expand it with fmx_expand_slices_kernel from 1024 hits per pattern on: at most
+    2048 blocks, each a run of consecutive 4096-hit slices -- only a block's first slice probes off[] for its first
+    pattern, the others start from the pattern the previous slice ended on, and slices inside one long range follow from
+    it.  ~10^7 hits (2400+ slices): long intervals with clusters of singletons and empty patterns in between, so that a
+    slice's first pattern sits anywhere from 0 to thousands of patterns behind the hint."""
     n = 250000
     rng = np.random.default_rng(17)
     if kind == "rlfm":
@@ -234,7 +235,7 @@ def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
         gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, sampling="row")
         oi = O.OracleIndex(t, 4, level=2)
     want = oi.get_sa(np.arange(n)).astype(np.uint64)
-    s, e = _mixed_intervals(n, rng, 60000, 62, 240000, 20000)
+    s, e = _mixed_intervals(n, rng, 6000, 62, 240000, 2000)     # ~1500 hits per pattern on average
     off, pos = gi.locate_many(s, e)
     assert int(off[-1]) > 2100 * 4096
     exp = _expect(want, s, e)

@@ -1602,6 +1602,24 @@ hipError_t fmx_dev_malloc(void **p, size_t bytes) {
   return e;
 }
 hipError_t fmx_dev_malloc_async(void **p, size_t bytes, hipStream_t st) {
+  // the device's default stream-ordered pool keeps up to 2 GiB of freed blocks instead of returning them to the driver at
+  // every synchronisation (release threshold 0 by default): a locate call's rows array then comes out of the pool
+  {
+    static std::mutex mu;
+    static bool done[kArenaDevices] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kArenaDevices) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!done[dev]) {
+        done[dev] = true;
+        hipMemPool_t pool = nullptr;
+        uint64_t keep = 2ull << 30;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess ||
+            hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+          (void)hipGetLastError();
+      }
+    }
+  }
   hipError_t e = hipMallocAsync(p, bytes, st);
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();

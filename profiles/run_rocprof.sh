@@ -35,12 +35,34 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_fetch4b", "pmc_write4b"):
     for f in glob.glob(tag + "/**/*counter_collection*.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             kn = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "")
-            k = (kn.split("(")[0][:90], row.get("Counter_Name", "?"))
+            name = kn.split("(")[0][:90]
+            if "fmx_locate_f3u_kernel" in name:      # one kernel, two shapes (config 3 / config 3b): keyed by grid
+                name += " @grid %s" % row.get("Grid_Size", "?")
+            k = (name, row.get("Counter_Name", "?"))
             agg[k][0] += 1
             agg[k][1] += float(row.get("Counter_Value", 0) or 0)
     out[tag] = {"%s|%s" % k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)}
                 for k, v in agg.items()}
 json.dump(out, open("pmc_summary.json", "w"), indent=1)
 PY
-rm -rf trace/*/*.db trace4b/*/*.db pmc_fetch pmc_write pmc_fetch4b pmc_write4b 2>/dev/null
+python3 - <<'PY'
+import csv, glob, collections
+for tag, name in (("trace", "bench"), ("trace4b", "config4b")):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(tag + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            if "fmx_" not in kn:
+                continue
+            g = (kn.split("(")[0].replace("void ", "")[:70], r.get("Grid_Size") or r.get("Grid_Size_X"),
+                 r.get("Workgroup_Size") or r.get("Workgroup_Size_X"))
+            agg[g].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open("kernel_stats_by_grid_%s.csv" % name, "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "grid_threads", "workgroup", "launches", "avg_ms", "min_ms"])
+        for k, v in sorted(agg.items()):
+            if sum(v) > 0.2:
+                w.writerow([k[0], k[1], k[2], len(v), round(sum(v) / len(v), 4), round(min(v), 4)])
+PY
+rm -rf trace trace4b pmc_fetch pmc_write pmc_fetch4b pmc_write4b 2>/dev/null
 ls -la $OUT

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--no-run-table", action="store_true")
     ap.add_argument("--narrow", action="store_true", help="the 32-bit engine (needs --log2n <= 31), for comparison")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--sweep-ep-blocks", default="", help="measurement build: count kernel ms per FMXW_EP_BLOCKS value "
+                    "(and 'group' = the group-per-pattern kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = L.lib()
@@ -56,6 +58,20 @@ def main():
         torch.cuda.synchronize()
         kms.append(float(lib.fmx_last_kernel_ms(h)))
     count_steps = int(lib.fmx_last_steps(h))
+    sweep = {}
+    for v in [x for x in a.sweep_ep_blocks.split(",") if x]:
+        if v == "group":
+            os.environ["FMXW_R_COUNT_GROUP"] = "1"
+        else:
+            os.environ["FMXW_EP_BLOCKS"] = v
+        ms = []
+        for _ in range(a.reps + 1):
+            count()
+            torch.cuda.synchronize()
+            ms.append(float(lib.fmx_last_kernel_ms(h)))
+        sweep[v] = round(min(ms[1:]), 4)
+        os.environ.pop("FMXW_R_COUNT_GROUP", None)
+        os.environ.pop("FMXW_EP_BLOCKS", None)
     assert bool(((e - s) >= 1).all()) and lib.fmx_stream_status(h) == 0
     k = min(a.locate_patterns, npat)
     offh = torch.empty(k + 1, dtype=torch.int64, device=dev)
@@ -96,7 +112,7 @@ def main():
         "level": a.level, "index_bytes": idx.heap_size(), "build_ms": round(float(lib.fmx_build_ms(h)), 1),
         "build_wall_s": round(wall, 2),
         "count": {"patterns": npat, "m": m, "kernel_ms": round(cm, 4), "pattern_chars_per_s": npat * m / (cm / 1e3),
-                  "steps": count_steps},
+                  "steps": count_steps, "sweep_ms": sweep},
         "locate": {"patterns": k, "hits": total, "call_ms": round(call_ms, 4), "walk_kernel_ms": round(lm, 4),
                    "hits_per_s": total / (call_ms / 1e3), "lf_steps": loc_steps,
                    "steps_per_hit": round(loc_steps / max(total, 1), 3)}}))

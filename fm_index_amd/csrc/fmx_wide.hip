@@ -16,6 +16,7 @@
 
 #define FMXW_BLOCK 256
 #define FMXW_MAX_BLOCKS 2048
+#define FMXW_EP_BLOCKS 1024u     // RLFM count, endpoint per lane: grid cap (as the 32-bit engine's ep_blocks)
 
 static inline unsigned fmxw_grid(uint64_t units) {
   uint64_t blocks = (units * FMX_GROUP + FMXW_BLOCK - 1) / FMXW_BLOCK;
@@ -1195,6 +1196,190 @@ __device__ __forceinline__ uint64_t fmxw_r_lane_lf(const FmxWideDev &w, uint64_t
   else st = fmxw_bits_lane_select(bv, lo);
   return f + row - st;
 }
+// ---- RLFM count with an interval ENDPOINT per lane (round 5; the shape of the 32-bit engine's fmx_count_ep_kernel, fmx_ep.h) ----
+// The group-per-pattern kernel above keeps one or two lines in flight per group through four dependent stages (B, S level
+// 0, S level 1, B' select).  Here lane 2q / 2q+1 of a group own the s / e end of the group's q-th pattern: the probes that
+// need one 16-byte piece (rank1 on B with its superblock base, the selects through the stored positions) are lane-wise --
+// 64 independent requests per wave instruction --, the ranks over the 128-byte records of S go in rounds: for q = 0..7
+// the group broadcasts endpoint q's (record, offset | code), all 8 lanes load their piece of it, and the popcounts are
+// reduced with three DPP adds and handed back to lane q, which adds the 64-bit base of ITS superblock.
+__device__ __forceinline__ uint32_t fmxw_grp_bcast(uint32_t v, uint32_t base, uint32_t q) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + q) << 2), (int)v);
+}
+struct FmxwProbe { uint4 pc; uint64_t pidx, base; uint32_t bit; };
+__device__ __forceinline__ FmxwProbe fmxw_ep_probe_issue(const FmxWideBits &bv, uint64_t i) {
+  FmxwProbe pr;
+  if (i > bv.len) i = bv.len;
+  pr.pidx = fmxw_div3(i >> 5);                        // i / 96
+  pr.bit = (uint32_t)(i - pr.pidx * FMX_BITS_PER_PIECE);
+  FMX_CHECK((pr.pidx >> 3) < bv.nrec && ((pr.pidx >> 3) >> bv.sb_shift) < bv.nsb);
+  pr.pc = bv.rec[pr.pidx];
+  pr.base = bv.base[(pr.pidx >> 3) >> bv.sb_shift];
+  return pr;
+}
+// rank1(i), the bit B[i] and the first one at or after i when it lies in the piece (FMXW_NONE otherwise)
+__device__ __forceinline__ uint64_t fmxw_ep_probe_rank(const FmxwProbe &pr, uint32_t &bit_i, uint64_t &next) {
+  const uint32_t bit = pr.bit;
+  const uint32_t m0 = fmx_lowmask(bit < 32u ? bit : 32u);
+  const uint32_t m1 = bit > 32u ? fmx_lowmask(bit - 32u < 32u ? bit - 32u : 32u) : 0u;
+  const uint32_t m2 = bit > 64u ? fmx_lowmask(bit - 64u) : 0u;
+  const uint32_t c = __popc(pr.pc.y & m0) + __popc(pr.pc.z & m1) + __popc(pr.pc.w & m2);
+  const uint32_t word = bit < 32u ? pr.pc.y : (bit < 64u ? pr.pc.z : pr.pc.w);
+  bit_i = (word >> (bit & 31u)) & 1u;
+  const uint32_t y = pr.pc.y & ~m0, z = pr.pc.z & ~m1, ww = pr.pc.w & ~m2;
+  uint32_t cand = 0xFFFFFFFFu;
+  if (y) cand = (uint32_t)__builtin_ctz(y);
+  else if (z) cand = 32u + (uint32_t)__builtin_ctz(z);
+  else if (ww) cand = 64u + (uint32_t)__builtin_ctz(ww);
+  next = cand != 0xFFFFFFFFu ? pr.pidx * FMX_BITS_PER_PIECE + cand : FMXW_NONE;
+  return pr.base + pr.pc.x + c;
+}
+// one round over a level of S: every lane passes ITS endpoint's position and level code and gets back the rank of the
+// code before that position RELATIVE to the position's superblock (< 2^31: sb_shift <= 31, checked at the launch) and
+// match = [the entry at the position has the code] (bit 31 of the same group sum).  Endpoints dead in every group of the
+// wave are skipped.
+template <int FMT>
+__device__ __forceinline__ void fmxw_ep_round(const uint4 *__restrict__ rec, uint64_t pos, uint32_t code, bool live,
+                                              uint32_t base, uint32_t g, uint32_t &rank, uint32_t &match) {
+  constexpr int SH = (FMT == 3) ? 8 : 7;
+  constexpr uint32_t OM = (FMT == 3) ? 255u : 127u;
+  constexpr uint32_t PER = (FMT == 3) ? 32u : 16u;
+  constexpr int PSH = (FMT == 3) ? 5 : 4;
+  const uint32_t ri = (uint32_t)(pos >> SH), oc = ((uint32_t)pos & OM) | (code << 8);
+  uint32_t bo[8];
+  uint4 p[8];
+  const unsigned long long lv = __ballot(live);
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
+    const uint32_t br = fmxw_grp_bcast(ri, base, q);
+    bo[q] = fmxw_grp_bcast(oc, base, q);
+    p[q] = rec[(size_t)br * 8u + g];
+  }
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
+    const uint32_t off = bo[q] & OM, cd = bo[q] >> 8;
+    const uint32_t mt = fmx_piece_match<FMT>(p[q], cd);
+    int nb = (int)off - (int)(g * PER);
+    nb = nb < 0 ? 0 : (nb > (int)PER ? (int)PER : nb);
+    uint32_t v = __popc(mt & (uint32_t)((1ull << nb) - 1ull));
+    if (FMT == 3) v += (g == cd) ? p[q].x : 0u;
+    else v += (g == (cd >> 1)) ? ((cd & 1u) ? p[q].y : p[q].x) : 0u;
+    v |= (g == (off >> PSH)) ? (((mt >> (off & (PER - 1u))) & 1u) << 31) : 0u;
+    const uint32_t sum = fmx_group_sum(v);
+    if (g == q) { rank = sum & 0x7FFFFFFFu; match = sum >> 31; }
+  }
+}
+// select1(k) by one lane; len when k >= #ones (vers-vecs RsVec::select1)
+__device__ __forceinline__ uint64_t fmxw_ep_select(const FmxWideBits &bv, uint64_t k) {
+  return k < bv.ones ? fmxw_bits_lane_select(bv, k) : bv.len;
+}
+// RLFMIndexBackend::lf_map2 for 8 endpoints per group (rlfmi.rs:135-143): j = b.rank1(i) and the bit b[i] lane-wise; ONE
+// rank chain at lo = b.rank1(i + 1) - 1 gives s.rank(lo, c) and m = [s[lo] == c], so s.rank(j, c) = that + (j > lo ? m : 0)
+// and get_l(i) == c is m (rlfmi.rs:137-138); then bp.select1(cs[c] + nr) and, when m, + i - b.select1(j) (rlfmi.rs:139-141).
+// Dead lanes pass i = 0, c = 0, live = false and ignore the result.
+template <class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_r_ep_lf_map2(const FmxWideDev &w, const GB &gbase, const GK &gk, uint32_t c, uint64_t i,
+                                                      bool live, uint32_t base, uint32_t g) {
+  const FmxwProbe pr = fmxw_ep_probe_issue(w.b, i);
+  uint32_t bit;
+  uint64_t nx;
+  const uint64_t j = fmxw_ep_probe_rank(pr, bit, nx);          // b.rank1(i)            rlfmi.rs:136
+  uint64_t pos = j - 1u + bit;                                 // b.rank1(i + 1) - 1    rlfmi.rs:124
+  uint32_t m = 1u;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    const uint32_t code = (c >> L.shift) & L.mask;
+    uint32_t r = 0, mt = 0;
+    FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
+    if (L.fmt == 3) fmxw_ep_round<3>(L.rec, pos, code, live, base, g, r, mt);
+    else fmxw_ep_round<4>(L.rec, pos, code, live, base, g, r, mt);
+    m &= mt;
+    pos = gbase(l, pos, code) + r;                             // the 64-bit base of the position's superblock
+  }
+  const uint64_t nr = gk(c) + pos + (bit ? 0u : m);            // cs[c] + s.rank(j, c)  rlfmi.rs:137,139
+  const bool need_st = live && m && nx == FMXW_NONE;           // the run start lies before the piece
+  uint64_t f = 0, st = nx;
+  if (w.bp.pos && w.b.pos) {                                   // stored positions: both selects are one load, issued together
+    uint64_t vf = 0, vs = 0;
+    if (live && nr < w.bp.ones) vf = w.bp.pos[nr];
+    if (need_st && j < w.b.ones) vs = w.b.pos[j];
+    f = nr < w.bp.ones ? vf : w.bp.len;
+    if (need_st) st = j < w.b.ones ? vs : w.b.len;
+  } else {
+    if (live) f = fmxw_ep_select(w.bp, nr);                    // bp.select1(cs[c] + nr)
+    if (need_st) st = fmxw_ep_select(w.b, j);
+  }
+  return m ? f + i - st : f;                                   // rlfmi.rs:138-142
+}
+// SearchWrapper::search for a batch (wrapper.rs:103-124) on a wide RLFM index, an interval endpoint per lane.  Pattern
+// slots are dealt to the groups first (slot = pair * ngroups + group), so a batch smaller than the grid has one live
+// lane pair per group and a round costs one record per level.
+template <bool GLDS>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_count_ep_kernel(
+    FmxWideDev w, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
+    const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
+    uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
+  FMXW_GBASES(w, GLDS);
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
+  const uint32_t is_e = g & 1u;
+  const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+  const uint64_t slot = (uint64_t)(g >> 1) * ngroups + (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+  const uint64_t nslots = ngroups * 4u;
+  const uint64_t ptot = npat ? off[npat] : 0;       // symbols the caller declares behind `pat`
+  uint64_t k = slot, pbeg = 0, j = 0, pos = 0, nsteps = 0;
+  bool active = k < npat, fresh = true;
+  uint32_t c = 0;
+  while (__any(active)) {
+    if (active && fresh) {
+      pbeg = off[k];
+      const uint64_t pend = off[k + 1];
+      j = pend - pbeg;
+      bool bad = pend < pbeg || pend > ptot;          // offsets that go backwards or leave the pattern buffer
+      if (s0e0) {                                     // Search::search on an existing Search   wrapper.rs:105-106
+        const uint64_t mine = s0e0[2 * k + is_e], other = s0e0[2 * k + (is_e ^ 1u)];
+        pos = mine;
+        bad |= mine > w.n || other > w.n;             // not a range of this index
+      } else {
+        pos = is_e ? w.n : 0ull;                      // SearchIndexWrapper::search: (0, len)   wrapper.rs:41
+      }
+      if (bad) {                                      // refuse, do not read
+        if (is_e) atomicOr(w.status, 1u << FMX_ERR_ARG);
+        pos = 0; j = 0;
+      }
+      c = j ? fmx_load_sym(pat, w.sym_bytes, pbeg + j - 1) : 0u;   // for c in pattern.iter().rev()   wrapper.rs:108
+      fresh = false;
+    }
+    bool stepping = active && j != 0;
+    if (stepping && c > w.max_character) {            // reference: panic on cs[c]
+      if (is_e) atomicOr(w.status, 1u << FMX_ERR_SYMBOL_RANGE);
+      pos = 0; j = 0; stepping = false;
+    }
+    const uint32_t cn = (stepping && j > 1) ? fmx_load_sym(pat, w.sym_bytes, pbeg + j - 2) : 0u;   // rides along with the probes
+    const uint64_t np = fmxw_r_ep_lf_map2(w, gbase, gk, stepping ? c : 0u, stepping ? pos : 0ull, stepping, base, g);   // wrapper.rs:109-110
+    if (stepping) {
+      pos = np;
+      c = cn;
+      j--;
+      nsteps += is_e ^ 1u;
+    }
+    const uint64_t other = (uint64_t)fmx_dpp_xor1((uint32_t)pos) | ((uint64_t)fmx_dpp_xor1((uint32_t)(pos >> 32)) << 32);
+    if (active && (j == 0 || pos == other)) {         // wrapper.rs:111-113
+      if (is_e) {
+        if (out_e) out_e[k] = pos;
+        if (out_cnt) out_cnt[k] = pos - other;        // wrapper.rs:132-134
+      } else if (out_s) {
+        out_s[k] = pos;
+      }
+      k += nslots;
+      active = k < npat;
+      fresh = true;
+    }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
 // text-order walks, a lane per walk: 64 consecutive hits per wave (the lanes run the same code; the walks differ in
 // length by at most 2^level - 1 steps)
 __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_walk_text_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
@@ -1505,7 +1690,24 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
 #define FMXW_GCNT(GLDS, RL)                                                                                        \
   hipLaunchKernelGGL((fmxw_g_count_kernel<GLDS, RL>), dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,       \
                      d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
-    if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_RLFM); else FMXW_GCNT(false, FMX_KIND_RLFM); }
+#ifdef FMX_MEASURE     // A/B switch of the measurement build: FMXW_R_COUNT_GROUP=1 = the group-per-pattern kernel of round 4
+    const bool r_group = getenv("FMXW_R_COUNT_GROUP") && atoi(getenv("FMXW_R_COUNT_GROUP")) != 0;   // read per launch
+#else
+    constexpr bool r_group = false;
+#endif
+    if (w.kind == FMX_KIND_RLFM && w.sb_shift <= 31u && !r_group) {  // an interval endpoint per lane (32 patterns per block at a time)
+      uint64_t eb = (npat + FMXW_BLOCK / 8 - 1) / (FMXW_BLOCK / 8);
+      uint64_t cap = FMXW_EP_BLOCKS;
+#ifdef FMX_MEASURE
+      if (const char *v = getenv("FMXW_EP_BLOCKS")) cap = (uint64_t)atol(v) > 0 ? (uint64_t)atol(v) : cap;   // read per launch: sweeps
+#endif
+      if (eb > cap) eb = cap;
+#define FMXW_RCNT(GLDS)                                                                                             \
+  hipLaunchKernelGGL(fmxw_r_count_ep_kernel<GLDS>, dim3((unsigned)eb), dim3(FMXW_BLOCK), 0, st, w, d_pat, d_off, npat, \
+                     d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
+      if (w.nsb <= FMXW_GLDS_SB) FMXW_RCNT(true); else FMXW_RCNT(false);
+    }
+    else if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_RLFM); else FMXW_GCNT(false, FMX_KIND_RLFM); }
     else if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_MULTI); else FMXW_GCNT(false, FMX_KIND_MULTI); }
     else if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_FM); else FMXW_GCNT(false, FMX_KIND_FM);
     fmxw_time_end(idx, st);

@@ -310,3 +310,51 @@ def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, d
     cb = ci.search_many(flat=flat2, off=off2)
     assert (cb.s == os2).all() and (cb.e == oe2).all() and not ci.walk_records()
     ci.close()
+
+
+# Round 5: RLFM count on the wide engine runs with an interval endpoint per lane (fmxw_r_count_ep_kernel).  Batches far
+# larger than the grid's slots (every lane pair refills many times), batches smaller than one block, one pattern, dense
+# B / B' (no stored positions: lane-wise record search) and sparse ones, one / two / three wavelet levels, a symbol outside
+# the alphabet (status word, not a crash), and ranges that are not ranges of the index.
+@pytest.mark.parametrize("n,sigma,mean_run,dtype", [
+    (70001, 4, 12, np.uint8), (50001, 20, 1, np.uint8), (45000, 255, 2, np.uint8), (30000, 1000, 11, np.uint16),
+    (40001, 70000, 1, np.uint32)])
+def test_wide_rlfm_count_endpoint_per_lane(n, sigma, mean_run, dtype):
+    t = _runs_text(n, sigma, 410 + n % 89, mean_run, dtype)
+    gi = F.RLFMIndex(F.Text.with_max_character(t, sigma), force_wide=True)
+    oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, kind="rlfm")
+    assert gi.is_wide()
+    for npat, m, seed in ((300000, 6, 3), (1, 9, 4), (5, 3, 5), (33, 40, 6), (4097, 1, 7)):
+        flat, off, _ = W.substring_patterns_np(t, npat, m, seed)
+        gb = gi.search_many(flat=flat, off=off)
+        os_, oe = oi.count_batch(flat, off)
+        assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts == oe - os_).all(), (npat, m)
+    flat, off = _ragged(200000, 11, sigma, 9, dtype)                # random symbols: most patterns end early, empty ones
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    # refinement from given ranges (wrapper.rs:105-106), the whole-index range and empty ranges among them
+    k = 5000
+    s0 = (W.splitmix64_np(21, 0, k) % np.uint64(n + 1)).astype(np.uint64)
+    e0 = np.minimum(s0 + (W.splitmix64_np(22, 0, k) % np.uint64(2000)), np.uint64(n)).astype(np.uint64)
+    s0[:3], e0[:3] = 0, n
+    se = np.stack([s0, e0], axis=1).reshape(-1).copy()
+    one = ((W.splitmix64_np(23, 0, k) % np.uint64(min(sigma, 200))) + np.uint64(1)).astype(dtype)
+    off1 = np.arange(k + 1, dtype=np.uint64)
+    ref = gi.search_many(flat=one, off=off1, s0e0=se)
+    rs, re_ = oi.count_batch(one, off1, s0e0=se)
+    assert (ref.s == rs).all() and (ref.e == re_).all()
+    if sigma < 255 or dtype != np.uint8:
+        bad = np.array([1, 1, sigma + 1], dtype=dtype)              # the search starts at the pattern's last symbol
+        with pytest.raises(F.Error) as ei:
+            gi.search_many(flat=bad, off=np.array([0, 3], np.uint64))
+        assert ei.value.code == L.ERR_SYMBOL_RANGE
+    se_bad = np.array([0, n + 5], dtype=np.uint64)
+    with pytest.raises(F.Error) as ei:
+        gi.search_many(flat=one[:1], off=off1[:2], s0e0=se_bad)
+    assert ei.value.code == L.ERR_ARG
+    flat, off, _ = W.substring_patterns_np(t, 100, 5, 8)            # the status word was cleared
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    gi.close()

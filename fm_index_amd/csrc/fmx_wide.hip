@@ -1271,6 +1271,41 @@ __device__ __forceinline__ void fmxw_ep_round(const uint4 *__restrict__ rec, uin
     if (g == q) { rank = sum & 0x7FFFFFFFu; match = sum >> 31; }
   }
 }
+// the same round for get_l + lf_map (fm_index.rs:82-91): the level code is READ at the position (WaveletMatrix::get) and
+// the rank is of that code
+template <int FMT>
+__device__ __forceinline__ void fmxw_ep_round_access(const uint4 *__restrict__ rec, uint64_t pos, bool live, uint32_t base,
+                                                     uint32_t g, uint32_t &rank, uint32_t &code) {
+  constexpr int SH = (FMT == 3) ? 8 : 7;
+  constexpr uint32_t OM = (FMT == 3) ? 255u : 127u;
+  constexpr uint32_t PER = (FMT == 3) ? 32u : 16u;
+  constexpr int PSH = (FMT == 3) ? 5 : 4;
+  const uint32_t ri = (uint32_t)(pos >> SH), of = (uint32_t)pos & OM;
+  uint32_t bo[8];
+  uint4 p[8];
+  const unsigned long long lv = __ballot(live);
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
+    const uint32_t br = fmxw_grp_bcast(ri, base, q);
+    bo[q] = fmxw_grp_bcast(of, base, q);
+    p[q] = rec[(size_t)br * 8u + g];
+  }
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++) {
+    if (!(lv & (0x0101010101010101ull << q))) continue;
+    const uint32_t off = bo[q];
+    const uint32_t cd = fmx_group_sum((g == (off >> PSH)) ? fmx_piece_code<FMT>(p[q], off & (PER - 1u)) : 0u);
+    const uint32_t mt = fmx_piece_match<FMT>(p[q], cd);
+    int nb = (int)off - (int)(g * PER);
+    nb = nb < 0 ? 0 : (nb > (int)PER ? (int)PER : nb);
+    uint32_t v = __popc(mt & (uint32_t)((1ull << nb) - 1ull));
+    if (FMT == 3) v += (g == cd) ? p[q].x : 0u;
+    else v += (g == (cd >> 1)) ? ((cd & 1u) ? p[q].y : p[q].x) : 0u;
+    const uint32_t sum = fmx_group_sum(v);
+    if (g == q) { rank = sum; code = cd; }
+  }
+}
 // select1(k) by one lane; len when k >= #ones (vers-vecs RsVec::select1)
 __device__ __forceinline__ uint64_t fmxw_ep_select(const FmxWideBits &bv, uint64_t k) {
   return k < bv.ones ? fmxw_bits_lane_select(bv, k) : bv.len;
@@ -1313,11 +1348,49 @@ __device__ __forceinline__ uint64_t fmxw_r_ep_lf_map2(const FmxWideDev &w, const
   }
   return m ? f + i - st : f;                                   // rlfmi.rs:138-142
 }
-// SearchWrapper::search for a batch (wrapper.rs:103-124) on a wide RLFM index, an interval endpoint per lane.  Pattern
+// FMIndexBackend / FMIndexMultiPiecesBackend::lf_map2 for 8 endpoints per group (fm_index.rs:93-95, multi_pieces.rs:147-153):
+// one rank round per wavelet level
+template <bool MP, class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_g_ep_lf_map2(const FmxWideDev &w, const GB &gbase, const GK &gk, uint32_t c, uint64_t i,
+                                                      bool live, uint32_t base, uint32_t g) {
+  uint64_t pos = i;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    const uint32_t code = (c >> L.shift) & L.mask;
+    uint32_t r = 0, mt = 0;
+    FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
+    if (L.fmt == 3) fmxw_ep_round<3>(L.rec, pos, code, live, base, g, r, mt);
+    else fmxw_ep_round<4>(L.rec, pos, code, live, base, g, r, mt);
+    pos = gbase(l, pos, code) + r;
+  }
+  uint64_t r = gk(c) + pos;
+  if (MP && c == 0u) r = fmxw_multi_zero(w, i, r);
+  return r;
+}
+// get_l + lf_map for 8 walks per group (fm_index.rs:82-91): access + rank along the same positions
+template <bool MP, class GB, class GK>
+__device__ __forceinline__ uint64_t fmxw_g_ep_lf_map(const FmxWideDev &w, const GB &gbase, const GK &gk, uint64_t i, bool live,
+                                                     uint32_t base, uint32_t g) {
+  uint64_t pos = i;
+  uint32_t sym = 0;
+  for (uint32_t l = 0; l < w.nlevels; l++) {
+    const FmxWideLevel &L = w.lv[l];
+    uint32_t r = 0, code = 0;
+    FMX_CHECK((pos >> (L.fmt == 3 ? 8 : 7)) < L.nrec);
+    if (L.fmt == 3) fmxw_ep_round_access<3>(L.rec, pos, live, base, g, r, code);
+    else fmxw_ep_round_access<4>(L.rec, pos, live, base, g, r, code);
+    sym |= code << L.shift;
+    pos = gbase(l, pos, code) + r;
+  }
+  uint64_t r = gk(sym) + pos;                                  // fm_index.rs:86-91
+  if (MP && sym == 0u) r = fmxw_multi_zero(w, i, r);
+  return r;
+}
+// SearchWrapper::search for a batch (wrapper.rs:103-124) on a wide generic index (KD: FM, RLFM, multi-pieces), an interval endpoint per lane.  Pattern
 // slots are dealt to the groups first (slot = pair * ngroups + group), so a batch smaller than the grid has one live
 // lane pair per group and a round costs one record per level.
-template <bool GLDS>
-__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_count_ep_kernel(
+template <bool GLDS, int KD>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_ep_kernel(
     FmxWideDev w, const void *__restrict__ pat, const uint64_t *__restrict__ off, uint64_t npat,
     const uint64_t *__restrict__ s0e0, uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e,
     uint64_t *__restrict__ out_cnt, uint64_t *__restrict__ steps_out) {
@@ -1357,7 +1430,9 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_count_ep_kernel(
       pos = 0; j = 0; stepping = false;
     }
     const uint32_t cn = (stepping && j > 1) ? fmx_load_sym(pat, w.sym_bytes, pbeg + j - 2) : 0u;   // rides along with the probes
-    const uint64_t np = fmxw_r_ep_lf_map2(w, gbase, gk, stepping ? c : 0u, stepping ? pos : 0ull, stepping, base, g);   // wrapper.rs:109-110
+    uint64_t np;                                      // wrapper.rs:109-110
+    if constexpr (KD == FMX_KIND_RLFM) np = fmxw_r_ep_lf_map2(w, gbase, gk, stepping ? c : 0u, stepping ? pos : 0ull, stepping, base, g);
+    else np = fmxw_g_ep_lf_map2<KD == FMX_KIND_MULTI>(w, gbase, gk, stepping ? c : 0u, stepping ? pos : 0ull, stepping, base, g);
     if (stepping) {
       pos = np;
       c = cn;
@@ -1376,6 +1451,48 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_r_count_ep_kernel(
       active = k < npat;
       fresh = true;
     }
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+
+// get_sa for a batch of rows on a generic FM / multi-pieces index with text-order samples, A WALK PER LANE (round 5): a
+// wave takes 64 consecutive hits through the walk together -- the phase probe of the start row lane-wise, then LF steps
+// (one access + rank round per level and group of eight walks, fmxw_ep_round_access) while any lane has steps to go (a walk
+// is SA[row] mod 2^level steps long), the final probe and the sample lane-wise.  64 lines in flight per wave in every
+// stage; the four-walks-per-group kernel above had 32 and ran at 0.42 of the request ceiling with 117 VGPRs.
+template <bool GLDS, bool MP>
+__global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_walk_text_ep_kernel(FmxWideDev w, uint64_t total, uint64_t *__restrict__ io,
+                                                                          uint64_t *__restrict__ steps_out) {
+  FMXW_GBASES(w, GLDS);
+  const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, base = lane & ~7u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t nsteps = 0;
+  for (uint64_t h0 = wave * 64u; h0 < total; h0 += nwaves * 64u) {
+    const uint64_t h = h0 + lane;
+    const bool in = h < total;
+    uint64_t row = in ? io[h] : 0ull;
+    const bool bad = in && row >= w.n;              // not a row of this index: refuse, do not read
+    const bool ok = in && !bad;
+    if (bad) atomicOr(w.status, 1u << FMX_ERR_ARG);
+    if (!ok) row = 0;
+    uint64_t r0;
+    uint32_t ph = fmxw_phase_probe(w, row, r0);
+    if (!ok) ph = 0;
+    nsteps += ph;
+    uint32_t left = ph;
+    while (__any(left != 0u)) {                     // None: i = lf_map(i); steps += 1        fm_index.rs:134-137
+      const bool live = left != 0u;
+      const uint64_t nr = fmxw_g_ep_lf_map<MP>(w, gbase, gk, live ? row : 0ull, live, base, g);
+      if (live) { row = nr; left--; }
+    }
+    if (ph) {                                       // the final row is a phase-0 row: its sample's index
+      [[maybe_unused]] const uint32_t p2 = fmxw_phase_probe(w, row, r0);
+      FMX_CHECK(p2 == 0u);
+    }
+    uint64_t v = (ok ? w.samples[r0] : 0ull) + ph;  // Some(sa) => (sa + steps) % len        fm_index.rs:131-132
+    if (v >= w.n) v -= w.n;
+    if (in) io[h] = ok ? v : ~0ull;
   }
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
@@ -1681,6 +1798,17 @@ static void fmxw_time_end(const fmx_index *idx, hipStream_t st) {
   }
 }
 
+// A/B switch of the measurement build (read per launch): FMXW_R_COUNT_GROUP=1 = round 4's group-per-pattern count and
+// four-walks-per-group text-order walk of the generic kernels; the shipped library reads no environment
+static inline bool fmxw_env_group() {
+#ifdef FMX_MEASURE
+  const char *v = getenv("FMXW_R_COUNT_GROUP");
+  return v && atoi(v) != 0;
+#else
+  return false;
+#endif
+}
+
 int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_off, uint64_t npat,
                       const uint64_t *d_s0e0, uint64_t *d_s, uint64_t *d_e, uint64_t *d_cnt, hipStream_t st) {
   if (npat == 0) return FMX_OK;
@@ -1690,22 +1818,20 @@ int fmxw_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d
 #define FMXW_GCNT(GLDS, RL)                                                                                        \
   hipLaunchKernelGGL((fmxw_g_count_kernel<GLDS, RL>), dim3(fmxw_grid(npat)), dim3(FMXW_BLOCK), 0, st, w, d_pat,       \
                      d_off, npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
-#ifdef FMX_MEASURE     // A/B switch of the measurement build: FMXW_R_COUNT_GROUP=1 = the group-per-pattern kernel of round 4
-    const bool r_group = getenv("FMXW_R_COUNT_GROUP") && atoi(getenv("FMXW_R_COUNT_GROUP")) != 0;   // read per launch
-#else
-    constexpr bool r_group = false;
-#endif
-    if (w.kind == FMX_KIND_RLFM && w.sb_shift <= 31u && !r_group) {  // an interval endpoint per lane (32 patterns per block at a time)
+    const bool r_group = fmxw_env_group();
+    if (w.sb_shift <= 31u && !r_group) {              // an interval endpoint per lane (32 patterns per block at a time)
       uint64_t eb = (npat + FMXW_BLOCK / 8 - 1) / (FMXW_BLOCK / 8);
       uint64_t cap = FMXW_EP_BLOCKS;
 #ifdef FMX_MEASURE
       if (const char *v = getenv("FMXW_EP_BLOCKS")) cap = (uint64_t)atol(v) > 0 ? (uint64_t)atol(v) : cap;   // read per launch: sweeps
 #endif
       if (eb > cap) eb = cap;
-#define FMXW_RCNT(GLDS)                                                                                             \
-  hipLaunchKernelGGL(fmxw_r_count_ep_kernel<GLDS>, dim3((unsigned)eb), dim3(FMXW_BLOCK), 0, st, w, d_pat, d_off, npat, \
-                     d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
-      if (w.nsb <= FMXW_GLDS_SB) FMXW_RCNT(true); else FMXW_RCNT(false);
+#define FMXW_RCNT(GLDS, KD)                                                                                         \
+  hipLaunchKernelGGL((fmxw_g_count_ep_kernel<GLDS, KD>), dim3((unsigned)eb), dim3(FMXW_BLOCK), 0, st, w, d_pat, d_off,  \
+                     npat, d_s0e0, d_s, d_e, d_cnt, idx->timing == 1 ? idx->d_steps : nullptr)
+      if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_RCNT(true, FMX_KIND_RLFM); else FMXW_RCNT(false, FMX_KIND_RLFM); }
+      else if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_RCNT(true, FMX_KIND_MULTI); else FMXW_RCNT(false, FMX_KIND_MULTI); }
+      else if (w.nsb <= FMXW_GLDS_SB) FMXW_RCNT(true, FMX_KIND_FM); else FMXW_RCNT(false, FMX_KIND_FM);
     }
     else if (w.kind == FMX_KIND_RLFM) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_RLFM); else FMXW_GCNT(false, FMX_KIND_RLFM); }
     else if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GCNT(true, FMX_KIND_MULTI); else FMXW_GCNT(false, FMX_KIND_MULTI); }
@@ -1753,7 +1879,14 @@ int fmxw_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t
       else hipLaunchKernelGGL(fmxw_r_walk_kernel<false>, dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps);
     } else if (w.kind == FMX_KIND_RLFM) {
       if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALK(true, FMX_KIND_RLFM); else FMXW_GWALK(false, FMX_KIND_RLFM);
-    } else if (w.phase) {                           // FM / multi-pieces with text-order samples: four walks per group
+    } else if (w.phase && !fmxw_env_group()) {      // FM / multi-pieces with text-order samples: a walk per lane
+      uint64_t blocks = (total + FMXW_BLOCK - 1) / FMXW_BLOCK;
+      if (blocks > FMXW_MAX_BLOCKS * 2) blocks = FMXW_MAX_BLOCKS * 2;
+#define FMXW_GWALKE(GLDS, MPF)                                                                                      \
+      hipLaunchKernelGGL((fmxw_g_walk_text_ep_kernel<GLDS, MPF>), dim3((unsigned)blocks), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps)
+      if (w.kind == FMX_KIND_MULTI) { if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALKE(true, true); else FMXW_GWALKE(false, true); }
+      else if (w.nsb <= FMXW_GLDS_SB) FMXW_GWALKE(true, false); else FMXW_GWALKE(false, false);
+    } else if (w.phase) {                           // measurement builds: round 4's four walks per group
       const unsigned grid = fmxw_grid((total + 3) / 4);
 #define FMXW_GWALKT(GLDS, MPF)                                                                                      \
       hipLaunchKernelGGL((fmxw_g_walk_text_kernel<GLDS, MPF>), dim3(grid), dim3(FMXW_BLOCK), 0, st, w, total, d_pos, steps)

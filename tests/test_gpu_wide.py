@@ -312,7 +312,7 @@ def test_wide_rlfm_equals_the_oracle_on_small_texts(n, sigma, level, mean_run, d
     ci.close()
 
 
-# Round 5: RLFM count on the wide engine runs with an interval endpoint per lane (fmxw_r_count_ep_kernel).  Batches far
+# Round 5: RLFM count on the wide engine runs with an interval endpoint per lane (fmxw_g_count_ep_kernel<RLFM>).  Batches far
 # larger than the grid's slots (every lane pair refills many times), batches smaller than one block, one pattern, dense
 # B / B' (no stored positions: lane-wise record search) and sparse ones, one / two / three wavelet levels, a symbol outside
 # the alphabet (status word, not a crash), and ranges that are not ranges of the index.
@@ -357,4 +357,57 @@ def test_wide_rlfm_count_endpoint_per_lane(n, sigma, mean_run, dtype):
     gb = gi.search_many(flat=flat, off=off)
     os_, oe = oi.count_batch(flat, off)
     assert (gb.s == os_).all() and (gb.e == oe).all()
+    gi.close()
+
+
+# Round 5: the generic wide kernels (byte alphabets, multi-pieces) count with an interval endpoint per lane
+# (fmxw_g_count_ep_kernel) and walk a lane per hit through text-order samples (fmxw_g_walk_text_ep_kernel).  Batches far
+# beyond the grid (refills / many 64-hit tickets per wave), tiny ones, every row, rows that are not rows of the index,
+# one / two / three wavelet levels, u16 symbols, several pieces (end markers: multi_pieces.rs:131-153).
+@pytest.mark.parametrize("n,sigma,level,dtype,pieces", [
+    (60001, 255, 2, np.uint8, 0), (40000, 20, 3, np.uint8, 0), (30011, 12, 1, np.uint8, 0), (50000, 1000, 2, np.uint16, 0),
+    (45000, 100, 2, np.uint8, 37), (20000, 12, 4, np.uint8, 5)])
+def test_wide_generic_lane_kernels(n, sigma, level, dtype, pieces):
+    t = ((W.splitmix64_np(77 + n % 31, 0, n) % np.uint64(sigma)) + np.uint64(1)).astype(dtype)
+    if pieces:                                                      # tests/testutil/mod.rs:7-32: no leading zero, no double
+        cut = 2 + 2 * (W.splitmix64_np(5, 0, pieces - 1) % np.uint64((n - 6) // 2)).astype(np.int64)   # zero, nonzero at n - 2
+        t[cut] = 0
+    t[-1] = 0
+    tx = F.Text.with_max_character(t, sigma)
+    if pieces:
+        gi = F.FMIndexMultiPiecesWithLocate(tx, level, force_wide=True)
+        oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level, kind="multi")
+    else:
+        gi = F.FMIndexWithLocate(tx, level, force_wide=True)
+        oi = O.OracleIndex(t if dtype == np.uint8 else t.astype(np.uint32), sigma, level=level)
+    assert gi.is_wide() and gi.text_order() == (1 <= gi.level() <= 4)   # generic levels (sigma > 7): phase pieces
+    for npat, m, seed in ((300000, 4, 3), (1, 6, 4), (7, 2, 5), (4097, 1, 7)):
+        flat, off, _ = W.substring_patterns_np(t, npat, m, seed)
+        gb = gi.search_many(flat=flat, off=off)
+        os_, oe = oi.count_batch(flat, off)
+        assert (gb.s == os_).all() and (gb.e == oe).all() and (gb.counts == oe - os_).all(), (npat, m)
+    flat, off = _ragged(150000, 9, min(sigma, 255), 9, np.uint8)
+    gb = gi.search_many(flat=flat, off=off)
+    os_, oe = oi.count_batch(flat, off)
+    assert (gb.s == os_).all() and (gb.e == oe).all()
+    rows = np.arange(n, dtype=np.uint64)
+    want = oi.get_sa(rows).astype(np.uint64)
+    lib = gi._lib
+    lib.fmx_set_timing(gi.handle(), 1)
+    _, pos = gi.locate_many(np.array([0], np.uint64), np.array([n], np.uint64))
+    steps = int(lib.fmx_last_steps(gi.handle()))
+    lib.fmx_set_timing(gi.handle(), 0)
+    assert (pos == want).all()
+    if gi.text_order():
+        assert steps == int((want & np.uint64((1 << gi.level()) - 1)).sum())       # a walk is SA[row] mod 2^level steps
+    # many short intervals (ragged tickets), in batch order
+    k = 20000
+    s = (W.splitmix64_np(31, 0, k) % np.uint64(n)).astype(np.uint64)
+    e = np.minimum(s + (W.splitmix64_np(32, 0, k) % np.uint64(9)), np.uint64(n)).astype(np.uint64)
+    goff, gpos = gi.locate_many(s, e)
+    assert (gpos == np.concatenate([want[int(a):int(b)] for a, b in zip(s, e)])).all()
+    assert (gi.get_sa(rows[::7][:5000]) == want[::7][:5000]).all()
+    with pytest.raises(F.Error):
+        gi.get_sa(np.array([3, n, 5], dtype=np.uint64))
+    assert (gi.get_sa(rows[:100]) == want[:100]).all()
     gi.close()

@@ -1835,6 +1835,7 @@ struct FmxTune {
                                  // round-4 pair expand + f3t / lane kernel chosen from the batch average
   long adj_clusters = 4;         // ... a ticket of at most this many runs of consecutive rows is walked a lane per hit
   long rl_ep_min = 1l << 18;     // RLFM: one walk per lane from this many hits
+  bool rl_unified = false;       // measurement builds (FMX_RL_UNIFIED=1): the RLFM lane kernel in one launch (slices expanded in LDS)
   long rl_lane_avg = 2;          // ... with the run table: a lane per walk on consecutive hits from this many hits per pattern
   long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
 };
@@ -2364,6 +2365,29 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix
     out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[h], nsteps);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
+#ifdef FMX_MEASURE
+// The same walk in ONE launch (round 5, measurement builds only: FMX_RL_UNIFIED=1): a block expands its slice of at most
+// 4096 hits in LDS (fmx_expand_slice: no rows array, no allocation, no expand launch) and its lanes walk them.  Measured
+// against the two launches (profiles/r05/locate_mix_rlfm_one_launch.jsonl): repetitive text 10^3 x 10^5 hits 1.31 against
+// 1.15 ms, mixed 1.48 against 1.20, config 4b 9.8 against 8.2 ms per batch -- the walk is bound by memory latency at full
+// occupancy, and a block that waits for its slice's expansion is 16 waves that do not walk; on a random text with the run
+// table (4.4 against 4.8 ms) it wins.  Not shipped.
+template <bool TEXT>
+__global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void fmx_locate_rl_u_kernel(
+    FmxDev ix, const uint64_t *__restrict__ s, const uint64_t *__restrict__ e, const uint64_t *__restrict__ off, uint64_t npat,
+    uint64_t total, uint32_t hits_per_block, uint64_t *__restrict__ out_pos, uint64_t *__restrict__ steps_out) {
+  __shared__ FmxSliceLds L;
+  const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
+  if (blo >= total) return;                           // block-uniform
+  const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
+  FMX_CHECK(hits_per_block <= FMX_U_SLICE);
+  if (fmx_expand_slice(L, s, e, off, npat, total, ix.n, blo, bn)) atomicOr(ix.status, 1u << FMX_ERR_ARG);
+  uint64_t nsteps = 0;
+  for (uint32_t x = threadIdx.x; x < bn; x += FMX_LOC_BLOCK)
+    out_pos[blo + x] = fmx_rlfm_lane_get_sa<TEXT>(ix, L.rows[x], nsteps);
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
+#endif
 
 // ---- locate launch helpers (c = FmxLocateCall) ----
 #define FMX_LOCQ_LAUNCH(c, gr, thr, hpb, chunk, Q, TEXT)                                             \
@@ -2515,6 +2539,13 @@ bool fmx_locate_is_one_launch(const fmx_index *idx) {
   return idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic && idx->dev.phase && idx->dev.walk &&
          tn.walk_records && tn.unified && !tn.alt;
 }
+#ifdef FMX_MEASURE
+// RLFM with the run table, batches that take the lane kernel (fmx_launch_locate below): one launch when asked for
+static bool fmx_locate_rl_one_launch(const fmx_index *idx, const FmxDev &dv, const FmxTune &tn, uint64_t npat, uint64_t total) {
+  return idx->kind == FMX_KIND_RLFM && !tn.generic && !tn.alt && tn.rl_unified && dv.lfrun && tn.walk_records && tn.wc &&
+         fmx_select_mode(idx, dv) > 0 && total >= (uint64_t)tn.rl_ep_min && total / npat >= (uint64_t)tn.rl_lane_avg;
+}
+#endif
 int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                       uint64_t npat, const uint64_t *d_off, uint64_t total, uint64_t *d_pos,
                       hipStream_t st, uint32_t *rows_ws) {
@@ -2525,7 +2556,12 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   const FmxTune tn = fmx_tune();
   const bool dna = idx->kind == FMX_KIND_FM && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic;
   // the default DNA index (text order + walk records): ONE kernel that expands its slices itself -- no rows array
-  const bool unified = fmx_locate_is_one_launch(idx);
+#ifdef FMX_MEASURE
+  const bool rl_unified = fmx_locate_rl_one_launch(idx, dv, tn, npat, total);
+#else
+  constexpr bool rl_unified = false;
+#endif
+  const bool unified = fmx_locate_is_one_launch(idx) || rl_unified;
   // every other path: rows in their own read-only buffer (the walk's loads never alias its stores).  The caller's
   // workspace when there is one (nothing but kernel launches then: graph-capturable, no pool shared between streams)
   uint32_t *rows = unified ? nullptr : rows_ws;
@@ -2554,6 +2590,12 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
   done = fmx_measure_locate(c, tn, sm);              // the alternative kernels, when one was asked for
 #endif
   if (done) {
+#ifdef FMX_MEASURE
+  } else if (rl_unified) {
+    const unsigned gr = (unsigned)((total + FMX_U_SLICE - 1) / FMX_U_SLICE);
+    if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_u_kernel<true>, dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, dv, d_s, d_e, d_off, npat, total, (uint32_t)FMX_U_SLICE, d_pos, c.steps);
+    else hipLaunchKernelGGL(fmx_locate_rl_u_kernel<false>, dim3(gr), dim3(FMX_LOC_BLOCK), 0, st, dv, d_s, d_e, d_off, npat, total, (uint32_t)FMX_U_SLICE, d_pos, c.steps);
+#endif
   } else if (unified) {
     // slices of at most 4096 hits (their rows live in LDS), at least 256 of them -- 512 for large batches: two
     // blocks per CU (64 VGPRs) -- and tickets of 64 hits once every wave gets that many (below: one hit per walk

@@ -615,7 +615,25 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
       const uint64_t A = ((uint64_t)(uint32_t)__shfl((int)(a >> 32), l) << 32) | (uint32_t)__shfl((int)a, l);
       const uint64_t O = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), l) << 32) | (uint32_t)__shfl((int)o, l);
       const uint64_t N = ((uint64_t)(uint32_t)__shfl((int)(cnt >> 32), l) << 32) | (uint32_t)__shfl((int)cnt, l);
-      for (uint64_t t = lane; t < N; t += 64) out_pos[O + t] = (T)(A + t);
+      // 16-byte stores (4 rows of 32 bits / 2 of 64) between a scalar head up to the first aligned slot and a scalar
+      // tail: a wave writes 1 KB per instruction instead of 256 bytes (config 4b, 750 hits per pattern: the expansion
+      // of its 7.9e8 rows was 1.03 ms of the 8.2 ms batch)
+      constexpr uint32_t V = 16u / (uint32_t)sizeof(T);
+      const uint64_t mis = (((uintptr_t)(out_pos + O)) / sizeof(T)) & (V - 1u);
+      const uint64_t h = (V - mis) & (V - 1u);       // rows in front of the first 16-byte slot (N > 32 > h)
+      if (lane < h) out_pos[O + lane] = (T)(A + lane);
+      const uint64_t nv = (N - h) / V;
+      for (uint64_t q = lane; q < nv; q += 64) {
+        const uint64_t t = h + q * V;
+        if constexpr (V == 4u) {
+          const uint32_t r = (uint32_t)(A + t);
+          *reinterpret_cast<uint4 *>(out_pos + O + t) = make_uint4(r, r + 1u, r + 2u, r + 3u);
+        } else {
+          *reinterpret_cast<ulonglong2 *>(out_pos + O + t) = make_ulonglong2(A + t, A + t + 1u);
+        }
+      }
+      const uint64_t done = h + nv * V;
+      if (lane < N - done) out_pos[O + done + lane] = (T)(A + done + lane);
     }
   }
 }

@@ -8,10 +8,13 @@
 // First half of the file: one-level alphabets (max_character <= 7, DNA); second half: the generic kernels for
 // larger byte alphabets (the multi-ary wavelet levels of the 32-bit engine with per-level bases and a 64-bit K[]).
 //
-// Shapes: a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel); locate: the text-order
-// walk over walk records with the hit queue, distributed walk state and write-combining ring of the 32-bit engine's
-// fmx_locate_f3t_kernel (one-level indexes), a group per walk (row-order samples, generic indexes), a lane per walk
-// (RLFM with the run table).  Third part: RLFMIndex (B / B' with 64-bit superblock bases, S on the generic levels).
+// Shapes: one-level indexes -- a group owns a pattern (count: the shape of the 32-bit engine's fmx_count_f3_kernel); locate:
+// the text-order walk over walk records with the hit queue, distributed walk state and write-combining ring of the
+// 32-bit engine's fmx_locate_f3t_kernel.  Generic indexes (round 5) -- count with an interval endpoint per lane
+// (fmxw_g_count_ep_kernel: FM, RLFM, multi-pieces; the shape of fmx_ep.h), text-order locate a walk per lane
+// (fmxw_g_walk_text_ep_kernel; RLFM with the run table: fmxw_r_walk_text_kernel / fmxw_r_walk_kernel), a group per walk for
+// row-order samples; the group-per-pattern / four-walks-per-group kernels of round 4 stay for the measurement build's A/B
+// (FMXW_R_COUNT_GROUP=1).  Third part: RLFMIndex (B / B' with 64-bit superblock bases, S on the generic levels).
 #include "fmx_device.h"
 
 #define FMXW_BLOCK 256

@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 # (The CPU baseline's threads are placed by the oracle itself, per batch -- OMP_PROC_BIND would narrow the
 # affinity mask of this Python thread for good, and with it the mask of every HIP / RCCL helper thread.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+#  * dmabuf IPC between the ranks of one node (the host driver of this pool supports nothing else: without it RCCL fails
+#    with `hipIpcGetMemHandle: invalid argument`); exported on the pool's boxes already, kept when the caller set it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 from benchmarks.legs.common import (PRETOUCH, Workload, counts_sha256, flush_c_stdio, golden_counts_sha,  # noqa: E402,F401

@@ -98,13 +98,14 @@ __global__ __launch_bounds__(FMX_BLOCK, 8) void fmx_count_kernel(
   uint32_t nsteps = 0;
 
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   while (active) {
     if (fresh) {
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = (uint32_t)(pend - pbeg);
       // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
-      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      const bool badoff = pend < pbeg || pbeg < pmin || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
       if (badoff) {
         if (g == 0) atomicOr(ix.status, 1u << FMX_ERR_ARG);
         j = 0;
@@ -175,10 +176,11 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_empty_kernel(
     const uint64_t *__restrict__ off, uint64_t npat, const uint64_t *__restrict__ s0e0,
     uint64_t *__restrict__ out_s, uint64_t *__restrict__ out_e, uint64_t *__restrict__ out_cnt) {
   const uint64_t ptot = npat ? off[npat] : 0;
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < npat; k += stride) {
     const uint64_t a = off[k], b = off[k + 1];
-    if (b < a || b > ptot || (s0e0 && (s0e0[2 * k] | s0e0[2 * k + 1]) != 0)) {
+    if (b < a || a < pmin || b > ptot || (s0e0 && (s0e0[2 * k] | s0e0[2 * k + 1]) != 0)) {
       atomicOr(status, 1u << FMX_ERR_ARG);
     } else if (b > a && fmx_load_sym(pat, sym_bytes, b - 1) > max_character) {   // the first step's cs[c]
       atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
     pbeg[q] = 0; j[q] = 0; s[q] = 0; e[q] = 0; c[q] = 0;
   }
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   while (any) {
 #pragma unroll
     for (int q = 0; q < PPG; q++) {
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
         j[q] = (uint32_t)(pend - pbeg[q]);
         // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on;
         // kept AHEAD of the table lookup: a trailing fix-up of (s, e, j) cost the pair kernel 30 %)
-        const bool badoff = pend < pbeg[q] || pend > ptot || pend - pbeg[q] > 0xFFFFFFFFull;
+        const bool badoff = pend < pbeg[q] || pbeg[q] < pmin || pend > ptot || pend - pbeg[q] > 0xFFFFFFFFull;
         if (badoff) {
           if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
           j[q] = 0;
@@ -354,13 +357,14 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
   uint32_t c2 = 0, c1 = 0;   // c2 = last unread symbol, c1 = the one before it
   uint32_t nsteps = 0;
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   while (active) {
     if (fresh) {
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = (uint32_t)(pend - pbeg);
       // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
-      const bool badoff = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      const bool badoff = pend < pbeg || pbeg < pmin || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
       if (badoff) {
         if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
         j = 0;
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_ep_kernel(
   const uint64_t slot = (uint64_t)(g >> 1) * ngroups + (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3);
   const uint64_t nslots = ngroups * 4u;
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
 
   uint64_t k = slot, pbeg = 0;
   bool active = k < npat, fresh = true;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_ep_kernel(
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = (uint32_t)(pend - pbeg);
-      bool bad = pend < pbeg || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      bool bad = pend < pbeg || pbeg < pmin || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
       if (s0e0) {            // Search::search on an existing Search (wrapper.rs:105-106)
         const uint64_t mine = s0e0[2 * k + is_e], other = s0e0[2 * k + (is_e ^ 1u)];
         pos = (uint32_t)mine;
@@ -2193,13 +2198,13 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
   __shared__ uint16_t u_walks[2][FMX_U_SLICE];        // ... their unfinished walks, round by round
   __shared__ uint8_t u_wlen[FMX_U_SLICE];             // ... and the length of every finished one
-  __shared__ unsigned int u_ntl, u_nal, u_nwalks[2];
+  __shared__ unsigned int u_ntl, u_nal, u_nwalks[2], u_ppos;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
   const uint32_t bn = (uint32_t)(total - blo < hits_per_block ? total - blo : hits_per_block);
   FMX_CHECK(hits_per_block <= FMX_U_SLICE && chunk >= 8u && chunk <= FMX_LCHUNK);
-  if (tid == 0) { u_ntl = 0; u_nal = 0; }
+  if (tid == 0) { u_ntl = 0; u_nal = 0; u_ppos = FMX_NOCHUNK; }
   if (fmx_expand_slice(L, s, e, off, npat, total, n, blo, bn)) atomicOr(status, 1u << FMX_ERR_ARG);
   uint32_t *const u_rows = L.rows;
   // ---- tickets: the adjacency of their rows ----
@@ -2211,10 +2216,25 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     const bool adjacent = chunk == FMX_LCHUNK && fmx_ticket_breaks(r, in, lane) < adj_clusters;
     if (lane == 0) {
       if (adjacent) u_alist[atomicAdd(&u_nal, 1u)] = (uint16_t)t;
-      else u_tlist[atomicAdd(&u_ntl, 1u)] = (uint16_t)t;
+      else {
+        const uint32_t p = atomicAdd(&u_ntl, 1u);
+        u_tlist[p] = (uint16_t)t;
+        if (t == ntick - 1u && bn % chunk != 0u) u_ppos = p;   // the slice's PARTIAL ticket (the last slice of the batch only)
+      }
     }
   }
   __syncthreads();
+  // The list fills in the order the waves' atomics land, but the hit queue takes an invalid hit index for "the slice has
+  // run dry" (FmxHitQueue::take32): a partial ticket must be the LAST one drawn, as it was when tickets were drawn in
+  // ascending order -- a wave that held it as c0 in front of a full c1 would retire its walk slots on the ticket's missing
+  // tail and never walk c1.  One thread moves it to the end of the list; the barrier at the top of
+  // fmx_f3t_walk orders the swap before any draw.
+  if (tid == 0 && u_ppos != FMX_NOCHUNK) {
+    const uint32_t p = u_ppos, last = u_ntl - 1u;
+    const uint16_t a = u_tlist[p];
+    u_tlist[p] = u_tlist[last];
+    u_tlist[last] = a;
+  }
   // ---- phase A: a lane per walk on the tickets of adjacent rows, in ROUNDS of one record visit per live walk ----
   // A wave that walks its 64 hits to the end runs as long as its longest walk -- 2^level - 1 visits -- with half of its
   // lanes done after the first visit and three quarters after the second (phases are uniform): config 3b spent 709 vector

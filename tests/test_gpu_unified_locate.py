@@ -73,6 +73,33 @@ def test_mixed_batches_equal_the_oracle(singles, longs, long_len, empties):
     gi.close()
 
 
+@pytest.mark.parametrize("longs,long_len", [(0, 0), (6, 3000)])
+def test_partial_last_ticket_of_scattered_batches(longs, long_len):
+    """>= 3e5 scattered singletons (tickets of 64 hits, Q = 4, the ring) whose total is NOT a multiple of
+    64 -- remainders below and above the 32 walk slots of a wave -- so that the last slice holds a partial ticket among
+    more than 16 non-adjacent ones.  The ticket list fills in the order the waves' atomics land; the partial ticket must
+    still be the last one drawn or a wave retires its slots on the ticket's missing tail and drops the ticket behind it.
+    Repeated launches (the order is a race), with and without long intervals in the last slice."""
+    n = (1 << 17) + 311
+    _, gi, oi = _index(n)
+    want = oi.get_sa(np.arange(n)).astype(np.uint64)
+    rng = np.random.default_rng(longs + 11)
+    for rem in (1, 9, 31, 32, 33, 63):
+        s, e = _mixed_intervals(n, rng, 300000, longs, long_len)
+        extra = (rem - int((e - s).sum())) % 64
+        xs = rng.integers(0, n, extra).astype(np.uint64)
+        s, e = np.concatenate([s, xs]), np.concatenate([e, xs + np.uint64(1)])
+        assert int((e - s).sum()) % 64 == rem
+        for _ in range(4):
+            # another order every time: the device scratch the positions land in still holds the previous launch's
+            # (correct) positions, and an unwritten slot must not read as a right answer
+            p = rng.permutation(len(s))
+            s, e = s[p], e[p]
+            off, pos = gi.locate_many(s, e)
+            assert (np.asarray(pos, np.uint64) == _expect(want, s, e)).all(), rem
+    gi.close()
+
+
 def test_more_than_2_20_patterns_mostly_empty():
     """1.3 M patterns (two rounds of the 1024-probe bracket search), almost all of them empty, the hits in clusters: a
     slice's first pattern sits thousands of patterns behind the previous slice's last"""

@@ -44,6 +44,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from benchmarks.legs.common import (PRETOUCH, Workload, counts_sha256, flush_c_stdio, golden_counts_sha,  # noqa: E402,F401
                                     golden_key, pretouch_device, ranges_sha256)
+from benchmarks.legs.cabi import config5_cabi_leg, results_on_host_leg  # noqa: E402
 from benchmarks.legs.cpu import cpu_baseline, host_cpu  # noqa: E402,F401
 from benchmarks.legs.dist import dist_report, open_process_group, rccl_1rank_leg  # noqa: E402
 from benchmarks.legs.extra import accel_legs, d2h_leg, ic_ab_leg, rlfm_leg, wide_leg  # noqa: E402
@@ -397,6 +398,20 @@ def run(args, world, pmc=None, pmc_seconds=0.0, pmc31=None):
             out["incl_d2h"] = {"error": repr(ex)}
     lap("incl_d2h")
 
+    # ---- SURVEY 8(d)'s protocol (patterns resident, results landed in host memory) and config 5 behind the C ABI
+    # (one host caller, fmx_count_batch_multi over the replicas of the index) ----
+    if single and not args.no_d2h:
+        try:
+            results_on_host_leg(out, wl, args)
+        except Exception as ex:  # noqa: BLE001
+            out["results_on_host"] = {"error": repr(ex)}
+    if single and wl.dna and not args.no_config5 and not args.no_d2h:
+        try:
+            config5_cabi_leg(out, wl, args, dev)
+        except Exception as ex:  # noqa: BLE001
+            out["config5_cabi"] = {"error": repr(ex)}
+    lap("results_on_host + config5_cabi")
+
     # ---- CPU baseline of the headline: rank 0 only, after the timed regions.  At N > 1 the other ranks wait in a
     # gloo barrier (a socket wait): an RCCL barrier would have their host threads spin on a stream and take CPU time
     # from the very cores the baseline is measured on ----
@@ -542,6 +557,9 @@ def headline(out, detail_path):
         "rccl_1rank_value": _get(out, "rccl_1rank", "value"),
         "value_auto": out.get("value_auto"),
         "value_incl_d2h": out.get("value_incl_d2h"),
+        "value_results_on_host": out.get("value_results_on_host"),
+        "config5_cabi_g1_value": _get(out, "config5_cabi", "g1", "value"),
+        "config5_cabi_matches_golden": _get(out, "config5_cabi", "matches_golden"),
         "wide_value": _get(out, "wide", "value"),
         "wide_locate_hits_per_s": _get(out, "wide", "locate", "hits_per_s"),
         "wide_build_ms": _get(out, "wide", "build_ms"),

@@ -43,6 +43,14 @@ SETS = {
 N_CU, N_SIMD, N_XCD = 256, 1024, 8
 
 
+def kernel_key(kn, grid):
+    """kernels by name; the one-launch DNA walk kernel also by grid (config 3 and config 3b run under one name)"""
+    key = kn.split("(")[0].replace("void ", "")[:100]
+    if "fmx_locate_f3u_kernel" in key and grid:
+        key += " @grid %s" % grid
+    return key
+
+
 def run_pass(name, counters, child, work):
     d = os.path.join(work, name)
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
@@ -63,7 +71,7 @@ def run_pass(name, counters, child, work):
                 kn = r.get("Kernel_Name", "")
                 if "fmx_" not in kn:
                     continue
-                key = kn.split("(")[0].replace("void ", "")[:100]
+                key = kernel_key(kn, r.get("Grid_Size"))
                 vals[key][r["Counter_Name"]].append(float(r.get("Counter_Value", 0) or 0))
     dur = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace*.csv"), recursive=True):
@@ -71,7 +79,7 @@ def run_pass(name, counters, child, work):
             for r in csv.DictReader(fh):
                 kn = r.get("Kernel_Name", "")
                 if "fmx_" in kn:
-                    dur[kn.split("(")[0].replace("void ", "")[:100]].append(
+                    dur[kernel_key(kn, r.get("Grid_Size"))].append(
                         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     shutil.rmtree(d, ignore_errors=True)
     return (vals, dur), None
@@ -142,7 +150,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="dna")
     ap.add_argument("--workload", default="dna")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06"))
     # (the TA / TCP sets take > 10 minutes per pass on this profiler: ask for them by name)
     ap.add_argument("--sets", default="ea_widths,l2,ea_wr,sq_insts,sq_states,utcl1")
     ap.add_argument("--child-args", default="", help="extra flags for bench.py --pmc-child, comma-separated: no-rlfm,no-accel")

@@ -99,15 +99,17 @@ def stored_traffic(workload_key, leg):
     return ent.get(leg)
 
 
-def set_miss_lines(r, traffic_bytes, stream_bytes, fetch_kb_raw=None):
+def set_miss_lines(r, traffic_bytes, stream_bytes, fetch_kb_raw=None, requests=None):
     """requests that left the L2 per second against the rate of dependent random requests the memory
-    system sustains.  FETCH_SIZE tallies 64 B per fabric request whatever its size (calibrated:
-    profiles/microbench/gather_fetch_calibration_r02.txt -- 16-, 32-, 64- and 128-byte random requests
-    all report 64 B), so requests = raw FETCH_SIZE / 64 B; without the raw counter, (traffic -
-    streamed bytes) / 128 B."""
+    system sustains.  `requests`: the counted read requests of the launch (TCC_EA0_RDREQ); the streamed part
+    (patterns, offsets: whole 128-byte lines) is taken out.  Without the counted figure: raw FETCH_SIZE / 64 B
+    (FETCH_SIZE tallies 64 B per fabric request whatever its size, profiles/microbench/gather_fetch_calibration_r02.txt),
+    or (traffic - streamed bytes) / 128 B."""
     t_s = r["avg_kernel_ms"] / 1e3
     r["stream_bytes"] = stream_bytes
-    if fetch_kb_raw:
+    if requests is not None:
+        req = max(requests - stream_bytes / float(LINE), 0.0)
+    elif fetch_kb_raw:
         req = max(fetch_kb_raw * 1024.0 - stream_bytes / 2.0, 0.0) / 64.0     # streamed lines are 128-B requests too
     else:
         req = max(traffic_bytes - stream_bytes, 0) / LINE
@@ -116,40 +118,59 @@ def set_miss_lines(r, traffic_bytes, stream_bytes, fetch_kb_raw=None):
     r["frac_of_gather_ceiling"] = round(req / t_s / (GATHER_CEILING_GLINES * 1e9), 4)
 
 
+def fabric_read_bytes(ent):
+    """read bytes that left the L2s in one launch, from the COUNTED request widths: 32 B x TCC_EA0_RDREQ_32B + 64 B x
+    _64B + 128 B x _128B (requests of no counted width -- none on these kernels -- are priced at 64 B, what FETCH_SIZE
+    assumes for every request).  None when the launch's widths were not collected."""
+    w = ent.get("rdreq") if ent else None
+    if not w or w.get("all") is None:
+        return None
+    r32, r64, r128 = w.get("32B") or 0.0, w.get("64B") or 0.0, w.get("128B") or 0.0
+    other = max(w["all"] - r32 - r64 - r128, 0.0)
+    return 32.0 * r32 + 64.0 * (r64 + other) + 128.0 * r128
+
+
 def price_traffic(roof, ent):
-    """FABRIC bytes of one launch from its counters (`ent`: fetch_kb_raw, write_kb, source) -> roof["traffic"],
-    "achieved", "frac".  gfx950's FETCH_SIZE reports 64 B per fabric request whatever its size.  A request
-    for a whole 128-byte record therefore moved twice what the counter says; a lane-wise probe (<= 16 bytes:
-    B / B' pieces, select blocks, positions, phase pieces, samples) moved the 64 B it reports.  The census
-    (same kernels, every request logged with its width) gives the share of record requests among the
-    requests of this launch, and
-        traffic = FETCH_SIZE x (1 + record share) + WRITE_SIZE.
-    For the all-record kernels (DNA count) that is the guide's 2 x FETCH_SIZE; for the run-length kernels,
-    half of whose requests are 16-byte probes, 2 x FETCH_SIZE overstated the bytes -- it is
-    kept as `traffic_upper`.  Without a census the upper bound is all there is, and `frac` says so."""
-    if not roof or not ent or not ent.get("fetch_kb_raw"):
+    """FABRIC bytes of one launch from its counters -> roof["traffic"], "achieved", "frac".  ONE basis for every
+    roofline object (round 6): the read requests of the launch counted BY WIDTH
+    (`ent["rdreq"]`: TCC_EA0_RDREQ and its _32B / _64B / _128B parts, one rocprofv3 pass) priced at their widths, plus
+    WRITE_SIZE:
+        traffic = 32 B x RDREQ_32B + 64 B x RDREQ_64B + 128 B x RDREQ_128B + WRITE_SIZE.
+    (Rounds 2-5 priced FETCH_SIZE -- 64 B per request whatever its width on gfx950 -- with the census's share of
+    128-byte record requests, which undercounts: a lane-wise 16-byte probe still fetches its 128-byte line, and the
+    counters say every fabric read of these kernels is 128 bytes wide.)  An entry without widths (profiles/traffic.json
+    of an earlier round: FETCH_SIZE only) is priced by the guide's rule, 2 x FETCH_SIZE + WRITE_SIZE, and the basis
+    says so."""
+    if not roof or not ent or not (ent.get("fetch_kb_raw") or ent.get("rdreq")):
         return
     t_s = roof["avg_kernel_ms"] / 1e3
-    fetch, write = ent["fetch_kb_raw"] * 1024.0, (ent.get("write_kb") or 0.0) * 1024.0
-    rec, prb = roof.get("requested_records"), roof.get("requested_probes")
-    share = rec / (rec + prb) if rec is not None and prb is not None and rec + prb > 0 else None
-    upper = int(2.0 * fetch + write)
-    tb = int(fetch * (1.0 + share) + write) if share is not None else upper
+    write = (ent.get("write_kb") or 0.0) * 1024.0
+    rd = fabric_read_bytes(ent)
+    requests = None
+    if rd is not None:
+        w = ent["rdreq"]
+        requests = float(w["all"])
+        tb = int(rd + write)
+        roof["read_request_widths"] = {k: int(w.get(k) or 0) for k in ("32B", "64B", "128B")}
+        roof["read_requests"] = int(requests)
+        roof["share_of_128B_requests"] = round((w.get("128B") or 0.0) / requests, 4) if requests else None
+        roof["basis"] = ("FABRIC bytes (what left the L2s, Infinity-Cache hits INCLUDED -- not all of it reached HBM, see "
+                         "hbm_frac_min): read requests counted by width (32 B x TCC_EA0_RDREQ_32B + 64 B x _64B + 128 B x "
+                         "_128B) + WRITE_SIZE, over the kernel time")
+        fetch_kb = requests * 64.0 / 1024.0            # what FETCH_SIZE would have reported (= RDREQ x 64 B)
+    else:
+        fetch_kb = ent["fetch_kb_raw"]
+        tb = int(2.0 * fetch_kb * 1024.0 + write)
+        roof["basis"] = ("FABRIC bytes by the guide's rule for gfx950: 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE tallies 64 B "
+                         "per 128-byte request; no request widths were collected for this entry)")
     roof["traffic"] = tb
-    roof["traffic_upper"] = upper
-    roof["record_share_of_requests"] = round(share, 4) if share is not None else None
     roof["traffic_source"] = ent.get("source")
     if ent.get("kernel"):
         roof["traffic_kernel"] = ent["kernel"]
-    roof["fetch_kb_raw"], roof["write_kb"] = ent["fetch_kb_raw"], ent.get("write_kb")
+    roof["fetch_kb_raw"], roof["write_kb"] = round(fetch_kb, 1), ent.get("write_kb")
     roof["achieved"] = round(tb / t_s / 1e9, 1)
     roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-    roof["frac_upper"] = round(upper / t_s / 1e9 / HBM_PEAK_GBS, 4)
-    set_miss_lines(roof, tb, roof.get("stream_bytes", 0), ent["fetch_kb_raw"])
-    roof["basis"] = ("FABRIC bytes (what left the L2s: TCC_EA0 requests, Infinity-Cache hits INCLUDED -- not all of it "
-                     "reached HBM, see hbm_frac_min): FETCH_SIZE x (1 + share of 128-byte record requests, from the "
-                     "census) + WRITE_SIZE, over the kernel time" if share is not None else
-                     "UPPER BOUND on the fabric bytes: 2 x FETCH_SIZE + WRITE_SIZE (no census of request widths in this run)")
+    set_miss_lines(roof, tb, roof.get("stream_bytes", 0), fetch_kb, requests)
     if roof.get("min_bytes"):
         roof["traffic_over_min_bytes"] = round(tb / roof["min_bytes"], 3)
     ic_split(roof)
@@ -356,9 +377,12 @@ def run_pmc_passes(args, npat=None, count_only=False, seed7=True):
     if count_only and seed7:
         child += ["--pattern-seed", "7"]
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # two passes (TCC has 4 counter slots: MI355X_MICROARCH.md "rocprofv3 PMC slots"): the read requests that left the
+        # L2s with their widths, and WRITE_SIZE.  FETCH_SIZE itself is TCC_EA0_RDREQ x 64 B on gfx950 (the guide's HBM
+        # section) -- the first pass holds it, with what it cannot say: how wide the requests were
+        for counter, names in (("RDREQ", RDREQ_COUNTERS), ("WRITE_SIZE", ["WRITE_SIZE"])):
             d = os.path.join(work, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
+            cmd = [exe, "--pmc"] + names + ["--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
             # its own session: on a timeout the WHOLE group goes (rocprofv3 and the `bench.py --pmc-child` under
             # it, which holds a 2^30 index) and is waited for before the timed run starts
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -379,7 +403,8 @@ def run_pmc_passes(args, npat=None, count_only=False, seed7=True):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     rows.extend(csv.DictReader(fh))
-            raw[counter] = pmc_aggregate(rows, counter)
+            for nm in names:
+                raw[nm] = pmc_aggregate(rows, nm)
     except OSError as ex:
         return {}, "rocprofv3 pass did not start: %r" % (ex,)
     finally:
@@ -389,22 +414,38 @@ def run_pmc_passes(args, npat=None, count_only=False, seed7=True):
         return pmc_per_dispatch(raw.get(counter, {}), subs, which)
     for leg, subs in PMC_LEGS.items():
         which = PMC_WHICH.get(leg, "largest")
-        kn, fetch_kb = per_dispatch("FETCH_SIZE", subs, which)
-        _, write_kb = per_dispatch("WRITE_SIZE", subs, which)
-        if kn is None or fetch_kb is None:
-            continue
-        # gfx950: FETCH_SIZE tallies 128-byte requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section;
-        # re-calibrated below on a kernel with a known byte count); WRITE_SIZE reads exactly
-        out[leg] = {"fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb or 0.0, 1),
-                    "kernel": kn.split("(")[0].replace("void ", ""),
-                    "source": "live rocprofv3 --pmc passes of this run"}
+        ent = pmc_entry(raw, subs, which)
+        if ent is not None:
+            out[leg] = ent
     # calibration in our own access pattern: k_mwm_pieces<3> reads the n-byte BWT exactly once
-    kn, kb = per_dispatch("FETCH_SIZE", ["k_mwm_pieces<3"])
+    c = pmc_entry(raw, ["k_mwm_pieces<3"], "largest")
     cal = None
-    if kb:
-        cal = {"kernel": "k_mwm_pieces<3>", "fetch_kb_raw": round(kb, 1), "expected_bytes": 1 << args.log2n,
-               "bytes_per_reported_byte": round((1 << args.log2n) / (kb * 1024), 3)}
+    if c:
+        rd = fabric_read_bytes(c)
+        cal = {"kernel": "k_mwm_pieces<3>", "fetch_kb_raw": c["fetch_kb_raw"], "read_request_widths": c["rdreq"],
+               "expected_bytes": 1 << args.log2n,
+               "bytes_per_reported_byte": round((1 << args.log2n) / (c["fetch_kb_raw"] * 1024), 3),     # FETCH_SIZE's factor
+               "bytes_per_width_priced_byte": round((1 << args.log2n) / rd, 3) if rd else None}       # ~1.0: widths are exact
     return out, cal
+
+
+RDREQ_COUNTERS = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+
+
+def pmc_entry(raw, subs, which):
+    """the counters of one leg's dominant kernel, per launch: {"rdreq": {"all", "32B", "64B", "128B"}, "fetch_kb_raw" (=
+    RDREQ x 64 B: what FETCH_SIZE reports on gfx950), "write_kb", "kernel", "source"}; None when the kernel is not in
+    the trace.  `raw`: {counter name: pmc_aggregate(...)}."""
+    kn, allreq = pmc_per_dispatch(raw.get("TCC_EA0_RDREQ_sum", {}), subs, which)
+    if kn is None or allreq is None:
+        return None
+    w = {"all": round(allreq, 1)}
+    for tag in ("32B", "64B", "128B"):
+        _, v = pmc_per_dispatch(raw.get("TCC_EA0_RDREQ_%s_sum" % tag, {}), subs, which)
+        w[tag] = round(v or 0.0, 1)
+    _, write_kb = pmc_per_dispatch(raw.get("WRITE_SIZE", {}), subs, which)
+    return {"rdreq": w, "fetch_kb_raw": round(allreq * 64.0 / 1024.0, 1), "write_kb": round(write_kb or 0.0, 1),
+            "kernel": kn.split("(")[0].replace("void ", ""), "source": "live rocprofv3 --pmc passes of this run"}
 
 
 
@@ -414,9 +455,9 @@ def apply_pmc(out, pmc, cal):
         out["pmc"] = {"status": cal}
     elif pmc:
         out["pmc"] = {"status": "ok", "calibration": cal,
-                      "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel-trace only) over "
-                              "`bench.py --pmc-child`; gfx950: FETCH_SIZE reports 64 B per request -> x (1 + share of "
-                              "128-byte record requests), see roofline.basis"}
+                      "note": "separate rocprofv3 --pmc passes (kernel-trace only) over `bench.py --pmc-child`: "
+                              "TCC_EA0_RDREQ with its _32B / _64B / _128B parts (FETCH_SIZE = RDREQ x 64 B on gfx950: "
+                              "the widths say what the requests really moved), and WRITE_SIZE; see roofline.basis"}
     else:
         out["pmc"] = {"status": "no counters collected"}
     redo(out.get("roofline"), pmc.get("dna_count"))

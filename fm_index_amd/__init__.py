@@ -21,7 +21,7 @@ from . import _lib as L
 
 __all__ = ["Text", "Error", "FMIndex", "FMIndexWithLocate", "RLFMIndex", "RLFMIndexWithLocate",
            "FMIndexMultiPieces", "FMIndexMultiPiecesWithLocate", "Search", "Match", "SearchBatch",
-           "pack_patterns"]
+           "Replicas", "pack_patterns"]
 
 
 class Error(Exception):
@@ -319,6 +319,17 @@ class _Index:
     def handle(self):
         return self._h
 
+    def device(self):
+        return int(self._lib.fmx_device(self._h))
+
+    def replicate(self, device=None):
+        """fmx_replicate: a second handle with its own copy of every HBM array, on `device` (default: this index's);
+        device-to-device copies, nothing is rebuilt ("index replicated on every GPU")."""
+        other = self.__class__.__new__(self.__class__)
+        other._lib, other._h, other._dtype = self._lib, C.c_void_p(), self._dtype
+        _check(self._lib.fmx_replicate(self._h, self.device() if device is None else int(device), C.byref(other._h)))
+        return other
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.fmx_free(self._h)
@@ -329,6 +340,63 @@ class _Index:
             self.close()
         except Exception:
             pass
+
+
+class Replicas:
+    """One batch over several replicas of an index from ONE host caller (include/fmx.h: fmx_count_batch_multi /
+    fmx_locate_batch_multi; BASELINE config 5).  Patterns are independent (wrapper.rs:103-124), so pattern k of N goes to
+    replica floor(k * G / N) and every shard's results land in place in the caller's arrays: the same SearchBatch /
+    (offsets, positions) as search_many / locate_many on one handle, bit for bit."""
+
+    def __init__(self, indexes):
+        self.indexes = list(indexes)
+        assert self.indexes, "at least one index"
+        self._lib = self.indexes[0]._lib
+        self._dtype = self.indexes[0]._dtype
+
+    @classmethod
+    def of(cls, index, devices):
+        """`index` stays replica 0; one more replica per entry of `devices`"""
+        return cls([index] + [index.replicate(d) for d in devices])
+
+    def __len__(self):
+        return len(self.indexes)
+
+    def _handles(self):
+        return (C.c_void_p * len(self.indexes))(*[ix.handle().value for ix in self.indexes])
+
+    def shard_range(self, nitems, r):
+        lo, hi = C.c_uint64(0), C.c_uint64(0)
+        self._lib.fmx_shard_range(nitems, len(self.indexes), r, C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    def search_many(self, patterns=None, flat=None, off=None, s0e0=None):
+        if flat is None:
+            flat, off = pack_patterns(patterns, self._dtype)
+        flat = _sym(flat, self._dtype)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        npat = len(off) - 1
+        s = np.zeros(max(npat, 1), dtype=np.uint64)
+        e = np.zeros(max(npat, 1), dtype=np.uint64)
+        c = np.zeros(max(npat, 1), dtype=np.uint64)
+        se = None if s0e0 is None else np.ascontiguousarray(s0e0, dtype=np.uint64)
+        _check(self._lib.fmx_count_batch_multi(self._handles(), len(self.indexes), _p(flat), _p(off), npat, _p(se),
+                                               _p(s), _p(e), _p(c)))
+        return SearchBatch(self, s[:npat], e[:npat], c[:npat])
+
+    def locate_many(self, s, e):
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        e = np.ascontiguousarray(e, dtype=np.uint64)
+        off = np.zeros(len(s) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(e - s, dtype=np.uint64)
+        pos = np.zeros(max(int(off[-1]), 1), dtype=np.uint64)
+        _check(self._lib.fmx_locate_batch_multi(self._handles(), len(self.indexes), _p(s), _p(e), len(s), _p(off), _p(pos)))
+        return off, pos[:int(off[-1])]
+
+    def close(self, keep_first=False):
+        for ix in self.indexes[1 if keep_first else 0:]:
+            ix.close()
+        self.indexes = self.indexes[:1] if keep_first else []
 
 
 class FMIndex(_Index):

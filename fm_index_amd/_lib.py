@@ -79,6 +79,11 @@ SYMBOLS = [
     ("fmx_locate_batch_ws_dev", _I, [_V, _V, _V, _U64, _V, _U64, _V, _V, _U64, _V]),
     ("fmx_offsets_workspace_bytes", _U64, [_U64]),
     ("fmx_offsets_ws_dev", _I, [_V, _V, _V, _U64, _V, _V, _U64, _V]),
+    ("fmx_replicate", _I, [_V, _I, C.POINTER(_V)]),
+    ("fmx_shard_range", None, [_U64, _U32, _U32, C.POINTER(_U64), C.POINTER(_U64)]),
+    ("fmx_count_batch_multi", _I, [_V, _U32, _V, _V, _U64, _V, _V, _V, _V]),
+    ("fmx_count_batch_multi_resident", _I, [_V, _U32, _V, _V, _U64, _V, _V, _V, _V]),
+    ("fmx_locate_batch_multi", _I, [_V, _U32, _V, _V, _U64, _V, _V]),
     ("fmx_set_timing", None, [_V, _I]),
     ("fmx_last_kernel_ms", _D, [_V]),
     ("fmx_series_kernel_ms", _D, [_V]),

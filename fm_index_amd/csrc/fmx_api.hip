@@ -670,19 +670,31 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   CHECK_IDX(idx);
   if (npat == 0) return FMX_OK;
   if (!pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
-  uint64_t total = pat_off[npat];
-  if (total && !pat) return fail(FMX_ERR_ARG, "pat is NULL");
+  const uint64_t total = pat_off[npat];
+  // The symbols this call reads are pat[first .. total): a caller that hands over a SLICE of a larger batch (entries
+  // a .. b of its offsets with the batch's pattern buffer -- fmx_count_batch_multi's shards) moves and stages that
+  // span only.  The kernels keep the caller's absolute offsets: they get the address the device copy WOULD have if it
+  // began at symbol 0 (never dereferenced below symbol `first`: every pattern's offsets are checked against the span).
+  const uint64_t first = pat_off[0];
+  if (first > total) return fail(FMX_ERR_ARG, "pat_off is not non-decreasing");
+  const uint64_t span = total - first;
+  if (span && !pat) return fail(FMX_ERR_ARG, "pat is NULL");
   const uint32_t sb = idx->sym_bytes;  // device symbol width
-  if (total * sb + npat * 48 + 128 <= kSmallUse && idx->sym_bytes_abi != 8) {
+  if (span * sb + npat * 48 + 128 <= kSmallUse && idx->sym_bytes_abi != 8) {
     if (SmallCtx *sx = small_ctx(idx->device)) {
       Arena a{sx};
       CallStatus cs(sx);
       FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
-      const size_t op = a.take(total * sb ? total * sb : 1), oo = a.take((npat + 1) * 8);
+      const size_t op = a.take(span * sb ? span * sb : 1), oo = a.take((npat + 1) * 8);
       const size_t ose = a.take(s0e0 ? npat * 16 : 0), in_end = a.off;
       const size_t os = a.take(npat * 8), oe = a.take(npat * 8), oc = a.take(npat * 8), ost = a.off;
-      if (total) memcpy(a.host<uint8_t>(op), pat, total * sb);
-      memcpy(a.host<uint8_t>(oo), pat_off, (npat + 1) * 8);
+      if (span) memcpy(a.host<uint8_t>(op), (const uint8_t *)pat + first * sb, span * sb);
+      if (first == 0) {
+        memcpy(a.host<uint8_t>(oo), pat_off, (npat + 1) * 8);
+      } else {                                  // offsets relative to the staged span (an entry below `first` wraps to
+        uint64_t *ho = a.host<uint64_t>(oo);    // a huge value: refused by the kernel like any offset that goes backwards)
+        for (uint64_t k = 0; k <= npat; k++) ho[k] = pat_off[k] - first;
+      }
       if (s0e0) memcpy(a.host<uint8_t>(ose), s0e0, npat * 16);
       FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
       if (int rc = fmx_launch_count(idx, a.dev<uint8_t>(op), a.dev<uint64_t>(oo), npat,
@@ -700,11 +712,11 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   // batches
   std::vector<uint32_t> narrow;
   const uint8_t *src = (const uint8_t *)pat;
-  if (idx->sym_bytes_abi == 8 && total) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
-    narrow.resize((size_t)total);
-    const uint64_t *p64 = (const uint64_t *)pat;
-    for (uint64_t i = 0; i < total; i++) narrow[i] = p64[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p64[i];
-    src = (const uint8_t *)narrow.data();
+  if (idx->sym_bytes_abi == 8 && span) {  // u64 patterns: narrow, saturating so out-of-range stays out of range
+    narrow.resize((size_t)span);
+    const uint64_t *p64 = (const uint64_t *)pat + first;
+    for (uint64_t i = 0; i < span; i++) narrow[i] = p64[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p64[i];
+    src = (const uint8_t *)narrow.data() - first * sb;     // src + first * sb = the first narrowed symbol
   }
   // Page-locked caller arrays (hipHostMalloc / hipHostRegister / torch pin_memory) can be DMA'd in place and are
   // visible to the GPU: the batch goes through a chunk pipeline over three role streams (below) -- DMA upload,
@@ -712,11 +724,11 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   // Built from hipMemcpyAsync alone it was slower than no pipeline at all: every hand-over between a DMA copy and
   // a kernel of the same stream costs tens of microseconds on this runtime (4.0 ms per 2^20 x 32 call with eight
   // chunks, 2.0 ms with two; benchmarks/gpu/pcie_probe.hip, hostpipe_sweep.sh).
-  const size_t b_pat = (size_t)total * sb, b_out = (size_t)npat * 8;
+  const size_t b_pat = (size_t)span * sb, b_out = (size_t)npat * 8;
   // (every array checked over its whole length, with the index's device current; one that is only partly
   // page-locked sends the call down the pageable path)
   const bool all_pinned = idx->sym_bytes_abi != 8 && !idx->timing && npat >= (1u << 16) &&
-                          device_view(pat, b_pat) && device_view(pat_off, (size_t)(npat + 1) * 8) &&
+                          device_view((const uint8_t *)pat + first * sb, b_pat) && device_view(pat_off, (size_t)(npat + 1) * 8) &&
                           (!s0e0 || device_view(s0e0, 2 * b_out)) && (!out_s || device_view(out_s, b_out)) &&
                           (!out_e || device_view(out_e, b_out)) && (!out_count || device_view(out_count, b_out));
   const uint64_t max_ch = 8;
@@ -774,8 +786,8 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
     FMX_HIP_DRAIN(hipMemsetAsync(status_dev(sx), 0, 4, s_k));   // ahead of every search in the search stream
     // the device copy of the symbols keeps the caller's alignment modulo 16, so that both sides of every
     // chunk's copy are aligned alike whatever pa is
-    uint8_t *d_pat_al = d_pat + ((uintptr_t)src & 15u);
-    const uint8_t *v_pat = (const uint8_t *)device_view(src);
+    uint8_t *d_pat_al = d_pat + ((uintptr_t)(src + first * sb) & 15u) - first * sb;   // (virtual: symbol 0 of the caller's buffer)
+    const uint8_t *v_pat = (const uint8_t *)device_view(src + first * sb) - first * sb;
     const uint64_t *v_off = (const uint64_t *)device_view(pat_off);
     const uint64_t *v_se = s0e0 ? (const uint64_t *)device_view(s0e0) : nullptr;
     uint64_t *v_os = out_s ? (uint64_t *)device_view(out_s) : nullptr;
@@ -785,7 +797,7 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       const uint64_t a = cut(k), b = cut(k + 1);
       if (b == a) continue;
       const uint64_t pa = pat_off[a], pb = pat_off[b];
-      if (pb < pa || pb > total) {
+      if (pb < pa || pb > total || pa < first) {
         drain();
         return fail(FMX_ERR_ARG, "pat_off is not non-decreasing");
       }
@@ -876,17 +888,18 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   for (uint64_t k = 0; k < nch; k++) {
     const uint64_t a = npat * k / nch, b = npat * (k + 1) / nch;
     const uint64_t pa = pat_off[a], pb = pat_off[b];
-    if (pb < pa || pb > total) {
+    if (pb < pa || pb > total || pa < first) {
       (void)hipStreamSynchronize(st[0]);
       (void)hipStreamSynchronize(st[1]);
       return fail(FMX_ERR_ARG, "pat_off is not non-decreasing");
     }
     hipStream_t S = st[k & 1];
+    uint8_t *const d_pat0 = d_pat - first * sb;          // (virtual: symbol 0 of the caller's buffer)
     if (pb > pa)
-      FMX_HIP(hipMemcpyAsync(d_pat + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, S));
+      FMX_HIP(hipMemcpyAsync(d_pat0 + pa * sb, src + pa * sb, (size_t)(pb - pa) * sb, hipMemcpyHostToDevice, S));
     if (s0e0)
       FMX_HIP(hipMemcpyAsync(d_se + 2 * a, s0e0 + 2 * a, (size_t)(b - a) * 16, hipMemcpyHostToDevice, S));
-    if (int rc = fmx_launch_count(idx, d_pat, d_off + a, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a,
+    if (int rc = fmx_launch_count(idx, d_pat0, d_off + a, b - a, s0e0 ? d_se + 2 * a : nullptr, d_s + a,
                                   d_e + a, d_c + a, S)) {
       (void)hipStreamSynchronize(st[0]);
       (void)hipStreamSynchronize(st[1]);
@@ -899,13 +912,22 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   return finish_host_call(sx);
 }
 
-int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
-                     const uint64_t *out_off, uint64_t *out_pos) {
+// off[k] -= base, k = 0 .. count (a slice of a larger batch's offsets -> offsets of its own)
+__global__ __launch_bounds__(256) void fmx_rebase_offsets_kernel(uint64_t *__restrict__ off, uint64_t base, uint64_t count) {
+  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= count; j += nth) off[j] -= base;
+}
+// `slice`: out_off[0 .. npat] are entries a .. b of a larger batch's offsets -- the slice's hits are
+// out_pos[out_off[0] .. out_off[npat]) and nothing in front of them is a gap (fmx_locate_batch_multi's shards)
+static int locate_host(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                       const uint64_t *out_off, uint64_t *out_pos, bool slice) {
   CHECK_IDX(idx);
   if (idx->dev.sa_level == FMX_NO_LOCATE) return fail(FMX_ERR_NO_LOCATE);
   if (npat == 0) return FMX_OK;
   if (!s || !e || !out_off) return fail(FMX_ERR_ARG, "NULL argument");
-  uint64_t total = out_off[npat];
+  const uint64_t base = slice ? out_off[0] : 0;
+  if (out_off[npat] < base) return fail(FMX_ERR_ARG, "out_off is not non-decreasing");
+  uint64_t total = out_off[npat] - base;
   if (total == 0) return FMX_OK;
   if (!out_pos) return fail(FMX_ERR_ARG, "out_pos is NULL");
   HostCall hc;
@@ -922,13 +944,66 @@ int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e,
   FMX_HIP(hipMemcpyAsync(d_s, s, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_e, e, b_in, hipMemcpyHostToDevice, S));
   FMX_HIP(hipMemcpyAsync(d_off, out_off, b_in + 8, hipMemcpyHostToDevice, S));
+  if (base) {
+    uint64_t blocks = (npat + 256) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(fmx_rebase_offsets_kernel, dim3((unsigned)blocks), dim3(256), 0, S, d_off, base, npat);
+  }
   if (int rc = fmx_launch_locate(idx, d_s, d_e, npat, d_off, total, d_pos, S, d_rows)) {
     (void)hipStreamSynchronize(S);
     return rc;
   }
-  FMX_HIP(hipMemcpyAsync(out_pos, d_pos, b_pos, hipMemcpyDeviceToHost, S));
+  FMX_HIP(hipMemcpyAsync(out_pos + base, d_pos, b_pos, hipMemcpyDeviceToHost, S));
   return finish_host_call(hc.sx);
 }
+int fmx_locate_batch(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                     const uint64_t *out_off, uint64_t *out_pos) {
+  return locate_host(idx, s, e, npat, out_off, out_pos, false);
+}
+int fmx_locate_batch_slice(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                           const uint64_t *out_off, uint64_t *out_pos) {
+  return locate_host(idx, s, e, npat, out_off, out_pos, true);
+}
+
+// Patterns already RESIDENT on the index's device, results into HOST arrays (SURVEY section 8d's protocol: uploads
+// excluded, "include D2H of results on the GPU side").  Page-locked result arrays are written by the search itself
+// (posted writes over the host link, 24 bytes per pattern); pageable ones go through device scratch and the runtime's
+// copies.  Synchronous, like every host-pointer call.
+int fmx_count_resident_slice(const fmx_index *idx, const void *d_pat, const uint64_t *d_pat_off, uint64_t npat,
+                             const uint64_t *d_s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count) {
+  CHECK_IDX(idx);
+  if (npat == 0) return FMX_OK;
+  if (!d_pat_off) return fail(FMX_ERR_ARG, "pat_off is NULL");
+  const size_t b_out = (size_t)npat * 8;
+  uint64_t *v_s = out_s ? (uint64_t *)device_view(out_s, b_out) : nullptr;
+  uint64_t *v_e = out_e ? (uint64_t *)device_view(out_e, b_out) : nullptr;
+  uint64_t *v_c = out_count ? (uint64_t *)device_view(out_count, b_out) : nullptr;
+  const bool direct = (!out_s || v_s) && (!out_e || v_e) && (!out_count || v_c);
+  HostCall hc;
+  FMX_HIP(hc.open(idx->device, direct ? 256 : 3 * HostCall::pad(b_out)));
+  SmallCtx *sx = hc.sx;
+  hipStream_t S = sx->st;
+  CallStatus cs(sx);
+  FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, S));
+  if (direct) {
+    if (int rc = fmx_launch_count(idx, d_pat, d_pat_off, npat, d_s0e0, v_s, v_e, v_c, S)) {
+      (void)hipStreamSynchronize(S);
+      return rc;
+    }
+    return finish_host_call(sx);
+  }
+  uint64_t *d_s = hc.take<uint64_t>(b_out), *d_e = hc.take<uint64_t>(b_out), *d_c = hc.take<uint64_t>(b_out);
+  if (int rc = fmx_launch_count(idx, d_pat, d_pat_off, npat, d_s0e0, out_s ? d_s : nullptr, out_e ? d_e : nullptr,
+                                out_count ? d_c : nullptr, S)) {
+    (void)hipStreamSynchronize(S);
+    return rc;
+  }
+  if (out_s) FMX_HIP(hipMemcpyAsync(out_s, d_s, b_out, hipMemcpyDeviceToHost, S));
+  if (out_e) FMX_HIP(hipMemcpyAsync(out_e, d_e, b_out, hipMemcpyDeviceToHost, S));
+  if (out_count) FMX_HIP(hipMemcpyAsync(out_count, d_c, b_out, hipMemcpyDeviceToHost, S));
+  return finish_host_call(sx);
+}
+void fmx_set_error_text(const char *text) { g_last_error = text ? text : ""; }
 
 static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const uint64_t *i,
                        uint64_t k, uint64_t *out) {
@@ -1603,6 +1678,118 @@ int fmx_load(const char *path, int device, fmx_index **out) {
   fclose(f);
   if (rc != FMX_OK) { fmx_free(idx); return rc; }
   idx->bytes = h.bytes;  // as reported by the index that was saved
+  *out = idx;
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fmx_replicate: a second handle with its own copy of every HBM array, on any device of the node (SURVEY section 8e:
+// "index replicated on every GPU").  The arrays travel device to device (hipMemcpyPeer over xGMI; staged through a
+// page-locked buffer when the runtime refuses the peer copy) -- no rebuild, no file, no host copy of the text.
+// ---------------------------------------------------------------------------
+namespace {
+hipError_t copy_between_devices(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  if (dst_dev == src_dev) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
+  hipError_t e = hipMemcpyPeer(dst, dst_dev, src, src_dev, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  // through the host, 64 MiB at a time (the current device is dst_dev: the caller's DeviceGuard)
+  void *stage = nullptr;
+  if ((e = hipHostMalloc(&stage, kChunk, hipHostMallocDefault)) != hipSuccess) return e;
+  for (size_t o = 0; o < bytes && e == hipSuccess; o += kChunk) {
+    const size_t m = bytes - o < kChunk ? bytes - o : kChunk;
+    if ((e = hipSetDevice(src_dev)) != hipSuccess) break;
+    e = hipMemcpy(stage, (const uint8_t *)src + o, m, hipMemcpyDeviceToHost);
+    const hipError_t back = hipSetDevice(dst_dev);
+    if (e == hipSuccess) e = back;
+    if (e == hipSuccess) e = hipMemcpy((uint8_t *)dst + o, stage, m, hipMemcpyHostToDevice);
+  }
+  (void)hipHostFree(stage);
+  return e;
+}
+// one array of the source index -> a new allocation on the current device, owned by `idx`
+int replicate_array(fmx_index *idx, const void **field, const void *src, int src_dev, uint64_t bytes) {
+  void *p = nullptr;
+  hipError_t e = fmx_dev_malloc(&p, bytes ? bytes : 8);
+  if (e != hipSuccess) return fmx_hip_fail(e, "fmx_dev_malloc(replica)", __LINE__);
+  if (int rc = fmx_keep(idx, p, bytes)) { (void)hipFree(p); return rc; }
+  *field = p;
+  if ((e = copy_between_devices(p, idx->device, src, src_dev, (size_t)bytes)) != hipSuccess)
+    return fmx_hip_fail(e, "copy of an index array between devices", __LINE__);
+  return FMX_OK;
+}
+}  // namespace
+
+int fmx_replicate(const fmx_index *src, int device, fmx_index **out) {
+  if (!out) return fail(FMX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!src) return fail(FMX_ERR_ARG, "index is NULL");
+  if (src->layout != FMX_LAYOUT)
+    return fail(FMX_ERR_ARG, "the index was made by another build of the library (rebuild libfmx*.so together)");
+  if (int rc = select_device(device)) return rc;
+  DeviceGuard dg;
+  FMX_HIP(dg.set(device));
+  // the source's pending work (a build that has just returned is complete; *_dev launches of the caller may not be)
+  // does not write the index: nothing to wait for
+  fmx_index *idx = (fmx_index *)calloc(1, sizeof(fmx_index));
+  if (!idx) return fail(FMX_ERR_ARG, "out of host memory");
+  *idx = *src;                                   // every scalar field; what a handle OWNS is reset below
+  idx->device = device;
+  idx->d_alloc = nullptr; idx->nalloc = 0; idx->cap_alloc = 0; idx->bytes = 0;
+  idx->h_cs = nullptr; idx->d_text = nullptr; idx->d_sa = nullptr; idx->d_sa64 = nullptr;   // FMX_FLAG_KEEP_SA arrays stay with the source
+  idx->flags &= ~FMX_FLAG_KEEP_SA;
+  idx->timing = 0; idx->ev0 = nullptr; idx->ev1 = nullptr; idx->ev_valid = 0; idx->ev_series = nullptr; idx->series_n = 0;
+  idx->dev.status = nullptr; idx->d_steps = nullptr;
+  int rc = FMX_OK;
+  do {
+    if (src->h_cs) {
+      idx->h_cs = (uint64_t *)calloc(src->max_character + 1, 8);
+      if (!idx->h_cs) { rc = fail(FMX_ERR_ARG, "out of host memory"); break; }
+      memcpy(idx->h_cs, src->h_cs, (src->max_character + 1) * 8);
+    }
+    // pointer fields of the copy are cleared BEFORE anything can fail: fmx_free must never see the source's arrays
+    if (src->is_wide) {
+      WideBlobs bc = wide_blobs(idx->wide, idx->nsamples);
+      for (int b = 0; b < bc.n; b++) *bc.field[b] = nullptr;
+      idx->wide.status = nullptr;
+    } else {
+      Blob bc[64];
+      const int nc = enumerate_blobs(idx->dev, idx->nsamples, bc);
+      for (int b = 0; b < nc; b++) *bc[b].field = nullptr;
+      idx->dev.walk = nullptr;
+    }
+    hipError_t e;
+    if ((e = alloc_handle_words(idx)) != hipSuccess) { rc = fmx_hip_fail(e, "handle resources", __LINE__); break; }
+    if (src->is_wide) {
+      FmxWideDev sw = src->wide;                 // (wide_blobs takes references into the struct it is given)
+      WideBlobs bs = wide_blobs(sw, src->nsamples);
+      // the same fields of the copy, in the same order: presence is decided by the SOURCE's pointers, so enumerate a struct
+      // that still has them and redirect the field addresses into idx->wide
+      FmxWideDev probe = src->wide;
+      WideBlobs bp = wide_blobs(probe, src->nsamples);
+      for (int b = 0; rc == FMX_OK && b < bs.n; b++) {
+        const void **field = (const void **)((uint8_t *)&idx->wide + ((const uint8_t *)bp.field[b] - (const uint8_t *)&probe));
+        rc = replicate_array(idx, field, *bs.field[b], src->device, bs.bytes[b]);
+      }
+      idx->wide.status = idx->dev.status;
+    } else {
+      FmxDev sd = src->dev, probe = src->dev;
+      Blob bs[64], bp[64];
+      const int nb = enumerate_blobs(sd, src->nsamples, bs);
+      (void)enumerate_blobs(probe, src->nsamples, bp);
+      for (int b = 0; rc == FMX_OK && b < nb; b++) {
+        const void **field = (const void **)((uint8_t *)&idx->dev + ((const uint8_t *)bp[b].field - (const uint8_t *)&probe));
+        rc = replicate_array(idx, field, *bs[b].field, src->device, bs[b].bytes);
+      }
+      // walk records: derived data, but copying 1.14 bytes per symbol beats deriving them again
+      if (rc == FMX_OK && src->dev.walk)
+        rc = replicate_array(idx, (const void **)&idx->dev.walk, src->dev.walk, src->device,
+                             ((uint64_t)src->dev.n / FMX_WALK_ROWS + 1u) * 128u);
+    }
+  } while (0);
+  if (rc != FMX_OK) { fmx_free(idx); return rc; }
+  idx->build_ms = 0.0;                           // (idx->bytes = what was copied: the source's FMX_FLAG_KEEP_SA arrays are not)
   *out = idx;
   return FMX_OK;
 }

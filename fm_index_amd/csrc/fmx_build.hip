@@ -1592,41 +1592,81 @@ int fmx_verify_sa_impl(const fmx_index *idx, uint64_t *violations) {
   return FMX_OK;
 }
 
-// idle small-build buffers of every device (include/fmx.h: fmx_release_scratch)
+static void fmx_async_pool_trim(int dev);
 hipError_t fmx_dev_malloc(void **p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
-    if (scratch_drop_current()) e = hipMalloc(p, bytes);
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) fmx_async_pool_trim(dev);   // what the library's stream-ordered pool retains
+    scratch_drop_current();
+    e = hipMalloc(p, bytes);
   }
   return e;
 }
-hipError_t fmx_dev_malloc_async(void **p, size_t bytes, hipStream_t st) {
-  // the device's default stream-ordered pool keeps up to 2 GiB of freed blocks instead of returning them to the driver at
-  // every synchronisation (release threshold 0 by default): a locate call's rows array then comes out of the pool
-  {
-    static std::mutex mu;
-    static bool done[kArenaDevices] = {};
-    int dev = -1;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kArenaDevices) {
-      std::lock_guard<std::mutex> lk(mu);
-      if (!done[dev]) {
-        done[dev] = true;
-        hipMemPool_t pool = nullptr;
-        uint64_t keep = 2ull << 30;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess ||
-            hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
-          (void)hipGetLastError();
-      }
+// Stream-ordered allocations of the launch paths (the rows array of the locate paths that keep one, the tile sums of
+// fmx_offsets_dev) come from a pool the LIBRARY owns, one per device: it keeps up to 2 GiB of freed blocks instead of
+// returning them to the driver at every synchronisation (the rows array of the next call then comes out of the pool)
+// without touching the attributes of the device's default pool, which the host application and other libraries
+// share.  hipMemPoolTrimTo gives the retained blocks back: when an allocation fails, and from
+// fmx_release_scratch.  Where the runtime cannot create a pool the allocation falls back to the default pool as it is.
+namespace {
+struct AsyncPools {
+  std::mutex mu;
+  hipMemPool_t pool[kArenaDevices] = {};
+  bool tried[kArenaDevices] = {};
+};
+AsyncPools &async_pools() {
+  static AsyncPools *p = new AsyncPools;         // leaked on purpose: nothing is freed at process exit
+  return *p;
+}
+hipMemPool_t async_pool_of(int dev) {
+  if (dev < 0 || dev >= kArenaDevices) return nullptr;
+  AsyncPools &ap = async_pools();
+  std::lock_guard<std::mutex> lk(ap.mu);
+  if (!ap.tried[dev]) {
+    ap.tried[dev] = true;
+    hipMemPoolProps props;
+    memset(&props, 0, sizeof props);
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    uint64_t keep = 2ull << 30;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool &&
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) {
+      ap.pool[dev] = pool;
+    } else {
+      (void)hipGetLastError();
+      if (pool) (void)hipMemPoolDestroy(pool);
     }
   }
-  hipError_t e = hipMallocAsync(p, bytes, st);
+  return ap.pool[dev];
+}
+void async_pool_trim(int dev) {
+  if (dev < 0 || dev >= kArenaDevices) return;
+  AsyncPools &ap = async_pools();
+  hipMemPool_t pool;
+  { std::lock_guard<std::mutex> lk(ap.mu); pool = ap.pool[dev]; }
+  if (pool && hipMemPoolTrimTo(pool, 0) != hipSuccess) (void)hipGetLastError();
+}
+}  // namespace
+hipError_t fmx_dev_malloc_async(void **p, size_t bytes, hipStream_t st) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  hipMemPool_t pool = async_pool_of(dev);
+  auto alloc = [&]() { return pool ? hipMallocFromPoolAsync(p, bytes, pool, st) : hipMallocAsync(p, bytes, st); };
+  hipError_t e = alloc();
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
-    if (scratch_drop_current()) e = hipMallocAsync(p, bytes, st);
+    async_pool_trim(dev);
+    scratch_drop_current();
+    e = alloc();
   }
   return e;
 }
+static void fmx_async_pool_trim(int dev) { async_pool_trim(dev); }
 hipError_t fmx_dev_mem_info(size_t *free_b, size_t *total_b) {
   hipError_t e = hipMemGetInfo(free_b, total_b);
   int dev = -1;
@@ -1635,9 +1675,23 @@ hipError_t fmx_dev_mem_info(size_t *free_b, size_t *total_b) {
     std::lock_guard<std::mutex> lk(sc.mu);
     *free_b += sc.held[dev];                       // idle scratch goes back to the driver when an allocation needs it
   }
+  if (e == hipSuccess && dev >= 0 && dev < kArenaDevices) {   // ... and so does what the library's stream-ordered pool retains
+    AsyncPools &ap = async_pools();
+    hipMemPool_t pool;
+    { std::lock_guard<std::mutex> lk(ap.mu); pool = ap.pool[dev]; }
+    uint64_t reserved = 0, used = 0;
+    if (pool && hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &reserved) == hipSuccess &&
+        hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &used) == hipSuccess && reserved > used)
+      *free_b += (size_t)(reserved - used);
+    else
+      (void)hipGetLastError();
+  }
   return e;
 }
+// idle small-build buffers of every device, the cache of large-build temporaries and what the library's stream-ordered
+// pools retain (include/fmx.h: fmx_release_scratch)
 void fmx_release_build_scratch(void) {
+  for (int d = 0; d < kArenaDevices; d++) async_pool_trim(d);
   ArenaPool &ap = arena_pool();
   std::vector<std::pair<int, uint8_t *>> drop;
   {

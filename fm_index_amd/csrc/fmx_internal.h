@@ -280,6 +280,14 @@ int fmx_hip_fail(hipError_t e, const char *what, int line);
   } while (0)
 
 int fmx_build_impl(fmx_index *idx, const void *d_text);
+// per-shard workers of the multi-device entry points (fmx_multi.hip); host pointers, synchronous
+//   fmx_locate_batch on entries a .. b of a larger batch's offsets: the hits are out_pos[out_off[0] .. out_off[npat])
+int fmx_locate_batch_slice(const fmx_index *idx, const uint64_t *s, const uint64_t *e, uint64_t npat,
+                           const uint64_t *out_off, uint64_t *out_pos);
+//   patterns resident on the index's device (DEVICE pointers), results into HOST arrays
+int fmx_count_resident_slice(const fmx_index *idx, const void *d_pat, const uint64_t *d_pat_off, uint64_t npat,
+                             const uint64_t *d_s0e0, uint64_t *out_s, uint64_t *out_e, uint64_t *out_count);
+void fmx_set_error_text(const char *text);    // fmx_last_error() of the calling thread, verbatim (a worker thread's message)
 // Index-owned (and any other long-lived) device memory.  The process-wide scratch cache of large builds (fmx_build.hip)
 // keeps idle blocks out of the driver's hands; an allocation that fails while the cache holds memory of the current
 // device returns that memory to the driver and is tried once more, and the room checks that decide the shape of an

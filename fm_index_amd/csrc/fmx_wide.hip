@@ -143,12 +143,13 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_count_kernel(
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   const uint64_t ptot = npat ? off[npat] : 0;       // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   uint64_t nsteps = 0;
   for (uint64_t k = gid; k < npat; k += ngroups) {
     const uint64_t pbeg = off[k], pend = off[k + 1];
     uint64_t j = pend - pbeg;
     // offsets that go backwards or leave the pattern buffer: refuse, do not read
-    bool bad = pend < pbeg || pend > ptot;
+    bool bad = pend < pbeg || pbeg < pmin || pend > ptot;
     uint64_t s = 0, e = w.n;                        // SearchIndexWrapper::search: (0, len)   wrapper.rs:41
     if (s0e0) {                                     // Search::search on an existing Search   wrapper.rs:105-106
       s = s0e0[2 * k];
@@ -942,11 +943,12 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_kernel(
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
   const uint64_t ptot = npat ? off[npat] : 0;       // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   uint64_t nsteps = 0;
   for (uint64_t k = gid; k < npat; k += ngroups) {
     const uint64_t pbeg = off[k], pend = off[k + 1];
     uint64_t j = pend - pbeg;
-    bool bad = pend < pbeg || pend > ptot;          // offsets that go backwards or leave the pattern buffer
+    bool bad = pend < pbeg || pbeg < pmin || pend > ptot;          // offsets that go backwards or leave the pattern buffer
     uint64_t s = 0, e = w.n;                        // SearchIndexWrapper::search: (0, len)   wrapper.rs:41
     if (s0e0) {                                     // Search::search on an existing Search   wrapper.rs:105-106
       s = s0e0[2 * k];
@@ -1404,6 +1406,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_ep_kernel(
   const uint64_t slot = (uint64_t)(g >> 1) * ngroups + (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3);
   const uint64_t nslots = ngroups * 4u;
   const uint64_t ptot = npat ? off[npat] : 0;       // symbols the caller declares behind `pat`
+  const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
   uint64_t k = slot, pbeg = 0, j = 0, pos = 0, nsteps = 0;
   bool active = k < npat, fresh = true;
   uint32_t c = 0;
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(FMXW_BLOCK) void fmxw_g_count_ep_kernel(
       pbeg = off[k];
       const uint64_t pend = off[k + 1];
       j = pend - pbeg;
-      bool bad = pend < pbeg || pend > ptot;          // offsets that go backwards or leave the pattern buffer
+      bool bad = pend < pbeg || pbeg < pmin || pend > ptot;          // offsets that go backwards or leave the pattern buffer
       if (s0e0) {                                     // Search::search on an existing Search   wrapper.rs:105-106
         const uint64_t mine = s0e0[2 * k + is_e], other = s0e0[2 * k + (is_e ^ 1u)];
         pos = mine;

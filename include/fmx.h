@@ -272,6 +272,42 @@ uint64_t fmx_offsets_workspace_bytes(uint64_t npat);
 int fmx_offsets_ws_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e, uint64_t npat,
                        uint64_t *d_out_off, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
+/* ---- one batch over several replicas of an index, from ONE host caller ------ */
+/* (SURVEY section 8e / BASELINE config 5.)  The driver of the reference (wrapper.rs:103-124, behind Search::search,
+ * frontend.rs:70-98) reads only immutable index state: patterns are independent, so a batch shards over G replicas of
+ * the index -- one per GPU of the node -- with no exchange but the gather of the results, and for a host caller the
+ * gather is the layout of its own arrays: every shard writes its results IN PLACE at its offset of the caller's
+ * out_* arrays.  Results are bit-identical to the one-handle call whatever G is.
+ *   shard r of G = patterns [ceil(N r / G), ceil(N (r + 1) / G))     (fmx_shard_range; pattern k -> floor(k G / N)),
+ * searched on idx[r] by a host thread of its own (shard 0 on the caller's) with that thread's streams, pinned staging
+ * and device scratch.  The handles must be replicas of ONE index (fmx_replicate, or fmx_build / fmx_load of the same
+ * text with the same parameters); several of them may sit on one device.  Error codes and fmx_last_error() are those
+ * of the first failing shard, in shard order. */
+/* a second handle holding its own copy of every HBM array of `src`, on `device` (any device of the node, src's own
+ * included): arrays travel device to device (hipMemcpyPeer over xGMI), nothing is rebuilt and the text is not needed.
+ * FMX_FLAG_KEEP_SA's text + suffix array stay with the source (the replica has neither). */
+int fmx_replicate(const fmx_index *src, int device, fmx_index **out);
+void fmx_shard_range(uint64_t nitems, uint32_t nshards, uint32_t r, uint64_t *begin, uint64_t *end);
+/* fmx_count_batch over `ndev` replicas: same arguments (HOST pointers), same results, same errors */
+int fmx_count_batch_multi(fmx_index *const *idx, uint32_t ndev, const void *pat, const uint64_t *pat_off,
+                          uint64_t npat, const uint64_t *s0e0, uint64_t *out_s, uint64_t *out_e,
+                          uint64_t *out_count);
+/* the same with every shard's patterns already RESIDENT on its device, results into HOST arrays -- the measurement
+ * protocol of SURVEY section 8d ("exclude ... H2D upload from both sides; include D2H of results on the GPU side";
+ * benches/count.rs:29-37 times results the caller can read).  d_pat[r] / d_pat_off[r] / d_s0e0[r] (nullable array,
+ * nullable entries) are DEVICE pointers on fmx_device(idx[r]) holding shard r's patterns: fmx_sym_bytes() wide
+ * symbols, (shard length + 1) offsets relative to d_pat[r], 2 x shard length refinement pairs.  Page-locked out_*
+ * arrays are written by the search kernels themselves (posted writes over the host link); pageable ones are staged. */
+int fmx_count_batch_multi_resident(fmx_index *const *idx, uint32_t ndev, const void *const *d_pat,
+                                   const uint64_t *const *d_pat_off, uint64_t npat,
+                                   const uint64_t *const *d_s0e0, uint64_t *out_s, uint64_t *out_e,
+                                   uint64_t *out_count);
+/* fmx_locate_batch over `ndev` replicas: shard r locates patterns [a, b) of the batch and writes
+ * out_pos[out_off[a] .. out_off[b]) -- the reference's iteration order (wrapper.rs:203-217), in place.
+ * out_off[0] must be 0. */
+int fmx_locate_batch_multi(fmx_index *const *idx, uint32_t ndev, const uint64_t *s, const uint64_t *e,
+                           uint64_t npat, const uint64_t *out_off, uint64_t *out_pos);
+
 /* ---- multi-pieces index (src/multi_pieces.rs, frontend.rs:46-68, 100-104) --- */
 /* SearchIndexWithMultiPieces::search_prefix / search_suffix / search_exact are the same
  * backward search with a different start and a filter (wrapper.rs:57-82):

@@ -93,6 +93,11 @@ impl<C: GpuCharacter> GpuBackend<C> {
         }
     }
 
+    /// takes ownership of a handle libfmx made (`fmx_replicate`, `fmx_load`)
+    pub(super) fn from_raw(h: *mut ffi::FmxIndex) -> Self {
+        GpuBackend { h, _c: PhantomData }
+    }
+
     pub fn level(&self) -> Option<usize> {
         match unsafe { ffi::fmx_level(self.h) } {
             ffi::FMX_NO_LOCATE => None,

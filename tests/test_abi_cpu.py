@@ -71,14 +71,14 @@ def build_readme_example(tmpdir):
     return exe
 
 
-def build_c_example(tmpdir):
-    """gcc (C99) build of tests/c/abi_example.c against libfmx.so: the ABI from plain C."""
+def build_c_example(tmpdir, name="abi_example"):
+    """gcc (C99) build of tests/c/<name>.c against libfmx.so: the ABI from plain C."""
     import subprocess
     from fm_index_amd import _lib
-    exe = os.path.join(str(tmpdir), "abi_example")
+    exe = os.path.join(str(tmpdir), name)
     subprocess.check_call([
         "gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-        os.path.join(ROOT, "tests", "c", "abi_example.c"), "-o", exe,
+        os.path.join(ROOT, "tests", "c", name + ".c"), "-o", exe,
         "-L" + os.path.dirname(_lib.LIB_PATH), "-lfmx",
         "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
     return exe
@@ -86,6 +86,7 @@ def build_c_example(tmpdir):
 
 def test_plain_c_program_compiles_and_links(tmp_path):
     assert os.path.exists(build_c_example(tmp_path))
+    assert os.path.exists(build_c_example(tmp_path, "abi_multi"))     # the multi-replica entry points from C99
 
 
 def test_cpp_host_mirror_compiles_and_links(tmp_path):

@@ -46,7 +46,7 @@ def test_config_3b_needs_a_second_grid():
 
 
 def test_roofline_fraction_never_exceeds_the_traffic_it_was_given():
-    r = B.make_roofline("k", 1.0, 10, 384, 1000, None, {"bytes": 4_000_000_000, "fetch_kb_raw": 1953125.0,
+    r = B.make_roofline("k", 1.0, 10, 384, 1000, None, {"rdreq": {"all": 31250000.0, "32B": 0.0, "64B": 0.0, "128B": 31250000.0},
                                                         "source": "test"})
     assert r["achieved"] == 4000.0 and r["frac"] == 0.5 and r["traffic"] == 4_000_000_000
     r = B.make_roofline("k", 1.0, 10, 384, 1000, {"requested_lines": 10**9}, None)
@@ -54,28 +54,50 @@ def test_roofline_fraction_never_exceeds_the_traffic_it_was_given():
 
 
 def test_counters_are_priced_by_request_width():
-    """FETCH_SIZE reports 64 B per fabric request: x 2 for a launch of 128-byte record requests only, x 1.5 when half
-    of the requests are <= 16-byte probes (the run-length kernels); 2 x FETCH stays as `traffic_upper`."""
-    ent = {"fetch_kb_raw": 1000000.0, "write_kb": 1000.0, "source": "test"}
-    all_records = {"requested_lines": 100, "requested_records": 100, "requested_probes": 0, "distinct_lines": 50}
-    half = {"requested_lines": 100, "requested_records": 50, "requested_probes": 50, "distinct_lines": 50}
-    r = B.make_roofline("k", 1.0, 10, 384, 0, all_records, ent)
-    assert r["traffic"] == r["traffic_upper"] == int(2 * 1000000.0 * 1024 + 1000.0 * 1024)
-    assert r["record_share_of_requests"] == 1.0 and r["frac"] == r["frac_upper"]
-    r = B.make_roofline("k", 1.0, 10, 384, 0, half, ent)
-    assert r["traffic"] == int(1.5 * 1000000.0 * 1024 + 1000.0 * 1024) and r["traffic_upper"] > r["traffic"]
-    assert r["record_share_of_requests"] == 0.5 and r["frac"] < r["frac_upper"]
-    assert r["requested_bytes"] == 50 * 128 + 50 * 16
-    # the request fraction does not depend on the widths
-    r2 = B.make_roofline("k", 1.0, 10, 384, 0, all_records, ent)
-    assert r["frac_of_gather_ceiling"] == r2["frac_of_gather_ceiling"]
-    # no census: the upper bound, and the basis says so
-    r = B.make_roofline("k", 1.0, 10, 384, 0, None, ent)
-    assert r["traffic"] == r["traffic_upper"] and "UPPER BOUND" in r["basis"]
+    """ONE basis for every roofline object: the read requests counted by width, priced at their
+    widths, + WRITE_SIZE.  The census share of rounds 2-5 is gone: a launch of lane-wise 16-byte probes whose fabric
+    requests are all 128 bytes wide moves 128 bytes per request."""
+    w128 = {"rdreq": {"all": 1000000.0, "32B": 0.0, "64B": 0.0, "128B": 1000000.0}, "write_kb": 1000.0, "source": "test"}
+    half_probes = {"requested_lines": 100, "requested_records": 50, "requested_probes": 50, "distinct_lines": 50}
+    r = B.make_roofline("k", 1.0, 10, 384, 0, half_probes, w128)
+    assert r["traffic"] == int(128 * 1000000.0 + 1000.0 * 1024)          # whatever the census says about probes
+    assert r["share_of_128B_requests"] == 1.0 and "frac_upper" not in r and "traffic_upper" not in r
+    assert r["achieved"] == round(r["traffic"] / 1e-3 / 1e9, 1) and r["frac"] == round(r["achieved"] / 8000.0, 4)
+    assert r["fetch_kb_raw"] == 1000000.0 * 64 / 1024                    # what FETCH_SIZE would have said
+    assert r["frac_of_gather_ceiling"] == round(1000000.0 / 1e-3 / 55e9, 4)
+    assert r["requested_bytes"] == 50 * 128 + 50 * 16                    # (the census still describes the requests made)
+    mixed = {"rdreq": {"all": 1000.0, "32B": 100.0, "64B": 300.0, "128B": 500.0}, "write_kb": 0.0, "source": "test"}
+    r = B.make_roofline("k", 1.0, 10, 384, 0, None, mixed)
+    assert r["traffic"] == 32 * 100 + 64 * (300 + 100) + 128 * 500        # 100 requests of no counted width: 64 B each
+    assert r["share_of_128B_requests"] == 0.5
+    # the figures of profiles/r05/kernel_pmc_bytes_rlfm.json (config 4 count): 0.82 of the fabric peak, not 0.61
+    rl = {"rdreq": {"all": 68018987.0, "32B": 0.0, "64B": 4075.0, "128B": 68014912.0}, "write_kb": 24576.0, "source": "r05"}
+    r = B.make_roofline("fmx_count_ep_kernel", 1.334, 1 << 24, 2560, 0, None, rl)
+    assert 0.815 <= r["frac"] <= 0.822, r["frac"]
+    # an entry of an earlier round (FETCH_SIZE only): the guide's rule, and the basis says so
+    old = {"fetch_kb_raw": 1000000.0, "write_kb": 1000.0, "source": "test"}
+    r = B.make_roofline("k", 1.0, 10, 384, 0, None, old)
+    assert r["traffic"] == int(2 * 1000000.0 * 1024 + 1000.0 * 1024) and "2 x FETCH_SIZE" in r["basis"]
+
+
+def test_the_width_counters_of_a_leg_come_from_the_same_launches():
+    names = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+    vals = {"TCC_EA0_RDREQ_sum": 32.2e6, "TCC_EA0_RDREQ_32B_sum": 0.0, "TCC_EA0_RDREQ_64B_sum": 1200.0,
+            "TCC_EA0_RDREQ_128B_sum": 32.2e6 - 1200.0}
+    rows = [row(COUNT, 524288, nm, vals[nm]) for nm in names for _ in range(3)]
+    rows += [row(COUNT, 524288, nm, vals[nm] / 50) for nm in names]          # the small side launch
+    rows += [row(COUNT, 524288, "WRITE_SIZE", 24576.0)] * 3
+    raw = {nm: B.pmc_aggregate(rows, nm) for nm in names + ["WRITE_SIZE"]}
+    from benchmarks.legs import roofline as R
+    ent = R.pmc_entry(raw, B.PMC_LEGS["dna_count"], "largest")
+    assert ent["rdreq"] == {"all": 32.2e6, "32B": 0.0, "64B": 1200.0, "128B": 32.2e6 - 1200.0} and ent["write_kb"] == 24576.0
+    assert ent["fetch_kb_raw"] == round(32.2e6 * 64 / 1024, 1)
+    assert R.pmc_entry(raw, ["no_such_kernel"], "largest") is None
+    assert R.fabric_read_bytes(ent) == 64 * 1200.0 + 128 * (32.2e6 - 1200.0)
 
 
 def test_two_stream_roofline_uses_the_same_bytes_over_the_shorter_time():
-    ent = {"fetch_kb_raw": 250000.0, "write_kb": 8192.0, "source": "test"}
+    ent = {"rdreq": {"all": 4000000.0, "32B": 0.0, "64B": 0.0, "128B": 4000000.0}, "write_kb": 8192.0, "source": "test"}
     cen = {"requested_lines": 4, "requested_records": 3, "requested_probes": 1, "distinct_lines": 4}
     leg = {"roofline": B.make_roofline("walk", 0.14, 1, 1, 0, cen, ent), "two_streams": {"ms_per_batch": 0.10}}
     B.two_stream_roofline(leg)

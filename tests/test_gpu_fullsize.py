@@ -1,5 +1,6 @@
 """BASELINE.json full sizes (n = 2^30) through size-independent properties:
-suffix-array sortedness + permutation checked on the device, count >= 1 for substrings, every
+suffix-array sortedness + permutation checked on the device AND completely on the host (the linear-time
+checker over all 2^30 rows, from the text alone), count >= 1 for substrings, every
 located position holds its pattern, the source position is among the hits, executed steps, and
 bit-identity with the CPU oracle (fed the exported BWT) on a pattern sample -- the FM path for
 config 2 / 3, the RLFM path (its own S / B / B' and the rlfmi.rs formulas) for config 4, which
@@ -34,46 +35,60 @@ def _count_dev(index, pat, off, npat):
     return s, e, c
 
 
-def _suffix_less(text, a, b, step=64):
-    """suffix text[a:] < suffix text[b:] for arrays of start positions, on the host: windows of `step` symbols until
-    the first differing symbol.  The text ends with its unique smallest symbol, so two different suffixes differ at or
-    before the end of the shorter one (reads past the end are clamped onto the terminator, which decides)."""
-    n = len(text)
-    less = np.zeros(len(a), dtype=bool)
-    undecided = np.ones(len(a), dtype=bool)
-    win = np.arange(step, dtype=np.int64)
-    o = 0
-    while undecided.any():
-        ii = np.nonzero(undecided)[0]
-        ta = text[np.minimum(a[ii, None] + o + win, n - 1)]
-        tb = text[np.minimum(b[ii, None] + o + win, n - 1)]
-        ne = ta != tb
-        has = ne.any(axis=1)
-        first = ne.argmax(axis=1)
-        r = np.nonzero(has)[0]
-        less[ii[r]] = ta[r, first[r]] < tb[r, first[r]]
-        undecided[ii[r]] = False
-        o += step
-        assert o < n
-    return less
+def _chunks(n, step):
+    return [(a, min(a + step, n)) for a in range(0, n, step)]
 
 
-def _independent_sa_spot_check(index, text, level, pairs=1 << 16, seed=91):
-    """The suffix array the GPU builder made, checked WITHOUT any kernel of the builder or the index:
-    random adjacent pairs (SA[i], SA[i+1]) are compared on the host against the TEXT itself (numpy, first differing
-    symbol), the exported L column against text[SA[i] - 1] on those rows (fm_index.rs:44-58), and EVERY exported
-    suffix-array sample against SA[k << level] (sample.rs:33-37: with text-order sampling each of them is a get_sa walk
-    through the index)."""
+def _full_sa_check(index, text, level, threads=16):
+    """The suffix array the GPU builder made, verified COMPLETELY on the host, without any kernel of the builder or the
+    index -- the linear-time checker (Burkhardt & Karkkainen): SA is a permutation of 0..n-1; for
+    every adjacent pair text[SA[i]] <= text[SA[i+1]], and where the first symbols are equal the rest decides:
+    ISA[SA[i] + 1] < ISA[SA[i+1] + 1].  Together these say the array is THE suffix array (sais.rs:546-557 is the naive
+    definition it must equal).  Then the L column over ALL rows against text[SA[i] - 1] (fm_index.rs:44-58), and EVERY
+    exported suffix-array sample against SA[k << level] (sample.rs:33-37: with text-order sampling each of them is a
+    get_sa walk through the index).  numpy over all n rows, in chunks over a thread pool (fancy indexing releases the
+    GIL); ~9 GB of host memory at n = 2^30."""
+    from concurrent.futures import ThreadPoolExecutor
     n = index.len()
     sa = index.export_sa()
     th = text.cpu().numpy()
-    assert sa.shape == (n,) and sa[0] == n - 1                  # the terminator suffix sorts first
-    i = (W.splitmix64_np(seed, 0, pairs) % np.uint64(n - 1)).astype(np.int64)
-    a, b = sa[i].astype(np.int64), sa[i + 1].astype(np.int64)
-    assert _suffix_less(th, a, b).all(), "adjacent suffixes out of order"
-    bwt = index.export_bwt()
-    want = np.where(a > 0, th[np.maximum(a - 1, 0)], 0)
-    assert (bwt[i] == want).all(), "L column differs from text[SA - 1]"
+    assert sa.shape == (n,) and th.shape == (n,) and sa[0] == n - 1     # the terminator suffix sorts first
+    step = 1 << 24
+    isa = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+
+    def scatter(ab):
+        a, b = ab
+        v = sa[a:b]
+        assert int(v.max()) < n
+        isa[v] = np.arange(a, b, dtype=np.uint32)
+
+    def ordered(ab):
+        a, b = ab
+        b = min(b, n - 1)                                                # pairs (i, i + 1), i < n - 1
+        s0, s1 = sa[a:b].astype(np.int64), sa[a + 1:b + 1].astype(np.int64)
+        c0, c1 = th[s0], th[s1]
+        if not (c0 <= c1).all():
+            return "first symbols out of order in rows %d..%d" % (a, b)
+        eq = np.nonzero(c0 == c1)[0]
+        # (equal first symbols: neither suffix is the terminator -- it is unique -- so SA + 1 < n)
+        if not (isa[s0[eq] + 1] < isa[s1[eq] + 1]).all():
+            return "suffixes with equal first symbols out of order in rows %d..%d" % (a, b)
+        return None
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(scatter, _chunks(n, step)))
+        assert not (isa == 0xFFFFFFFF).any(), "SA is not a permutation"    # n values < n, every slot hit: each exactly once
+        bad = [m for m in ex.map(ordered, _chunks(n, step)) if m]
+        assert not bad, bad[:3]
+        del isa
+        bwt = index.export_bwt()
+
+        def lcol(ab):
+            a, b = ab
+            v = sa[a:b].astype(np.int64)
+            want = np.where(v > 0, th[np.maximum(v - 1, 0)], 0)
+            return bool((bwt[a:b] == want).all())
+        assert all(ex.map(lcol, _chunks(n, step))), "L column differs from text[SA - 1]"
     smp = index.export_sa_samples()
     assert smp.shape == (((n - 1) >> level) + 1,) and (smp == sa[::1 << level]).all(), "samples differ from SA[k << level]"
     del sa, th, bwt, smp
@@ -88,7 +103,7 @@ def test_config2_config3_dna_1gb():
     index = F.FMIndexWithLocate.from_device_text(text.data_ptr(), N, 4, level=2, keep_sa=True)
     assert index.len() == N and index.level() == 2
     assert index.verify_sa() == 0                      # the array IS the suffix array (device-side check)
-    _independent_sa_spot_check(index, text, 2)         # ... and says the host, from the text alone
+    _full_sa_check(index, text, 2)                     # ... and says the host, from the text alone, for EVERY row
     assert index.text_order() and index.walk_records()  # the default DNA index of round 4
     npat, m = 1 << 20, 32
     pat, off, pos = W.substring_patterns_torch(text, npat, m, 3)
@@ -154,7 +169,7 @@ def test_config4_rlfm_byte_text_1gb():
     pat, off, pos = W.substring_patterns_torch(text, npat, m, 6)
     lib = L.lib()
     rl = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), N, 255, level=3, keep_sa=True)
-    _independent_sa_spot_check(rl, text, 3, seed=92)
+    _full_sa_check(rl, text, 3)
     s, e, c = _count_dev(rl, pat, off, npat)
     assert bool((c >= 1).all())
     runs = int(lib.fmx_num_runs(rl.handle()))

@@ -17,6 +17,8 @@ C_TO_RUST = {
     "const char*": "*const c_char", "void*": "*mut c_void", "const void*": "*const c_void",
     "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "uint32_t*": "*mut u32",
     "fmx_index*": "*mut FmxIndex", "const fmx_index*": "*const FmxIndex", "fmx_index**": "*mut *mut FmxIndex",
+    "fmx_index*const*": "*const *mut FmxIndex", "const void*const*": "*const *const c_void",
+    "const uint64_t*const*": "*const *const u64",
 }
 
 

@@ -292,7 +292,10 @@ def run(args, world, pmc=None, pmc_seconds=0.0, pmc31=None):
     if not args.no_census and rank == 0:
         cen = run_census(wl, lambda cl: wl.count(lib=cl), npat * m * (8 if wl.rlfm else 3) + (1 << 20))
     key = "%s:%d:%d:%d" % (args.workload, npat, m, args.log2n)
-    kname = {"dna": "fmx_count_f3_kernel<1,false,false>"}.get(
+    # the DEFAULT DNA index of 2^24+ symbols carries the pair index and the k-mer start table (round 6: same (s, e), 2.2 x
+    # the rate); the plain index -- the reference's loop step for step -- is the `plain` object / `value_plain`
+    accelerated = wl.accelerated()
+    kname = {"dna": "fmx_count_pair_kernel<true>" if accelerated else "fmx_count_f3_kernel<1,false,false>"}.get(
         args.workload, "fmx_count_ep_kernel" if wl.rlfm else "fmx_count_kernel<FMX_KIND_FM>")
     roofline = make_roofline(kname, avg_kernel_ms, chars_per_step_rank, wl.ref_bytes_per_char(), stream_bytes,
                              cen, stored_traffic(key, "count"), table_bytes=wl.count_table_bytes())
@@ -308,7 +311,10 @@ def run(args, world, pmc=None, pmc_seconds=0.0, pmc31=None):
                    "total_patterns": total_pat, "pattern_seed": wl.pattern_seed,
                    "parallelism": "patterns sharded x%d, index replicated" % world,
                    "index_bytes": wl.index.heap_size(), "build_ms": round(wl.build_ms, 1),
-                   "textgen_s": round(wl.textgen_s, 2)},
+                   "textgen_s": round(wl.textgen_s, 2),
+                   "index": ("default index: pair index + k-mer start table (k = %d) next to the plain count records "
+                             "(FMX_FLAG_PLAIN vetoes; `plain` / `value_plain` is that index)" % wl.index.kmer_k())
+                   if accelerated else "plain index"},
         "roofline": roofline,
         # sha256 over the int64 little-endian counts of ALL patterns of the global set in input order: equal at
         # every G for the same global set ("multi-GPU output identical to 1-GPU output")
@@ -344,7 +350,10 @@ def run(args, world, pmc=None, pmc_seconds=0.0, pmc31=None):
         torch.cuda.synchronize()
 
     lap("import + text + build + headline")
-    # ---- opt-in accelerators: same patterns, results asserted identical to the plain index ----
+    # ---- the plain index (FMX_FLAG_PLAIN: the reference's loop step for step) and each accelerator alone: same
+    # patterns, (s, e) asserted identical to the headline's on all of them ----
+    if accelerated:
+        out["value_auto"] = value                      # (rounds 4-5 printed the accelerated index under this key)
     if single and not args.no_accel:
         accel_legs(out, wl, args, rflat)
     del rflat
@@ -520,7 +529,9 @@ def headline(out, detail_path):
         h["config"]["workload"] = h["config"]["workload"][:300]
     r = out.get("roofline") or {}
     h["roofline"] = {k: r.get(k) for k in ROOF_KEYS}
-    h["roofline"]["basis"] = ("fabric bytes (L2 -> Infinity Cache / HBM; PMC FETCH_SIZE corrected + WRITE_SIZE) / kernel ms"
+    h["roofline"]["basis"] = (("fabric bytes (L2 -> Infinity Cache / HBM): read requests counted by width (TCC_EA0_RDREQ_"
+                               "32B/64B/128B) + WRITE_SIZE, / kernel ms" if r.get("read_request_widths") else
+                               "fabric bytes (L2 -> Infinity Cache / HBM): 2 x FETCH_SIZE + WRITE_SIZE, / kernel ms")
                               if r.get("traffic") else "no PMC traffic in this run")
     cb = out.get("cpu_baseline")
     if cb:
@@ -555,6 +566,10 @@ def headline(out, detail_path):
         "config5_g1_value": _get(out, "config5_g1", "value"),
         "config5_g1_matches_golden": _get(out, "config5_g1", "matches_golden", "counts_sha256"),
         "rccl_1rank_value": _get(out, "rccl_1rank", "value"),
+        "value_plain": out.get("value_plain"),
+        "plain_kernel": _get(out, "plain", "roofline", "kernel"),
+        "plain_frac": _get(out, "plain", "roofline", "frac"),
+        "plain_frac_of_gather_ceiling": _get(out, "plain", "roofline", "frac_of_gather_ceiling"),
         "value_auto": out.get("value_auto"),
         "value_incl_d2h": out.get("value_incl_d2h"),
         "value_results_on_host": out.get("value_results_on_host"),

@@ -42,6 +42,9 @@ def main():
     if a.kind == "dna":
         text = W.dna_text_torch(n, 1, dev)
         idx = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=2)
+    elif a.kind == "dna-row":           # the reference's own row-order sampling: a rows array + the cooperative row-order walk
+        text = W.dna_text_torch(n, 1, dev)
+        idx = F.FMIndexWithLocate.from_device_text(text.data_ptr(), n, 4, level=2, sampling="row")
     elif a.kind == "rlfm-random":       # config 4's text (about one run per row) with FMX_FLAG_RUN_TABLE
         text = W.byte_text_torch(n, 4, dev)
         idx = F.RLFMIndexWithLocate.from_device_text(text.data_ptr(), n, 255, level=2, run_table=True)

@@ -91,10 +91,20 @@ class Workload:
     def ref_bytes_per_char(self):
         return 2 * (2 * self.Lbits + 4) * 64 if self.rlfm else 2 * self.Lbits * 64
 
+    def accelerated(self):
+        """does the index run the accelerated count kernel (pair index + k-mer start table: the default DNA index of
+        2^24+ symbols since round 6)?"""
+        return bool(self.dna and self.index.has_pair_index() and self.index.kmer_k())
+
     def count_table_bytes(self):
         """bytes of index the count kernel's random record reads spread over: DNA = one 128-byte
-        fmt-3 record per 256 rows; other kinds: not modelled (None)"""
-        return (self.n // 256 + 1) * 128 if self.dna else None
+        fmt-3 record per 256 rows -- on the accelerated index one fmt-4 pair record per 128 rows (the plain records serve
+        a pattern's odd last step only) + the k-mer table; other kinds: not modelled (None)"""
+        if not self.dna:
+            return None
+        if self.accelerated():
+            return (self.n // 128 + 1) * 128 + (8 << (2 * self.index.kmer_k()))
+        return (self.n // 256 + 1) * 128
 
     def locate_table_bytes(self):
         """... and the walk kernel's: 112-row walk records + the u32 samples (DNA index with walk records)"""

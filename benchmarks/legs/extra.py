@@ -9,20 +9,21 @@ from .locate import locate_leg
 from .roofline import make_roofline, price_traffic, run_census, stored_traffic
 
 def accel_legs(out, wl, args, rflat):
-    """the opt-in count accelerators on the config-2 patterns: pair index, k-mer start table, and both -- the last one
-    built with FMX_FLAG_AUTO (the builder adds both when the index qualifies and the device has room) and reported as
-    `value_auto`.  (s, e) asserted identical to the plain index on all patterns; each leg gets the roofline object of
-    the headline (census of its own launch, counters of its own kernel from the live PMC passes)."""
+    """the config-2 patterns on the PLAIN index (FMX_FLAG_PLAIN: the reference's loop step for step, one rank per interval
+    end and symbol -- `plain` / `value_plain`, the headline of rounds 1-5) and on each count accelerator alone (pair index,
+    k-mer start table).  (s, e) asserted identical to the headline index's on all patterns -- config 2 and, when given,
+    config 2b (early-exit pairs); each leg gets the roofline object of the headline (census of its own launch, counters
+    of its own kernel from the live PMC passes)."""
     torch, F, lib = wl.torch, wl.F, wl.lib
     legs = []
+    if wl.dna and wl.accelerated():
+        legs.append(("plain", dict(plain=True), "FMX_FLAG_PLAIN: no accelerators", "fmx_count_f3_kernel<1,false,false>"))
     if wl.dna:
-        legs.append(("pair_index", dict(pair_index=True), "opt-in FMX_FLAG_PAIR_INDEX", "fmx_count_pair_kernel<false>"))
-    legs.append(("kmer_table", dict(kmer_table=True), "opt-in FMX_FLAG_KMER_TABLE",
+        legs.append(("pair_index", dict(plain=True, pair_index=True), "FMX_FLAG_PLAIN | FMX_FLAG_PAIR_INDEX",
+                     "fmx_count_pair_kernel<false>"))
+    legs.append(("kmer_table", dict(plain=True, kmer_table=True) if wl.dna else dict(kmer_table=True),
+                 "FMX_FLAG_PLAIN | FMX_FLAG_KMER_TABLE" if wl.dna else "opt-in FMX_FLAG_KMER_TABLE",
                  "fmx_count_f3_kernel<1,false,true>" if wl.dna else "fmx_count_ep_kernel<..., true>"))
-    if wl.dna:
-        legs.append(("kmer_table+pair_index", dict(auto=True),
-                     "FMX_FLAG_AUTO: the builder added FMX_FLAG_KMER_TABLE | FMX_FLAG_PAIR_INDEX (DNA-like FM index, "
-                     "n >= 2^24, four times the index free on the device)", "fmx_count_pair_kernel<true>"))
     npat, m = wl.npat, wl.m
     stream_bytes = npat * m + (npat + 1) * 8 + 2 * npat * 8
     for leg_name, leg_kw, leg_note, kname in legs:
@@ -31,10 +32,6 @@ def accel_legs(out, wl, args, rflat):
                                                                             device=wl.local, **leg_kw)
             if leg_kw.get("kmer_table") and pidx.kmer_k() == 0:
                 out[leg_name] = {"skipped": "FMX_FLAG_KMER_TABLE is ignored for this kind / alphabet"}
-                pidx.close()
-                continue
-            if leg_kw.get("auto") and not (pidx.kmer_k() and pidx.has_pair_index()):
-                out[leg_name] = {"skipped": "FMX_FLAG_AUTO left the index plain (n < 2^24, or not enough free HBM)"}
                 pidx.close()
                 continue
             ps = torch.empty(npat, dtype=torch.int64, device=wl.dev)
@@ -49,7 +46,7 @@ def accel_legs(out, wl, args, rflat):
                 pstep(wl.pat)
             torch.cuda.synchronize()
             pms = event_time_ms(torch, wl.stream, lambda: pstep(wl.pat), args.steps)
-            assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != plain index"
+            assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != the headline index"
             cen = None
             if not args.no_census:
                 cen = run_census(wl, lambda cl: pstep(wl.pat, cl), npat * m * 3 + (1 << 20))
@@ -57,11 +54,12 @@ def accel_legs(out, wl, args, rflat):
                              "index_bytes": pidx.heap_size(), "kmer_k": pidx.kmer_k(),
                              "pair_index": pidx.has_pair_index(),
                              "build_ms": round(float(lib.fmx_build_ms(pidx.handle())), 1),
-                             "note": leg_note + "; (s,e) identical to the plain-index run",
+                             "note": leg_note + "; (s,e) identical to the headline index's",
                              "roofline": make_roofline(kname, pms, npat * m, wl.ref_bytes_per_char(), stream_bytes, cen,
                                                        None)}
-            if leg_kw.get("auto"):
-                out["value_auto"] = out[leg_name]["value"]
+            if leg_name == "plain":
+                out["value_plain"] = out[leg_name]["value"]
+                out[leg_name]["roofline"]["table_bytes"] = (wl.n // 256 + 1) * 128
             if rflat is not None:
                 # config 2b patterns (uniform random, mostly absent) through the same index
                 wl.count(pat=rflat)
@@ -69,7 +67,7 @@ def accel_legs(out, wl, args, rflat):
                     pstep(rflat)
                 torch.cuda.synchronize()
                 rms2 = event_time_ms(torch, wl.stream, lambda: pstep(rflat), args.steps)
-                assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != plain index (2b)"
+                assert bool((ps == wl.d_s).all()) and bool((pe == wl.d_e).all()), leg_name + " != the headline index (2b)"
                 out[leg_name]["early_exit_ms_per_step"] = rms2
                 out[leg_name]["early_exit_offered_chars_per_s"] = npat * m / (rms2 / 1e3)
                 wl.count()                            # restore the config-2 (s, e)
@@ -321,7 +319,7 @@ def ic_ab_leg(out, args, dev, local, pmc31):
                                                  w.count_table_bytes() / float(256 << 20), npat, m),
              "value": npat * m / (ms / 1e3), "unit": "pattern-chars/s", "ms_per_step": ms,
              "build_ms": round(w.build_ms, 1), "roofline": roof}
-        h = out.get("roofline") or {}
+        h = (out.get("plain") or {}).get("roofline") or out.get("roofline") or {}     # the same kernel at n = 2^30
         if h.get("avg_kernel_ms"):
             o["ms_vs_headline"] = round(ms / h["avg_kernel_ms"], 4)
         if h.get("fabric_requests") and roof.get("fabric_requests"):

@@ -327,7 +327,7 @@ def pmc_child(args):
             del lstep3b
     if not args.no_accel:            # the opt-in count accelerators on the same patterns
         import fm_index_amd as F
-        for kw in (dict(pair_index=True), dict(kmer_table=True), dict(auto=True)):
+        for kw in (dict(plain=True), dict(plain=True, pair_index=True), dict(plain=True, kmer_table=True)):
             pidx = F.FMIndex.from_device_text(wl.text.data_ptr(), wl.n, wl.maxc, device=local, **kw)
             for _ in range(reps):
                 rc = wl.lib.fmx_count_batch_dev(pidx.handle(), C.c_void_p(wl.pat.data_ptr()), C.c_void_p(wl.off.data_ptr()),
@@ -460,8 +460,9 @@ def apply_pmc(out, pmc, cal):
                               "the widths say what the requests really moved), and WRITE_SIZE; see roofline.basis"}
     else:
         out["pmc"] = {"status": "no counters collected"}
-    redo(out.get("roofline"), pmc.get("dna_count"))
-    for leg, key in (("pair_index", "dna_count_pair"), ("kmer_table", "dna_count_kmer"), ("kmer_table+pair_index", "dna_count_both")):
+    accelerated = "fmx_count_pair_kernel<true>" in ((out.get("roofline") or {}).get("kernel") or "")
+    redo(out.get("roofline"), pmc.get("dna_count_both" if accelerated else "dna_count"))
+    for leg, key in (("plain", "dna_count"), ("pair_index", "dna_count_pair"), ("kmer_table", "dna_count_kmer")):
         redo((out.get(leg) or {}).get("roofline"), pmc.get(key))
     redo(out.get("locate", {}).get("roofline"), pmc.get("dna_locate"))
     redo(out.get("locate_3b", {}).get("roofline"), pmc.get("dna_locate_3b"))

@@ -107,7 +107,7 @@ class Text:
 
 
 def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_records=True, auto=False,
-           keep_scratch=False, run_table=False):
+           keep_scratch=False, run_table=False, plain=False):
     """build flags of include/fmx.h; sampling: None (the builder's choice), "text" or "row"
     (FMX_FLAG_TEXT_ORDER / FMX_FLAG_ROW_ORDER: which rows carry a suffix-array sample)."""
     if sampling not in (None, "text", "row"):
@@ -116,14 +116,17 @@ def _flags(keep_sa, pair_index, kmer_table, sampling, force_wide=False, walk_rec
             (L.FLAG_KMER_TABLE if kmer_table else 0) | (L.FLAG_TEXT_ORDER if sampling == "text" else 0) |
             (L.FLAG_ROW_ORDER if sampling == "row" else 0) | (L.FLAG_FORCE_WIDE if force_wide else 0) |
             (0 if walk_records else L.FLAG_NO_WALK_RECORDS) | (L.FLAG_AUTO if auto else 0) |
-            (L.FLAG_KEEP_SCRATCH if keep_scratch else 0) | (L.FLAG_RUN_TABLE if run_table else 0))
+            (L.FLAG_KEEP_SCRATCH if keep_scratch else 0) | (L.FLAG_RUN_TABLE if run_table else 0) |
+            (L.FLAG_PLAIN if plain else 0))
 
 
 class _Index:
     _kind = L.KIND_FM
 
     def __init__(self, text, level=None, device=0, keep_sa=False, pair_index=False, kmer_table=False,
-                 sampling=None, force_wide=False, walk_records=True, auto=False, run_table=False):
+                 sampling=None, force_wide=False, walk_records=True, auto=False, run_table=False, plain=False):
+        """plain=True: FMX_FLAG_PLAIN -- no count accelerators unless asked for by name (the default DNA-like FM index of
+        2^24+ symbols gets the pair index and the k-mer start table when the device has room; same results)"""
         if not isinstance(text, Text):
             text = Text(text)
         self._lib = L.lib()
@@ -135,14 +138,14 @@ class _Index:
                                  text.max_character(),
                                  self._kind, lvl,
                                  _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
-                                        run_table=run_table),
+                                        run_table=run_table, plain=plain),
                                  device, C.byref(self._h))
         _check(rc)
 
     @classmethod
     def from_device_text(cls, d_text_ptr, n, max_character, level=None, device=0, keep_sa=False,
                          pair_index=False, sym_bytes=1, kmer_table=False, sampling=None, force_wide=False,
-                         walk_records=True, auto=False, keep_scratch=False, run_table=False):
+                         walk_records=True, auto=False, keep_scratch=False, run_table=False, plain=False):
         """text already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
         self = cls.__new__(cls)
         self._lib = L.lib()
@@ -151,7 +154,7 @@ class _Index:
         lvl = L.NO_LOCATE if level is None else int(level)
         _check(self._lib.fmx_build_dev(C.c_void_p(d_text_ptr), n, sym_bytes, max_character, cls._kind, lvl,
                                        _flags(keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
-                                              keep_scratch, run_table),
+                                              keep_scratch, run_table, plain),
                                        device, C.byref(self._h)))
         return self
 
@@ -403,8 +406,9 @@ class FMIndex(_Index):
     """FMIndex::new(&text) (frontend.rs:195-203) -- count only."""
     _kind = L.KIND_FM
 
-    def __init__(self, text, device=0, keep_sa=False, pair_index=False, kmer_table=False, force_wide=False, auto=False):
-        super().__init__(text, None, device, keep_sa, pair_index, kmer_table, None, force_wide, auto=auto)
+    def __init__(self, text, device=0, keep_sa=False, pair_index=False, kmer_table=False, force_wide=False, auto=False,
+                 plain=False):
+        super().__init__(text, None, device, keep_sa, pair_index, kmer_table, None, force_wide, auto=auto, plain=plain)
 
 
 class FMIndexWithLocate(_Index):
@@ -412,8 +416,9 @@ class FMIndexWithLocate(_Index):
     _kind = L.KIND_FM
 
     def __init__(self, text, level, device=0, keep_sa=False, pair_index=False, kmer_table=False, sampling=None,
-                 force_wide=False, walk_records=True, auto=False):
-        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto)
+                 force_wide=False, walk_records=True, auto=False, plain=False):
+        super().__init__(text, level, device, keep_sa, pair_index, kmer_table, sampling, force_wide, walk_records, auto,
+                         plain=plain)
 
 
 class RLFMIndex(_Index):

@@ -31,6 +31,7 @@ FLAG_NO_WALK_RECORDS = 64
 FLAG_AUTO = 128
 FLAG_KEEP_SCRATCH = 256
 FLAG_RUN_TABLE = 512
+FLAG_PLAIN = 1024
 
 # every symbol include/fmx.h declares: (name, restype, argtypes)
 _V, _U64, _U32, _I, _D = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double

@@ -148,12 +148,13 @@ static int build_common(const void *text, int text_on_device, uint64_t n, uint32
   DeviceGuard dg;
   FMX_HIP(dg.set(device));
 
-  // FMX_FLAG_AUTO: the two count accelerators (pair index + k-mer start table: same (s, e), fewer probes -- 2.2 x on
-  // the 1 GiB DNA text) where they pay and the device has room: a DNA-like FM index of at least 2^24 symbols, and four
-  // times the finished index free on the device now.  A pure space / throughput trade: the caller vetoes it by not
-  // passing the flag.
-  if ((flags & FMX_FLAG_AUTO) && kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 4 && n >= (1ull << 24) &&
-      !fmx_wide_n(n) && !(flags & FMX_FLAG_FORCE_WIDE)) {
+  // The two count accelerators (pair index + k-mer start table: the same (s, e) as SearchWrapper::search on every
+  // pattern, early-exit pairs included, with fewer probes -- 2.2 x on the 1 GiB DNA text) are part of the DEFAULT index
+  // where they pay and the device has room (round 6; FMX_FLAG_AUTO asked for exactly this in rounds 4-5): a DNA-like
+  // FM index of 2^24 .. 2^31 symbols with four times the finished index free on the device now.  Parity is what the
+  // caller is promised, not the number of probes; a pure space / throughput trade that FMX_FLAG_PLAIN vetoes.
+  if (!(flags & FMX_FLAG_PLAIN) && kind == FMX_KIND_FM && sym_bytes == 1 && max_character <= 4 && n >= (1ull << 24) &&
+      n < (1ull << 31) && !fmx_wide_n(n) && !(flags & FMX_FLAG_FORCE_WIDE)) {
     const uint64_t samples = level == FMX_NO_LOCATE ? 0 : (level >= 32 ? n * 4 : ((n - 1) >> level) * 4 + n * 2);
     const uint64_t index_est = n / 2 + n + (128ull << 20) + samples;      // records + pair records + table + locate arrays
     size_t free_b = 0, total_b = 0;

@@ -575,11 +575,18 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_ep_kernel(
 // exclusive offsets -> rows: rows[off[k] + j] = s[k] + j   (wrapper.rs:203-217: i = s..e-1
 // ascending).  One LANE per pattern writes short ranges itself; ranges longer than 32 rows are
 // written by the whole wave, one after the other (ballot over the lanes that hold one).
+// Ranges of FMX_EXPAND_DEFER rows or more are not written by their pattern's wave (a wave sustains ~17 GB/s of such
+// stores: ten patterns of 10^7 hits among 10^6 singletons kept ten waves busy for 3 ms) but listed in
+// `longs` -- longs[0] = entries, then {first row, first slot, rows} each, FMX_EXPAND_LONGCAP at most (a range that finds
+// the list full is written here after all) -- for fmx_expand_long_kernel, which writes every listed range with the
+// whole grid.  The choice is per RANGE, not per batch average.  longs == NULL: every range is written here.
+#define FMX_EXPAND_DEFER (1u << 16)
+#define FMX_EXPAND_LONGCAP 4096u
 template <typename T>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
     const uint64_t *__restrict__ s, const uint64_t *__restrict__ e,
     const uint64_t *__restrict__ off, uint64_t npat, T *__restrict__ out_pos, uint64_t total,
-    uint64_t n, uint32_t *status) {
+    uint64_t n, uint32_t *status, unsigned long long *__restrict__ longs = nullptr) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -620,6 +627,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
       const uint64_t A = ((uint64_t)(uint32_t)__shfl((int)(a >> 32), l) << 32) | (uint32_t)__shfl((int)a, l);
       const uint64_t O = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), l) << 32) | (uint32_t)__shfl((int)o, l);
       const uint64_t N = ((uint64_t)(uint32_t)__shfl((int)(cnt >> 32), l) << 32) | (uint32_t)__shfl((int)cnt, l);
+      if (longs && N >= FMX_EXPAND_DEFER) {          // wave-uniform
+        unsigned long long q = 0;
+        if (lane == 0) q = atomicAdd(&longs[0], 1ull);
+        q = ((unsigned long long)(uint32_t)__shfl((int)(q >> 32), 0) << 32) | (uint32_t)__shfl((int)q, 0);
+        if (q < FMX_EXPAND_LONGCAP) {
+          if (lane == 0) { longs[2u + 3u * q] = A; longs[3u + 3u * q] = O; longs[4u + 3u * q] = N; }
+          continue;
+        }
+      }
       // 16-byte stores (4 rows of 32 bits / 2 of 64) between a scalar head up to the first aligned slot and a scalar
       // tail: a wave writes 1 KB per instruction instead of 256 bytes (config 4b, 750 hits per pattern: the expansion
       // of its 7.9e8 rows was 1.03 ms of the 8.2 ms batch)
@@ -640,6 +656,35 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
       const uint64_t done = h + nv * V;
       if (lane < N - done) out_pos[O + done + lane] = (T)(A + done + lane);
     }
+  }
+}
+
+// the listed long ranges (fmx_expand_kernel), every one of them by the whole grid: 16-byte stores between a scalar head
+// and tail, as above.  An empty list costs the launch (~2 us).
+template <typename T>
+__global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_long_kernel(const unsigned long long *__restrict__ longs,
+                                                                    T *__restrict__ out_pos) {
+  unsigned long long nl = longs[0];
+  if (nl > FMX_EXPAND_LONGCAP) nl = FMX_EXPAND_LONGCAP;
+  constexpr uint32_t V = 16u / (uint32_t)sizeof(T);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+  for (unsigned long long i = 0; i < nl; i++) {
+    const uint64_t A = longs[2u + 3u * i], O = longs[3u + 3u * i], N = longs[4u + 3u * i];
+    const uint64_t mis = (((uintptr_t)(out_pos + O)) / sizeof(T)) & (V - 1u);
+    const uint64_t h = (V - mis) & (V - 1u);         // rows in front of the first 16-byte slot (N >= 2^16 > h)
+    if (tid < h) out_pos[O + tid] = (T)(A + tid);
+    const uint64_t nv = (N - h) / V;
+    for (uint64_t q = tid; q < nv; q += nth) {
+      const uint64_t t = h + q * V;
+      if constexpr (V == 4u) {
+        const uint32_t r = (uint32_t)(A + t);
+        *reinterpret_cast<uint4 *>(out_pos + O + t) = make_uint4(r, r + 1u, r + 2u, r + 3u);
+      } else {
+        *reinterpret_cast<ulonglong2 *>(out_pos + O + t) = make_ulonglong2(A + t, A + t + 1u);
+      }
+    }
+    const uint64_t done = h + nv * V;
+    if (tid < N - done) out_pos[O + done + tid] = (T)(A + done + tid);
   }
 }
 
@@ -2549,8 +2594,13 @@ uint64_t fmx_offsets_tile_bytes(uint64_t npat) {
   if (ntiles == 0) ntiles = 1;
   return ((ntiles + 1) * sizeof(uint64_t) + 255u) & ~(uint64_t)255u;
 }
-uint64_t fmx_locate_rows_bytes(uint64_t total) {
+// rows[total] (u32) + the list of long ranges behind them (fmx_expand_kernel: counter + FMX_EXPAND_LONGCAP entries)
+static inline uint64_t fmx_rows_part_bytes(uint64_t total) {
   return ((total ? total : 1) * sizeof(uint32_t) + 255u) & ~(uint64_t)255u;
+}
+static const uint64_t kLongListBytes = (2u + 3u * (uint64_t)FMX_EXPAND_LONGCAP) * sizeof(unsigned long long);
+uint64_t fmx_locate_rows_bytes(uint64_t total) {
+  return fmx_rows_part_bytes(total) + ((kLongListBytes + 255u) & ~(uint64_t)255u);
 }
 
 int fmx_launch_offsets(const uint64_t *d_s, const uint64_t *d_e, uint64_t npat, uint64_t *d_off,
@@ -2617,8 +2667,14 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // pattern (config 4: 24 against 51 us per 2^20 singletons; config 4b, 750 hits per pattern: 1.0 against 5.1 ms)
     uint64_t eb = (npat + FMX_BLOCK - 1) / FMX_BLOCK;
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
+    // per RANGE (round 6): a batch that can hold a range of 2^16+ rows lists such ranges for a second, grid-wide pass
+    // instead of leaving each to one wave (10^6 singletons + ten patterns of 10^7 hits: 3.4 ms for the batch against
+    // 0.15 + 1.09 for its parts); 16 bytes of memset and one -- usually empty -- launch per batch of 2^18+ hits
+    unsigned long long *longs = total >= (1u << 18) ? (unsigned long long *)((uint8_t *)rows + fmx_rows_part_bytes(total)) : nullptr;
+    if (longs) FMX_HIP(hipMemsetAsync(longs, 0, 16, st));
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
-                       d_off, npat, rows, total, dv.n, dv.status);
+                       d_off, npat, rows, total, dv.n, dv.status, longs);
+    if (longs) hipLaunchKernelGGL(fmx_expand_long_kernel<uint32_t>, dim3(2048), dim3(FMX_BLOCK), 0, st, longs, rows);
   }
   fmx_time_begin(idx, st);
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};

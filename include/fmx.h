@@ -108,12 +108,16 @@ typedef struct fmx_index fmx_index;
  * sample per hit.  +1.14 bytes per text symbol of HBM; derived from the other arrays (not stored in index files).
  * This flag builds the index without them (the round-3 text-order walk). */
 #define FMX_FLAG_NO_WALK_RECORDS 64u
-/* Let the builder add the two count accelerators -- FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE -- when they pay and
- * the device has room: FMX_KIND_FM over u8 symbols with max_character <= 4, n >= 2^24, and at least four times the
- * finished index free on the device at build time (2.2 x the count rate on a 1 GiB DNA text for 2.1 x the count
- * structures).  Results are bit-identical either way (see the two flags); fmx_has_pair_index() / fmx_kmer_k() tell
- * what the index got. */
+/* DEFAULT since round 6 (this flag asked for it in rounds 4-5 and is still accepted): the builder adds the two count
+ * accelerators -- FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE -- when they pay and the device has room: FMX_KIND_FM over
+ * u8 symbols with max_character <= 4, 2^24 <= n < 2^31, and at least four times the finished index free on the device at
+ * build time (2.2 x the count rate on a 1 GiB DNA text for 2.1 x the count structures).  Results are bit-identical
+ * either way (see the two flags: the reference's (s, e) on every pattern, the pair left by the early exit of
+ * wrapper.rs:111-113 included); fmx_has_pair_index() / fmx_kmer_k() tell what the index got.  FMX_FLAG_PLAIN vetoes. */
 #define FMX_FLAG_AUTO 128u
+/* never add the count accelerators by default: the index runs the reference's loop step for step, one rank per
+ * interval end and pattern symbol (the explicit FMX_FLAG_PAIR_INDEX / FMX_FLAG_KMER_TABLE are still honoured) */
+#define FMX_FLAG_PLAIN 1024u
 /* Keep ALL of this build's temporaries in the library's scratch cache (see fmx_release_scratch) whatever their size,
  * up to three quarters of the device -- for a process that builds several very large indexes in a row (a text of
  * 2^32 symbols needs 137 GB of scratch: above the cache's default cap, so the second such build would pay the

@@ -83,22 +83,34 @@ def test_pair_index_not_applicable_falls_back():
         assert g2.search(p).get_range() == oi.search(p)
 
 
-def test_flag_auto_adds_both_accelerators_where_they_pay():
-    """FMX_FLAG_AUTO (round 4): a DNA-like FM index of >= 2^24 symbols gets the pair index and the k-mer start table
-    when the device has room; a shorter text, a larger alphabet or another kind stays plain.  Same (s, e) either way."""
+def test_the_default_index_gets_both_accelerators_where_they_pay():
+    """Round 6: a DNA-like FM index of >= 2^24 symbols gets the pair index and the k-mer start table by DEFAULT when the
+    device has room (FMX_FLAG_AUTO asked for it in rounds 4-5 and is still accepted); FMX_FLAG_PLAIN vetoes; a shorter
+    text, a larger alphabet or another kind stays plain.  Same (s, e) either way -- the oracle's."""
     n = 1 << 24
     t = W.dna_text_np(n, 3)
     tx = F.Text.with_max_character(t, 4)
-    ga = F.FMIndexWithLocate(tx, 2, auto=True)
-    g1 = F.FMIndex(tx)
-    assert ga.has_pair_index() and ga.kmer_k() >= 8 and not g1.has_pair_index() and g1.kmer_k() == 0
+    ga = F.FMIndexWithLocate(tx, 2)
+    gb = F.FMIndex(tx, auto=True)
+    g1 = F.FMIndex(tx, plain=True)
+    assert ga.has_pair_index() and ga.kmer_k() >= 8 and gb.has_pair_index() and gb.kmer_k() == ga.kmer_k()
+    assert not g1.has_pair_index() and g1.kmer_k() == 0
     flat, off, _ = W.substring_patterns_np(t, 20000, 21, 5)
     rflat, roff = W.ragged_patterns_np(20000, 40, 4, 6)
     for f, o in ((flat, off), (rflat, roff)):
-        ba, b1 = ga.search_many(flat=f, off=o), g1.search_many(flat=f, off=o)
-        assert (ba.s == b1.s).all() and (ba.e == b1.e).all()
-    ga.close(); g1.close()
-    small = F.FMIndex(F.Text.with_max_character(W.dna_text_np(1 << 20, 3), 4), auto=True)
+        ba, bb, b1 = ga.search_many(flat=f, off=o), gb.search_many(flat=f, off=o), g1.search_many(flat=f, off=o)
+        assert (ba.s == b1.s).all() and (ba.e == b1.e).all() and (bb.s == b1.s).all() and (bb.e == b1.e).all()
+    oi = O.OracleIndex.from_bwt(g1.export_bwt(), g1.export_cs(), 4)
+    so, eo = oi.count_batch(rflat[:int(roff[4000])], roff[:4001], nthreads=8)
+    b = ga.search_many(flat=rflat, off=roff)
+    assert (so == b.s[:4000]).all() and (eo == b.e[:4000]).all()
+    oi.close()
+    ga.close(); gb.close(); g1.close()
+    small = F.FMIndex(F.Text.with_max_character(W.dna_text_np(1 << 20, 3), 4))
     assert not small.has_pair_index() and small.kmer_k() == 0
-    wide_alpha = F.FMIndex(F.Text.with_max_character(W.byte_text_np(1 << 24, 4), 255), auto=True)
+    wide_alpha = F.FMIndex(F.Text.with_max_character(W.byte_text_np(1 << 24, 4), 255))
     assert not wide_alpha.has_pair_index() and wide_alpha.kmer_k() == 0
+    # the named flags are still honoured next to the veto
+    only_pair = F.FMIndex(tx, plain=True, pair_index=True)
+    assert only_pair.has_pair_index() and only_pair.kmer_k() == 0
+    only_pair.close()

@@ -240,8 +240,9 @@ def test_rlfm_run_table_mixed_batches(sampling, level, singles, longs, long_len)
     gi.close()
 
 
+@pytest.mark.parametrize("shape", ["slices", "deferred"])
 @pytest.mark.parametrize("kind", ["rlfm", "fm_bytes", "dna_row_order"])
-def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
+def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind, shape):
     """The paths that keep a rows array expand it with fmx_expand_slices_kernel from 1024 hits per pattern on: at most
     2048 blocks, each a run of consecutive 4096-hit slices -- only a block's first slice probes off[] for its first
     pattern, the others start from the pattern the previous slice ended on, and slices inside one long range follow from
@@ -262,9 +263,20 @@ def test_rows_of_large_batches_are_expanded_in_consecutive_slices(kind):
         gi = F.FMIndexWithLocate(F.Text.with_max_character(t, 4), 2, sampling="row")
         oi = O.OracleIndex(t, 4, level=2)
     want = oi.get_sa(np.arange(n)).astype(np.uint64)
-    s, e = _mixed_intervals(n, rng, 6000, 62, 240000, 2000)     # ~1500 hits per pattern on average
+    if shape == "slices":
+        s, e = _mixed_intervals(n, rng, 6000, 62, 240000, 2000)     # ~1500 hits per pattern on average
+    else:
+        # round 6, per RANGE: a low batch average (~40 hits per pattern: the lane-per-pattern expansion) with a few
+        # ranges of 2^16+ rows in it -- those are listed and written by a second, grid-wide pass (fmx_expand_long_kernel),
+        # ranges just below the threshold by their pattern's wave
+        s, e = _mixed_intervals(n, rng, 50000, 9, 240000, 3000)
+        s2, e2 = _mixed_intervals(n, rng, 0, 4, 65000, 0)
+        s, e = np.concatenate([s, s2]), np.concatenate([e, e2])
+        p = rng.permutation(len(s))
+        s, e = s[p], e[p]
+        assert ((e - s) >= (1 << 16)).sum() >= 5 and int((e - s).sum()) // len(s) < 1024
     off, pos = gi.locate_many(s, e)
-    assert int(off[-1]) > 2100 * 4096
+    assert int(off[-1]) > (2100 * 4096 if shape == "slices" else 1 << 20)
     exp = _expect(want, s, e)
     assert (np.asarray(pos, np.uint64) == exp).all()
     gi.close()

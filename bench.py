@@ -44,7 +44,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from benchmarks.legs.common import (PRETOUCH, Workload, counts_sha256, flush_c_stdio, golden_counts_sha,  # noqa: E402,F401
                                     golden_key, pretouch_device, ranges_sha256)
-from benchmarks.legs.cabi import config5_cabi_leg, results_on_host_leg  # noqa: E402
+from benchmarks.legs.cabi import config5_cabi_leg, results_on_host_leg, single_call_leg  # noqa: E402
 from benchmarks.legs.cpu import cpu_baseline, host_cpu  # noqa: E402,F401
 from benchmarks.legs.dist import dist_report, open_process_group, rccl_1rank_leg  # noqa: E402
 from benchmarks.legs.extra import accel_legs, d2h_leg, ic_ab_leg, rlfm_leg, wide_leg  # noqa: E402
@@ -437,6 +437,14 @@ def run(args, world, pmc=None, pmc_seconds=0.0, pmc31=None):
             dist.barrier(group=side)
     lap("cpu_baseline")
 
+    # ---- one-at-a-time callers: latency of one pattern, break-even batch size against the one-thread CPU port ----
+    if single and wl.dna and not args.no_cpu_baseline and not args.no_d2h:
+        try:
+            single_call_leg(out, wl, args)
+        except Exception as ex:  # noqa: BLE001
+            out["single_call"] = {"error": repr(ex)}
+    lap("single_call")
+
     # ---- config 4 (RLFMIndex, sigma = 255) as its own object ----
     wr = None
     if single and wl.dna and not args.no_rlfm:
@@ -573,7 +581,11 @@ def headline(out, detail_path):
         "value_auto": out.get("value_auto"),
         "value_incl_d2h": out.get("value_incl_d2h"),
         "value_results_on_host": out.get("value_results_on_host"),
+        "one_pattern_call_us": _get(out, "single_call", "n_2^30", "one_pattern_us"),
+        "break_even_batch": _get(out, "single_call", "n_2^30", "break_even_batch"),
+        "break_even_batch_n50000": _get(out, "single_call", "n_50000", "break_even_batch"),
         "config5_cabi_g1_value": _get(out, "config5_cabi", "g1", "value"),
+        "config5_cabi_g1_resident_value": _get(out, "config5_cabi", "g1_resident", "value"),
         "config5_cabi_matches_golden": _get(out, "config5_cabi", "matches_golden"),
         "wide_value": _get(out, "wide", "value"),
         "wide_locate_hits_per_s": _get(out, "wide", "locate", "hits_per_s"),

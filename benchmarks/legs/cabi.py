@@ -108,6 +108,38 @@ def config5_cabi_leg(out, wl, args, dev):
             assert r["matches_golden"], "config5 through the C ABI differs from tests/golden/config5_counts.json"
         return r
 
+    def run_resident(handles, g, devices, reps):
+        """the same set with every shard's patterns RESIDENT on its replica's device (uploads excluded), results
+        into the page-locked host arrays: fmx_count_batch_multi_resident"""
+        keep, d_pat, d_off = [], (C.c_void_p * g)(), (C.c_void_p * g)()
+        for r in range(g):
+            a = (T * r + g - 1) // g
+            b = (T * (r + 1) + g - 1) // g
+            dv = torch.device("cuda", devices[r])
+            fp = hp[a * m:b * m].to(dv)
+            fo = (torch.arange(b - a + 1, dtype=torch.int64, device=dv) * m).contiguous()
+            keep += [fp, fo]
+            d_pat[r], d_off[r] = fp.data_ptr(), fo.data_ptr()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+        def call():
+            rc = lib.fmx_count_batch_multi_resident(handles, g, d_pat, d_off, T, None, C.c_void_p(hs.data_ptr()),
+                                                    C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+            if rc != 0:
+                raise RuntimeError(lib.fmx_last_error().decode())
+        for a_ in (hs, he, hc):
+            a_.zero_()
+        dt = _time_calls(call, reps, warm=2)
+        sha, rsha = counts_sha256(hc.numpy()), ranges_sha256(hs.numpy(), he.numpy())
+        r = {"replicas": g, "ms_per_step": dt * 1e3, "value": T * m / dt, "counts_sha256": sha, "ranges_sha256": rsha,
+             "patterns": "resident on the replicas' devices", "results": "(s, e, count) in page-locked host arrays"}
+        if gold is not None:
+            r["matches_golden"] = gold[0] == sha and gold[1] in (None, rsha)
+            assert r["matches_golden"], "config5 (resident) through the C ABI differs from tests/golden/config5_counts.json"
+        del keep
+        return r
+
     reps = max(4, args.steps // 5)
     ndev = torch.cuda.device_count()
     others = []
@@ -123,9 +155,11 @@ def config5_cabi_leg(out, wl, args, dev):
         handles = (C.c_void_p * g)(wl.h.value, *[h.value for h in others])
         o["g%d" % g] = run(handles, g, reps)
         o["g%d" % g]["devices"] = [dev.index] + devs
+        o["g%d_resident" % g] = run_resident(handles, g, [dev.index] + devs, reps)
         if g > 1:                                          # the one-device point of the same curve
             o["g1"] = run((C.c_void_p * 1)(wl.h.value), 1, reps)
             o["g1"]["devices"] = [dev.index]
+            o["g1_resident"] = run_resident((C.c_void_p * 1)(wl.h.value), 1, [dev.index], reps)
     finally:
         for h in others:
             lib.fmx_free(h)
@@ -142,6 +176,7 @@ def config5_cabi_leg(out, wl, args, dev):
             reps3.append(h)
         handles = (C.c_void_p * 3)(wl.h.value, reps3[0].value, reps3[1].value)
         o["three_replicas_one_device"] = run(handles, 3, max(3, reps // 2))
+        o["three_replicas_one_device_resident"] = run_resident(handles, 3, [dev.index] * 3, max(3, reps // 2))
     finally:
         for h in reps3:
             lib.fmx_free(h)
@@ -150,3 +185,79 @@ def config5_cabi_leg(out, wl, args, dev):
     o["matches_golden"] = all(v.get("matches_golden", True) for v in o.values() if isinstance(v, dict))
     out["config5_cabi"] = o
     del hp, ho, hs, he, hc
+
+
+def single_call_leg(out, wl, args):
+    """One-at-a-time callers: the latency of ONE pattern through the host-pointer
+    entry point the trait shim's `search_range` uses, the per-call time of small batches, and the batch size from which a
+    call beats the one-thread CPU port of the reference (`benches/count.rs:20-52` times one `search(p).count()` at a
+    time) -- on the bench's 1 GiB index (the CPU walks DRAM there) and on a 50 000-symbol text that sits in the CPU's
+    caches (the reference's own benchmark size).  Every query still runs on the GPU: no CPU fallback."""
+    import numpy as np
+    import fm_index_amd as F
+    from fm_index_amd import workload as W
+    from oracle import fm_oracle as O
+    lib = wl.lib
+    m = wl.m
+    sizes = (1, 4, 16, 64, 256, 1024, 4096, 16384)
+
+    def gpu_sweep(handle, flat, off):
+        res = {}
+        s, e, c = (np.zeros(max(sizes), np.uint64) for _ in range(3))
+        for b in sizes:
+            o = np.ascontiguousarray(off[:b + 1])
+            f = np.ascontiguousarray(flat[:int(o[-1])])
+
+            def call():
+                rc = lib.fmx_count_batch(handle, f.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), b, None,
+                                         s.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                         c.ctypes.data_as(C.c_void_p))
+                if rc != 0:
+                    raise RuntimeError(lib.fmx_last_error().decode())
+            res[b] = _time_calls(call, 200 if b <= 1024 else 50, warm=5) * 1e6
+        return res
+
+    def break_even(gpu_us, cpu_us_per_pattern):
+        for b in sizes:
+            if gpu_us[b] <= b * cpu_us_per_pattern:
+                return b
+        return None
+
+    o = {"what": "fmx_count_batch (host pointers, pageable arrays, synchronous) per call, microseconds, by batch size; "
+                 "break_even_batch = smallest measured batch whose call takes no longer than the one-thread CPU port needs "
+                 "for the same patterns"}
+    # (a) the bench's index: n = 2^30
+    flat = wl.pat[:max(sizes) * m].cpu().numpy()
+    off = np.arange(max(sizes) + 1, dtype=np.uint64) * np.uint64(m)
+    big = gpu_sweep(wl.h, flat, off)
+    cb = out.get("cpu_baseline") or {}
+    cpu_big = m / cb["single_thread_value"] * 1e6 if cb.get("single_thread_value") else None
+    o["n_2^%d" % args.log2n] = {"gpu_us_per_call": {str(k): round(v, 1) for k, v in big.items()},
+                                "one_pattern_us": round(big[1], 1),
+                                "cpu_1_thread_us_per_pattern": round(cpu_big, 2) if cpu_big else None,
+                                "break_even_batch": break_even(big, cpu_big) if cpu_big else None}
+    # (b) the reference's benchmark size: 50 000 symbols, cache-resident on the CPU
+    n2 = 50000
+    t2 = W.dna_text_np(n2, 11)
+    g2 = F.FMIndex(F.Text.with_max_character(t2, 4), device=wl.local)
+    o2 = O.OracleIndex(t2, 4)
+    f2, off2, _ = W.substring_patterns_np(t2, max(sizes), m, 12)
+    small = gpu_sweep(g2.handle(), f2, off2)
+    o2.count_batch(f2, off2, nthreads=1)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        so, eo = o2.count_batch(f2, off2, nthreads=1)
+    cpu_small = (time.perf_counter() - t0) / 5 / max(sizes) * 1e6
+    b = g2.search_many(flat=f2, off=off2)
+    assert (b.s == so).all() and (b.e == eo).all()
+    o["n_50000"] = {"gpu_us_per_call": {str(k): round(v, 1) for k, v in small.items()}, "one_pattern_us": round(small[1], 1),
+                    "cpu_1_thread_us_per_pattern": round(cpu_small, 2), "break_even_batch": break_even(small, cpu_small)}
+    g2.close()
+    o2.close()
+    # the one-element trait calls of the shim (one kernel launch each)
+    row = int(wl.d_s[0].item())
+    for name, fn in (("fmx_lf_map2", lambda: lib.fmx_lf_map2(wl.h, 2, row)), ("fmx_get_sa", lambda: lib.fmx_get_sa(wl.h, row))):
+        if name == "fmx_get_sa" and wl.level is None:
+            continue
+        o[name + "_us"] = round(_time_calls(fn, 200, warm=5) * 1e6, 1)
+    out["single_call"] = o

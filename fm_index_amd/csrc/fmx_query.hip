@@ -338,18 +338,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_f3_kernel(
 // collapses the interval, the single step for the LAST symbol decides whether the reference
 // would have stopped after one symbol (then ITS (s, e) is returned) or after two.
 // ---------------------------------------------------------------------------
-// PPG (round 6): patterns a group advances concurrently -- independent chains.  With the table and the pair records a
-// 32-symbol pattern is ~13 dependent round trips, three of them its START (offsets -> the symbols of the k-mer code ->
-// the table entry) with one request in flight per group: the kernel ran at 0.68 of the request ceiling where the plain
-// kernel (32 round trips of two requests) reaches 0.93.  Here a pattern is a little state machine whose start stages
-// take one round each, like a step:
-//     stage 0  its offsets (and the given range of a refinement)           -> length, start pair
-//     stage 1  its last symbols (two per lane, as fmx_kmer_code reads them) -> k-mer code, or the first two symbols
-//     stage 2  the table entry + the two symbols in front of the k-mer      -> (s, e) after kmer_k steps
-//     stage 3  one (pair) step per round                                                     wrapper.rs:108-114
-// and every round issues the loads of ALL the group's patterns -- whatever their stages -- before it waits once: the
-// start of one pattern travels under the steps of the other.
-template <bool KM, int PPG = 1>
+// (Round 6 measured two ways of putting more requests in flight per wave here -- the kernel runs at 0.68 of the request
+// ceiling where the plain kernel reaches 0.93, three of a pattern's ~13 dependent round trips being its start: offsets,
+// the k-mer code's symbols, the table entry -- and dropped both (profiles/r06/pair_kernel_ab.txt; this kernel: 0.324 ms
+// per 2^20 x 32 symbols): two patterns per group with the record loads of both issued before one wait, 0.42 ms
+// (0.52 with one pattern in that form: loads and rank decode in separate loops cost more than the second chain
+// brings); a pattern as a state machine whose start stages take one round each like a step, every load of a round
+// issued before one wait, 0.50-0.64 ms -- the groups of a wave sit in different stages, their loads serialise on shared
+// destination registers or take the kernel to 104 VGPRs, and the divergent round costs more than it hides.)
+template <bool KM>
 __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
     const uint4 *__restrict__ rec1, const uint4 *__restrict__ rec2, uint32_t n,
     uint32_t max_character, uint32_t row0, uint32_t row1, uint32_t *status,
@@ -361,178 +358,115 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / FMX_GROUP;
   const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / FMX_GROUP;
 
-  uint64_t k[PPG], pbeg[PPG];
-  bool active[PPG];
-  uint32_t stage[PPG], j[PPG], s[PPG], e[PPG];
-  uint32_t c2[PPG], c1[PPG];   // c2 = last unread symbol, c1 = the one before it
+  uint64_t k = gid;
+  bool active = k < npat, fresh = true;
+  uint64_t pbeg = 0;
+  uint32_t j = 0, s = 0, e = 0;
+  uint32_t c2 = 0, c1 = 0;   // c2 = last unread symbol, c1 = the one before it
   uint32_t nsteps = 0;
-  bool any = false;
-#pragma unroll
-  for (int q = 0; q < PPG; q++) {
-    k[q] = gid + (uint64_t)q * ngroups;
-    active[q] = k[q] < npat;
-    stage[q] = 0;
-    any |= active[q];
-    pbeg[q] = 0; j[q] = 0; s[q] = 0; e[q] = 0; c2[q] = 0; c1[q] = 0;
-  }
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
   const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
-  while (any) {
-    // ---- every load of this round, for every pattern of the group, by stage ----
-    uint4 ra[PPG], rb[PPG];        // stage 0: {off[k], off[k+1]}, {s0, e0}; 1: symbols; 2: table entry, symbols; 3: records
-    uint32_t n1[PPG], n2[PPG];
-    bool pair[PPG];
-#pragma unroll
-    for (int q = 0; q < PPG; q++) {
-      ra[q] = make_uint4(0u, 0u, 0u, 0u); rb[q] = ra[q];
-      n1[q] = 0; n2[q] = 0; pair[q] = false;
-      if (!active[q]) continue;
-      if (stage[q] == 0u) {
-        const uint64_t o0 = off[k[q]], o1 = off[k[q] + 1];
-        ra[q] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)o1, (uint32_t)(o1 >> 32));
-        if (s0e0) {
-          const uint64_t s64 = s0e0[2 * k[q]], e64 = s0e0[2 * k[q] + 1];
-          rb[q] = make_uint4((uint32_t)s64, (uint32_t)(s64 >> 32), (uint32_t)e64, (uint32_t)(e64 >> 32));
+  while (active) {
+    if (fresh) {
+      pbeg = off[k];
+      const uint64_t pend = off[k + 1];
+      j = (uint32_t)(pend - pbeg);
+      // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
+      const bool badoff = pend < pbeg || pbeg < pmin || pend > ptot || pend - pbeg > 0xFFFFFFFFull;
+      if (badoff) {
+        if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+        j = 0;
+      }
+      if (s0e0) {
+        const uint64_t s64 = s0e0[2 * k], e64 = s0e0[2 * k + 1];
+        s = (uint32_t)s64;
+        e = (uint32_t)e64;
+        if (s64 > n || e64 > n || badoff) {            // not a range of this index: refuse, do not read
+          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
+          s = 0; e = 0; j = 0;
         }
-      } else if (stage[q] == 1u) {
-        // the pattern's last symbols, t-th from the back in lane t and t + 8 (fmx_kmer_code's layout); without a table
-        // (or a pattern shorter than its k) only the last two are needed
-        const uint32_t want = (KM && !s0e0 && j[q] >= kmer_k) ? kmer_k : (j[q] < 2u ? j[q] : 2u);
-        if (g < want) ra[q].x = pat[pbeg[q] + j[q] - 1u - g];
-        if (g + 8u < want) ra[q].y = pat[pbeg[q] + j[q] - 9u - g];
-      } else if (stage[q] == 2u) {
-        FMX_TOUCH_G0N(g, &kmer[s[q]]);
-        const uint2 se = kmer[s[q]];                  // (the code waits in s[q])
-        ra[q].x = se.x; ra[q].y = se.y;
-        const uint32_t rest = j[q] - kmer_k;          // symbols in front of the k-mer
-        if (rest > 0u) ra[q].z = pat[pbeg[q] + rest - 1u];
-        if (rest > 1u) ra[q].w = pat[pbeg[q] + rest - 2u];
-      } else if (j[q] != 0u && c2[q] <= max_character) {
-        pair[q] = j[q] >= 2u && (c2[q] - 1u) < 4u && (c1[q] - 1u) < 4u;
+      } else {
+        s = 0;
+        e = badoff ? 0u : n;
+        if (KM && j >= kmer_k) {                       // the first kmer_k steps from the table
+          uint32_t code;
+          if (fmx_kmer_code(pat, pbeg + j, kmer_k, kmer_bits, max_character, g, code)) {
+            FMX_TOUCH_G0N(g, &kmer[code]);
+            const uint2 se = kmer[code];
+            s = se.x;
+            e = se.y;
+            j = se.x == se.y ? 0u : j - kmer_k;        // empty already: the reference's break
+            nsteps += kmer_k;
+          }
+        }
+      }
+      c2 = j ? pat[pbeg + j - 1] : 0u;
+      c1 = j > 1 ? pat[pbeg + j - 2] : 0u;
+      fresh = false;
+    }
+    bool done = (j == 0);
+    if (!done) {
+      if (c2 > max_character) {                        // reference: panic on cs[c]
+        if (g == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
+        s = 0; e = 0; done = true;
+      } else {
+        const bool pair = j >= 2 && (c2 - 1u) < 4u && (c1 - 1u) < 4u;
         // the two symbols after these ride along with the record loads
-        if (j[q] > 2u) n1[q] = pat[pbeg[q] + j[q] - 3u];
-        if (j[q] > 3u) n2[q] = pat[pbeg[q] + j[q] - 4u];
-        if (pair[q]) {
-          FMX_CHECK((s[q] >> 7) < n / 128u + 1u && (e[q] >> 7) < n / 128u + 1u);
-          FMX_TOUCH_G0(g, &rec2[(size_t)(s[q] >> 7) * 8u]);
-          if ((e[q] >> 7) != (s[q] >> 7)) FMX_TOUCH_G0(g, &rec2[(size_t)(e[q] >> 7) * 8u]);
-          ra[q] = rec2[(size_t)(s[q] >> 7) * 8u + g];
-          rb[q] = rec2[(size_t)(e[q] >> 7) * 8u + g];
+        const uint32_t n1 = j > 2 ? pat[pbeg + j - 3] : 0u;
+        const uint32_t n2 = j > 3 ? pat[pbeg + j - 4] : 0u;
+        uint32_t used;
+        if (pair) {
+          const uint32_t code = (c1 - 1u) * 4u + (c2 - 1u);
+          FMX_CHECK((s >> 7) < n / 128u + 1u && (e >> 7) < n / 128u + 1u);
+          FMX_TOUCH_G0(g, &rec2[(size_t)(s >> 7) * 8u]);
+          if ((e >> 7) != (s >> 7)) FMX_TOUCH_G0(g, &rec2[(size_t)(e >> 7) * 8u]);
+          const uint4 a = rec2[(size_t)(s >> 7) * 8u + g];
+          const uint4 b = rec2[(size_t)(e >> 7) * 8u + g];
+          uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(a, s & 127u, code, g));
+          uint32_t ne = fmx_group_sum(fmx_piece_rank<4>(b, e & 127u, code, g));
+          if (code == 0u) {  // the two rows without a 2-gram are stored as code 0
+            ns -= (uint32_t)(s > row0) + (uint32_t)(s > row1);
+            ne -= (uint32_t)(e > row0) + (uint32_t)(e > row1);
+          }
+          used = 2;
+          if (ns == ne) {
+            // would the reference already have stopped after the last symbol alone?
+            FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
+            FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
+            if ((e >> 8) != (s >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
+            const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
+            const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
+            const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));
+            const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(b1, e & 255u, c2, g));
+            if (s1 == e1) { ns = s1; ne = e1; used = 1; }
+          }
+          s = ns; e = ne;
         } else {
-          FMX_CHECK((s[q] >> 8) < n / 256u + 1u && (e[q] >> 8) < n / 256u + 1u);
-          FMX_TOUCH_G0(g, &rec1[(size_t)(s[q] >> 8) * 8u]);
-          if ((e[q] >> 8) != (s[q] >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e[q] >> 8) * 8u]);
-          ra[q] = rec1[(size_t)(s[q] >> 8) * 8u + g];
-          rb[q] = rec1[(size_t)(e[q] >> 8) * 8u + g];
+          FMX_CHECK((s >> 8) < n / 256u + 1u && (e >> 8) < n / 256u + 1u);
+          FMX_TOUCH_G0(g, &rec1[(size_t)(s >> 8) * 8u]);
+          if ((e >> 8) != (s >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e >> 8) * 8u]);
+          const uint4 a1 = rec1[(size_t)(s >> 8) * 8u + g];
+          const uint4 b1 = rec1[(size_t)(e >> 8) * 8u + g];
+          const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s & 255u, c2, g));  // wrapper.rs:109
+          const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(b1, e & 255u, c2, g));  // wrapper.rs:110
+          s = s1; e = e1;
+          used = 1;
         }
+        nsteps += used;
+        j -= used;
+        if (used == 2) { c2 = n1; c1 = n2; } else { c2 = c1; c1 = n1; }
+        if (s == e || j == 0) done = true;             // wrapper.rs:111-113
       }
     }
-    // ---- what the loads say ----
-    any = false;
-#pragma unroll
-    for (int q = 0; q < PPG; q++) {
-      if (!active[q]) continue;
-      bool done = false;
-      if (stage[q] == 0u) {
-        pbeg[q] = (uint64_t)ra[q].x | ((uint64_t)ra[q].y << 32);
-        const uint64_t pend = (uint64_t)ra[q].z | ((uint64_t)ra[q].w << 32);
-        j[q] = (uint32_t)(pend - pbeg[q]);
-        // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
-        const bool badoff = pend < pbeg[q] || pbeg[q] < pmin || pend > ptot || pend - pbeg[q] > 0xFFFFFFFFull;
-        if (badoff) {
-          if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
-          j[q] = 0;
-        }
-        if (s0e0) {                                    // Search::search on an existing Search (wrapper.rs:105-106)
-          const uint64_t s64 = (uint64_t)rb[q].x | ((uint64_t)rb[q].y << 32), e64 = (uint64_t)rb[q].z | ((uint64_t)rb[q].w << 32);
-          s[q] = (uint32_t)s64;
-          e[q] = (uint32_t)e64;
-          if (s64 > n || e64 > n || badoff) {          // not a range of this index: refuse, do not read
-            if (g == 0) atomicOr(status, 1u << FMX_ERR_ARG);
-            s[q] = 0; e[q] = 0; j[q] = 0;
-          }
-        } else {                                       // (0, len)   wrapper.rs:41
-          s[q] = 0;
-          e[q] = badoff ? 0u : n;
-        }
-        if (j[q] == 0u) done = true; else stage[q] = 1u;
-      } else if (stage[q] == 1u) {
-        // symbol t from the back sits in lane t (ra.x) / lane t - 8 (ra.y)
-        const uint32_t last = fmx_group_sum(g == 0u ? ra[q].x : 0u), before = fmx_group_sum(g == 1u ? ra[q].x : 0u);
-        bool table = KM && !s0e0 && j[q] >= kmer_k;
-        if (table) {                                   // fmx_kmer_code on the loaded symbols
-          uint32_t part = 0, bad = 0;
-          if (g < kmer_k) {
-            bad |= (uint32_t)((ra[q].x - 1u) >= max_character);
-            part |= ((ra[q].x - 1u) & ((1u << kmer_bits) - 1u)) << (kmer_bits * (kmer_k - 1u - g));
-          }
-          if (g + 8u < kmer_k) {
-            bad |= (uint32_t)((ra[q].y - 1u) >= max_character);
-            part |= ((ra[q].y - 1u) & ((1u << kmer_bits) - 1u)) << (kmer_bits * (kmer_k - 9u - g));
-          }
-          const uint32_t code = fmx_group_sum(part);   // disjoint bit fields: sum == or
-          table = fmx_group_sum(bad) == 0u;            // a 0 or out-of-range symbol among them: the stepwise path decides
-          if (table) { s[q] = code; stage[q] = 2u; }   // (the code waits in s[q]; e[q] keeps n)
-        }
-        if (!table) { c2[q] = last; c1[q] = j[q] > 1u ? before : 0u; stage[q] = 3u; }
-      } else if (stage[q] == 2u) {
-        s[q] = ra[q].x;
-        e[q] = ra[q].y;
-        nsteps += kmer_k;
-        j[q] = s[q] == e[q] ? 0u : j[q] - kmer_k;      // empty already: the reference's break
-        c2[q] = j[q] ? ra[q].z : 0u;
-        c1[q] = j[q] > 1u ? ra[q].w : 0u;
-        if (j[q] == 0u) done = true; else stage[q] = 3u;
-      } else {
-        if (c2[q] > max_character) {                   // reference: panic on cs[c]
-          if (g == 0) atomicOr(status, 1u << FMX_ERR_SYMBOL_RANGE);
-          s[q] = 0; e[q] = 0; done = true;
-        } else {
-          uint32_t used;
-          if (pair[q]) {
-            const uint32_t code = (c1[q] - 1u) * 4u + (c2[q] - 1u);
-            uint32_t ns = fmx_group_sum(fmx_piece_rank<4>(ra[q], s[q] & 127u, code, g));
-            uint32_t ne = fmx_group_sum(fmx_piece_rank<4>(rb[q], e[q] & 127u, code, g));
-            if (code == 0u) {  // the two rows without a 2-gram are stored as code 0
-              ns -= (uint32_t)(s[q] > row0) + (uint32_t)(s[q] > row1);
-              ne -= (uint32_t)(e[q] > row0) + (uint32_t)(e[q] > row1);
-            }
-            used = 2;
-            if (ns == ne) {
-              // would the reference already have stopped after the last symbol alone?
-              FMX_CHECK((s[q] >> 8) < n / 256u + 1u && (e[q] >> 8) < n / 256u + 1u);
-              FMX_TOUCH_G0(g, &rec1[(size_t)(s[q] >> 8) * 8u]);
-              if ((e[q] >> 8) != (s[q] >> 8)) FMX_TOUCH_G0(g, &rec1[(size_t)(e[q] >> 8) * 8u]);
-              const uint4 a1 = rec1[(size_t)(s[q] >> 8) * 8u + g];
-              const uint4 b1 = rec1[(size_t)(e[q] >> 8) * 8u + g];
-              const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(a1, s[q] & 255u, c2[q], g));
-              const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(b1, e[q] & 255u, c2[q], g));
-              if (s1 == e1) { ns = s1; ne = e1; used = 1; }
-            }
-            s[q] = ns; e[q] = ne;
-          } else {
-            const uint32_t s1 = fmx_group_sum(fmx_piece_rank<3>(ra[q], s[q] & 255u, c2[q], g));  // wrapper.rs:109
-            const uint32_t e1 = fmx_group_sum(fmx_piece_rank<3>(rb[q], e[q] & 255u, c2[q], g));  // wrapper.rs:110
-            s[q] = s1; e[q] = e1;
-            used = 1;
-          }
-          nsteps += used;
-          j[q] -= used;
-          if (used == 2) { c2[q] = n1[q]; c1[q] = n2[q]; } else { c2[q] = c1[q]; c1[q] = n1[q]; }
-          if (s[q] == e[q] || j[q] == 0) done = true;  // wrapper.rs:111-113
-        }
+    if (done) {
+      if (g == 0) {
+        if (out_s) out_s[k] = s;
+        if (out_e) out_e[k] = e;
+        if (out_cnt) out_cnt[k] = (uint64_t)(e - s);
       }
-      if (done) {
-        if (g == 0) {
-          if (out_s) out_s[k[q]] = s[q];
-          if (out_e) out_e[k[q]] = e[q];
-          if (out_cnt) out_cnt[k[q]] = (uint64_t)(e[q] - s[q]);   // wrapper.rs:132-134
-        }
-        k[q] += (uint64_t)PPG * ngroups;
-        active[q] = k[q] < npat;
-        stage[q] = 0;
-      }
-      any |= active[q];
+      k += ngroups;
+      active = k < npat;
+      fresh = true;
     }
   }
   if (steps_out && g == 0 && nsteps)
@@ -1980,7 +1914,6 @@ struct FmxTune {
   bool rl_unified = false;       // measurement builds (FMX_RL_UNIFIED=1): the RLFM lane kernel in one launch (slices expanded in LDS)
   long rl_lane_avg = 2;          // ... with the run table: a lane per walk on consecutive hits from this many hits per pattern
   long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
-  int pair_ppg = 0;              // pair-index count: patterns per group, 0 = by batch size
 };
 // everything a count / locate launch needs, for the launch helpers below and in fmx_measure.inc
 struct FmxCountCall {
@@ -2012,9 +1945,8 @@ static inline int fmx_select_mode(const fmx_index *idx, const FmxDev &dv) {
                      (c).dv.bw.lv[0].rec, (c).dv.n, (c).dv.max_character, (c).dv.status, (c).dv.kmer,  \
                      (c).dv.kmer_k, (c).dv.kmer_bits, (const uint8_t *)(c).pat, (c).off, (c).npat,     \
                      (c).s0e0, (c).s, (c).e, (c).cnt, (c).steps)
-#define FMX_PAIR_LAUNCH(c, KM, PPG)                                                                  \
-  hipLaunchKernelGGL((fmx_count_pair_kernel<KM, PPG>),                                                 \
-                     dim3(fmx_grid_capped(((c).npat + PPG - 1) / PPG, (c).grid)), dim3(FMX_BLOCK), 0, (c).st, \
+#define FMX_PAIR_LAUNCH(c, KM)                                                                       \
+  hipLaunchKernelGGL(fmx_count_pair_kernel<KM>, dim3((c).grid), dim3(FMX_BLOCK), 0, (c).st,            \
                      (c).dv.bw.lv[0].rec, (c).dv.pair_rec, (c).dv.n, (c).dv.max_character,             \
                      (c).dv.pair_row0, (c).dv.pair_row1, (c).dv.status, (c).dv.kmer, (c).dv.kmer_k,    \
                      (c).dv.kmer_bits, (const uint8_t *)(c).pat, (c).off, (c).npat, (c).s0e0, (c).s,   \
@@ -2641,11 +2573,7 @@ int fmx_launch_count(const fmx_index *idx, const void *d_pat, const uint64_t *d_
   if (done) {
   } else if (dv.pair_rec && idx->sym_bytes == 1 && tn.use_pair && !tn.generic) {
     // opt-in pair index: two symbols per probe
-    // two patterns per group (round 6: more requests in flight per wave; the start of one pattern under the
-    // steps of the other) once the batch fills the grid twice over; FMX_PAIR_PPG=1|2 in measurement builds
-    const int ppg = tn.pair_ppg ? tn.pair_ppg : (npat >= 2ull * FMX_MAX_BLOCKS * (FMX_BLOCK / FMX_GROUP) ? 2 : 1);
-    if (ppg == 2) { if (c.km) FMX_PAIR_LAUNCH(c, true, 2); else FMX_PAIR_LAUNCH(c, false, 2); }
-    else { if (c.km) FMX_PAIR_LAUNCH(c, true, 1); else FMX_PAIR_LAUNCH(c, false, 1); }
+    if (c.km) FMX_PAIR_LAUNCH(c, true); else FMX_PAIR_LAUNCH(c, false);
   } else if (idx->kind == FMX_KIND_FM && idx->sym_bytes == 1 && w.nlevels == 1 && w.lv[0].fmt == 3 && !tn.generic) {
     // DNA (one 3-bit level): one 128-byte line per interval end and step, group per pattern
     if (c.km) FMX_F3_LAUNCH(c, 1, false, true); else FMX_F3_LAUNCH(c, 1, false, false);

@@ -581,6 +581,7 @@ def headline(out, detail_path):
         "value_auto": out.get("value_auto"),
         "value_incl_d2h": out.get("value_incl_d2h"),
         "value_results_on_host": out.get("value_results_on_host"),
+        "value_ranges_on_host": out.get("value_ranges_on_host"),
         "one_pattern_call_us": _get(out, "single_call", "n_2^30", "one_pattern_us"),
         "break_even_batch": _get(out, "single_call", "n_2^30", "break_even_batch"),
         "break_even_batch_n50000": _get(out, "single_call", "n_50000", "break_even_batch"),

@@ -1,6 +1,8 @@
 """FMX_BUILD_TRACE of the config-2 build (n = 2^30 DNA) three times in one process: what of build_ms is the driver's
 memory management (hipMalloc / hipFree of the builder's scratch) and what is kernels"""
 import sys, os, time
+# (FMX_BUILD_TRACE is read by the measurement build only since round 6: FMX_LIB=fm_index_amd/libfmx_measure.so)
+os.environ.setdefault("FMX_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "fm_index_amd", "libfmx_measure.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fm_index_amd as F

@@ -20,8 +20,9 @@ def _time_calls(fn, reps, warm=2):
 
 def results_on_host_leg(out, wl, args):
     """config 2's batch (2^20 x len-32, resident in HBM) through fmx_count_batch_multi_resident on ONE handle: every call
-    ends with (s, e, count) -- or the counts alone -- readable in page-locked host arrays.  `value_results_on_host` is the
-    (s, e, count) figure; never the headline `value` (whose results stay in HBM)."""
+    ends with the counts -- or (s, e, count) -- readable in page-locked host arrays.  `value_results_on_host` is the
+    counts figure (`search(p).count()`), `value_ranges_on_host` the (s, e, count) one; never the headline `value` (whose
+    results stay in HBM)."""
     torch, lib = wl.torch, wl.lib
     npat, m = wl.npat, wl.m
     hs, he, hc = (torch.zeros(npat, dtype=torch.int64).pin_memory() for _ in range(3))
@@ -54,7 +55,10 @@ def results_on_host_leg(out, wl, args):
             raise RuntimeError(lib.fmx_last_error().decode())
     dt_pg = _time_calls(call_pageable, max(5, reps // 2))
     assert (pc == hc.numpy()).all() and (ps == hs.numpy()).all()
-    out["value_results_on_host"] = npat * m / dt_full
+    # BASELINE's count metric is `search(p).count()` (benches/count.rs:29-37): the COUNTS landed in host memory are the
+    # protocol number; (s, e, count) -- 24 bytes per pattern over a ~56 GB/s host link -- is reported next to it
+    out["value_results_on_host"] = npat * m / dt_cnt
+    out["value_ranges_on_host"] = npat * m / dt_full
     out["results_on_host"] = {
         "protocol": "SURVEY 8(d): patterns resident in HBM, one synchronous call per batch, results readable in host "
                     "memory when it returns (fmx_count_batch_multi_resident, 1 handle); page-locked result arrays are "
@@ -62,7 +66,8 @@ def results_on_host_leg(out, wl, args):
         "s_e_count_ms_per_call": dt_full * 1e3, "s_e_count_value": npat * m / dt_full, "bytes_out_s_e_count": 24 * npat,
         "count_only_ms_per_call": dt_cnt * 1e3, "count_only_value": npat * m / dt_cnt, "bytes_out_count_only": 8 * npat,
         "pageable_s_e_count_ms_per_call": dt_pg * 1e3, "pageable_s_e_count_value": npat * m / dt_pg,
-        "vs_value": round(npat * m / dt_full / out["value"], 4)}
+        "value_results_on_host_is": "count_only", "vs_value": round(npat * m / dt_cnt / out["value"], 4),
+        "s_e_count_vs_value": round(npat * m / dt_full / out["value"], 4)}
     del hs, he, hc
 
 
@@ -123,19 +128,17 @@ def config5_cabi_leg(out, wl, args, dev):
         for d in set(devices):
             torch.cuda.synchronize(d)
 
-        def call():
-            rc = lib.fmx_count_batch_multi_resident(handles, g, d_pat, d_off, T, None, C.c_void_p(hs.data_ptr()),
-                                                    C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+        def call():                               # config 5 gathers the COUNTS: 8 bytes per pattern
+            rc = lib.fmx_count_batch_multi_resident(handles, g, d_pat, d_off, T, None, None, None, C.c_void_p(hc.data_ptr()))
             if rc != 0:
                 raise RuntimeError(lib.fmx_last_error().decode())
-        for a_ in (hs, he, hc):
-            a_.zero_()
+        hc.zero_()
         dt = _time_calls(call, reps, warm=2)
-        sha, rsha = counts_sha256(hc.numpy()), ranges_sha256(hs.numpy(), he.numpy())
-        r = {"replicas": g, "ms_per_step": dt * 1e3, "value": T * m / dt, "counts_sha256": sha, "ranges_sha256": rsha,
-             "patterns": "resident on the replicas' devices", "results": "(s, e, count) in page-locked host arrays"}
+        sha = counts_sha256(hc.numpy())
+        r = {"replicas": g, "ms_per_step": dt * 1e3, "value": T * m / dt, "counts_sha256": sha,
+             "patterns": "resident on the replicas' devices", "results": "counts in a page-locked host array"}
         if gold is not None:
-            r["matches_golden"] = gold[0] == sha and gold[1] in (None, rsha)
+            r["matches_golden"] = gold[0] == sha
             assert r["matches_golden"], "config5 (resident) through the C ABI differs from tests/golden/config5_counts.json"
         del keep
         return r

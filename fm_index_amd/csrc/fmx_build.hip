@@ -19,6 +19,16 @@
 #include <chrono>
 #include "fmx_device.h"
 
+// FMX_BUILD_TRACE=1 (elapsed ms after each build phase on stderr) is read by the measurement builds only: the shipped
+// library reads no environment variable at all
+static inline bool fmx_build_trace() {
+#ifdef FMX_MEASURE
+  return getenv("FMX_BUILD_TRACE") != nullptr;
+#else
+  return false;
+#endif
+}
+
 #define BLK 256
 
 namespace {
@@ -940,7 +950,7 @@ int suffix_sort(const T *d_text, uint32_t n, uint32_t sym_bits, uint32_t *d_sa, 
   uint64_t *keys_a, *keys_b;
   uint32_t *vals_b, *rank = nullptr, *head = nullptr;
   unsigned int *d_ng;
-  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  static const bool trace = fmx_build_trace();
   auto ts0 = std::chrono::steady_clock::now();
   auto mark = [&](const char *what, uint64_t h) {
     if (!trace) return;
@@ -1764,7 +1774,7 @@ template <typename T>
 static int build_impl_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
   // FMX_BUILD_TRACE=1: elapsed ms after each phase on stderr (each mark synchronises the device)
-  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  static const bool trace = fmx_build_trace();
   auto mark = [&](const char *what) {
     if (!trace) return;
     (void)hipDeviceSynchronize();
@@ -2475,7 +2485,7 @@ int suffix_sort_wide(const T *d_text, uint64_t n, uint32_t sym_bits, uint64_t *d
   uint64_t *keys_a, *keys_b, *vals_b, *rank = nullptr;
   auto need_rank = [&]() -> hipError_t { return rank ? hipSuccess : pool.get(&rank, n); };
   unsigned int *d_ng;
-  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  static const bool trace = fmx_build_trace();
   auto ts0 = std::chrono::steady_clock::now();
   auto mark = [&](const char *what, uint64_t h) {
     if (!trace) return;
@@ -2996,7 +3006,7 @@ static int build_rlfm_wide(fmx_index *idx, T *d_L, uint64_t n, uint32_t L, DevPo
 template <typename T>
 static int build_wide_t(fmx_index *idx, const T *d_text) {
   auto t0 = std::chrono::steady_clock::now();
-  static const bool trace = getenv("FMX_BUILD_TRACE") != nullptr;
+  static const bool trace = fmx_build_trace();
   auto mark = [&](const char *what) {
     if (!trace) return;
     (void)hipDeviceSynchronize();

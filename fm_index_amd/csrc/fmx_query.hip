@@ -2129,6 +2129,19 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   // lane 0 of the wave touches the LDS word)
   uint64_t k_lo = 0, span = npat;
   if (k_hint && *k_hint != ~0ull) { k_lo = *k_hint; span = 0; }
+  // Round 6: about a pattern per hit (config 3: 2^20 patterns, 2^20 hits) -> the slice's first pattern sits where the
+  // offsets would put it if every pattern had the same number of hits, give or take a few hundred.  The expansion
+  // starts 512 patterns in front of that GUESS without probing -- the probe round is a dependent round trip + two
+  // barriers in front of every block's first walk -- and the first round of loads checks it (off[k_lo] <= blo); a
+  // wrong guess (skewed batches) costs that round and falls back to the probes.
+  bool guessed = false;
+  if (span > FMX_U_PATS && dense && npat <= total) {
+    const uint64_t kg = (uint64_t)(((unsigned __int128)blo * npat) / total);
+    k_lo = kg > 512u ? kg - 512u : 0;
+    span = 0;
+    guessed = true;
+  }
+probe:
   while (span > FMX_U_PATS) {                         // block-uniform
     const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
     const uint64_t c = k_lo + (uint64_t)tid * step;
@@ -2172,6 +2185,15 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
     // the round's last pattern + 1: does it still start inside the slice?
     bool more = false;
     if (tid == FMX_LOC_BLOCK - 1u && kc + per_round < npat) more = off[kc + per_round] < bhi;
+    if (guessed) {                                    // block-uniform; the first round of a guessed start only
+      guessed = false;
+      // the slice's first pattern lies at or behind k_lo iff off[k_lo] <= blo (thread 0 holds off[k_lo]; k_lo == 0 needs no check)
+      if (__syncthreads_or((int)(tid == 0 && k_lo != 0 && o[0] > blo))) {
+        k_lo = 0;
+        span = npat;
+        goto probe;                                   // nothing has been written yet
+      }
+    }
 #pragma unroll
     for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
       if (!need[j]) continue;

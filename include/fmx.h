@@ -248,7 +248,12 @@ int fmx_stream_status(const fmx_index *idx);
 /* (wrapper.rs:137-139, 203-217, 238-242 -> fm_index.rs:127-140, sample.rs:46-60)
  *     out_pos[out_off[k] + j] = get_sa(s[k] + j),  j = 0 .. e[k]-s[k]-1
  * i.e. suffix-array order, exactly the reference's iteration order.  `out_off` has
- * npat+1 entries (exclusive scan of the counts; out_off[npat] = total hits). */
+ * npat+1 entries (exclusive scan of the counts; out_off[npat] = total hits).
+ * Arguments that are not of this index are reported as FMX_ERR_ARG and never dereferenced: a range with e > len(), a
+ * range that does not fit between its offset and total_hits, offsets that leave slots uncovered (the slots take the
+ * position of row 0).  What is examined is every range that claims slots of out_pos -- on every path; a range whose
+ * slots lie entirely at or beyond total_hits, or whose offsets leave it no slot at all although e > s, writes nothing,
+ * and whether it is reported depends on the path the batch takes. */
 int fmx_locate_batch_dev(const fmx_index *idx, const uint64_t *d_s, const uint64_t *d_e,
                          uint64_t npat, const uint64_t *d_out_off, uint64_t total_hits,
                          uint64_t *d_out_pos, void *stream);

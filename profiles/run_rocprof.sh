@@ -3,9 +3,10 @@
 # repo root):   bash profiles/run_rocprof.sh <tag> ["extra bench flags"]
 # Pass 1: --kernel-trace --stats of the bench command (per-kernel durations; bench.py's own HIP-event
 #         figures of the same run land in bench_trace.json and must agree).
-# Pass 2/3: --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own runs over `bench.py --pmc-child` (the
-#         same passes bench.py runs live for roofline.traffic) -- TCC slots: MI355X_MICROARCH.md
-#         "rocprofv3 PMC slots"; counters are never combined with trace domains.
+# Pass 2/3: --pmc TCC_EA0_RDREQ_sum + its _32B / _64B / _128B parts (FETCH_SIZE = RDREQ x 64 B on gfx950; the widths say
+#         what the requests moved) and --pmc WRITE_SIZE in their own runs over `bench.py --pmc-child` (the same passes
+#         bench.py runs live for roofline.traffic) -- TCC slots: MI355X_MICROARCH.md "rocprofv3 PMC slots"; counters are
+#         never combined with trace domains.
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -15,13 +16,14 @@ cd /tmp && export TMPDIR=/tmp
 # --no-config5 / --no-rccl-check: the 8 M-pattern batch runs the same count kernel on another shape (5 ms per launch)
 # 20 timed steps: the first launches of a kernel in a process run slower (cold TLB / caches: 0.70-0.77 ms against 0.63-0.65
 # for the count kernel) and must not weigh on the per-kernel average the bench line is compared with
+RD="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-census --no-early-exit --no-d2h --no-wide --no-config5 --no-rccl-check --no-ic-ab ${2:---no-accel}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS --detail-out $OUT/bench_trace_detail.json > $OUT/bench_trace.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc $RD --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_write.out 2> $OUT/pmc_write.err
 # config 4b (repetitive text, RLFM): fmx_locate_rl_lane_kernel -- its own trace and counter passes
 rocprofv3 --kernel-trace --stats -d $OUT/trace4b --output-format csv -- python3 $REPO/bench.py --workload rep-rlfm --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-census --no-d2h --no-accel --no-rccl-check --detail-out $OUT/bench_trace4b_detail.json > $OUT/bench_trace4b.json 2> $OUT/trace4b.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_fetch4b.out 2> $OUT/pmc_fetch4b.err
+rocprofv3 --pmc $RD --kernel-trace -d $OUT/pmc_fetch4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_fetch4b.out 2> $OUT/pmc_fetch4b.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_write4b.out 2> $OUT/pmc_write4b.err
 # keep only the small summaries (the full traces can be large)
 cd $OUT

@@ -366,10 +366,15 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_count_pair_kernel(
   uint32_t nsteps = 0;
   const uint64_t ptot = npat ? off[npat] : 0;   // symbols the caller declares behind `pat`
   const uint64_t pmin = npat ? off[0] : 0;      // ... starting at this symbol (a slice of a larger batch keeps its absolute offsets)
+  // the offsets of the group's NEXT pattern are requested when the current one starts (round 6): the start of a pattern
+  // is three dependent round trips -- offsets, the k-mer code's symbols, the table entry -- of its ~13, and this one
+  // travels under the current pattern's steps
+  uint64_t nbeg = active ? off[k] : 0, nend = active ? off[k + 1] : 0;
   while (active) {
     if (fresh) {
-      pbeg = off[k];
-      const uint64_t pend = off[k + 1];
+      pbeg = nbeg;
+      const uint64_t pend = nend;
+      if (k + ngroups < npat) { nbeg = off[k + ngroups]; nend = off[k + ngroups + 1]; }
       j = (uint32_t)(pend - pbeg);
       // offsets that go backwards or leave the pattern buffer: refuse, do not read (j = 0 from here on)
       const bool badoff = pend < pbeg || pbeg < pmin || pend > ptot || pend - pbeg > 0xFFFFFFFFull;

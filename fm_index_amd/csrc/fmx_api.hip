@@ -444,6 +444,7 @@ struct SmallCtx {
   hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr;
   hipEvent_t ev_in[kPipeEvents], ev_k[kPipeEvents], ev_off[kPipeEvents];   // symbols up / kernel done / offsets up, per chunk
   uint8_t *h = nullptr, *d = nullptr;
+  uint8_t *hd = nullptr;                   // the device's address of h (page-locked: the GPU can write it), NULL if unmapped
   uint8_t *big = nullptr;
   size_t big_cap = 0;
 };
@@ -493,7 +494,7 @@ SmallCtx *small_ctx(int device) {
       ok = hipEventCreateWithFlags(&c.ev_in[made], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c.ev_k[made], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c.ev_off[made], hipEventDisableTiming) == hipSuccess;
-    if (!ok || hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocDefault) != hipSuccess ||
+    if (!ok || hipHostMalloc((void **)&c.h, kSmallCap, hipHostMallocMapped) != hipSuccess ||
         fmx_dev_malloc((void **)&c.d, kSmallCap) != hipSuccess) {
       (void)hipStreamDestroy(c.st);
       (void)hipStreamDestroy(c.st2);
@@ -502,6 +503,10 @@ SmallCtx *small_ctx(int device) {
       c.st = nullptr;
       return nullptr;
     }
+  }
+  if (!c.hd) {
+    void *dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, c.h, 0) == hipSuccess) c.hd = (uint8_t *)dv; else (void)hipGetLastError();
   }
   return &c;
 }
@@ -547,6 +552,7 @@ struct Arena {  // bump allocator over the two mirrored buffers
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 15) & ~size_t(15); return o; }
   template <typename T> T *host(size_t o) const { return (T *)(c->h + o); }
   template <typename T> T *dev(size_t o) const { return (T *)(c->d + o); }
+  template <typename T> T *mapped(size_t o) const { return (T *)(c->hd + o); }   // the host buffer as the GPU sees it
 };
 struct Scratch {  // device buffers freed on scope exit
   void *p[12];
@@ -566,6 +572,9 @@ uint32_t *status_dev(SmallCtx *sx) { return (uint32_t *)(sx->d + kSmallUse); }
 uint32_t *status_host(SmallCtx *sx) { return (uint32_t *)(sx->h + kSmallUse); }
 struct CallStatus {
   explicit CallStatus(SmallCtx *sx) { t_call_status = status_dev(sx); }
+  CallStatus(SmallCtx *sx, bool in_host_buffer) {      // the status word of the page-locked staging buffer itself
+    t_call_status = in_host_buffer ? (uint32_t *)(sx->hd + kSmallUse) : status_dev(sx);
+  }
   ~CallStatus() { t_call_status = nullptr; }
 };
 int status_result(uint32_t bits) {
@@ -581,6 +590,16 @@ int finish_host_call(SmallCtx *sx, hipStream_t other = nullptr) {
   FMX_HIP(hipMemcpyAsync(status_host(sx), status_dev(sx), sizeof(uint32_t), hipMemcpyDeviceToHost, sx->st));
   FMX_HIP(hipStreamSynchronize(sx->st));
   if (other) FMX_HIP(hipStreamSynchronize(other));
+  return status_result(*status_host(sx));
+}
+// Small calls (round 6): the kernels write their results and the call's status word STRAIGHT into the thread's
+// page-locked staging buffer (posted writes over the host link: a few dozen bytes) -- one upload, one launch, one
+// synchronise, where rounds 1-5 ran a memset, the upload, the launch, two downloads and the synchronise: the fixed
+// cost of a one-pattern call is the runtime's per-operation cost, and there are three fewer of them.  (The INPUTS still
+// travel by copy: a kernel that read its pattern symbol by symbol over the host link would pay that link's latency in
+// every step.)
+int finish_mapped_call(SmallCtx *sx) {
+  FMX_HIP(hipStreamSynchronize(sx->st));
   return status_result(*status_host(sx));
 }
 }  // namespace
@@ -684,8 +703,9 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
   if (span * sb + npat * 48 + 128 <= kSmallUse && idx->sym_bytes_abi != 8) {
     if (SmallCtx *sx = small_ctx(idx->device)) {
       Arena a{sx};
-      CallStatus cs(sx);
-      FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
+      const bool mapped = sx->hd != nullptr;
+      CallStatus cs(sx, mapped);
+      if (mapped) *status_host(sx) = 0; else FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
       const size_t op = a.take(span * sb ? span * sb : 1), oo = a.take((npat + 1) * 8);
       const size_t ose = a.take(s0e0 ? npat * 16 : 0), in_end = a.off;
       const size_t os = a.take(npat * 8), oe = a.take(npat * 8), oc = a.take(npat * 8), ost = a.off;
@@ -698,12 +718,23 @@ int fmx_count_batch(const fmx_index *idx, const void *pat, const uint64_t *pat_o
       }
       if (s0e0) memcpy(a.host<uint8_t>(ose), s0e0, npat * 16);
       FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
-      if (int rc = fmx_launch_count(idx, a.dev<uint8_t>(op), a.dev<uint64_t>(oo), npat,
-                                    s0e0 ? a.dev<uint64_t>(ose) : nullptr, a.dev<uint64_t>(os),
-                                    a.dev<uint64_t>(oe), a.dev<uint64_t>(oc), sx->st))
-        return rc;
-      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), a.dev<uint8_t>(os), (size_t)(ost - os), hipMemcpyDeviceToHost, sx->st));
-      const int rc = finish_host_call(sx);
+      int rc;
+      if (mapped) {
+        if ((rc = fmx_launch_count(idx, a.dev<uint8_t>(op), a.dev<uint64_t>(oo), npat,
+                                   s0e0 ? a.dev<uint64_t>(ose) : nullptr, a.mapped<uint64_t>(os),
+                                   a.mapped<uint64_t>(oe), a.mapped<uint64_t>(oc), sx->st)) != FMX_OK) {
+          (void)hipStreamSynchronize(sx->st);
+          return rc;
+        }
+        rc = finish_mapped_call(sx);
+      } else {
+        if ((rc = fmx_launch_count(idx, a.dev<uint8_t>(op), a.dev<uint64_t>(oo), npat,
+                                   s0e0 ? a.dev<uint64_t>(ose) : nullptr, a.dev<uint64_t>(os),
+                                   a.dev<uint64_t>(oe), a.dev<uint64_t>(oc), sx->st)) != FMX_OK)
+          return rc;
+        FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(os), a.dev<uint8_t>(os), (size_t)(ost - os), hipMemcpyDeviceToHost, sx->st));
+        rc = finish_host_call(sx);
+      }
       if (out_s) memcpy(out_s, a.host<uint8_t>(os), npat * 8);
       if (out_e) memcpy(out_e, a.host<uint8_t>(oe), npat * 8);
       if (out_count) memcpy(out_count, a.host<uint8_t>(oc), npat * 8);
@@ -1015,18 +1046,26 @@ static int scalar_host(const fmx_index *idx, int op, const uint64_t *c, const ui
   if (k * 24 + 64 <= kSmallUse) {
     if (SmallCtx *sx = small_ctx(idx->device)) {
       Arena a{sx};
-      CallStatus cs(sx);
-      FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
+      const bool mapped = sx->hd != nullptr;
+      CallStatus cs(sx, mapped);
+      if (mapped) *status_host(sx) = 0; else FMX_HIP(hipMemsetAsync(status_dev(sx), 0, 4, sx->st));
       const size_t oi = a.take(k * 8), oc = a.take(c ? k * 8 : 0), in_end = a.off;
       const size_t oo = a.take(k * 8);
       memcpy(a.host<uint8_t>(oi), i, k * 8);
       if (c) memcpy(a.host<uint8_t>(oc), c, k * 8);
       FMX_HIP(hipMemcpyAsync(sx->d, sx->h, in_end, hipMemcpyHostToDevice, sx->st));
-      if (int rc = fmx_launch_scalar(idx, op, c ? a.dev<uint64_t>(oc) : nullptr, a.dev<uint64_t>(oi), k,
-                                     a.dev<uint64_t>(oo), sx->st))
+      int rc = fmx_launch_scalar(idx, op, c ? a.dev<uint64_t>(oc) : nullptr, a.dev<uint64_t>(oi), k,
+                                 mapped ? a.mapped<uint64_t>(oo) : a.dev<uint64_t>(oo), sx->st);
+      if (rc != FMX_OK) {
+        (void)hipStreamSynchronize(sx->st);
         return rc;
-      FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(oo), a.dev<uint8_t>(oo), k * 8, hipMemcpyDeviceToHost, sx->st));
-      const int rc = finish_host_call(sx);
+      }
+      if (mapped) {
+        rc = finish_mapped_call(sx);
+      } else {
+        FMX_HIP(hipMemcpyAsync(a.host<uint8_t>(oo), a.dev<uint8_t>(oo), k * 8, hipMemcpyDeviceToHost, sx->st));
+        rc = finish_host_call(sx);
+      }
       memcpy(out, a.host<uint8_t>(oo), k * 8);
       return rc;
     }

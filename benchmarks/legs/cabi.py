@@ -9,13 +9,20 @@ from .common import counts_sha256, golden_counts_sha, ranges_sha256
 from .dist import CONFIG5_PATTERNS, CONFIG5_SEED
 
 
-def _time_calls(fn, reps, warm=2):
+def _time_calls(fn, reps, warm=2, stats=None):
+    """seconds per synchronous call: the MEDIAN of `reps` individually timed calls (a host-side hiccup -- one 49 ms stall
+    among ten 0.3 ms calls was seen on one box -- must not become the figure); `stats` (a dict) receives mean and max"""
     for _ in range(warm):
         fn()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         fn()
-    return (time.perf_counter() - t0) / reps
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    if stats is not None:
+        stats.update({"calls": reps, "mean_ms": sum(ts) / reps * 1e3, "max_ms": ts[-1] * 1e3, "min_ms": ts[0] * 1e3})
+    return ts[reps // 2]
 
 
 def results_on_host_leg(out, wl, args):
@@ -37,12 +44,13 @@ def results_on_host_leg(out, wl, args):
                                                 C.c_void_p(he.data_ptr()) if full else None, C.c_void_p(hc.data_ptr()))
         if rc != 0:
             raise RuntimeError(lib.fmx_last_error().decode())
-    reps = max(10, args.steps // 2)
-    dt_full = _time_calls(lambda: call(True), reps)
+    reps = max(20, args.steps // 2)
+    st_full, st_cnt = {}, {}
+    dt_full = _time_calls(lambda: call(True), reps, stats=st_full)
     assert bool((hs.to(wl.dev) == wl.d_s).all()) and bool((he.to(wl.dev) == wl.d_e).all()) and \
         bool((hc.to(wl.dev) == wl.d_c).all()), "results_on_host: (s, e, count) differ from the device-resident results"
     hc.zero_()
-    dt_cnt = _time_calls(lambda: call(False), reps)
+    dt_cnt = _time_calls(lambda: call(False), reps, stats=st_cnt)
     assert bool((hc.to(wl.dev) == wl.d_c).all())
     # pageable result arrays: device scratch + the runtime's copies
     import numpy as np
@@ -66,6 +74,7 @@ def results_on_host_leg(out, wl, args):
         "s_e_count_ms_per_call": dt_full * 1e3, "s_e_count_value": npat * m / dt_full, "bytes_out_s_e_count": 24 * npat,
         "count_only_ms_per_call": dt_cnt * 1e3, "count_only_value": npat * m / dt_cnt, "bytes_out_count_only": 8 * npat,
         "pageable_s_e_count_ms_per_call": dt_pg * 1e3, "pageable_s_e_count_value": npat * m / dt_pg,
+        "timing": "median of individually timed synchronous calls", "s_e_count_calls": st_full, "count_only_calls": st_cnt,
         "value_results_on_host_is": "count_only", "vs_value": round(npat * m / dt_cnt / out["value"], 4),
         "s_e_count_vs_value": round(npat * m / dt_full / out["value"], 4)}
     del hs, he, hc

@@ -672,6 +672,9 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_expand_kernel(
   }
 }
 
+__global__ void fmx_zero_words_kernel(unsigned long long *p, uint32_t nwords) {
+  if (threadIdx.x < nwords) p[threadIdx.x] = 0ull;
+}
 // the listed long ranges (fmx_expand_kernel), every one of them by the whole grid: 16-byte stores between a scalar head
 // and tail, as above.  An empty list costs the launch (~2 us).
 template <typename T>
@@ -2134,19 +2137,9 @@ __device__ __forceinline__ bool fmx_expand_slice(FmxSliceLds &L, const uint64_t 
   // lane 0 of the wave touches the LDS word)
   uint64_t k_lo = 0, span = npat;
   if (k_hint && *k_hint != ~0ull) { k_lo = *k_hint; span = 0; }
-  // Round 6: about a pattern per hit (config 3: 2^20 patterns, 2^20 hits) -> the slice's first pattern sits where the
-  // offsets would put it if every pattern had the same number of hits, give or take a few hundred.  The expansion
-  // starts 512 patterns in front of that GUESS without probing -- the probe round is a dependent round trip + two
-  // barriers in front of every block's first walk -- and the first round of loads checks it (off[k_lo] <= blo); a
-  // wrong guess (skewed batches) costs that round and falls back to the probes.
-  bool guessed = false;
-  if (span > FMX_U_PATS && dense && npat <= total) {
-    const uint64_t kg = (uint64_t)(((unsigned __int128)blo * npat) / total);
-    k_lo = kg > 512u ? kg - 512u : 0;
-    span = 0;
-    guessed = true;
-  }
-probe:
+  // (Round 6 measured a GUESSED start for batches of about a pattern per hit -- 512 patterns in front of blo * npat /
+  // total, checked by the first round of loads, no probe round -- on the same box against this probe round: 0.0877 /
+  // 0.0887 ms per 2^20 hits with the guess, 0.0845 / 0.0860 without; dropped.)
   while (span > FMX_U_PATS) {                         // block-uniform
     const uint64_t step = (span + FMX_LOC_BLOCK - 1) / FMX_LOC_BLOCK;
     const uint64_t c = k_lo + (uint64_t)tid * step;
@@ -2190,15 +2183,6 @@ probe:
     // the round's last pattern + 1: does it still start inside the slice?
     bool more = false;
     if (tid == FMX_LOC_BLOCK - 1u && kc + per_round < npat) more = off[kc + per_round] < bhi;
-    if (guessed) {                                    // block-uniform; the first round of a guessed start only
-      guessed = false;
-      // the slice's first pattern lies at or behind k_lo iff off[k_lo] <= blo (thread 0 holds off[k_lo]; k_lo == 0 needs no check)
-      if (__syncthreads_or((int)(tid == 0 && k_lo != 0 && o[0] > blo))) {
-        k_lo = 0;
-        span = npat;
-        goto probe;                                   // nothing has been written yet
-      }
-    }
 #pragma unroll
     for (uint32_t j = 0; j < FMX_U_PATS / FMX_LOC_BLOCK; j++) {
       if (!need[j]) continue;
@@ -2704,9 +2688,10 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     if (eb > FMX_MAX_BLOCKS * 4) eb = FMX_MAX_BLOCKS * 4;
     // per RANGE (round 6): a batch that can hold a range of 2^16+ rows lists such ranges for a second, grid-wide pass
     // instead of leaving each to one wave (10^6 singletons + ten patterns of 10^7 hits: 3.4 ms for the batch against
-    // 0.15 + 1.09 for its parts); 16 bytes of memset and one -- usually empty -- launch per batch of 2^18+ hits
+    // 0.15 + 1.09 for its parts); a 16-byte clear and one -- usually empty -- launch per batch of 2^18+ hits
     unsigned long long *longs = total >= (1u << 18) ? (unsigned long long *)((uint8_t *)rows + fmx_rows_part_bytes(total)) : nullptr;
-    if (longs) FMX_HIP(hipMemsetAsync(longs, 0, 16, st));
+    if (longs) hipLaunchKernelGGL(fmx_zero_words_kernel, dim3(1), dim3(64), 0, st, longs, 2u);   // (a kernel, not a memset: the
+                                                      // workspace forms promise kernel launches only)
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                        d_off, npat, rows, total, dv.n, dv.status, longs);
     if (longs) hipLaunchKernelGGL(fmx_expand_long_kernel<uint32_t>, dim3(2048), dim3(FMX_BLOCK), 0, st, longs, rows);

@@ -2694,7 +2694,8 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
                                                       // workspace forms promise kernel launches only)
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,
                        d_off, npat, rows, total, dv.n, dv.status, longs);
-    if (longs) hipLaunchKernelGGL(fmx_expand_long_kernel<uint32_t>, dim3(2048), dim3(FMX_BLOCK), 0, st, longs, rows);
+    // (512 blocks: an empty list -- the usual case -- costs the launch, and 2048 blocks that only read the counter took 5 us)
+    if (longs) hipLaunchKernelGGL(fmx_expand_long_kernel<uint32_t>, dim3(512), dim3(FMX_BLOCK), 0, st, longs, rows);
   }
   fmx_time_begin(idx, st);
   const FmxLocateCall c{idx, dv, total, rows, d_pos, idx->timing == 1 ? idx->d_steps : nullptr, st};

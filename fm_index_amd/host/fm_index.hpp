@@ -16,6 +16,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <cstring>
@@ -83,7 +84,8 @@ class Search {  // frontend.rs:70-84
 
 class Index {
  public:
-  // `flags`: FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE opt into the small-alphabet accelerators
+  // `flags`: FMX_FLAG_PLAIN vetoes the count accelerators a DNA-like FM index of 2^24+ symbols gets by default (round 6);
+  // FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE ask for them by name
   Index(const Text &text, uint32_t kind, uint32_t level, int device = 0, uint32_t flags = 0) {
     check(fmx_build(text.text().data(), text.text().size(), 1, text.max_character(), kind, level, flags,
                     device, &h_));
@@ -111,8 +113,32 @@ class Index {
     check(fmx_count_batch(h_, flat.data(), off.data(), patterns.size(), nullptr, s.data(), e.data(),
                           nullptr));
   }
+  // fmx_replicate: a second index with its own copy of the HBM arrays on `device` (no rebuild)
+  std::unique_ptr<Index> replicate(int device) const {
+    fmx_index *h = nullptr;
+    check(fmx_replicate(h_, device, &h));
+    return std::unique_ptr<Index>(new Index(h));
+  }
+  // search_many over `replicas` (this index = replica 0): contiguous shards, results in place (fmx_count_batch_multi)
+  void search_many_sharded(const std::vector<const Index *> &replicas, const std::vector<std::vector<uint8_t>> &patterns,
+                           std::vector<uint64_t> &s, std::vector<uint64_t> &e) const {
+    std::vector<uint8_t> flat;
+    std::vector<uint64_t> off(1, 0);
+    for (auto &p : patterns) {
+      flat.insert(flat.end(), p.begin(), p.end());
+      off.push_back(flat.size());
+    }
+    if (flat.empty()) flat.push_back(0);
+    s.assign(patterns.size(), 0);
+    e.assign(patterns.size(), 0);
+    std::vector<fmx_index *> hs(1, h_);
+    for (const Index *r : replicas) hs.push_back(r->h_);
+    check(fmx_count_batch_multi(hs.data(), (uint32_t)hs.size(), flat.data(), off.data(), patterns.size(), nullptr,
+                                s.data(), e.data(), nullptr));
+  }
 
  private:
+  explicit Index(fmx_index *h) : h_(h) {}
   fmx_index *h_ = nullptr;
 };
 

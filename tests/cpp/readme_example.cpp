@@ -47,6 +47,15 @@ int main(int argc, char **argv) {
     } catch (const fmx::Error &e) {
       std::printf("error %s\n", e.what());
     }
+    {  // one batch over three replicas of the index (fmx_replicate + fmx_count_batch_multi): the one-handle results
+      auto r1 = index.replicate(0), r2 = index.replicate(0);
+      std::vector<std::vector<uint8_t>> pats;
+      for (const char *w : {"dolor", "ipsum", "e", "zzz", "", "in", "o"}) pats.emplace_back(w, w + std::strlen(w));
+      std::vector<uint64_t> s1, e1, s3, e3;
+      index.search_many(pats, s1, e1);
+      index.search_many_sharded({r1.get(), r2.get()}, pats, s3, e3);
+      std::printf("sharded %s\n", (s1 == s3 && e1 == e3) ? "same" : "DIFFERENT");
+    }
   } catch (const fmx::Error &e) {
     std::printf("FAILED %d %s\n", e.code, e.what());
     return 1;

@@ -26,6 +26,7 @@ def test_readme_example_cpp(golden, tmp_path):
     assert lines[6] == "suffix 0 1 2"                       # examples/multi_pieces.rs:80-87
     assert lines[7] == "prefix 0"                           # examples/multi_pieces.rs:70-77
     assert lines[8] == "error invalid text: the given text must end with exactly one zero character"
+    assert lines[9] == "sharded same"                       # fmx_replicate + fmx_count_batch_multi through the C++ mirror
 
 
 def test_plain_c_example_runs(tmp_path):

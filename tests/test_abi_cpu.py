@@ -108,3 +108,32 @@ def test_header_is_plain_c99(tmp_path):
                            "-fsyntax-only", str(src)])
     code = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, "fmx.h")).read(), flags=re.S)
     assert "torch" not in code and "hipStream_t" not in code and "#include <hip" not in code
+
+
+def test_shard_range_is_the_partition_of_the_python_harness():
+    """fmx_shard_range (pure host code: callable without a GPU) = fm_index_amd.sharding.shard_range for every (N, G, r):
+    the one-process C-ABI path and the one-process-per-GPU path cut a batch at the same patterns; the shards are
+    contiguous, cover the batch and differ by at most one pattern."""
+    import ctypes as C
+    from fm_index_amd import _lib, sharding
+    lib = _lib.lib()
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    for n in (0, 1, 2, 7, 8, 9, 1000, 8193, 8388608, (1 << 40) + 12345):
+        for g in (1, 2, 3, 5, 8, 64):
+            prev, sizes = 0, []
+            for r in range(g):
+                lib.fmx_shard_range(n, g, r, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == sharding.shard_range(n, r, g), (n, g, r)
+                assert lo.value == prev and hi.value >= lo.value
+                prev = hi.value
+                sizes.append(hi.value - lo.value)
+            assert prev == n and max(sizes) - min(sizes) <= 1
+    lib.fmx_shard_range(10, 4, 9, C.byref(lo), C.byref(hi))      # r >= G: empty
+    assert (lo.value, hi.value) == (0, 0)
+    # the multi-replica entry points refuse an empty or NULL handle list before anything touches a device
+    assert lib.fmx_count_batch_multi(None, 0, None, None, 3, None, None, None, None) == _lib.ERR_ARG
+    hs = (C.c_void_p * 2)(None, None)
+    assert lib.fmx_count_batch_multi(hs, 2, None, None, 3, None, None, None, None) == _lib.ERR_ARG
+    assert lib.fmx_locate_batch_multi(hs, 2, None, None, 3, None, None) == _lib.ERR_ARG
+    out = C.c_void_p()
+    assert lib.fmx_replicate(None, 0, C.byref(out)) == _lib.ERR_ARG and not out.value

@@ -95,6 +95,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic live")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cabi-child", action="store_true",
+                    help="no bench line: config 5 through the C ABI over every device this ONE process sees (fmx_replicate + "
+                         "fmx_count_batch_multi[_resident] at G = 1, 2, 4, 8 replicas on distinct devices); prints one JSON "
+                         "object.  The default N = 1 run starts it as a child when it sees more than one device")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real path) | gloo (rehearsal of the N>1 code path: all ranks "
                          "share cuda:0 and gather through host memory)")
@@ -133,11 +137,15 @@ def main():
         from fm_index_amd import launcher
         sys.exit(launcher.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and not args.pmc_child:
+    if world != args.gpus and not args.pmc_child and not args.cabi_child:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
                  "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     if args.pmc_child:
         pmc_child(args)
+        return
+    if args.cabi_child:
+        from benchmarks.legs.cabi import cabi_child
+        cabi_child(args)
         return
     # fabric traffic (L2 -> Infinity Cache / HBM) of this build, measured now: rocprofv3 --pmc passes over a child of this
     # script.  Started BEFORE this process touches the GPU (no torch import yet): the children are
@@ -511,6 +519,15 @@ def _get(d, *keys):
     return d
 
 
+def _cabi_gmax(out):
+    """config 5 through the C ABI at the largest G of the child run (patterns resident, counts to the host), or None"""
+    pts = _get(out, "config5_cabi", "multi_device", "points") or {}
+    if not pts:
+        return None
+    g = max(pts, key=lambda k: int(k[1:]))
+    return _get(pts[g], "resident_patterns", "value")
+
+
 def _sig(v, digits=4):
     """floats of the side legs to `digits` significant digits (the headline's own numbers stay exact)"""
     if isinstance(v, float) and v == v and v not in (float("inf"), float("-inf")) and v != 0.0:
@@ -588,6 +605,8 @@ def headline(out, detail_path):
         "config5_cabi_g1_value": _get(out, "config5_cabi", "g1", "value"),
         "config5_cabi_g1_resident_value": _get(out, "config5_cabi", "g1_resident", "value"),
         "config5_cabi_matches_golden": _get(out, "config5_cabi", "matches_golden"),
+        "config5_cabi_devices": _get(out, "config5_cabi", "multi_device", "devices_visible"),
+        "config5_cabi_gmax_resident_value": _cabi_gmax(out),
         "wide_value": _get(out, "wide", "value"),
         "wide_locate_hits_per_s": _get(out, "wide", "locate", "hits_per_s"),
         "wide_build_ms": _get(out, "wide", "build_ms"),

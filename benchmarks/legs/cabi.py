@@ -3,6 +3,10 @@ fmx_count_batch_multi_resident), and the SURVEY 8(d) protocol number: patterns r
 memory ("exclude index build and H2D upload from both sides; include D2H of results on the GPU side";
 benches/count.rs:29-37 times results the caller can read)."""
 import ctypes as C
+import json
+import os
+import subprocess
+import sys
 import time
 
 from .common import counts_sha256, golden_counts_sha, ranges_sha256
@@ -153,28 +157,16 @@ def config5_cabi_leg(out, wl, args, dev):
         return r
 
     reps = max(4, args.steps // 5)
+    # G = 1 in this process
+    o["g1"] = run((C.c_void_p * 1)(wl.h.value), 1, reps)
+    o["g1"]["devices"] = [dev.index]
+    o["g1_resident"] = run_resident((C.c_void_p * 1)(wl.h.value), 1, [dev.index], reps)
+    # G = 2, 4, 8 ... replicas on DISTINCT devices, when the process sees more than one: in a CHILD process with a
+    # timeout (`bench.py --cabi-child`) -- no box this code was developed on has a second GPU, and neither a peer copy
+    # that hangs nor a worker thread that faults may take the headline line with it
     ndev = torch.cuda.device_count()
-    others = []
-    try:
-        # G = the devices of this process: replica r on device r (device `dev.index` holds the workload's own handle)
-        devs = [d for d in range(ndev) if d != dev.index]
-        for d in devs:
-            h = C.c_void_p()
-            if lib.fmx_replicate(wl.h, d, C.byref(h)) != 0:
-                raise RuntimeError(lib.fmx_last_error().decode())
-            others.append(h)
-        g = 1 + len(others)
-        handles = (C.c_void_p * g)(wl.h.value, *[h.value for h in others])
-        o["g%d" % g] = run(handles, g, reps)
-        o["g%d" % g]["devices"] = [dev.index] + devs
-        o["g%d_resident" % g] = run_resident(handles, g, [dev.index] + devs, reps)
-        if g > 1:                                          # the one-device point of the same curve
-            o["g1"] = run((C.c_void_p * 1)(wl.h.value), 1, reps)
-            o["g1"]["devices"] = [dev.index]
-            o["g1_resident"] = run_resident((C.c_void_p * 1)(wl.h.value), 1, [dev.index], reps)
-    finally:
-        for h in others:
-            lib.fmx_free(h)
+    if ndev > 1 or os.environ.get("FMX_BENCH_CABI_CHILD"):
+        o["multi_device"] = run_cabi_child(args, max(ndev, 1))
     # the sharding on ONE device: three replicas of the index on this GPU, ragged shards (T / 3)
     reps3 = []
     try:
@@ -273,3 +265,127 @@ def single_call_leg(out, wl, args):
             continue
         o[name + "_us"] = round(_time_calls(fn, 200, warm=5) * 1e6, 1)
     out["single_call"] = o
+
+
+def run_cabi_child(args, ndev, timeout=240):
+    """`bench.py --cabi-child` in its own session: returns its JSON object, or {"error": ...}"""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--cabi-child", "--log2n", str(args.log2n), "--plen", str(args.plen),
+           "--steps", str(max(4, args.steps // 5))]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            outb, errb = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, 9)
+            except OSError:
+                pass
+            p.communicate()
+            return {"error": "bench.py --cabi-child timed out after %d s (process group killed)" % timeout, "devices": ndev}
+        lines = [ln for ln in outb.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": "bench.py --cabi-child failed (rc %s): %s" % (p.returncode, errb.decode(errors="replace")[-400:]),
+                    "devices": ndev}
+        return json.loads(lines[-1])
+    except OSError as ex:
+        return {"error": repr(ex), "devices": ndev}
+
+
+def cabi_child(args):
+    """The program behind `bench.py --cabi-child`: config 5 through the C ABI over the devices of ONE process.  Builds the
+    default DNA index on device 0, replicates it onto every other visible device (fmx_replicate: device-to-device
+    copies), and runs the 8 388 608-pattern set through fmx_count_batch_multi (page-locked host patterns in, (s, e, count)
+    in place) and fmx_count_batch_multi_resident (patterns resident per device, counts to the host) at G = 1, 2, 4, 8, ...
+    replicas on G distinct devices.  Every point's hashes are compared with tests/golden/config5_counts.json.  Prints ONE
+    JSON object."""
+    import argparse
+    import torch
+    import fm_index_amd as F
+    from fm_index_amd import _lib as L
+    from fm_index_amd import workload as W
+    from .common import golden_key
+    lib = L.lib()
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n, m = 1 << args.log2n, args.plen
+    T = CONFIG5_PATTERNS if args.log2n >= 30 else 1 << 17
+    t0 = time.perf_counter()
+    text = W.dna_text_torch(n, 1, dev)
+    index = F.FMIndex.from_device_text(text.data_ptr(), n, 4, device=0)
+    out = {"devices_visible": ndev, "text_len": n, "total_patterns": T, "unit": "pattern-chars/s",
+           "index_bytes": index.heap_size(), "accelerated": bool(index.has_pair_index() and index.kmer_k()),
+           "build_s": round(time.perf_counter() - t0, 2)}
+    hp = torch.empty(T * m, dtype=torch.uint8).pin_memory()
+    ar = torch.arange(m, dtype=torch.int64, device=dev)[None, :]
+    for lo in range(0, T, 1 << 20):
+        k = min(1 << 20, T - lo)
+        src = W.umod_torch(W.splitmix64_torch(CONFIG5_SEED, lo, k, dev), n - 1 - m)
+        hp[lo * m:(lo + k) * m].copy_(text[src[:, None] + ar].reshape(-1))
+    ho = (torch.arange(T + 1, dtype=torch.int64) * m).pin_memory()
+    hs, he, hc = (torch.zeros(T, dtype=torch.int64).pin_memory() for _ in range(3))
+    gold = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
+                               "config5_counts.json")) as f:
+            ent = json.load(f)["entries"].get(golden_key("dna", args.log2n, CONFIG5_SEED, T, m))
+        gold = (ent["counts_sha256"], ent.get("ranges_sha256")) if ent else None
+    except (OSError, ValueError):
+        pass
+    replicas = [index]
+    t0 = time.perf_counter()
+    for d in range(1, ndev):
+        replicas.append(index.replicate(d))
+    for d in range(ndev):
+        torch.cuda.synchronize(d)
+    out["replicate_s"] = round(time.perf_counter() - t0, 3)
+    reps = max(3, args.steps)
+    points = {}
+    gs = sorted({g for g in (1, 2, 4, 8, 16, ndev) if 1 <= g <= ndev})
+    for g in gs:
+        handles = (C.c_void_p * g)(*[replicas[r].handle().value for r in range(g)])
+
+        def call_host():
+            rc = lib.fmx_count_batch_multi(handles, g, C.c_void_p(hp.data_ptr()), C.c_void_p(ho.data_ptr()), T, None,
+                                           C.c_void_p(hs.data_ptr()), C.c_void_p(he.data_ptr()), C.c_void_p(hc.data_ptr()))
+            if rc != 0:
+                raise RuntimeError(lib.fmx_last_error().decode())
+        for a_ in (hs, he, hc):
+            a_.zero_()
+        dt = _time_calls(call_host, reps, warm=2)
+        sha, rsha = counts_sha256(hc.numpy()), ranges_sha256(hs.numpy(), he.numpy())
+        pt = {"host_patterns": {"ms_per_step": dt * 1e3, "value": T * m / dt, "counts_sha256": sha[:16],
+                                "matches_golden": (gold[0] == sha and gold[1] in (None, rsha)) if gold else None}}
+        keep, d_pat, d_off = [], (C.c_void_p * g)(), (C.c_void_p * g)()
+        for r in range(g):
+            a = (T * r + g - 1) // g
+            b = (T * (r + 1) + g - 1) // g
+            dv = torch.device("cuda", r)
+            fp = hp[a * m:b * m].to(dv)
+            fo = (torch.arange(b - a + 1, dtype=torch.int64, device=dv) * m).contiguous()
+            keep += [fp, fo]
+            d_pat[r], d_off[r] = fp.data_ptr(), fo.data_ptr()
+        for r in range(g):
+            torch.cuda.synchronize(r)
+
+        def call_resident():
+            rc = lib.fmx_count_batch_multi_resident(handles, g, d_pat, d_off, T, None, None, None, C.c_void_p(hc.data_ptr()))
+            if rc != 0:
+                raise RuntimeError(lib.fmx_last_error().decode())
+        hc.zero_()
+        dt = _time_calls(call_resident, reps, warm=2)
+        sha = counts_sha256(hc.numpy())
+        pt["resident_patterns"] = {"ms_per_step": dt * 1e3, "value": T * m / dt, "counts_sha256": sha[:16],
+                                   "matches_golden": (gold[0] == sha) if gold else None}
+        del keep
+        points["g%d" % g] = pt
+    out["points"] = points
+    out["matches_golden"] = all(v[k]["matches_golden"] in (True, None) for v in points.values() for k in v)
+    for r in replicas[1:]:
+        r.close()
+    index.close()
+    print(json.dumps(out))

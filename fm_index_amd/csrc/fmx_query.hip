@@ -2689,7 +2689,10 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
     // per RANGE (round 6): a batch that can hold a range of 2^16+ rows lists such ranges for a second, grid-wide pass
     // instead of leaving each to one wave (10^6 singletons + ten patterns of 10^7 hits: 3.4 ms for the batch against
     // 0.15 + 1.09 for its parts); a 16-byte clear and one -- usually empty -- launch per batch of 2^18+ hits
-    unsigned long long *longs = total >= (1u << 18) ? (unsigned long long *)((uint8_t *)rows + fmx_rows_part_bytes(total)) : nullptr;
+    // (... and only when the batch has at least 2^16 hits MORE than patterns: with a hit per pattern -- configs 3 / 4 --
+    // no range can be that long, and the two extra launches cost such a batch 5-8 %: 0.129 -> 0.139 ms with the run table)
+    unsigned long long *longs = (total >= (1u << 18) && total >= npat + FMX_EXPAND_DEFER)
+                                    ? (unsigned long long *)((uint8_t *)rows + fmx_rows_part_bytes(total)) : nullptr;
     if (longs) hipLaunchKernelGGL(fmx_zero_words_kernel, dim3(1), dim3(64), 0, st, longs, 2u);   // (a kernel, not a memset: the
                                                       // workspace forms promise kernel launches only)
     hipLaunchKernelGGL(fmx_expand_kernel<uint32_t>, dim3((unsigned)eb), dim3(FMX_BLOCK), 0, st, d_s, d_e,

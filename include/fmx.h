@@ -27,7 +27,9 @@
  *    (a hipStream_t passed as void*; NULL = the default stream).  The plain
  *    variants take HOST pointers, copy, run the same kernels, and synchronise.
  *  - A handle is immutable after build: any number of threads may issue queries
- *    on it concurrently; build/free are exclusive.
+ *    on it concurrently; build/free are exclusive.  fmx_replicate() copies an index onto another GPU of the node and
+ *    the *_multi entry points run ONE batch over several replicas from one host caller (results in place in the caller's
+ *    arrays: bit-identical to the one-handle call).
  *  - All compute runs in HIP kernels on the GPU.  There is no CPU fallback:
  *    every call fails with FMX_ERR_HIP when no device is usable.
  */

@@ -222,6 +222,18 @@ def main():
             goff, gpos = gi.locate_many(gb.s[small], gb.e[small])
             ooff, opos = oi.locate_batch(os_[small], oe[small])
             assert (goff == ooff).all() and (gpos == opos).all(), ("locate", it, kind, n, maxc, level)
+        # round 6: the same batch over 2..4 replicas of the index through ONE call (fmx_replicate + fmx_*_batch_multi):
+        # contiguous ragged shards, results in place -- must be the one-handle results
+        if rng.random() < 0.3:
+            g = int(rng.integers(2, 5))
+            reps = F.Replicas.of(gi, [0] * (g - 1))
+            mb = reps.search_many(flat=flat, off=off, s0e0=se)
+            assert (mb.s == os_).all() and (mb.e == oe).all(), ("count_multi", it, kind, n, maxc, level, g)
+            if level is not None:
+                moff, mpos = reps.locate_many(os_[small], oe[small])
+                assert (moff == ooff).all() and (mpos == opos).all(), ("locate_multi", it, kind, n, maxc, level, g)
+            reps.close(keep_first=True)
+            stats["replicas"] = stats.get("replicas", 0) + 1
         rows = rng.integers(0, n, size=min(n, 64)).astype(np.uint64)
         assert (gi.get_l(rows) == oi.get_l(rows)).all(), ("get_l", it, kind)
         assert (gi.lf_map(rows) == oi.lf_map(rows)).all(), ("lf_map", it, kind)

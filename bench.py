@@ -579,6 +579,7 @@ def headline(out, detail_path):
         "locate_3b_frac": _get(out, "locate_3b", "roofline", "frac"),
         "rlfm_value": _get(out, "rlfm", "value"),
         "rlfm_frac": _get(out, "rlfm", "roofline", "frac"),
+        "rlfm_value_plain": _get(out, "rlfm", "plain", "value"),
         "rlfm_index_bytes": _get(out, "rlfm", "config", "index_bytes"),
         "rlfm_locate_hits_per_s": _get(out, "rlfm", "locate", "hits_per_s"),
         "rlfm_locate_frac": _get(out, "rlfm", "locate", "roofline", "frac"),

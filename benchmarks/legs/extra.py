@@ -262,6 +262,28 @@ def rlfm_leg(out, args, dev, local):
         co.close()
     except Exception as ex:  # noqa: BLE001
         o["config"]["count_only_index_bytes"] = repr(ex)
+    # the default RLFM index of 2^24+ symbols carries the k-mer start table (round 6); the plain one next to it
+    o["config"]["kmer_k"] = wr.index.kmer_k()
+    if wr.index.kmer_k() and not args.no_accel:
+        try:
+            pl = wr.F.RLFMIndex.from_device_text(wr.text.data_ptr(), wr.n, wr.maxc, device=local, plain=True)
+            ps = torch.empty(npat, dtype=torch.int64, device=wr.dev)
+            pe = torch.empty(npat, dtype=torch.int64, device=wr.dev)
+
+            def pstep():
+                rc = wr.lib.fmx_count_batch_dev(pl.handle(), C.c_void_p(wr.pat.data_ptr()), C.c_void_p(wr.off.data_ptr()), npat,
+                                                None, C.c_void_p(ps.data_ptr()), C.c_void_p(pe.data_ptr()), None, wr.sp)
+                assert rc == 0
+            for _ in range(args.warmup):
+                pstep()
+            torch.cuda.synchronize()
+            pms = event_time_ms(torch, wr.stream, pstep, args.steps)
+            assert bool((ps == wr.d_s).all()) and bool((pe == wr.d_e).all()), "plain RLFM index != default RLFM index"
+            o["plain"] = {"value": npat * m / (pms / 1e3), "ms_per_step": pms, "index_bytes": pl.heap_size(),
+                          "note": "FMX_FLAG_PLAIN: no k-mer start table; (s, e) identical on all patterns"}
+            pl.close()
+        except Exception as ex:  # noqa: BLE001
+            o["plain"] = {"error": repr(ex)}
     o["config"]["run_table"] = bool(wr.index.walk_records())
     o["config"]["space_policy"] = ("run table (4 B per run) only when r <= n/4 or FMX_FLAG_RUN_TABLE: this text has %.2f runs "
                                    "per row" % (o["config"]["runs"] / float(wr.n)))

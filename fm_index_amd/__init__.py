@@ -425,8 +425,8 @@ class RLFMIndex(_Index):
     """RLFMIndex::new(&text) (frontend.rs:223-231)."""
     _kind = L.KIND_RLFM
 
-    def __init__(self, text, device=0, keep_sa=False, kmer_table=False, force_wide=False):
-        super().__init__(text, None, device, keep_sa, False, kmer_table, None, force_wide)
+    def __init__(self, text, device=0, keep_sa=False, kmer_table=False, force_wide=False, plain=False):
+        super().__init__(text, None, device, keep_sa, False, kmer_table, None, force_wide, plain=plain)
 
 
 class RLFMIndexWithLocate(_Index):
@@ -434,11 +434,11 @@ class RLFMIndexWithLocate(_Index):
     _kind = L.KIND_RLFM
 
     def __init__(self, text, level, device=0, keep_sa=False, kmer_table=False, sampling=None, walk_records=True,
-                 force_wide=False, run_table=False):
+                 force_wide=False, run_table=False, plain=False):
         """run_table=True: FMX_FLAG_RUN_TABLE -- the run table whatever the text's runs-per-row ratio (the builder adds
         it by itself when r <= n / 4)"""
         super().__init__(text, level, device, keep_sa, False, kmer_table, sampling, force_wide, walk_records,
-                         run_table=run_table)
+                         run_table=run_table, plain=plain)
 
 
 class FMIndexMultiPieces(_Index):

@@ -113,7 +113,8 @@ typedef struct fmx_index fmx_index;
 /* DEFAULT since round 6 (this flag asked for it in rounds 4-5 and is still accepted): the builder adds the two count
  * accelerators -- FMX_FLAG_PAIR_INDEX | FMX_FLAG_KMER_TABLE -- when they pay and the device has room: FMX_KIND_FM over
  * u8 symbols with max_character <= 4, 2^24 <= n < 2^31, and at least four times the finished index free on the device at
- * build time (2.2 x the count rate on a 1 GiB DNA text for 2.1 x the count structures).  Results are bit-identical
+ * build time (2.2 x the count rate on a 1 GiB DNA text for 2.1 x the count structures); FMX_KIND_RLFM over u8 symbols of
+ * that size gets the k-mer start table alone (1.22 x the count rate on a 1 GiB byte text for 4 % more index).  Results are bit-identical
  * either way (see the two flags: the reference's (s, e) on every pattern, the pair left by the early exit of
  * wrapper.rs:111-113 included); fmx_has_pair_index() / fmx_kmer_k() tell what the index got.  FMX_FLAG_PLAIN vetoes. */
 #define FMX_FLAG_AUTO 128u

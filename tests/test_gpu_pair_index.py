@@ -114,3 +114,26 @@ def test_the_default_index_gets_both_accelerators_where_they_pay():
     only_pair = F.FMIndex(tx, plain=True, pair_index=True)
     assert only_pair.has_pair_index() and only_pair.kmer_k() == 0
     only_pair.close()
+
+
+def test_the_default_rlfm_index_gets_the_kmer_table():
+    """Round 6: a run-length index over u8 symbols of >= 2^24 symbols gets the k-mer start table by default (k = 3 at a
+    byte alphabet); FMX_FLAG_PLAIN vetoes; same (s, e) -- the oracle's RLFM path."""
+    n = 1 << 24
+    t = W.byte_text_np(n, 7)
+    tx = F.Text(t)
+    gd = F.RLFMIndex(tx)
+    gp = F.RLFMIndex(tx, plain=True)
+    assert gd.kmer_k() >= 2 and gp.kmer_k() == 0 and gd.heap_size() > gp.heap_size()      # (k = 2 here: the table stays below n / 2 bytes; 3 at n = 2^30)
+    flat, off, _ = W.substring_patterns_np(t, 20000, 16, 8)
+    rflat, roff = W.ragged_patterns_np(20000, 7, 255, 9)
+    for f, o in ((flat, off), (rflat, roff)):
+        a, b = gd.search_many(flat=f, off=o), gp.search_many(flat=f, off=o)
+        assert (a.s == b.s).all() and (a.e == b.e).all()
+    oi = O.OracleIndex.from_bwt(gp.export_bwt(), gp.export_cs(), 255, kind="rlfm")
+    so, eo = oi.count_batch(flat[:4000 * 16], off[:4001], nthreads=8)
+    a = gd.search_many(flat=flat, off=off)
+    assert (so == a.s[:4000]).all() and (eo == a.e[:4000]).all()
+    oi.close()
+    gd.close(); gp.close()
+    assert F.RLFMIndex(F.Text(W.byte_text_np(1 << 20, 7))).kmer_k() == 0          # a shorter text stays plain

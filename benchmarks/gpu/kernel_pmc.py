@@ -51,13 +51,16 @@ def kernel_key(kn, grid):
     return key
 
 
+PASS_TIMEOUT = [600]
+
+
 def run_pass(name, counters, child, work):
     d = os.path.join(work, name)
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-d", d, "--output-format", "csv", "--"] + child
     p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, start_new_session=True)
     try:
-        _, err = p.communicate(timeout=600)
+        _, err = p.communicate(timeout=PASS_TIMEOUT[0])
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, 9)
         p.communicate()
@@ -153,11 +156,16 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06"))
     # (the TA / TCP sets take > 10 minutes per pass on this profiler: ask for them by name)
     ap.add_argument("--sets", default="ea_widths,l2,ea_wr,sq_insts,sq_states,utcl1")
-    ap.add_argument("--child-args", default="", help="extra flags for bench.py --pmc-child, comma-separated: no-rlfm,no-accel")
+    ap.add_argument("--child-args", default="", help="extra flags for bench.py --pmc-child, comma-separated: no-rlfm,no-accel,log2n=27")
+    ap.add_argument("--pass-timeout", type=int, default=600, help="seconds per counter pass (the TA / TCP sets are slow)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    PASS_TIMEOUT[0] = a.pass_timeout
     work = os.path.join("/tmp", "fmx_kernel_pmc_%d" % os.getpid())
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", a.workload] + ["--" + x for x in a.child_args.split(",") if x]
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", a.workload]
+    for x in a.child_args.split(","):              # "no-rlfm" -> --no-rlfm; "log2n=27" -> --log2n 27
+        if x:
+            child += ["--" + x.split("=", 1)[0]] + x.split("=", 1)[1:]
     counters = collections.defaultdict(dict)
     durs = collections.defaultdict(list)
     notes = {}

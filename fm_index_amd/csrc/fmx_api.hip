@@ -1740,6 +1740,9 @@ namespace {
 hipError_t copy_between_devices(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes) {
   if (!bytes) return hipSuccess;
   if (dst_dev == src_dev) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
+  // (direct copies over xGMI need peer access from the current device -- dst_dev -- to the source; already enabled, or
+  // not available between the two, are both fine: hipMemcpyPeer stages through the host where it must)
+  if (hipDeviceEnablePeerAccess(src_dev, 0) != hipSuccess) (void)hipGetLastError();
   hipError_t e = hipMemcpyPeer(dst, dst_dev, src, src_dev, bytes);
   if (e == hipSuccess) return e;
   (void)hipGetLastError();

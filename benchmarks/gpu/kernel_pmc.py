@@ -33,6 +33,7 @@ SETS = {
                  "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
     "sq_states": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM",
                   "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+    "sq_smem": ["SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INST_CYCLES_SALU", "SQ_WAVE_CYCLES"],
     "ta": ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum",
            "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_BUSY_max", "GRBM_GUI_ACTIVE"],
     "tcp": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum",

@@ -10,6 +10,8 @@
 #   soak <seconds> [seed] [lib|shipped] [long]   tests/fuzz_gpu_vs_oracle.py (optionally on another libfmx*.so; `long` =
 #                        the long-interval batches: lane-per-walk kernels, per-ticket dispatch, every select branch)
 #   variant "<envs>" [flags]   bench.py on the measurement build under each environment of the list (FMX_VARIANT=.., grid knobs)
+#   ablib "<libs>" [flags]     bench.py once per library of the list (file names under fm_index_amd/, e.g. a copy of the last
+#                        build next to the new one), same box, in the order given: A/B of two builds of a kernel
 #   pmc             benchmarks/gpu/kernel_pmc.py: counters per query kernel (what bounds it)
 #   mix [args]      benchmarks/gpu/locate_mix.py (DNA and RLFM): shipped library, then the measurement build on each path
 #   py <script> [args]   any python script under benchmarks/
@@ -64,6 +66,21 @@ except Exception as ex:
     print(sys.argv[2], 'ERR', ex)
 PY
   done | tee $O/variants.txt ;;
+ablib)
+  LIST=$1; shift
+  for v in $LIST; do
+    ( export FMX_LIB=$PWD/fm_index_amd/$v; timeout 900 python3 bench.py --no-pmc --no-census --no-cpu-baseline --no-accel --no-early-exit --no-d2h --no-wide --no-ic-ab --no-config5 --no-rccl-check "$@" --detail-out $O/ablib_$v.json > /dev/null 2> $O/ablib_$v.err )
+    python3 - $O/ablib_$v.json "$v" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    l, b, r = d.get('locate') or {}, d.get('locate_3b') or {}, d.get('rlfm') or {}
+    print(sys.argv[2], 'count ms', round(d['ms_per_step'], 4), '| locate', {k: l.get(k) for k in ('ms_per_batch', 'walk_kernel_ms')},
+          '| 3b', {k: b.get(k) for k in ('ms_per_batch', 'walk_kernel_ms')}, '| positions', (l.get('positions_sha256') or '')[:12], (b.get('positions_sha256') or '')[:12])
+except Exception as ex:
+    print(sys.argv[2], 'ERR', ex)
+PY
+  done | tee -a $O/ablib.txt ;;
 pmc)
   # what bounds each kernel: benchmarks/gpu/kernel_pmc.py for the DNA, config-4b and config-4 workloads
   timeout 900 python3 benchmarks/gpu/kernel_pmc.py --tag dna --workload dna --child-args no-accel,no-rlfm --out $O 2>&1 | tail -n 12

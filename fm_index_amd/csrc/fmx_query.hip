@@ -2262,7 +2262,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   __shared__ uint16_t u_alist[FMX_U_SLICE / 8];       // tickets walked a lane per hit
   __shared__ uint16_t u_walks[2][FMX_U_SLICE];        // ... their unfinished walks, round by round
   __shared__ uint8_t u_wlen[FMX_U_SLICE];             // ... and the length of every finished one
-  __shared__ unsigned int u_ntl, u_nal, u_nwalks[2], u_ppos;
+  __shared__ unsigned int u_ntl, u_nal, u_ppos;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint64_t blo = (uint64_t)blockIdx.x * hits_per_block;
   if (blo >= total) return;                           // block-uniform
@@ -2307,52 +2307,68 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   // u_rows[slot]) that every round compacts: the visits executed are the visits needed, max(phase, 1) per hit.
   const uint32_t nal = u_nal, ntl = u_ntl;
   if (nal) {                                          // block-uniform
+    // Round 6: every WAVE runs the rounds of its own tickets (u_alist[wv], u_alist[wv + 16], ...: at most four) on its own
+    // quarter-kilobyte of the lists, with no block barrier and no atomic in between.  Rounds shared by the block
+    // (round 5) put all sixteen waves into the same step at the same time -- all of them waiting for their records,
+    // then all of them decoding -- and the block went at the pace of its slowest wave five times per slice.
+    constexpr uint32_t kWaves = FMX_LOC_BLOCK / 64u, kOwn = FMX_U_SLICE / kWaves;     // 16 waves, 256 hits each
+    uint16_t *const own0 = u_walks[0] + wv * kOwn, *const own1 = u_walks[1] + wv * kOwn;
     uint32_t nsteps = 0;
-    uint32_t cnt = nal * FMX_LCHUNK;                  // live walks of this round (block-uniform)
-    for (uint32_t round = 0; cnt != 0u; round++) {
-      uint16_t *const cur = u_walks[(round & 1u) ^ 1u], *const nxt = u_walks[round & 1u];
-      if (tid == 0) u_nwalks[round & 1u] = 0;
-      __syncthreads();
-      for (uint32_t i0 = wv * 64u; i0 < cnt; i0 += FMX_LOC_BLOCK) {     // wave-uniform: 64 consecutive entries per wave
+    uint32_t cnt = 0;                                 // unfinished walks of this wave (wave-uniform)
+    for (uint32_t a = wv; a < nal; a += kWaves) {     // round 0: the tickets themselves
+      const uint32_t x = (uint32_t)u_alist[a] * FMX_LCHUNK + lane;
+      bool more = false;
+      uint32_t wsteps = 0;
+      if (x < bn) {
+        uint32_t ph;
+        const uint32_t v = fmx_walk_lane_visit(walk, n, u_rows[x], ph);
+        wsteps = ph;                                  // the walk is exactly SA[row] mod 2^level steps long
+        u_rows[x] = v;                                // lf_map(row) -- or, for a walk that ends here, its sample's index
+        if (ph <= 1u) {                               // this row's sample (phase 0) or the next row's (phase 1)
+          u_wlen[x] = (uint8_t)wsteps;
+          nsteps += wsteps;
+        } else {                                      // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+          more = true;
+        }
+      }
+      const unsigned long long mm = __ballot(more);   // the wave's unfinished walks, appended in hit order
+      if (more) own0[cnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)(x | (wsteps << 12));
+      cnt += (uint32_t)__popcll(mm);
+    }
+    for (uint32_t round = 1; cnt != 0u; round++) {
+      const uint16_t *const cur = (round & 1u) ? own0 : own1;
+      uint16_t *const nxt = (round & 1u) ? own1 : own0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");        // the list entries other lanes of this wave wrote
+      uint32_t ncnt = 0;
+      for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
         const uint32_t i = i0 + lane;
+        bool more = false;
         uint32_t x = 0, wsteps = 0;
-        bool live = i < cnt;
-        if (round == 0u) {                            // the tickets themselves
-          x = (uint32_t)u_alist[i >> 6] * FMX_LCHUNK + lane;
-          live = x < bn;
-        } else if (live) {
+        if (i < cnt) {
           const uint32_t en = cur[i];
           x = en & 0xFFFu;
           wsteps = en >> 12;
-        }
-        bool more = false;
-        if (live) {
           uint32_t ph;
           const uint32_t v = fmx_walk_lane_visit(walk, n, u_rows[x], ph);
-          if (round == 0u) wsteps = ph;               // the walk is exactly SA[row] mod 2^level steps long
-          u_rows[x] = v;                              // lf_map(row) -- or, for a walk that ends here, its sample's index
-          if (ph <= 1u) {                             // this row's sample (phase 0) or the next row's (phase 1)
+          u_rows[x] = v;
+          if (ph <= 1u) {
             u_wlen[x] = (uint8_t)wsteps;
             nsteps += wsteps;
-          } else {                                    // None: i = lf_map(i); steps += 1   fm_index.rs:134-137
+          } else {
             more = true;
           }
         }
         const unsigned long long mm = __ballot(more);
-        if (mm) {                                     // wave-uniform: the wave's unfinished walks, appended in hit order
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&u_nwalks[round & 1u], (unsigned int)__popcll(mm));
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (more) nxt[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)(x | (wsteps << 12));
-        }
+        if (more) nxt[ncnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)(x | (wsteps << 12));
+        ncnt += (uint32_t)__popcll(mm);
       }
-      __syncthreads();
-      cnt = u_nwalks[round & 1u];
+      cnt = ncnt;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     // every walk of these tickets has left the index of its sample in u_rows[slot]: the samples in one sweep (no load
     // waits for a visit any more; adjacent rows' samples are neighbours), the positions as contiguous 512-byte lines
-    for (uint32_t i = wv; i < nal; i += FMX_LOC_BLOCK / 64u) {
-      const uint32_t x = (uint32_t)u_alist[i] * FMX_LCHUNK + lane;
+    for (uint32_t a = wv; a < nal; a += kWaves) {
+      const uint32_t x = (uint32_t)u_alist[a] * FMX_LCHUNK + lane;
       if (x < bn) {
         const uint32_t si = u_rows[x];
         FMX_CHECK(si < nsamples);

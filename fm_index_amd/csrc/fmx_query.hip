@@ -2303,7 +2303,7 @@ __global__ __launch_bounds__(FMX_LOC_BLOCK) __attribute__((amdgpu_waves_per_eu(8
   // A wave that walks its 64 hits to the end runs as long as its longest walk -- 2^level - 1 visits -- with half of its
   // lanes done after the first visit and three quarters after the second (phases are uniform): config 3b spent 709 vector
   // instructions per hit that way and was bound by exactly that (VALU busy 0.93, profiles/r05/kernel_pmc_dna.json).  Here
-  // the block keeps the unfinished walks in a list (LDS: slot | the walk's length << 12; the walk's row stays in
+  // the unfinished walks are kept in a list (LDS: slot | the walk's length << 12; the walk's row stays in
   // u_rows[slot]) that every round compacts: the visits executed are the visits needed, max(phase, 1) per hit.
   const uint32_t nal = u_nal, ntl = u_ntl;
   if (nal) {                                          // block-uniform

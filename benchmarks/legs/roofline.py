@@ -240,7 +240,7 @@ PMC_LEGS = {   # leg -> substrings identifying its dominant kernel in the counte
     "dna_locate_3b": [WALK_KERNEL, LANE_WALK_KERNEL],     # the same kernel on a larger grid (told apart by the grid)
     "rlfm_count": ["fmx_count_ep_kernel", "fmx_count_kernel"],
     "rlfm_locate": ["fmx_locate_ep_kernel", "fmx_locate_kernel"],
-    "rlfm_locate_lane": ["fmx_locate_rl_lane_kernel"],          # config 4b: 64+ hits per pattern (--workload rep-rlfm)
+    "rlfm_locate_lane": ["fmx_locate_rl_rounds_kernel", "fmx_locate_rl_lane_kernel"],   # config 4b: 2+ hits per pattern (--workload rep-rlfm)
 }
 
 

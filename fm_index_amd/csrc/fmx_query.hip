@@ -1921,6 +1921,8 @@ struct FmxTune {
   long rl_ep_min = 1l << 18;     // RLFM: one walk per lane from this many hits
   bool rl_unified = false;       // measurement builds (FMX_RL_UNIFIED=1): the RLFM lane kernel in one launch (slices expanded in LDS)
   long rl_lane_avg = 2;          // ... with the run table: a lane per walk on consecutive hits from this many hits per pattern
+  bool rl_rounds = true;         // ... in rounds, four tickets per wave at a time (fmx_locate_rl_rounds_kernel); false = round 5's kernel
+  long rl_rounds_blocks = 32768; // ... grid cap (config 4b: 2048 blocks 9.2 ms, 4096 7.8, 8192 7.5, 32768 7.3, 131072 7.35, 10^6 7.8)
   long fm_ep_min = 4l << 20;     // FM over several levels: one walk per lane from this many hits
 };
 // everything a count / locate launch needs, for the launch helpers below and in fmx_measure.inc
@@ -2483,6 +2485,198 @@ __global__ __launch_bounds__(FMX_BLOCK) void fmx_locate_rl_lane_kernel(FmxDev ix
     out_pos[h] = fmx_rlfm_lane_get_sa<TEXT>(ix, rows[h], nsteps);
   if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
 }
+// ---- the same walks in ROUNDS, four tickets per wave at a time (round 6) ---------------------------------------------------
+// fmx_locate_rl_lane_kernel above is bound by the chain of dependent round trips of a wave, at full occupancy (82 % of
+// its wave cycles parked on s_waitcnt, 22 G requests/s of the 55 the chip serves: profiles/r06/kernel_pmc_rep_rlfm_2p27.json):
+// a wave takes 64 hits through rows -> phase probe -> (B piece -> table entry) x its LONGEST walk -> phase probe -> sample,
+// ten trips one after the other with half of its lanes idle in the step loop, and 8.0 ms / (1.2e7 tickets / 8192 resident
+// waves) / 10 trips = 0.53 us per trip says that is all the time there is.  Here a wave owns 256 consecutive hits: their
+// rows, probes, LF steps and samples are requested FOUR tickets at a time (independent loads issued back to back: one
+// trip serves 256 hits), and the unfinished walks are kept as a packed list in the wave's own LDS (slot | steps so far),
+// compacted every round with a ballot -- no block barrier, no atomic -- so that a round issues loads for the walks that
+// still run and for nothing else.  Same results as the kernel above for every hit (any order of the LF steps of
+// different walks is the reference's get_sa per hit: rlfmi.rs:172-190).
+#define FMX_RLR_BLOCK 256
+#define FMX_RLR_HITS 256u            // per wave and pass
+struct FmxRlrLds {
+  uint32_t row[FMX_RLR_HITS];        // the walk's current row; once it has ended, the index of its sample
+  uint32_t list[2][FMX_RLR_HITS];    // unfinished walks: slot | LF steps taken << 8
+  uint32_t len[FMX_RLR_HITS];        // LF steps of the finished walk
+};
+// B piece of `row` requested (stage A of an LF step)
+__device__ __forceinline__ uint4 fmx_rlr_piece(const FmxDev &ix, uint32_t row) {
+  const uint32_t pidx = fmx_div3(row >> 5);           // row / 96
+  FMX_CHECK(pidx < ix.b.nrec * 8u);
+  FMX_TOUCH(&ix.b.rec[pidx]);
+  return ix.b.rec[pidx];
+}
+// stage B: the run of the row, its table entry requested, and -- when the run starts in front of the piece -- the one
+// load that answers select1 (stored position or select block); st = the run's first row when the piece holds it
+struct FmxRlrStep { uint32_t lo, f, st, aux; uint4 blk; int mode; };   // mode 0: st known; 1: aux = position; 2: blk; 3: search
+__device__ __forceinline__ FmxRlrStep fmx_rlr_entry(const FmxDev &ix, uint32_t row, const uint4 pc) {
+  FmxRlrStep r;
+  const uint32_t pidx = fmx_div3(row >> 5);
+  const uint32_t b1 = row - pidx * FMX_BITS_PER_PIECE + 1u;   // bits [0, bit] of the piece
+  const uint32_t m0 = fmx_lowmask(b1 < 32u ? b1 : 32u);
+  const uint32_t m1 = b1 > 32u ? fmx_lowmask(b1 - 32u < 32u ? b1 - 32u : 32u) : 0u;
+  const uint32_t m2 = b1 > 64u ? fmx_lowmask(b1 - 64u) : 0u;
+  const uint32_t y = pc.y & m0, z = pc.z & m1, w = pc.w & m2;
+  r.lo = pc.x + __popc(y) + __popc(z) + __popc(w) - 1u;       // the run of the row
+  FMX_CHECK(r.lo < ix.b.ones);
+  FMX_TOUCH(&ix.lfrun[r.lo]);
+  r.f = ix.lfrun[r.lo];                                       // lf_map(first row of the run)
+  r.mode = 0; r.st = 0; r.aux = 0; r.blk = make_uint4(0, 0, 0, 0);
+  if (w) r.st = pidx * FMX_BITS_PER_PIECE + 95u - (uint32_t)__builtin_clz(w);
+  else if (z) r.st = pidx * FMX_BITS_PER_PIECE + 63u - (uint32_t)__builtin_clz(z);
+  else if (y) r.st = pidx * FMX_BITS_PER_PIECE + 31u - (uint32_t)__builtin_clz(y);
+  else if (ix.b.pos) { r.mode = 1; FMX_TOUCH(&ix.b.pos[r.lo]); r.aux = ix.b.pos[r.lo]; }
+  else if (ix.b.dsel) { r.mode = 2; FMX_TOUCH(&ix.b.dsel[r.lo >> ix.b.dsel_shift]); r.blk = ix.b.dsel[r.lo >> ix.b.dsel_shift]; }
+  else r.mode = 3;
+  return r;
+}
+// stage C: lf_map(row) = table entry + offset of the row in its run                                   rlfmi.rs:127-133
+__device__ __forceinline__ uint32_t fmx_rlr_finish(const FmxDev &ix, uint32_t row, const FmxRlrStep &r) {
+  uint32_t st = r.st;
+  if (r.mode == 1) st = r.aux;
+  else if (r.mode == 2 && r.blk.x != 0xFFFFFFFFu) st = fmx_dsel_pos(r.blk, r.lo, ix.b.dsel_shift);
+  else if (r.mode >= 2) st = fmx_bits_lane_select(ix.b, r.lo);          // hints + record search (rare)
+  return r.f + row - st;
+}
+template <bool TEXT>
+__global__ __launch_bounds__(FMX_RLR_BLOCK) void fmx_locate_rl_rounds_kernel(FmxDev ix, uint64_t total,
+                                                                            const uint32_t *__restrict__ rows,
+                                                                            uint64_t *__restrict__ out_pos,
+                                                                            uint64_t *__restrict__ steps_out) {
+  __shared__ FmxRlrLds lds[FMX_RLR_BLOCK / 64];
+  const uint32_t lane = threadIdx.x & 63u;
+  FmxRlrLds &W = lds[threadIdx.x >> 6];
+  const uint64_t nwaves = (uint64_t)gridDim.x * (FMX_RLR_BLOCK / 64);
+  const uint64_t wave = (uint64_t)blockIdx.x * (FMX_RLR_BLOCK / 64) + (threadIdx.x >> 6);
+  const uint32_t lmask = (1u << ix.sa_level) - 1u;
+  uint64_t nsteps = 0;
+  for (uint64_t h0 = wave * FMX_RLR_HITS; h0 < total; h0 += nwaves * FMX_RLR_HITS) {       // wave-uniform
+    const uint32_t m = (uint32_t)(total - h0 < FMX_RLR_HITS ? total - h0 : FMX_RLR_HITS);
+    uint32_t cnt = 0;                                 // unfinished walks (wave-uniform)
+    // ---- the hits' rows, and where their walks stand at the start ----
+    {
+      uint32_t row[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t x = j * 64u + lane;
+        row[j] = x < m ? rows[h0 + x] : 0u;
+        FMX_CHECK(row[j] < ix.n);                     // (the expand kernels write every slot with a row of this index)
+      }
+      uint32_t left[4], si[4];
+      if (TEXT) {                                     // SA[row] mod 2^level steps to go; phase 0: the row's own sample
+        uint4 pp[4]; uint32_t t[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          const uint32_t pi = fmx_phase_piece(row[j], ix.sa_level, t[j]);
+          FMX_TOUCH(&ix.phase[pi]);
+          pp[j] = ix.phase[pi];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) left[j] = fmx_phase_decode(pp[j], t[j], ix.sa_level, si[j]);
+      } else {                                        // the reference's rows (sample.rs:46-60): a sampled row ends the walk
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) { left[j] = row[j] & lmask; si[j] = row[j] >> ix.sa_level; }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t x = j * 64u + lane;
+        const bool more = x < m && left[j] != 0u;
+        if (x < m) { W.row[x] = more ? row[j] : si[j]; W.len[x] = TEXT ? left[j] : 0u; }    // TEXT: the walk's length is known
+        const unsigned long long mm = __ballot(more);
+        if (more) W.list[0][cnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = x;
+        cnt += (uint32_t)__popcll(mm);
+      }
+    }
+    // ---- rounds of one LF step per unfinished walk; a walk that ends leaves its sample's index (or, TEXT, its last row) ----
+    for (uint32_t round = 0; cnt != 0u; round++) {
+      const uint32_t *const cur = W.list[round & 1u];
+      uint32_t *const nxt = W.list[(round & 1u) ^ 1u];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // what other lanes of this wave wrote to the lists
+      uint32_t ncnt = 0;
+      for (uint32_t i0 = 0; i0 < cnt; i0 += 256u) {              // (once: cnt <= 256)
+        uint32_t en[4], row[4];
+        uint4 pc[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          const uint32_t i = i0 + j * 64u + lane;
+          en[j] = i < cnt ? cur[i] : 0u;
+          row[j] = i < cnt ? W.row[en[j] & 0xFFu] : 0u;           // (a lane beyond the list steps row 0 and drops the result)
+          pc[j] = fmx_rlr_piece(ix, row[j]);
+        }
+        FmxRlrStep st[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) st[j] = fmx_rlr_entry(ix, row[j], pc[j]);
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          const uint32_t i = i0 + j * 64u + lane, x = en[j] & 0xFFu, done = (en[j] >> 8) + 1u;
+          const uint32_t nr = fmx_rlr_finish(ix, row[j], st[j]);
+          bool more = false;
+          if (i < cnt) {
+            FMX_CHECK(nr < ix.n);
+            // TEXT: the walk is exactly `left` steps long and its length was stored at the start; else a sampled row ends it
+            const bool last = TEXT ? done == W.len[x] : (nr & lmask) == 0u;
+            W.row[x] = (!TEXT && last) ? nr >> ix.sa_level : nr;
+            if (!TEXT && last) W.len[x] = done;
+            more = !last;
+          }
+          const unsigned long long mm = __ballot(more);
+          if (more) nxt[ncnt + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = x | (done << 8);
+          ncnt += (uint32_t)__popcll(mm);
+        }
+      }
+      cnt = ncnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // ---- TEXT: the walks that moved end on a phase-0 row: its sample's index from the phase piece ----
+    if (TEXT) {
+      uint32_t r2[4], t[4];
+      uint4 pp[4];
+      bool moved[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t x = j * 64u + lane;
+        moved[j] = x < m && W.len[x] != 0u;
+        r2[j] = moved[j] ? W.row[x] : 0u;
+        const uint32_t pi = fmx_phase_piece(r2[j], ix.sa_level, t[j]);
+        if (moved[j]) FMX_TOUCH(&ix.phase[pi]);
+        pp[j] = ix.phase[pi];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        uint32_t si;
+        [[maybe_unused]] const uint32_t p2 = fmx_phase_decode(pp[j], t[j], ix.sa_level, si);
+        FMX_CHECK(!moved[j] || p2 == 0u);
+        if (moved[j]) W.row[j * 64u + lane] = si;
+      }
+    }
+    // ---- the samples, the positions: (sa + steps) % len                                            rlfmi.rs:178-182 ----
+    {
+      uint32_t si[4], sv[4], ln[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t x = j * 64u + lane;
+        si[j] = x < m ? W.row[x] : 0u;
+        ln[j] = x < m ? W.len[x] : 0u;
+        FMX_CHECK(si[j] < ix.nsamples);
+        if (x < m) FMX_TOUCH(&ix.samples[si[j]]);
+        sv[j] = ix.samples[si[j]];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t x = j * 64u + lane;
+        uint64_t v = (uint64_t)sv[j] + ln[j];
+        if (v >= ix.n) v -= ix.n;
+        if (x < m) { out_pos[h0 + x] = v; nsteps += ln[j]; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");        // the next pass reuses the wave's lists
+  }
+  if (steps_out && nsteps) atomicAdd((unsigned long long *)steps_out, (unsigned long long)nsteps);
+}
 #ifdef FMX_MEASURE
 // The same walk in ONE launch (round 5, measurement builds only: FMX_RL_UNIFIED=1): a block expands its slice of at most
 // 4096 hits in LDS (fmx_expand_slice: no rows array, no allocation, no expand launch) and its lanes walk them.  Measured
@@ -2834,10 +3028,18 @@ int fmx_launch_locate(const fmx_index *idx, const uint64_t *d_s, const uint64_t 
         // kernel's edge on scattered rows is 15 % at best with the run table (two lane-wise requests per step either
         // way), less than what splitting a batch costs (profiles/r05/locate_mix_*.jsonl).  Round 4 took this kernel from
         // an average of 64 hits per pattern on, which sent the second batch above (average 3.5) to the queue kernel.
-        uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
-        if (lb > 8192) lb = 8192;
-        if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
-        else hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<false>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        if (tn.rl_rounds) {                                       // round 6: four tickets per wave at a time, in rounds
+          const uint64_t per_block = (uint64_t)FMX_RLR_HITS * (FMX_RLR_BLOCK / 64);
+          uint64_t lb = (total + per_block - 1) / per_block;
+          if (lb > (uint64_t)tn.rl_rounds_blocks) lb = (uint64_t)tn.rl_rounds_blocks;
+          if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_rounds_kernel<true>, dim3((unsigned)lb), dim3(FMX_RLR_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+          else hipLaunchKernelGGL(fmx_locate_rl_rounds_kernel<false>, dim3((unsigned)lb), dim3(FMX_RLR_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        } else {
+          uint64_t lb = (total + FMX_BLOCK - 1) / FMX_BLOCK;
+          if (lb > 8192) lb = 8192;
+          if (dv.phase) hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<true>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+          else hipLaunchKernelGGL(fmx_locate_rl_lane_kernel<false>, dim3((unsigned)lb), dim3(FMX_BLOCK), 0, c.st, c.dv, c.total, c.rows, c.pos, c.steps);
+        }
       }
       else if (dv.lfrun && tn.walk_records && tn.wc) {          // the run table: two lane-wise requests per LF step
         if (sm == 1) FMX_EPL_LFR(c, gr, thr, hpb, 1); else FMX_EPL_LFR(c, gr, thr, hpb, 2);

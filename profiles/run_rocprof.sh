@@ -21,7 +21,7 @@ ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-census --no-early-ex
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS --detail-out $OUT/bench_trace_detail.json > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc $RD --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py --pmc-child > $OUT/pmc_write.out 2> $OUT/pmc_write.err
-# config 4b (repetitive text, RLFM): fmx_locate_rl_lane_kernel -- its own trace and counter passes
+# config 4b (repetitive text, RLFM): fmx_locate_rl_rounds_kernel (fmx_locate_rl_lane_kernel until round 5) -- its own trace and counter passes
 rocprofv3 --kernel-trace --stats -d $OUT/trace4b --output-format csv -- python3 $REPO/bench.py --workload rep-rlfm --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-census --no-d2h --no-accel --no-rccl-check --detail-out $OUT/bench_trace4b_detail.json > $OUT/bench_trace4b.json 2> $OUT/trace4b.err
 rocprofv3 --pmc $RD --kernel-trace -d $OUT/pmc_fetch4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_fetch4b.out 2> $OUT/pmc_fetch4b.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write4b --output-format csv -- python3 $REPO/bench.py --pmc-child --workload rep-rlfm > $OUT/pmc_write4b.out 2> $OUT/pmc_write4b.err

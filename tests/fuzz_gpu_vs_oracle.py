@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def long_intervals(budget, seed, max_iters):
     """`long` mode (round 5): the kernels that walk LONG intervals -- the one-launch DNA kernel with its
     per-ticket choice (fmx_locate_f3u_kernel: lane per hit / cooperative walk), the RLFM lane-per-walk kernel
-    (fmx_locate_rl_lane_kernel) next to the endpoint-per-lane one -- on batches that cross their dispatch thresholds
+    (fmx_locate_rl_rounds_kernel) next to the endpoint-per-lane one -- on batches that cross their dispatch thresholds
     (>= 64 hits per pattern; >= 2^16 DNA / 2^18 RLFM hits), in text and row order, skewed batches (singletons + a few huge
     intervals), and RLFM texts whose run-length mix reaches every branch of fmx_bits_lane_select: stored positions (sparse
     B), select blocks of every size (dense B), and the hint + record search (a long run inside a dense vector, so that

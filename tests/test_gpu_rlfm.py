@@ -264,10 +264,11 @@ def test_large_hit_batches_take_the_walk_per_lane_kernel(gen):
     assert (goff == ooff).all() and (gpos == opos).all(), gen
 
 
-@pytest.mark.parametrize("sampling,level", [(None, 3), ("row", 2), (None, 1), ("row", 0)])
+@pytest.mark.parametrize("sampling,level", [(None, 3), ("row", 2), (None, 1), ("row", 0), (None, 4), ("row", 6)])
 def test_long_intervals_take_the_lane_per_walk_kernel(sampling, level):
     """batches that average 64+ hits per pattern (and 2^18+ hits in all) on an index with the run table go through
-    fmx_locate_rl_lane_kernel -- a lane per walk on consecutive hits (round 4) -- in text order and in row order: the exact
+    fmx_locate_rl_rounds_kernel -- a lane per walk on consecutive hits (round 4), since round 6 in rounds of one LF step
+    over four tickets per wave -- in text order and in row order: the exact
     sequences of the oracle, and of the same index without the run table (the endpoint-per-lane / group kernels)"""
     n = 300000
     t = W.repetitive_text_np(n, 11, base_len=512, mut_per_1024=4)

@@ -223,7 +223,7 @@ def test_workspace_form_and_two_streams_share_nothing():
 @pytest.mark.parametrize("singles,longs,long_len", [(60000, 60, 6000), (100000, 0, 0), (0, 8, 70000), (150000, 3, 90000)])
 def test_rlfm_run_table_mixed_batches(sampling, level, singles, longs, long_len):
     """RLFM with the run table (round 5): batches of 2^18+ hits that average two or more hits per pattern take
-    fmx_locate_rl_lane_kernel (two walks per lane on consecutive hits, every stage's loads paired) for every hit -- mixed
+    fmx_locate_rl_rounds_kernel (a lane per walk on consecutive hits, four tickets per wave in rounds) for every hit -- mixed
     and skewed batches included; batches of about one hit per pattern take the queue kernel.  The oracle's ordered
     positions either way, in text and in row order."""
     n = 300000

@@ -103,7 +103,10 @@ def locate_leg(out, wl, args, world, rank, dist, gloo, key, dest=None, legname="
     if not args.no_census and rank == 0:
         cen = run_census(wl, lambda cl: wl.locate(lib=cl), lf_steps * (8 if wl.rlfm else 2) + 4 * total_hits + (1 << 20))
     ref_bytes = lf_steps * wl.Lbits * 64 + total_hits * 64   # steps*L*64 + 64 per hit
-    kname = dna_walk_kernel(wl) if wl.dna else ("fmx_locate_ep_kernel" if wl.rlfm else "fmx_locate_kernel<FMX_KIND_FM>")
+    # RLFM: batches of two or more hits per pattern on an index with the run table take the lane walk in rounds
+    rl_lane = wl.rlfm and wl.index.walk_records() and total_hits >= 2 * npat and total_hits >= (1 << 18)
+    kname = dna_walk_kernel(wl) if wl.dna else (("fmx_locate_rl_rounds_kernel" if rl_lane else "fmx_locate_ep_kernel")
+                                                if wl.rlfm else "fmx_locate_kernel<FMX_KIND_FM>")
     # streamed bytes: the positions, and the rows array (read) -- or, for the one-launch DNA kernel, s / e / off
     lstream = total_hits * 8 + (npat * 24 if (wl.dna and wl.index.walk_records()) else total_hits * 4)
     roof = make_roofline(kname, kavg_ms, 1, ref_bytes, lstream, cen,
